@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+PKG = os.path.join(ROOT, "python-paillier_amd")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def c_oracle():
+    from oracle.paillier_oracle import COracle, build_c_oracle
+    build_c_oracle()
+    return COracle()
+
+
+def load_golden(key_bits):
+    import json
+    with open(os.path.join(GOLDEN, "paillier_%d.json" % key_bits)) as f:
+        return json.load(f)
+
+
+def load_kat():
+    import json
+    with open(os.path.join(GOLDEN, "reference_kat.json")) as f:
+        return json.load(f)
