@@ -1,0 +1,129 @@
+/*
+ * phe_hip.h — C-ABI of the MI355X (gfx950) batched Paillier engine.
+ *
+ * This is the drop-in boundary for the one data-parallel hot path of data61/python-paillier
+ * (`phe` 1.5.0).  The reference has no FFI of its own: its backend seam is the three module
+ * functions phe/util.py:38-50 (powmod), :53-64 (mulmod), :85-103 (invert), called one Python int
+ * at a time from the five raw_* functions of phe/paillier.py.  A scalar seam cannot batch, so the
+ * boundary sits one level up and every entry point below replaces a whole loop of calls to one of
+ * those raw_* functions (file:line cited per function).  INTEGRATION.md shows the ctypes stub a
+ * python-paillier maintainer would add.
+ *
+ * Conventions
+ *   - Numbers are little-endian arrays of uint32 limbs ("int.to_bytes(4*limbs, 'little')").
+ *     Batches are row-major (batch, limbs), caller-owned.
+ *   - n_limbs  = limbs of n (e.g. 64 for a 2048-bit key);  ciphertexts have ct_limbs = 2*n_limbs.
+ *   - Every function returns a status: PHE_HIP_OK, or an error with a message retrievable through
+ *     phe_hip_last_error() (thread-local).  Nothing throws across the boundary.  Argument/range
+ *     validation that the reference does in Python (TypeError/ValueError) stays in the host
+ *     language; the kernels compute on whatever limbs they are given, modulo the stated ranges.
+ *   - Plain functions take HOST pointers and are synchronous (upload, compute, download).
+ *     *_dev functions take DEVICE pointers (hipMalloc'd / torch CUDA tensors) and enqueue on
+ *     `stream` (a hipStream_t passed as void*, NULL = default stream) without synchronising.
+ *   - A context is bound to one device and is not thread-safe; use one per host thread / rank.
+ *   - All results are canonical residues, bit-identical to the reference's gmpy2/CPython values.
+ */
+#ifndef PHE_HIP_H
+#define PHE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHE_HIP_OK 0
+#define PHE_HIP_EINVAL 1      /* bad argument (NULL, size mismatch, unsupported key width, even modulus) */
+#define PHE_HIP_EHIP 2        /* HIP runtime error (no device, out of memory, launch failure) */
+#define PHE_HIP_ENOINVERSE 3  /* an element has no inverse: reference raises ZeroDivisionError (phe/util.py:96-102) */
+
+typedef struct phe_hip_ctx phe_hip_ctx;
+
+/* Message for the last non-OK status returned on this thread. */
+const char* phe_hip_last_error(void);
+
+/* Number of visible HIP devices. */
+int phe_hip_device_count(int* count);
+
+/* ---- contexts ---------------------------------------------------------------------------- */
+
+/* Public-key context: what PaillierPublicKey.__init__ holds (phe/paillier.py:86-90) plus the
+ * Montgomery constants of n^2 and the window schedule of the exponent n. */
+int phe_hip_ctx_create_public(const uint32_t* n, int n_limbs, int device, phe_hip_ctx** out);
+
+/* Private-key context: additionally what PaillierPrivateKey.__init__ holds (phe/paillier.py:217-235).
+ * p < q required (the reference orders them at :224-229); hp, hq, p_inverse are the values the
+ * reference computes at :233-235 (the host language passes them in; they are once-per-key). */
+int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p, const uint32_t* q,
+                               const uint32_t* hp, const uint32_t* hq, const uint32_t* p_inverse,
+                               int pq_limbs, int device, phe_hip_ctx** out);
+
+void phe_hip_ctx_destroy(phe_hip_ctx* ctx);
+
+/* Geometry chosen for this key: limbs-per-lane of the n^2 kernels and of the p^2/q^2 kernels,
+ * and the number of 16-lane limb groups one launch keeps in flight. Any pointer may be NULL. */
+int phe_hip_ctx_info(const phe_hip_ctx* ctx, int* n_limbs, int* ct_limbs, int* lanes_limbs_pub,
+                     int* lane_limbs_priv, int* rows_in_flight, int* has_private);
+
+/* Tuning: workgroups (256 threads = 16 limb groups) resident per CU for the modexp kernels. */
+int phe_hip_ctx_set_blocks_per_cu(phe_hip_ctx* ctx, int blocks_per_cu);
+
+/* ---- the hot path, host buffers ------------------------------------------------------------ */
+
+/* c[i] = (1 + n*m[i]) * r[i]^n mod n^2      — PaillierPublicKey.raw_encrypt(m, r_value=r),
+ * phe/paillier.py:102-139.  m: (batch, n_limbs) any value < 2^(32*n_limbs) (m >= n wraps like the
+ * reference's `% nsquare`, :134);  r: (batch, n_limbs), 0 < r < n;  c: (batch, ct_limbs). */
+int phe_hip_encrypt(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch);
+
+/* c_out[i] = c_in[i] * r[i]^n mod n^2       — EncryptedNumber.obfuscate(), phe/paillier.py:603-624
+ * (with the obfuscator r an explicit input; the reference draws it at :621). */
+int phe_hip_obfuscate(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t* r, uint32_t* c_out, size_t batch);
+
+/* m[i] = PaillierPrivateKey.raw_decrypt(c[i]) — phe/paillier.py:328-354 incl. l_function :362-364
+ * and crt :366-374.  c: (batch, ct_limbs) < n^2;  m: (batch, n_limbs).  Needs a private context. */
+int phe_hip_decrypt(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t batch);
+
+/* out[i] = a[i]*b[i] mod n^2                — EncryptedNumber._raw_add, phe/paillier.py:705-719
+ * (= phe.util.mulmod, phe/util.py:53-64).  a, b, out: (batch, ct_limbs); b < n^2. */
+int phe_hip_mulmod(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t batch);
+
+/* out[i] = base[i]^e[i] mod n^2             — the powmod of EncryptedNumber._raw_mul,
+ * phe/paillier.py:749/:751 (= phe.util.powmod, phe/util.py:38-50).  base: (batch, ct_limbs) < n^2;
+ * e: (batch, exp_limbs).  The negative-scalar branch (:745-749) is composed by the host from
+ * phe_hip_invert + this function, partitioned on the same threshold n - max_int. */
+int phe_hip_powmod(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, uint32_t* out,
+                   size_t batch);
+
+/* out[i] = a[i]^-1 mod n^2                  — phe.util.invert (phe/util.py:85-103) as used at
+ * phe/paillier.py:747.  Montgomery's simultaneous inversion: a product tree of mulmod launches, ONE
+ * scalar inversion of the root, and the tree walked back down.  On PHE_HIP_ENOINVERSE *bad_index
+ * is the first row with gcd(a, n^2) != 1 (the reference raises ZeroDivisionError for it). */
+int phe_hip_invert(phe_hip_ctx* ctx, const uint32_t* a, uint32_t* out, size_t batch, size_t* bad_index);
+
+/* ---- the hot path, device buffers (resident operands; asynchronous on `stream`) -------------- */
+int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch, void* stream);
+int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t* r, uint32_t* c_out, size_t batch, void* stream);
+int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t batch, void* stream);
+int phe_hip_mulmod_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t batch, void* stream);
+/* max_exp_bits: upper bound on the bit length of every e[i] (0 = 32*exp_limbs) */
+int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, int max_exp_bits,
+                       uint32_t* out, size_t batch, void* stream);
+
+/* ---- device memory helpers for hosts without a tensor library ------------------------------- */
+int phe_hip_malloc(phe_hip_ctx* ctx, size_t bytes, void** dptr);
+int phe_hip_free(phe_hip_ctx* ctx, void* dptr);
+int phe_hip_memcpy_h2d(phe_hip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+int phe_hip_memcpy_d2h(phe_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int phe_hip_stream_sync(phe_hip_ctx* ctx, void* stream);
+
+/* ---- diagnostics ----------------------------------------------------------------------------- */
+/* Runs the three DPP row primitives and the ballot on lane ids: out is (4, 64) uint32:
+ * row 0 = row_down1(lane), row 1 = row_up1(lane), row 2 = row_bcast0(lane), row 3 = lane parity
+ * ballot folded per lane.  Used by tests/test_gpu_prims.py to pin the emulator's semantics. */
+int phe_hip_selftest_prims(int device, uint32_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHE_HIP_H */

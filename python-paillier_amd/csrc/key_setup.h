@@ -1,0 +1,319 @@
+// key_setup.h — host-side, once-per-key derivation of the constants the kernels consume.
+//
+// The reference derives its per-key values in PaillierPublicKey.__init__ (phe/paillier.py:86-90:
+// n, nsquare, max_int) and PaillierPrivateKey.__init__ (:217-235: p<q, psquare, qsquare,
+// p_inverse, hp, hq).  The Montgomery-domain companions needed by mont_core.h / decrypt_tail.h
+// (R mod N, R^2, R^3, -N^-1 mod 2^32, n*R mod n^2, p^-1 mod W^h, hp*W^h mod p, the sliding-window
+// schedule of an exponent) are computed here with a deliberately tiny schoolbook bignum: this is
+// cold code, a few hundred microseconds per key.
+//
+// Pure C++ (no HIP): also compiled into the CPU emulator used by tests/.
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <stdexcept>
+#include <vector>
+
+namespace phe {
+namespace host {
+
+using Big = std::vector<uint32_t>;  // little-endian limbs, fixed length chosen by the caller
+
+inline Big big_from(const uint32_t* p, int limbs, int width) {
+    Big r((size_t)width, 0u);
+    for (int i = 0; i < limbs && i < width; ++i) r[(size_t)i] = p[i];
+    for (int i = width; i < limbs; ++i)
+        if (p[i]) throw std::invalid_argument("value does not fit the limb width");
+    return r;
+}
+inline int big_bits(const Big& a) {
+    for (int i = (int)a.size() - 1; i >= 0; --i)
+        if (a[(size_t)i]) return 32 * i + 32 - __builtin_clz(a[(size_t)i]);
+    return 0;
+}
+inline bool big_is_zero(const Big& a) { return big_bits(a) == 0; }
+inline int big_cmp(const Big& a, const Big& b) {  // same length
+    for (int i = (int)a.size() - 1; i >= 0; --i)
+        if (a[(size_t)i] != b[(size_t)i]) return a[(size_t)i] < b[(size_t)i] ? -1 : 1;
+    return 0;
+}
+inline uint32_t big_sub_inplace(Big& a, const Big& b) {  // a -= b, returns borrow
+    uint64_t br = 0;
+    for (size_t i = 0; i < a.size(); ++i) {
+        const uint64_t d = (uint64_t)a[i] - b[i] - br;
+        a[i] = (uint32_t)d;
+        br = (d >> 63) & 1u;
+    }
+    return (uint32_t)br;
+}
+inline uint32_t big_add_inplace(Big& a, const Big& b) {
+    uint64_t c = 0;
+    for (size_t i = 0; i < a.size(); ++i) {
+        const uint64_t s = (uint64_t)a[i] + b[i] + c;
+        a[i] = (uint32_t)s;
+        c = s >> 32;
+    }
+    return (uint32_t)c;
+}
+// a = 2a mod n  (a < n)
+inline void big_double_mod(Big& a, const Big& n) {
+    uint32_t top = 0;
+    for (size_t i = 0; i < a.size(); ++i) {
+        const uint32_t v = a[i];
+        a[i] = (v << 1) | top;
+        top = v >> 31;
+    }
+    if (top || big_cmp(a, n) >= 0) big_sub_inplace(a, n);
+}
+// a * 2^k mod n
+inline Big big_shift_mod(Big a, int k, const Big& n) {
+    for (int i = 0; i < k; ++i) big_double_mod(a, n);
+    return a;
+}
+inline Big big_mul(const Big& a, const Big& b) {  // full product, a.size()+b.size() limbs
+    Big r(a.size() + b.size(), 0u);
+    for (size_t i = 0; i < a.size(); ++i) {
+        uint64_t c = 0;
+        for (size_t j = 0; j < b.size(); ++j) {
+            const uint64_t s = (uint64_t)a[i] * b[j] + r[i + j] + c;
+            r[i + j] = (uint32_t)s;
+            c = s >> 32;
+        }
+        r[i + b.size()] = (uint32_t)c;
+    }
+    return r;
+}
+inline Big big_resize(Big a, int width) {
+    for (size_t i = (size_t)width; i < a.size(); ++i)
+        if (a[i]) throw std::invalid_argument("value does not fit the limb width");
+    a.resize((size_t)width, 0u);
+    return a;
+}
+// a mod n for a < n * 2^(32*extra) by binary long division (cold path, sizes are tiny)
+inline Big big_mod(const Big& a, const Big& n) {
+    const int w = (int)n.size();
+    Big r((size_t)w, 0u);
+    for (int bit = big_bits(a) - 1; bit >= 0; --bit) {
+        big_double_mod(r, n);
+        if ((a[(size_t)(bit >> 5)] >> (bit & 31)) & 1u) {
+            Big one((size_t)w, 0u);
+            one[0] = 1;
+            if (big_add_inplace(r, one) || big_cmp(r, n) >= 0) big_sub_inplace(r, n);
+        }
+    }
+    return r;
+}
+// -n^-1 mod 2^32 for odd n
+inline uint32_t neg_inv32(uint32_t n0) {
+    uint32_t x = n0;  // correct to 3 bits
+    for (int i = 0; i < 5; ++i) x *= 2u - n0 * x;
+    return 0u - x;
+}
+// a^-1 mod 2^(32*h) for odd a (Newton/Hensel lifting on whole words)
+inline Big inv_mod_pow2(const Big& a, int h) {
+    Big x((size_t)h, 0u);
+    x[0] = 0u - neg_inv32(a[0]);
+    for (int have = 1; have < h; have *= 2) {
+        // x <- x * (2 - a*x)  mod W^h
+        Big ax = big_mul(a, x);
+        ax.resize((size_t)h);
+        Big two((size_t)h, 0u);
+        two[0] = 2;
+        big_sub_inplace(two, ax);
+        Big nx = big_mul(x, two);
+        nx.resize((size_t)h);
+        x = nx;
+    }
+    return x;
+}
+
+// Everything mont_core.h needs for one modulus, padded to S = 16*L words.
+struct ModulusPack {
+    int L = 0, S = 0;
+    Big n, r1, r2, r3, aux;
+    uint32_t n0inv = 0;
+};
+
+inline int pick_L(int limbs) {
+    static const int kSupported[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    for (int L : kSupported)
+        if (16 * L >= limbs) return L;
+    return 0;  // modulus too wide for the compiled kernels
+}
+
+// aux_src (optional, < N): aux = aux_src * R mod N.  min_limbs forces a minimum width (both CRT
+// halves of a private key share one L).
+inline ModulusPack build_modulus(const Big& N_any, const Big* aux_src, int min_limbs = 0) {
+    const int limbs = std::max((big_bits(N_any) + 31) / 32, min_limbs);
+    ModulusPack m;
+    m.L = pick_L(limbs);
+    if (m.L == 0) throw std::invalid_argument("modulus wider than 8192 bits is not supported");
+    m.S = 16 * m.L;
+    m.n = big_resize(N_any, m.S);
+    if ((m.n[0] & 1u) == 0u) throw std::invalid_argument("modulus must be odd");
+    m.n0inv = neg_inv32(m.n[0]);
+    Big one((size_t)m.S, 0u);
+    one[0] = 1;
+    if (big_cmp(one, m.n) >= 0) throw std::invalid_argument("modulus must be > 1");
+    m.r1 = big_shift_mod(one, 32 * m.S, m.n);
+    m.r2 = big_shift_mod(m.r1, 32 * m.S, m.n);
+    m.r3 = big_shift_mod(m.r2, 32 * m.S, m.n);
+    if (aux_src) {
+        Big a = big_resize(*aux_src, m.S);
+        if (big_cmp(a, m.n) >= 0) throw std::invalid_argument("aux value must be < modulus");
+        m.aux = big_shift_mod(a, 32 * m.S, m.n);
+    } else {
+        m.aux.assign((size_t)m.S, 0u);
+    }
+    return m;
+}
+
+// Left-to-right sliding-window schedule for a batch-uniform exponent e > 0.
+// Table entry idx holds base^(2*idx+1).  Op word = (squarings << 8) | (idx + 1); idx+1 == 0 means
+// squarings only.  first_idx is the entry the accumulator is initialised from.
+struct Schedule {
+    int window = 1;
+    int tbl_entries = 1;
+    int first_idx = 0;
+    std::vector<uint32_t> ops;
+    // algorithmic counts, for reporting
+    int squarings = 0, multiplies = 0;
+};
+
+inline int pick_window(int exp_bits) {
+    if (exp_bits <= 8) return 1;
+    if (exp_bits <= 24) return 2;
+    if (exp_bits <= 80) return 3;
+    if (exp_bits <= 240) return 4;
+    return 5;
+}
+
+inline Schedule build_schedule(const Big& e, int window = 0) {
+    const int bits = big_bits(e);
+    if (bits == 0) throw std::invalid_argument("exponent must be positive");
+    Schedule s;
+    s.window = window > 0 ? window : pick_window(bits);
+    s.tbl_entries = 1 << (s.window - 1);
+    auto bit = [&](int i) -> uint32_t { return i < 0 ? 0u : (e[(size_t)(i >> 5)] >> (i & 31)) & 1u; };
+    int i = bits - 1;
+    bool first = true;
+    int pending_sq = 0;
+    while (i >= 0) {
+        if (!bit(i)) {
+            ++pending_sq;
+            --i;
+            continue;
+        }
+        // longest window [i .. j] of at most `window` bits that ends in a 1
+        int j = std::max(i - s.window + 1, 0);
+        while (!bit(j)) ++j;
+        uint32_t v = 0;
+        for (int k = i; k >= j; --k) v = (v << 1) | bit(k);
+        const int len = i - j + 1;
+        const int idx = (int)(v >> 1);
+        if (first) {
+            s.first_idx = idx;
+            first = false;
+        } else {
+            int nsq = pending_sq + len;
+            while (nsq > 0xffffff) {  // cannot happen for sane sizes; keep the encoding honest
+                s.ops.push_back(0xffffffu << 8);
+                s.squarings += 0xffffff;
+                nsq -= 0xffffff;
+            }
+            s.ops.push_back(((uint32_t)nsq << 8) | (uint32_t)(idx + 1));
+            s.squarings += nsq;
+            s.multiplies += 1;
+        }
+        pending_sq = 0;
+        i = j - 1;
+    }
+    if (pending_sq) {
+        s.ops.push_back((uint32_t)pending_sq << 8);
+        s.squarings += pending_sq;
+    }
+    return s;
+}
+
+// Constants of the CRT tail (decrypt_tail.h); p < q enforced by the caller like phe/paillier.py:224-229.
+struct TailPack {
+    int h = 0;
+    Big p, q, pinvw, qinvw, hp_r, hq_r, pinvq_r;
+    uint32_t p0inv = 0, q0inv = 0;
+};
+
+inline TailPack build_tail(const Big& p_any, const Big& q_any, const Big& hp_any, const Big& hq_any,
+                           const Big& pinv_any) {
+    TailPack t;
+    t.h = (std::max(big_bits(p_any), big_bits(q_any)) + 31) / 32;
+    t.p = big_resize(p_any, t.h);
+    t.q = big_resize(q_any, t.h);
+    if (((t.p[0] & t.q[0]) & 1u) == 0u) throw std::invalid_argument("p and q must be odd");
+    if (big_cmp(t.p, t.q) >= 0) throw std::invalid_argument("expected p < q");
+    Big hp = big_resize(hp_any, t.h), hq = big_resize(hq_any, t.h), pinv = big_resize(pinv_any, t.h);
+    if (big_cmp(hp, t.p) >= 0 || big_cmp(hq, t.q) >= 0 || big_cmp(pinv, t.q) >= 0)
+        throw std::invalid_argument("hp/hq/p_inverse out of range");
+    t.pinvw = inv_mod_pow2(t.p, t.h);
+    t.qinvw = inv_mod_pow2(t.q, t.h);
+    t.hp_r = big_shift_mod(hp, 32 * t.h, t.p);
+    t.hq_r = big_shift_mod(hq, 32 * t.h, t.q);
+    t.pinvq_r = big_shift_mod(pinv, 32 * t.h, t.q);
+    t.p0inv = neg_inv32(t.p[0]);
+    t.q0inv = neg_inv32(t.q[0]);
+    return t;
+}
+
+// Public-key side: modulus n^2, exponent n (phe/paillier.py:137, :622), aux = n*R for 1 + n*m.
+struct PublicPlan {
+    int s1 = 0, s2 = 0;  // ABI widths: limbs of n / of a ciphertext (= 2*s1)
+    Big n;               // s1 limbs
+    ModulusPack nsq;
+    Schedule exp_n;
+};
+
+inline PublicPlan build_public(const uint32_t* n, int n_limbs) {
+    PublicPlan P;
+    P.s1 = n_limbs;
+    P.s2 = 2 * n_limbs;
+    P.n = big_from(n, n_limbs, n_limbs);
+    if (big_bits(P.n) < 2) throw std::invalid_argument("n too small");
+    Big nsq = big_mul(P.n, P.n);
+    P.nsq = build_modulus(nsq, &P.n);
+    P.exp_n = build_schedule(P.n);
+    return P;
+}
+
+// Private-key side: moduli p^2, q^2 with exponents p-1, q-1 (phe/paillier.py:347, :351) + CRT tail.
+struct PrivatePlan {
+    int s1 = 0, s2 = 0;
+    ModulusPack psq, qsq;  // same L
+    Schedule exp_p, exp_q;
+    TailPack tail;
+};
+
+inline PrivatePlan build_private(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const uint32_t* hq,
+                                 const uint32_t* p_inverse, int pq_limbs, int n_limbs) {
+    PrivatePlan P;
+    P.s1 = n_limbs;
+    P.s2 = 2 * n_limbs;
+    Big bp = big_from(p, pq_limbs, pq_limbs), bq = big_from(q, pq_limbs, pq_limbs);
+    P.tail = build_tail(bp, bq, big_from(hp, pq_limbs, pq_limbs), big_from(hq, pq_limbs, pq_limbs),
+                        big_from(p_inverse, pq_limbs, pq_limbs));
+    Big psq = big_mul(bp, bp), qsq = big_mul(bq, bq);
+    // the wide input c (s2 limbs) is split at S words, so S >= s1 is required
+    const int min_limbs = std::max(n_limbs, (big_bits(qsq) + 31) / 32);
+    P.psq = build_modulus(psq, nullptr, min_limbs);
+    P.qsq = build_modulus(qsq, nullptr, min_limbs);
+    Big one((size_t)pq_limbs, 0u);
+    one[0] = 1;
+    Big pm1 = bp, qm1 = bq;
+    big_sub_inplace(pm1, one);
+    big_sub_inplace(qm1, one);
+    P.exp_p = build_schedule(pm1);
+    P.exp_q = build_schedule(qm1);
+    return P;
+}
+
+}  // namespace host
+}  // namespace phe

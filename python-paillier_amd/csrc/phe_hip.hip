@@ -1,0 +1,731 @@
+// phe_hip.hip — gfx950 kernels and the C-ABI (include/phe_hip.h) of the batched Paillier engine.
+//
+// Kernels (all hand-written for CDNA4; the arithmetic lives in mont_core.h / decrypt_tail.h):
+//   k_modexp_uniform<L, MODE>  batch-uniform exponent: encrypt / obfuscate (e = n, mod n^2) and the
+//                              two CRT halves of decrypt (e = p-1 mod p^2, e = q-1 mod q^2)
+//   k_modexp_var<L>            per-element exponent (powmod of _raw_mul)
+//   k_mulmod<L>                a*b mod n^2 (_raw_add, and the product tree of batched inversion)
+//   k_decrypt_tail             L-function, *hp, CRT recombination, one ciphertext per thread
+// Launch geometry: 256-thread workgroups = 4 wavefronts = 16 limb groups; the grid is sized to the
+// resident capacity (CUs x blocks_per_cu) and each limb group strides over the batch, so the
+// window tables (one per resident limb group) stay L2/MALL-resident regardless of batch size.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "../../include/phe_hip.h"
+// clang-format off
+#include "wave_gfx950.h"
+#include "mont_core.h"
+#include "decrypt_tail.h"
+#include "key_setup.h"
+// clang-format on
+
+using namespace phe;
+using host::Big;
+
+// ------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------
+constexpr int kBlock = 256;               // threads per workgroup
+constexpr int kRowsPerBlock = kBlock / 16;  // limb groups per workgroup
+
+template <int L, int MODE>
+__global__ void __launch_bounds__(kBlock) k_modexp_uniform(UniformArgs A) {
+    constexpr int S = 16 * L;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kRowsPerBlock * (S + kLdsPad)];
+    const uint32_t row = threadIdx.x >> 4;
+    modexp_uniform_body<L, MODE>(A, lds + row * (S + kLdsPad), blockIdx.x * kRowsPerBlock + row,
+                                 gridDim.x * kRowsPerBlock, threadIdx.x & 63u);
+}
+
+template <int L>
+__global__ void __launch_bounds__(kBlock) k_modexp_var(VarArgs A) {
+    constexpr int S = 16 * L;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kRowsPerBlock * (S + kLdsPad)];
+    const uint32_t row = threadIdx.x >> 4;
+    modexp_var_body<L>(A, lds + row * (S + kLdsPad), blockIdx.x * kRowsPerBlock + row,
+                       gridDim.x * kRowsPerBlock, threadIdx.x & 63u);
+}
+
+template <int L>
+__global__ void __launch_bounds__(kBlock) k_mulmod(MulArgs A) {
+    constexpr int S = 16 * L;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kRowsPerBlock * (S + kLdsPad)];
+    const uint32_t row = threadIdx.x >> 4;
+    mulmod_body<L>(A, lds + row * (S + kLdsPad), blockIdx.x * kRowsPerBlock + row,
+                   gridDim.x * kRowsPerBlock, threadIdx.x & 63u);
+}
+
+constexpr int kTailBlock = 64;
+__global__ void __launch_bounds__(kTailBlock) k_decrypt_tail(TailArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t tail_ws[];
+    const uint64_t item = (uint64_t)blockIdx.x * kTailBlock + threadIdx.x;
+    if (item >= A.batch) return;
+    const TailWs ws{tail_ws + threadIdx.x, kTailBlock};
+    decrypt_tail_one(A, ws, item);
+}
+
+__global__ void k_selftest_prims(uint32_t* out) {
+    const uint32_t lane = threadIdx.x & 63u;
+    out[lane] = wave::row_down1(lane + 100u);
+    out[64 + lane] = wave::row_up1(lane + 100u);
+    out[128 + lane] = wave::row_bcast0(lane + 100u);
+    const uint64_t b = wave::ballot((lane % 3u) == 0u);
+    out[192 + lane] = (uint32_t)(b >> lane) & 1u;
+    if (lane < 2) out[256 + lane] = (uint32_t)(b >> (32 * lane));
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(PHE_HIP_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+    } while (0)
+
+struct DevModulus {  // device copies of a host::ModulusPack
+    int L = 0, S = 0;
+    uint32_t* blob = nullptr;  // n | r1 | r2 | r3 | aux
+    ModConsts c{};
+};
+struct DevSchedule {
+    uint32_t* ops = nullptr;
+    int n_ops = 0, first_idx = 0, tbl_entries = 1;
+};
+struct DevTail {
+    uint32_t* blob = nullptr;
+    TailConsts k{};
+};
+
+struct phe_hip_ctx {
+    int device = 0;
+    int n_cus = 256;
+    int blocks_per_cu = 2;
+    bool has_private = false;
+    host::PublicPlan pub;
+    host::PrivatePlan priv;
+    DevModulus d_nsq, d_psq, d_qsq;
+    DevSchedule d_exp_n, d_exp_p, d_exp_q;
+    DevTail d_tail;
+    // grow-only device scratch
+    uint32_t* table = nullptr;
+    size_t table_words = 0;
+    uint32_t* scratch = nullptr;  // decrypt intermediates x_p | x_q
+    size_t scratch_words = 0;
+    // staging for the host-pointer entry points
+    uint32_t* stage[3] = {nullptr, nullptr, nullptr};
+    size_t stage_words[3] = {0, 0, 0};
+};
+
+static int upload_modulus(const host::ModulusPack& m, DevModulus& d) {
+    d.L = m.L;
+    d.S = m.S;
+    const size_t words = (size_t)5 * m.S;
+    HIP_TRY(hipMalloc((void**)&d.blob, words * 4));
+    std::vector<uint32_t> h(words);
+    const Big* parts[5] = {&m.n, &m.r1, &m.r2, &m.r3, &m.aux};
+    for (int i = 0; i < 5; ++i) memcpy(h.data() + (size_t)i * m.S, parts[i]->data(), (size_t)m.S * 4);
+    HIP_TRY(hipMemcpy(d.blob, h.data(), words * 4, hipMemcpyHostToDevice));
+    d.c.n = d.blob;
+    d.c.r1 = d.blob + m.S;
+    d.c.r2 = d.blob + 2 * m.S;
+    d.c.r3 = d.blob + 3 * m.S;
+    d.c.aux = d.blob + 4 * m.S;
+    d.c.n0inv = m.n0inv;
+    return PHE_HIP_OK;
+}
+static int upload_schedule(const host::Schedule& s, DevSchedule& d) {
+    d.n_ops = (int)s.ops.size();
+    d.first_idx = s.first_idx;
+    d.tbl_entries = s.tbl_entries;
+    const size_t bytes = std::max<size_t>(1, s.ops.size()) * 4;
+    HIP_TRY(hipMalloc((void**)&d.ops, bytes));
+    if (!s.ops.empty()) HIP_TRY(hipMemcpy(d.ops, s.ops.data(), s.ops.size() * 4, hipMemcpyHostToDevice));
+    return PHE_HIP_OK;
+}
+static int upload_tail(const host::TailPack& t, DevTail& d) {
+    const int h = t.h;
+    std::vector<uint32_t> hbuf((size_t)7 * h);
+    const Big* parts[7] = {&t.p, &t.q, &t.pinvw, &t.qinvw, &t.hp_r, &t.hq_r, &t.pinvq_r};
+    for (int i = 0; i < 7; ++i) memcpy(hbuf.data() + (size_t)i * h, parts[i]->data(), (size_t)h * 4);
+    HIP_TRY(hipMalloc((void**)&d.blob, hbuf.size() * 4));
+    HIP_TRY(hipMemcpy(d.blob, hbuf.data(), hbuf.size() * 4, hipMemcpyHostToDevice));
+    d.k.h = h;
+    d.k.p = d.blob;
+    d.k.q = d.blob + h;
+    d.k.pinvw = d.blob + 2 * h;
+    d.k.qinvw = d.blob + 3 * h;
+    d.k.hp_r = d.blob + 4 * h;
+    d.k.hq_r = d.blob + 5 * h;
+    d.k.pinvq_r = d.blob + 6 * h;
+    d.k.p0inv = t.p0inv;
+    d.k.q0inv = t.q0inv;
+    return PHE_HIP_OK;
+}
+
+static int ensure_words(uint32_t** buf, size_t* have, size_t need) {
+    if (need <= *have) return PHE_HIP_OK;
+    if (*buf) HIP_TRY(hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+    HIP_TRY(hipMalloc((void**)buf, need * 4));
+    *have = need;
+    return PHE_HIP_OK;
+}
+
+static int grid_blocks(const phe_hip_ctx* ctx, size_t batch) {
+    const size_t want = (batch + kRowsPerBlock - 1) / kRowsPerBlock;
+    const size_t cap = (size_t)ctx->n_cus * (size_t)ctx->blocks_per_cu;
+    return (int)std::max<size_t>(1, std::min(want, cap));
+}
+
+#define DISPATCH_L(L_, CALL)                                                             \
+    switch (L_) {                                                                        \
+        case 1: { constexpr int LL = 1; CALL; break; }                                   \
+        case 2: { constexpr int LL = 2; CALL; break; }                                   \
+        case 3: { constexpr int LL = 3; CALL; break; }                                   \
+        case 4: { constexpr int LL = 4; CALL; break; }                                   \
+        case 6: { constexpr int LL = 6; CALL; break; }                                   \
+        case 8: { constexpr int LL = 8; CALL; break; }                                   \
+        case 12: { constexpr int LL = 12; CALL; break; }                                 \
+        case 16: { constexpr int LL = 16; CALL; break; }                                 \
+        default: return fail(PHE_HIP_EINVAL, "unsupported limbs-per-lane");              \
+    }
+
+// ------------------------------------------------------------------------------------------------
+// launches (device pointers)
+// ------------------------------------------------------------------------------------------------
+template <int L, int MODE>
+static void go_uniform(int blocks, hipStream_t st, const UniformArgs& A) {
+    k_modexp_uniform<L, MODE><<<dim3(blocks), dim3(kBlock), 0, st>>>(A);
+}
+template <int L>
+static void go_var(int blocks, hipStream_t st, const VarArgs& A) {
+    k_modexp_var<L><<<dim3(blocks), dim3(kBlock), 0, st>>>(A);
+}
+template <int L>
+static void go_mul(int blocks, hipStream_t st, const MulArgs& A) {
+    k_mulmod<L><<<dim3(blocks), dim3(kBlock), 0, st>>>(A);
+}
+
+template <int MODE>
+static int launch_uniform(phe_hip_ctx* ctx, const DevModulus& M, const DevSchedule& E, const uint32_t* base,
+                          int base_limbs, const uint32_t* post, int post_limbs, uint32_t* out, int out_limbs,
+                          size_t batch, hipStream_t stream) {
+    const int blocks = grid_blocks(ctx, batch);
+    const size_t rows = (size_t)blocks * kRowsPerBlock;
+    int rc = ensure_words(&ctx->table, &ctx->table_words, rows * (size_t)E.tbl_entries * M.S);
+    if (rc) return rc;
+    UniformArgs A;
+    A.mod = M.c;
+    A.sched = E.ops;
+    A.n_ops = E.n_ops;
+    A.first_idx = E.first_idx;
+    A.tbl_entries = E.tbl_entries;
+    A.base = base;
+    A.base_limbs = base_limbs;
+    A.post = post;
+    A.post_limbs = post_limbs;
+    A.out = out;
+    A.out_limbs = out_limbs;
+    A.table = ctx->table;
+    A.batch = batch;
+    DISPATCH_L(M.L, (go_uniform<LL, MODE>(blocks, stream, A)));
+    HIP_TRY(hipGetLastError());
+    return PHE_HIP_OK;
+}
+
+static int launch_var(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* base, int base_limbs,
+                      const uint32_t* e, int exp_limbs, int max_bits, uint32_t* out, int out_limbs, size_t batch,
+                      hipStream_t stream) {
+    VarArgs A;
+    A.mod = M.c;
+    A.base = base;
+    A.base_limbs = base_limbs;
+    A.exps = e;
+    A.exp_limbs = exp_limbs;
+    A.window = host::pick_window(max_bits);
+    A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
+    A.out = out;
+    A.out_limbs = out_limbs;
+    A.batch = batch;
+    const int blocks = grid_blocks(ctx, batch);
+    const size_t rows = (size_t)blocks * kRowsPerBlock;
+    int rc = ensure_words(&ctx->table, &ctx->table_words, rows * ((size_t)1 << A.window) * M.S);
+    if (rc) return rc;
+    A.table = ctx->table;
+    DISPATCH_L(M.L, (go_var<LL>(blocks, stream, A)));
+    HIP_TRY(hipGetLastError());
+    return PHE_HIP_OK;
+}
+
+static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, size_t a_stride, const uint32_t* b,
+                      size_t b_stride, uint32_t* out, size_t out_stride, int limbs, size_t batch,
+                      hipStream_t stream) {
+    MulArgs A;
+    A.mod = M.c;
+    A.a = a;
+    A.b = b;
+    A.out = out;
+    A.a_stride = a_stride;
+    A.b_stride = b_stride;
+    A.out_stride = out_stride;
+    A.limbs = limbs;
+    A.batch = batch;
+    // memory-light kernel: let every CU hold as many groups as the batch offers (cap 8 blocks/CU)
+    const size_t want = (batch + kRowsPerBlock - 1) / kRowsPerBlock;
+    const int blocks = (int)std::max<size_t>(1, std::min(want, (size_t)ctx->n_cus * 8));
+    DISPATCH_L(M.L, (go_mul<LL>(blocks, stream, A)));
+    HIP_TRY(hipGetLastError());
+    return PHE_HIP_OK;
+}
+
+static int check_ctx(const phe_hip_ctx* ctx) {
+    if (!ctx) return fail(PHE_HIP_EINVAL, "null context");
+    return PHE_HIP_OK;
+}
+static int bind_device(const phe_hip_ctx* ctx) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    return PHE_HIP_OK;
+}
+
+extern "C" {
+
+const char* phe_hip_last_error(void) { return g_err.c_str(); }
+
+int phe_hip_device_count(int* count) {
+    if (!count) return fail(PHE_HIP_EINVAL, "null count");
+    HIP_TRY(hipGetDeviceCount(count));
+    return PHE_HIP_OK;
+}
+
+static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int device) {
+    if (!n || n_limbs < 1) return fail(PHE_HIP_EINVAL, "n / n_limbs invalid");
+    ctx->device = device;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (const char* e = getenv("PHE_HIP_BLOCKS_PER_CU")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 8) ctx->blocks_per_cu = v;
+    }
+    try {
+        ctx->pub = host::build_public(n, n_limbs);
+    } catch (const std::exception& ex) {
+        return fail(PHE_HIP_EINVAL, ex.what());
+    }
+    int rc = upload_modulus(ctx->pub.nsq, ctx->d_nsq);
+    if (!rc) rc = upload_schedule(ctx->pub.exp_n, ctx->d_exp_n);
+    return rc;
+}
+
+int phe_hip_ctx_create_public(const uint32_t* n, int n_limbs, int device, phe_hip_ctx** out) {
+    if (!out) return fail(PHE_HIP_EINVAL, "null out");
+    phe_hip_ctx* ctx = new phe_hip_ctx();
+    int rc = ctx_common(ctx, n, n_limbs, device);
+    if (rc) {
+        phe_hip_ctx_destroy(ctx);
+        return rc;
+    }
+    *out = ctx;
+    return PHE_HIP_OK;
+}
+
+int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p, const uint32_t* q,
+                               const uint32_t* hp, const uint32_t* hq, const uint32_t* p_inverse, int pq_limbs,
+                               int device, phe_hip_ctx** out) {
+    if (!out) return fail(PHE_HIP_EINVAL, "null out");
+    if (!p || !q || !hp || !hq || !p_inverse || pq_limbs < 1) return fail(PHE_HIP_EINVAL, "private key material missing");
+    phe_hip_ctx* ctx = new phe_hip_ctx();
+    int rc = ctx_common(ctx, n, n_limbs, device);
+    if (!rc) {
+        try {
+            ctx->priv = host::build_private(p, q, hp, hq, p_inverse, pq_limbs, n_limbs);
+            // p*q == n, like phe/paillier.py:218-219
+            Big prod = host::big_mul(ctx->priv.tail.p, ctx->priv.tail.q);
+            Big nn = host::big_from(n, n_limbs, (int)prod.size() > n_limbs ? (int)prod.size() : n_limbs);
+            prod.resize(nn.size(), 0u);
+            if (host::big_cmp(prod, nn) != 0) throw std::invalid_argument("given public key does not match the given p and q.");
+        } catch (const std::exception& ex) {
+            rc = fail(PHE_HIP_EINVAL, ex.what());
+        }
+    }
+    if (!rc) rc = upload_modulus(ctx->priv.psq, ctx->d_psq);
+    if (!rc) rc = upload_modulus(ctx->priv.qsq, ctx->d_qsq);
+    if (!rc) rc = upload_schedule(ctx->priv.exp_p, ctx->d_exp_p);
+    if (!rc) rc = upload_schedule(ctx->priv.exp_q, ctx->d_exp_q);
+    if (!rc) rc = upload_tail(ctx->priv.tail, ctx->d_tail);
+    if (!rc) {
+        const size_t lds = (size_t)tail_ws_words(ctx->priv.tail.h) * kTailBlock * 4;
+        if (lds > 160 * 1024) rc = fail(PHE_HIP_EINVAL, "p/q too wide for the CRT tail kernel");
+        else if (lds > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_decrypt_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) rc = fail(PHE_HIP_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+        }
+    }
+    if (rc) {
+        phe_hip_ctx_destroy(ctx);
+        return rc;
+    }
+    ctx->has_private = true;
+    *out = ctx;
+    return PHE_HIP_OK;
+}
+
+void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    uint32_t* bufs[] = {ctx->d_nsq.blob, ctx->d_psq.blob, ctx->d_qsq.blob, ctx->d_exp_n.ops, ctx->d_exp_p.ops,
+                        ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->scratch, ctx->stage[0], ctx->stage[1],
+                        ctx->stage[2]};
+    for (uint32_t* b : bufs)
+        if (b) (void)hipFree(b);
+    delete ctx;
+}
+
+int phe_hip_ctx_info(const phe_hip_ctx* ctx, int* n_limbs, int* ct_limbs, int* lane_limbs_pub, int* lane_limbs_priv,
+                     int* rows_in_flight, int* has_private) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (n_limbs) *n_limbs = ctx->pub.s1;
+    if (ct_limbs) *ct_limbs = ctx->pub.s2;
+    if (lane_limbs_pub) *lane_limbs_pub = ctx->pub.nsq.L;
+    if (lane_limbs_priv) *lane_limbs_priv = ctx->has_private ? ctx->priv.psq.L : 0;
+    if (rows_in_flight) *rows_in_flight = ctx->n_cus * ctx->blocks_per_cu * kRowsPerBlock;
+    if (has_private) *has_private = ctx->has_private ? 1 : 0;
+    return PHE_HIP_OK;
+}
+
+int phe_hip_ctx_set_blocks_per_cu(phe_hip_ctx* ctx, int blocks_per_cu) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (blocks_per_cu < 1 || blocks_per_cu > 8) return fail(PHE_HIP_EINVAL, "blocks_per_cu must be in 1..8");
+    ctx->blocks_per_cu = blocks_per_cu;
+    return PHE_HIP_OK;
+}
+
+// ---- device-pointer entry points -----------------------------------------------------------------
+int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!m || !r || !c) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    return launch_uniform<kModeEncrypt>(ctx, ctx->d_nsq, ctx->d_exp_n, r, ctx->pub.s1, m, ctx->pub.s1, c, ctx->pub.s2,
+                                        batch, (hipStream_t)stream);
+}
+
+int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t* r, uint32_t* c_out, size_t batch,
+                          void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!c_in || !r || !c_out) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    return launch_uniform<kModeObfuscate>(ctx, ctx->d_nsq, ctx->d_exp_n, r, ctx->pub.s1, c_in, ctx->pub.s2, c_out,
+                                          ctx->pub.s2, batch, (hipStream_t)stream);
+}
+
+int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t batch, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (!ctx->has_private) return fail(PHE_HIP_EINVAL, "decrypt needs a private-key context");
+    if (batch == 0) return PHE_HIP_OK;
+    if (!c || !m) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    const int S = ctx->d_psq.S;
+    int rc = ensure_words(&ctx->scratch, &ctx->scratch_words, (size_t)2 * batch * S);
+    if (rc) return rc;
+    uint32_t* xp = ctx->scratch;
+    uint32_t* xq = ctx->scratch + batch * (size_t)S;
+    hipStream_t st = (hipStream_t)stream;
+    rc = launch_uniform<kModeHalfDecrypt>(ctx, ctx->d_psq, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0, xp, S, batch, st);
+    if (rc) return rc;
+    rc = launch_uniform<kModeHalfDecrypt>(ctx, ctx->d_qsq, ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0, xq, S, batch, st);
+    if (rc) return rc;
+    TailArgs T;
+    T.k = ctx->d_tail.k;
+    T.xp = xp;
+    T.xq = xq;
+    T.x_stride = S;
+    T.m_out = m;
+    T.out_limbs = ctx->pub.s1;
+    T.batch = batch;
+    const size_t lds = (size_t)tail_ws_words(T.k.h) * kTailBlock * 4;
+    const int blocks = (int)((batch + kTailBlock - 1) / kTailBlock);
+    k_decrypt_tail<<<dim3(blocks), dim3(kTailBlock), lds, st>>>(T);
+    HIP_TRY(hipGetLastError());
+    return PHE_HIP_OK;
+}
+
+int phe_hip_mulmod_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t batch, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!a || !b || !out) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    const size_t s2 = (size_t)ctx->pub.s2;
+    return launch_mul(ctx, ctx->d_nsq, a, s2, b, s2, out, s2, ctx->pub.s2, batch, (hipStream_t)stream);
+}
+
+int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, int max_exp_bits,
+                       uint32_t* out, size_t batch, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!base || !e || !out || exp_limbs < 1) return fail(PHE_HIP_EINVAL, "null buffer / exp_limbs");
+    if (max_exp_bits <= 0 || max_exp_bits > 32 * exp_limbs) max_exp_bits = 32 * exp_limbs;
+    if (int rc = bind_device(ctx)) return rc;
+    return launch_var(ctx, ctx->d_nsq, base, ctx->pub.s2, e, exp_limbs, max_exp_bits, out, ctx->pub.s2, batch,
+                      (hipStream_t)stream);
+}
+
+// ---- host-pointer entry points ------------------------------------------------------------------
+static int stage_in(phe_hip_ctx* ctx, int slot, const uint32_t* host_ptr, size_t words) {
+    int rc = ensure_words(&ctx->stage[slot], &ctx->stage_words[slot], words);
+    if (rc) return rc;
+    if (host_ptr) HIP_TRY(hipMemcpy(ctx->stage[slot], host_ptr, words * 4, hipMemcpyHostToDevice));
+    return PHE_HIP_OK;
+}
+
+int phe_hip_encrypt(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!m || !r || !c) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    const size_t s1 = (size_t)ctx->pub.s1, s2 = (size_t)ctx->pub.s2;
+    int rc = stage_in(ctx, 0, m, batch * s1);
+    if (!rc) rc = stage_in(ctx, 1, r, batch * s1);
+    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
+    if (!rc) rc = phe_hip_encrypt_dev(ctx, ctx->stage[0], ctx->stage[1], ctx->stage[2], batch, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(c, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));
+    return PHE_HIP_OK;
+}
+
+int phe_hip_obfuscate(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t* r, uint32_t* c_out, size_t batch) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!c_in || !r || !c_out) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    const size_t s1 = (size_t)ctx->pub.s1, s2 = (size_t)ctx->pub.s2;
+    int rc = stage_in(ctx, 0, c_in, batch * s2);
+    if (!rc) rc = stage_in(ctx, 1, r, batch * s1);
+    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
+    if (!rc) rc = phe_hip_obfuscate_dev(ctx, ctx->stage[0], ctx->stage[1], ctx->stage[2], batch, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(c_out, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));
+    return PHE_HIP_OK;
+}
+
+int phe_hip_decrypt(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t batch) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!c || !m) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    const size_t s1 = (size_t)ctx->pub.s1, s2 = (size_t)ctx->pub.s2;
+    int rc = stage_in(ctx, 0, c, batch * s2);
+    if (!rc) rc = stage_in(ctx, 1, nullptr, batch * s1);
+    if (!rc) rc = phe_hip_decrypt_dev(ctx, ctx->stage[0], ctx->stage[1], batch, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(m, ctx->stage[1], batch * s1 * 4, hipMemcpyDeviceToHost));
+    return PHE_HIP_OK;
+}
+
+int phe_hip_mulmod(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t batch) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!a || !b || !out) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    const size_t s2 = (size_t)ctx->pub.s2;
+    int rc = stage_in(ctx, 0, a, batch * s2);
+    if (!rc) rc = stage_in(ctx, 1, b, batch * s2);
+    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
+    if (!rc) rc = phe_hip_mulmod_dev(ctx, ctx->stage[0], ctx->stage[1], ctx->stage[2], batch, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));
+    return PHE_HIP_OK;
+}
+
+int phe_hip_powmod(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, uint32_t* out, size_t batch) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!base || !e || !out || exp_limbs < 1) return fail(PHE_HIP_EINVAL, "null buffer / exp_limbs");
+    if (int rc = bind_device(ctx)) return rc;
+    int max_bits = 0;
+    for (size_t i = 0; i < batch; ++i) {
+        const uint32_t* row = e + i * (size_t)exp_limbs;
+        for (int k = exp_limbs - 1; k >= 0; --k)
+            if (row[k]) {
+                max_bits = std::max(max_bits, 32 * k + 32 - __builtin_clz(row[k]));
+                break;
+            }
+    }
+    if (max_bits == 0) max_bits = 1;
+    const size_t s2 = (size_t)ctx->pub.s2;
+    int rc = stage_in(ctx, 0, base, batch * s2);
+    if (!rc) rc = stage_in(ctx, 1, e, batch * (size_t)exp_limbs);
+    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
+    if (!rc) rc = phe_hip_powmod_dev(ctx, ctx->stage[0], ctx->stage[1], exp_limbs, max_bits, ctx->stage[2], batch, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));
+    return PHE_HIP_OK;
+}
+
+// ---- batched inversion (Montgomery's trick over a product tree) ------------------------------------
+// host scalar inverse of an odd-modulus residue (binary extended Euclid); false if gcd != 1
+static bool host_invert(const Big& a_in, const Big& N, Big& out) {
+    const size_t w = N.size();
+    Big u = a_in, v = N, x1(w, 0u), x2(w, 0u);
+    x1[0] = 1;
+    auto is_one = [](const Big& x) {
+        if (x[0] != 1) return false;
+        for (size_t i = 1; i < x.size(); ++i)
+            if (x[i]) return false;
+        return true;
+    };
+    auto halve_mod = [&](Big& x) {  // x <- x/2 mod N
+        uint32_t carry = 0;
+        if (x[0] & 1u) carry = host::big_add_inplace(x, N);
+        for (size_t i = 0; i + 1 < w; ++i) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+        x[w - 1] = (x[w - 1] >> 1) | (carry << 31);
+    };
+    auto shr1 = [&](Big& x) {
+        for (size_t i = 0; i + 1 < w; ++i) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+        x[w - 1] >>= 1;
+    };
+    if (host::big_is_zero(u)) return false;
+    while (!is_one(u) && !is_one(v)) {
+        while ((u[0] & 1u) == 0u) { shr1(u); halve_mod(x1); }
+        while ((v[0] & 1u) == 0u) { shr1(v); halve_mod(x2); }
+        if (host::big_cmp(u, v) >= 0) {
+            host::big_sub_inplace(u, v);
+            if (host::big_sub_inplace(x1, x2)) host::big_add_inplace(x1, N);
+            if (host::big_is_zero(u)) return false;  // gcd = v != 1
+        } else {
+            host::big_sub_inplace(v, u);
+            if (host::big_sub_inplace(x2, x1)) host::big_add_inplace(x2, N);
+        }
+    }
+    out = is_one(u) ? x1 : x2;
+    return true;
+}
+
+int phe_hip_invert(phe_hip_ctx* ctx, const uint32_t* a, uint32_t* out, size_t batch, size_t* bad_index) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!a || !out) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    const int s2 = ctx->pub.s2;
+    const size_t w = (size_t)s2;
+    const DevModulus& M = ctx->d_nsq;
+    // level sizes of the product tree
+    std::vector<size_t> cnt{batch};
+    while (cnt.back() > 1) cnt.push_back((cnt.back() + 1) / 2);
+    std::vector<size_t> off(cnt.size());
+    size_t total = 0;
+    for (size_t k = 0; k < cnt.size(); ++k) { off[k] = total; total += cnt[k]; }
+    // prod tree in stage[0], inverse tree in stage[1]
+    int rc = stage_in(ctx, 0, nullptr, total * w);
+    if (!rc) rc = stage_in(ctx, 1, nullptr, total * w);
+    if (rc) return rc;
+    uint32_t* prod = ctx->stage[0];
+    uint32_t* inv = ctx->stage[1];
+    HIP_TRY(hipMemcpy(prod, a, batch * w * 4, hipMemcpyHostToDevice));
+    for (size_t k = 0; k + 1 < cnt.size(); ++k) {
+        const size_t pairs = cnt[k] / 2;
+        uint32_t* src = prod + off[k] * w;
+        uint32_t* dst = prod + off[k + 1] * w;
+        if (pairs) {
+            rc = launch_mul(ctx, M, src, 2 * w, src + w, 2 * w, dst, w, s2, pairs, nullptr);
+            if (rc) return rc;
+        }
+        if (cnt[k] & 1) HIP_TRY(hipMemcpyAsync(dst + pairs * w, src + (cnt[k] - 1) * w, w * 4, hipMemcpyDeviceToDevice, nullptr));
+    }
+    // one scalar inversion of the root on the host
+    Big root(w), N = host::big_from(ctx->pub.nsq.n.data(), s2, s2), rinv;  // n^2 < W^s2
+    HIP_TRY(hipMemcpy(root.data(), prod + off.back() * w, w * 4, hipMemcpyDeviceToHost));
+    bool reduced_ok = host::big_cmp(root, N) < 0;
+    if (!reduced_ok || !host_invert(root, N, rinv)) {
+        // slow path only on failure: find the first row that is not a unit (or not reduced)
+        std::vector<uint32_t> h(batch * w);
+        memcpy(h.data(), a, batch * w * 4);
+        for (size_t i = 0; i < batch; ++i) {
+            Big x(h.begin() + (long)(i * w), h.begin() + (long)((i + 1) * w)), tmp;
+            Big xr = host::big_cmp(x, N) < 0 ? x : host::big_mod(x, N);
+            if (!host_invert(xr, N, tmp)) {
+                if (bad_index) *bad_index = i;
+                return fail(PHE_HIP_ENOINVERSE, "invert() no inverse exists");
+            }
+        }
+        return fail(PHE_HIP_EINVAL, "inversion failed although every element is a unit (operands must be < n^2)");
+    }
+    HIP_TRY(hipMemcpy(inv + off.back() * w, rinv.data(), w * 4, hipMemcpyHostToDevice));
+    for (size_t k = cnt.size() - 1; k-- > 0;) {
+        const size_t pairs = cnt[k] / 2;
+        uint32_t* p = prod + off[k] * w;
+        uint32_t* up = inv + off[k + 1] * w;
+        uint32_t* dn = inv + off[k] * w;
+        if (pairs) {
+            // inv[2i] = up[i] * prod[2i+1];  inv[2i+1] = up[i] * prod[2i]
+            rc = launch_mul(ctx, M, up, w, p + w, 2 * w, dn, 2 * w, s2, pairs, nullptr);
+            if (!rc) rc = launch_mul(ctx, M, up, w, p, 2 * w, dn + w, 2 * w, s2, pairs, nullptr);
+            if (rc) return rc;
+        }
+        if (cnt[k] & 1) HIP_TRY(hipMemcpyAsync(dn + (cnt[k] - 1) * w, up + pairs * w, w * 4, hipMemcpyDeviceToDevice, nullptr));
+    }
+    HIP_TRY(hipMemcpy(out, inv, batch * w * 4, hipMemcpyDeviceToHost));
+    return PHE_HIP_OK;
+}
+
+// ---- memory helpers ---------------------------------------------------------------------------------
+int phe_hip_malloc(phe_hip_ctx* ctx, size_t bytes, void** dptr) {
+    if (check_ctx(ctx) || !dptr) return fail(PHE_HIP_EINVAL, "null argument");
+    if (int rc = bind_device(ctx)) return rc;
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 4));
+    return PHE_HIP_OK;
+}
+int phe_hip_free(phe_hip_ctx* ctx, void* dptr) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (int rc = bind_device(ctx)) return rc;
+    if (dptr) HIP_TRY(hipFree(dptr));
+    return PHE_HIP_OK;
+}
+int phe_hip_memcpy_h2d(phe_hip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (int rc = bind_device(ctx)) return rc;
+    HIP_TRY(hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return PHE_HIP_OK;
+}
+int phe_hip_memcpy_d2h(phe_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (int rc = bind_device(ctx)) return rc;
+    HIP_TRY(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return PHE_HIP_OK;
+}
+int phe_hip_stream_sync(phe_hip_ctx* ctx, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (int rc = bind_device(ctx)) return rc;
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return PHE_HIP_OK;
+}
+
+int phe_hip_selftest_prims(int device, uint32_t* out) {
+    if (!out) return fail(PHE_HIP_EINVAL, "null out");
+    HIP_TRY(hipSetDevice(device));
+    uint32_t* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 258 * 4));
+    k_selftest_prims<<<dim3(1), dim3(64), 0, nullptr>>>(d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, d, 258 * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(d));
+    return PHE_HIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,228 @@
+// tests/emu/emu_driver.cpp — TEST INFRASTRUCTURE.
+// Compiles the device algorithm headers (csrc/mont_core.h, csrc/decrypt_tail.h) and the host
+// key setup (csrc/key_setup.h) for the CPU, with tests/emu/wave_emu.h standing in for the
+// wavefront, and exposes a C interface shaped like the product C-ABI so CPU-only tests can
+// compare the very code the GPU runs against the oracle.  Not part of the product: the product
+// library has no CPU execution path.
+#include "wave_emu.h"
+// clang-format off
+#include "../../python-paillier_amd/csrc/mont_core.h"
+#include "../../python-paillier_amd/csrc/decrypt_tail.h"
+#include "../../python-paillier_amd/csrc/key_setup.h"
+// clang-format on
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+using namespace phe;
+using host::Big;
+
+static thread_local std::string g_err;
+
+#define DISPATCH_L(L_, CALL)                                   \
+    switch (L_) {                                              \
+        case 1: { constexpr int LL = 1; CALL; break; }         \
+        case 2: { constexpr int LL = 2; CALL; break; }         \
+        case 3: { constexpr int LL = 3; CALL; break; }         \
+        case 4: { constexpr int LL = 4; CALL; break; }         \
+        case 6: { constexpr int LL = 6; CALL; break; }         \
+        case 8: { constexpr int LL = 8; CALL; break; }         \
+        case 12: { constexpr int LL = 12; CALL; break; }       \
+        case 16: { constexpr int LL = 16; CALL; break; }       \
+        default: throw std::invalid_argument("unsupported L"); \
+    }
+
+static ModConsts consts_of(const host::ModulusPack& m) {
+    ModConsts c;
+    c.n = m.n.data(); c.r1 = m.r1.data(); c.r2 = m.r2.data(); c.r3 = m.r3.data(); c.aux = m.aux.data();
+    c.n0inv = m.n0inv;
+    return c;
+}
+
+// number of emulated waves: enough rows for the batch, capped (rows loop over items like the GPU grid)
+static int waves_for(uint64_t B, int cap = 2) {
+    int w = (int)((B + 3) / 4);
+    return w < 1 ? 1 : (w > cap ? cap : w);
+}
+
+template <int L, int MODE>
+static void run_uniform(UniformArgs A, int n_waves) {
+    constexpr int S = 16 * L;
+    const uint32_t total_rows = 4u * (uint32_t)n_waves;
+    std::vector<uint32_t> table((size_t)total_rows * (size_t)A.tbl_entries * S);
+    A.table = table.data();
+    for (int w = 0; w < n_waves; ++w) {
+        std::vector<uint32_t> lds(4 * (S + kLdsPad));
+        wave::run_wave([&](uint32_t lane) {
+            const uint32_t row = lane >> 4;
+            modexp_uniform_body<L, MODE>(A, lds.data() + row * (S + kLdsPad), (uint32_t)w * 4u + row, total_rows, lane);
+        });
+    }
+}
+
+template <int L>
+static void run_var(VarArgs A, int n_waves) {
+    constexpr int S = 16 * L;
+    const uint32_t total_rows = 4u * (uint32_t)n_waves;
+    std::vector<uint32_t> table((size_t)total_rows * ((size_t)1 << A.window) * S);
+    A.table = table.data();
+    for (int w = 0; w < n_waves; ++w) {
+        std::vector<uint32_t> lds(4 * (S + kLdsPad));
+        wave::run_wave([&](uint32_t lane) {
+            const uint32_t row = lane >> 4;
+            modexp_var_body<L>(A, lds.data() + row * (S + kLdsPad), (uint32_t)w * 4u + row, total_rows, lane);
+        });
+    }
+}
+
+template <int L>
+static void run_mul(MulArgs A, int n_waves) {
+    constexpr int S = 16 * L;
+    const uint32_t total_rows = 4u * (uint32_t)n_waves;
+    for (int w = 0; w < n_waves; ++w) {
+        std::vector<uint32_t> lds(4 * (S + kLdsPad));
+        wave::run_wave([&](uint32_t lane) {
+            const uint32_t row = lane >> 4;
+            mulmod_body<L>(A, lds.data() + row * (S + kLdsPad), (uint32_t)w * 4u + row, total_rows, lane);
+        });
+    }
+}
+
+extern "C" {
+
+const char* emu_last_error() { return g_err.c_str(); }
+
+// four independent products a[r]*b[r]*R^-1 mod n, one per DPP row; all arrays are 16*L words per row
+int emu_montmul(int L, const uint32_t* a, const uint32_t* b, const uint32_t* n, uint32_t* out) {
+    try {
+        DISPATCH_L(L, ({
+            constexpr int S = 16 * LL;
+            std::vector<uint32_t> lds(4 * (S + kLdsPad));
+            const uint32_t n0inv = host::neg_inv32(n[0]);
+            wave::run_wave([&](uint32_t lane) {
+                const uint32_t row = lane >> 4, g = lane & 15;
+                uint32_t* lrow = lds.data() + row * (S + kLdsPad);
+                uint32_t x[LL], y[LL], nn[LL], r[LL];
+                load_row<LL>(x, a + row * S, g);
+                load_row<LL>(y, b + row * S, g);
+                load_row<LL>(nn, n, g);
+                lds_put<LL>(lrow, x, g);
+                montmul<LL>(r, lrow, y, nn, n0inv, lane);
+                store_row<LL>(out + row * S, r, g);
+            });
+        }));
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// encrypt (c_in == nullptr) or obfuscate (c_in != nullptr: out = c_in * r^n mod n^2)
+int emu_encrypt(const uint32_t* n, int n_limbs, const uint32_t* m, const uint32_t* r, const uint32_t* c_in,
+                uint32_t* c_out, uint64_t B) {
+    try {
+        if (B == 0) return 0;
+        host::PublicPlan P = host::build_public(n, n_limbs);
+        UniformArgs A;
+        memset(&A, 0, sizeof A);
+        A.mod = consts_of(P.nsq);
+        A.sched = P.exp_n.ops.data(); A.n_ops = (int)P.exp_n.ops.size();
+        A.first_idx = P.exp_n.first_idx; A.tbl_entries = P.exp_n.tbl_entries;
+        A.base = r; A.base_limbs = P.s1;
+        A.post = c_in ? c_in : m; A.post_limbs = c_in ? P.s2 : P.s1;
+        A.out = c_out; A.out_limbs = P.s2; A.batch = B;
+        const int nw = waves_for(B);
+        if (c_in) { DISPATCH_L(P.nsq.L, (run_uniform<LL, kModeObfuscate>(A, nw))); }
+        else { DISPATCH_L(P.nsq.L, (run_uniform<LL, kModeEncrypt>(A, nw))); }
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+int emu_decrypt(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const uint32_t* hq,
+                const uint32_t* p_inverse, int pq_limbs, int n_limbs, const uint32_t* c, uint32_t* m_out,
+                uint64_t B) {
+    try {
+        if (B == 0) return 0;
+        host::PrivatePlan P = host::build_private(p, q, hp, hq, p_inverse, pq_limbs, n_limbs);
+        const int S = P.psq.S;
+        std::vector<uint32_t> xp((size_t)B * S), xq((size_t)B * S);
+        const int nw = waves_for(B);
+        for (int half = 0; half < 2; ++half) {
+            const host::ModulusPack& M = half ? P.qsq : P.psq;
+            const host::Schedule& E = half ? P.exp_q : P.exp_p;
+            UniformArgs A;
+            memset(&A, 0, sizeof A);
+            A.mod = consts_of(M);
+            A.sched = E.ops.data(); A.n_ops = (int)E.ops.size();
+            A.first_idx = E.first_idx; A.tbl_entries = E.tbl_entries;
+            A.base = c; A.base_limbs = P.s2;
+            A.out = half ? xq.data() : xp.data(); A.out_limbs = S; A.batch = B;
+            DISPATCH_L(M.L, (run_uniform<LL, kModeHalfDecrypt>(A, nw)));
+        }
+        TailArgs T;
+        memset(&T, 0, sizeof T);
+        const host::TailPack& K = P.tail;
+        T.k.h = K.h; T.k.p = K.p.data(); T.k.q = K.q.data(); T.k.pinvw = K.pinvw.data(); T.k.qinvw = K.qinvw.data();
+        T.k.hp_r = K.hp_r.data(); T.k.hq_r = K.hq_r.data(); T.k.pinvq_r = K.pinvq_r.data();
+        T.k.p0inv = K.p0inv; T.k.q0inv = K.q0inv;
+        T.xp = xp.data(); T.xq = xq.data(); T.x_stride = S; T.m_out = m_out; T.out_limbs = P.s1; T.batch = B;
+        std::vector<uint32_t> wsbuf((size_t)tail_ws_words(K.h));
+        for (uint64_t i = 0; i < B; ++i) {
+            TailWs ws{wsbuf.data(), 1};
+            decrypt_tail_one(T, ws, i);
+        }
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// out = a*b mod N, rows of `limbs` words (N given in `limbs` words too)
+int emu_mulmod(const uint32_t* N, int limbs, const uint32_t* a, const uint32_t* b, uint32_t* out, uint64_t B) {
+    try {
+        if (B == 0) return 0;
+        host::ModulusPack M = host::build_modulus(host::big_from(N, limbs, limbs), nullptr);
+        MulArgs A;
+        memset(&A, 0, sizeof A);
+        A.mod = consts_of(M); A.a = a; A.b = b; A.limbs = limbs; A.out = out; A.batch = B;
+        A.a_stride = A.b_stride = A.out_stride = (size_t)limbs;
+        DISPATCH_L(M.L, (run_mul<LL>(A, waves_for(B))));
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// out = base^exp mod N with per-row exponents
+int emu_powmod_var(const uint32_t* N, int limbs, const uint32_t* base, const uint32_t* exps, int exp_limbs,
+                   uint32_t* out, uint64_t B) {
+    try {
+        if (B == 0) return 0;
+        host::ModulusPack M = host::build_modulus(host::big_from(N, limbs, limbs), nullptr);
+        int max_bits = 0;
+        for (uint64_t i = 0; i < B; ++i) {
+            Big e = host::big_from(exps + i * exp_limbs, exp_limbs, exp_limbs);
+            max_bits = std::max(max_bits, host::big_bits(e));
+        }
+        VarArgs A;
+        memset(&A, 0, sizeof A);
+        A.mod = consts_of(M); A.base = base; A.base_limbs = limbs; A.exps = exps; A.exp_limbs = exp_limbs;
+        A.window = host::pick_window(max_bits);
+        A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
+        A.out = out; A.out_limbs = limbs; A.batch = B;
+        DISPATCH_L(M.L, (run_var<LL>(A, waves_for(B))));
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// key-setup introspection: which = 0:n 1:r1 2:r2 3:r3 4:aux (S words each); returns S, L in *L_out
+int emu_public_constants(const uint32_t* n, int n_limbs, int which, uint32_t* out, int* L_out, uint32_t* n0inv,
+                         int* sched_info /* window, tbl_entries, first_idx, n_ops, squarings, multiplies */) {
+    try {
+        host::PublicPlan P = host::build_public(n, n_limbs);
+        const Big* src[] = {&P.nsq.n, &P.nsq.r1, &P.nsq.r2, &P.nsq.r3, &P.nsq.aux};
+        memcpy(out, src[which]->data(), sizeof(uint32_t) * (size_t)P.nsq.S);
+        *L_out = P.nsq.L;
+        *n0inv = P.nsq.n0inv;
+        sched_info[0] = P.exp_n.window; sched_info[1] = P.exp_n.tbl_entries; sched_info[2] = P.exp_n.first_idx;
+        sched_info[3] = (int)P.exp_n.ops.size(); sched_info[4] = P.exp_n.squarings; sched_info[5] = P.exp_n.multiplies;
+        return P.nsq.S;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+
+}  // extern "C"

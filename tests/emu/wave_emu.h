@@ -1,0 +1,136 @@
+// tests/emu/wave_emu.h — TEST INFRASTRUCTURE: a host stand-in for csrc/wave_gfx950.h.
+//
+// Runs the 64 lanes of one wavefront as 64 ucontext fibers so that mont_core.h (the code the
+// GPU executes) can be exercised on a CPU-only box.  Cross-lane primitives exchange values
+// through a double-buffered mailbox and yield to the scheduler; all lanes must execute the same
+// sequence of cross-lane primitives (true for these kernels: control flow is wave-uniform).
+// Semantics mirror the DPP forms documented in wave_gfx950.h; tests/test_gpu_prims.py checks
+// the real instructions against the same expectations on the GPU.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <ucontext.h>
+
+#include <functional>
+
+#define PHE_DEV inline
+
+namespace wave {
+
+constexpr int kRow = 16;
+constexpr int kLanes = 64;
+
+struct Emu {
+    ucontext_t sched;
+    ucontext_t fib[kLanes];
+    char* stacks[kLanes];
+    bool done[kLanes];
+    int cur = 0;
+    unsigned phase = 0;  // per-lane phase counters advance in lock step
+    unsigned lane_phase[kLanes];
+    uint32_t box[2][kLanes];
+    std::function<void(uint32_t)> body;
+};
+
+inline Emu*& emu() {
+    static thread_local Emu* e = nullptr;
+    return e;
+}
+
+inline void yield_all() {
+    Emu* e = emu();
+    swapcontext(&e->fib[e->cur], &e->sched);
+}
+
+inline void fiber_entry() {
+    Emu* e = emu();
+    const int l = e->cur;
+    e->body((uint32_t)l);
+    e->done[l] = true;
+    swapcontext(&e->fib[l], &e->sched);
+}
+
+// run `body(lane)` for the 64 lanes of one wave
+inline void run_wave(const std::function<void(uint32_t)>& body) {
+    Emu* e = new Emu();
+    Emu* prev = emu();
+    emu() = e;
+    e->body = body;
+    const size_t kStack = 1u << 20;
+    for (int l = 0; l < kLanes; ++l) {
+        e->done[l] = false;
+        e->lane_phase[l] = 0;
+        e->stacks[l] = (char*)malloc(kStack);
+        getcontext(&e->fib[l]);
+        e->fib[l].uc_stack.ss_sp = e->stacks[l];
+        e->fib[l].uc_stack.ss_size = kStack;
+        e->fib[l].uc_link = &e->sched;
+        makecontext(&e->fib[l], (void (*)())fiber_entry, 0);
+    }
+    for (;;) {
+        bool any = false;
+        for (int l = 0; l < kLanes; ++l) {
+            if (e->done[l]) continue;
+            any = true;
+            e->cur = l;
+            swapcontext(&e->sched, &e->fib[l]);
+        }
+        if (!any) break;
+    }
+    for (int l = 0; l < kLanes; ++l) free(e->stacks[l]);
+    emu() = prev;
+    delete e;
+}
+
+inline uint32_t lane_id() { return (uint32_t)emu()->cur; }
+
+// post x, wait for every lane, then read lane `src` (or 0 if src < 0)
+template <typename F>
+inline uint32_t exchange(uint32_t x, F src_of) {
+    Emu* e = emu();
+    const int l = e->cur;
+    const unsigned ph = e->lane_phase[l]++ & 1u;
+    e->box[ph][l] = x;
+    yield_all();
+    const int src = src_of(l);
+    return src < 0 ? 0u : e->box[ph][src];
+}
+
+inline uint32_t row_down1(uint32_t x) {
+    return exchange(x, [](int l) { return (l & 15) == 15 ? -1 : l + 1; });
+}
+inline uint32_t row_up1(uint32_t x) {
+    return exchange(x, [](int l) { return (l & 15) == 0 ? -1 : l - 1; });
+}
+inline uint32_t row_bcast0(uint32_t x) {
+    return exchange(x, [](int l) { return l & ~15; });
+}
+inline uint64_t ballot(bool p) {
+    Emu* e = emu();
+    const int l = e->cur;
+    const unsigned ph = e->lane_phase[l]++ & 1u;
+    e->box[ph][l] = p ? 1u : 0u;
+    yield_all();
+    uint64_t m = 0;
+    for (int i = 0; i < kLanes; ++i) m |= (uint64_t)(e->box[ph][i] & 1u) << i;
+    return m;
+}
+inline void lds_fence() {
+    Emu* e = emu();
+    e->lane_phase[e->cur]++;
+    yield_all();
+}
+
+inline uint64_t mad(uint32_t a, uint32_t b, uint32_t c) { return (uint64_t)a * b + c; }
+inline uint32_t addc(uint32_t a, uint32_t b, uint32_t cin, uint32_t& cout) {
+    const uint64_t s = (uint64_t)a + b + cin;
+    cout = (uint32_t)(s >> 32);
+    return (uint32_t)s;
+}
+inline uint32_t subb(uint32_t a, uint32_t b, uint32_t bin, uint32_t& bout) {
+    const uint64_t d = (uint64_t)a - b - bin;
+    bout = (uint32_t)(d >> 63);
+    return (uint32_t)d;
+}
+
+}  // namespace wave

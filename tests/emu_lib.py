@@ -1,0 +1,76 @@
+"""ctypes binding of tests/emu/libphe_emu.so (TEST INFRASTRUCTURE: the device algorithm headers compiled
+for the CPU on a fiber-based wavefront emulator)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+EMU_DIR = os.path.join(HERE, "emu")
+LIB = os.path.join(EMU_DIR, "libphe_emu.so")
+
+
+def P(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Emu:
+    def __init__(self):
+        subprocess.check_call(["make", "-C", EMU_DIR, "-s"])
+        self.L = ctypes.CDLL(LIB)
+        self.L.emu_last_error.restype = ctypes.c_char_p
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.L.emu_last_error().decode())
+
+    def montmul(self, L, a, b, n):
+        out = np.zeros((4, 16 * L), np.uint32)
+        self._ck(self.L.emu_montmul(L, P(a), P(b), P(n), P(out)))
+        return out
+
+    def encrypt(self, n, m, r):
+        s1 = n.shape[0]
+        out = np.zeros((m.shape[0], 2 * s1), np.uint32)
+        self._ck(self.L.emu_encrypt(P(n), s1, P(m), P(r), None, P(out), ctypes.c_uint64(m.shape[0])))
+        return out
+
+    def obfuscate(self, n, c_in, r):
+        s1 = n.shape[0]
+        out = np.zeros((c_in.shape[0], 2 * s1), np.uint32)
+        self._ck(self.L.emu_encrypt(P(n), s1, None, P(r), P(c_in), P(out), ctypes.c_uint64(c_in.shape[0])))
+        return out
+
+    def decrypt(self, p, q, hp, hq, pinv, n_limbs, c):
+        out = np.zeros((c.shape[0], n_limbs), np.uint32)
+        self._ck(self.L.emu_decrypt(P(p), P(q), P(hp), P(hq), P(pinv), p.shape[0], n_limbs, P(c), P(out),
+                                    ctypes.c_uint64(c.shape[0])))
+        return out
+
+    def mulmod(self, N, a, b):
+        out = np.zeros_like(a)
+        self._ck(self.L.emu_mulmod(P(N), N.shape[0], P(a), P(b), P(out), ctypes.c_uint64(a.shape[0])))
+        return out
+
+    def powmod_var(self, N, base, exps):
+        out = np.zeros_like(base)
+        self._ck(self.L.emu_powmod_var(P(N), N.shape[0], P(base), P(exps), exps.shape[1], P(out),
+                                       ctypes.c_uint64(base.shape[0])))
+        return out
+
+    def public_constants(self, n):
+        s1 = n.shape[0]
+        res = {}
+        L = ctypes.c_int(0)
+        n0 = ctypes.c_uint32(0)
+        info = (ctypes.c_int * 6)()
+        for which, name in enumerate(["n", "r1", "r2", "r3", "aux"]):
+            buf = np.zeros(1024, np.uint32)
+            S = self.L.emu_public_constants(P(n), s1, which, P(buf), ctypes.byref(L), ctypes.byref(n0), info)
+            if S < 0:
+                raise RuntimeError(self.L.emu_last_error().decode())
+            res[name] = buf[:S].copy()
+        res.update(L=L.value, S=S, n0inv=n0.value, window=info[0], tbl_entries=info[1], first_idx=info[2],
+                   n_ops=info[3], squarings=info[4], multiplies=info[5])
+        return res
