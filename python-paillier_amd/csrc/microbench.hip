@@ -1,0 +1,231 @@
+// microbench.hip — calibration of the gfx950 integer-VALU roofline this engine is priced against.
+//
+// SURVEY.md 8(d) assumes v_mad_u64_u32 is a quarter-rate op (peak 9.83e12 MAC32/s at 256 CUs,
+// 2.4 GHz).  This standalone tool measures the sustained issue rate of the instructions the
+// Montgomery kernels are made of (and of a few alternatives: 24-bit multiplies, f64 FMA), so that
+// bench.py's roofline.peak is a measured number.  Every test runs 8 independent dependency chains
+// per lane, 8 waves per SIMD, all CUs; results are printed as one JSON object.
+//
+//   hipcc --offload-arch=gfx950 -O3 microbench.hip -o phe_microbench && ./phe_microbench
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+#define CK(x)                                                                     \
+    do {                                                                          \
+        hipError_t e_ = (x);                                                      \
+        if (e_ != hipSuccess) {                                                   \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_));               \
+            return 1;                                                             \
+        }                                                                         \
+    } while (0)
+
+constexpr int kIters = 16384;  // loop trips; each trip issues 8 (x OPS_PER) instructions per lane
+constexpr int kChains = 8;
+
+#define KERNEL_BEGIN(NAME)                                                         \
+    __global__ void __launch_bounds__(256) NAME(uint32_t* out, uint32_t seed) {    \
+        const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;                \
+        uint32_t a = seed * 2654435761u + tid, b = (seed ^ tid) | 1u;              \
+        (void)a; (void)b;
+
+#define KERNEL_END(RESULT)                                                         \
+        if ((RESULT) == 0x12345678u) out[tid] = (RESULT);                          \
+    }
+
+// --- 32-bit accumulator tests -----------------------------------------------------------------
+#define DEF_U32_TEST(NAME, ASM)                                                    \
+    KERNEL_BEGIN(NAME)                                                             \
+        uint32_t x[kChains];                                                       \
+        for (int i = 0; i < kChains; ++i) x[i] = a + i;                            \
+        for (int it = 0; it < kIters; ++it) {                                      \
+            _Pragma("unroll") for (int i = 0; i < kChains; ++i)                    \
+                asm volatile(ASM : "+v"(x[i]) : "v"(a), "v"(b) : "vcc", "s20", "s21");  \
+        }                                                                          \
+        uint32_t r = 0;                                                            \
+        for (int i = 0; i < kChains; ++i) r ^= x[i];                               \
+    KERNEL_END(r)
+
+DEF_U32_TEST(k_add_u32, "v_add_u32 %0, %0, %1")
+DEF_U32_TEST(k_mov_b32, "v_mov_b32 %0, %1")
+DEF_U32_TEST(k_mul_lo_u32, "v_mul_lo_u32 %0, %0, %2")
+DEF_U32_TEST(k_mul_hi_u32, "v_mul_hi_u32 %0, %0, %2")
+DEF_U32_TEST(k_mad_u32_u24, "v_mad_u32_u24 %0, %1, %2, %0")
+DEF_U32_TEST(k_mul_hi_u32_u24, "v_mul_hi_u32_u24 %0, %0, %2")
+DEF_U32_TEST(k_fma_f32, "v_fma_f32 %0, %1, %2, %0")
+DEF_U32_TEST(k_dpp_row_shl1, "v_mov_b32_dpp %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+DEF_U32_TEST(k_dpp_newbcast, "v_mov_b32_dpp %0, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf")
+DEF_U32_TEST(k_addc_chain, "v_addc_co_u32 %0, vcc, %0, %1, vcc")
+DEF_U32_TEST(k_add_co_addc_pair, "v_add_co_u32 %0, s[20:21], %0, %1\n\tv_addc_co_u32 %0, s[20:21], %0, %2, s[20:21]")
+DEF_U32_TEST(k_cndmask, "v_cndmask_b32 %0, %0, %1, vcc")
+DEF_U32_TEST(k_cndmask_sgpr, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]")
+DEF_U32_TEST(k_and_b32, "v_and_b32 %0, %0, %1")
+DEF_U32_TEST(k_alignbit, "v_alignbit_b32 %0, %0, %1, 30")
+
+// --- 64-bit accumulator tests -----------------------------------------------------------------
+#define DEF_U64_TEST(NAME, ASM)                                                    \
+    KERNEL_BEGIN(NAME)                                                             \
+        uint64_t x[kChains];                                                       \
+        for (int i = 0; i < kChains; ++i) x[i] = ((uint64_t)b << 32) | (a + i);    \
+        for (int it = 0; it < kIters; ++it) {                                      \
+            _Pragma("unroll") for (int i = 0; i < kChains; ++i)                    \
+                asm volatile(ASM : "+v"(x[i]) : "v"(a), "v"(b) : "vcc");           \
+        }                                                                          \
+        uint64_t r = 0;                                                            \
+        for (int i = 0; i < kChains; ++i) r ^= x[i];                               \
+    KERNEL_END((uint32_t)(r ^ (r >> 32)))
+
+DEF_U64_TEST(k_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %2, %0")
+DEF_U64_TEST(k_fma_f64, "v_fma_f64 %0, %0, %0, %0")
+DEF_U64_TEST(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 1, %0")
+DEF_U64_TEST(k_lshrrev_b64, "v_lshrrev_b64 %0, 1, %0")
+
+// --- the inner-loop mix of mont_core.h: mad + addc (+ mov), to see what co-issues ---------------
+KERNEL_BEGIN(k_mix_mad_addc)
+    uint64_t x[kChains];
+    uint32_t y[kChains];
+    for (int i = 0; i < kChains; ++i) { x[i] = a + i; y[i] = b + i; }
+    for (int it = 0; it < kIters; ++it) {
+        _Pragma("unroll") for (int i = 0; i < kChains; ++i) {
+            asm volatile("v_mad_u64_u32 %0, s[20:21], %2, %3, %0\n\tv_addc_co_u32 %1, vcc, %1, %2, vcc"
+                         : "+v"(x[i]), "+v"(y[i]) : "v"(a), "v"(b) : "vcc", "s20", "s21");
+        }
+    }
+    uint64_t r = 0;
+    for (int i = 0; i < kChains; ++i) r ^= x[i] ^ y[i];
+KERNEL_END((uint32_t)(r ^ (r >> 32)))
+
+KERNEL_BEGIN(k_mix_mad_addc_mov)
+    uint64_t x[kChains];
+    uint32_t y[kChains], z[kChains];
+    for (int i = 0; i < kChains; ++i) { x[i] = a + i; y[i] = b + i; z[i] = i; }
+    for (int it = 0; it < kIters; ++it) {
+        _Pragma("unroll") for (int i = 0; i < kChains; ++i) {
+            asm volatile("v_mad_u64_u32 %0, s[20:21], %3, %4, %0\n\tv_addc_co_u32 %1, vcc, %1, %3, vcc\n\tv_mov_b32 %2, %4"
+                         : "+v"(x[i]), "+v"(y[i]), "+v"(z[i]) : "v"(a), "v"(b) : "vcc", "s20", "s21");
+        }
+    }
+    uint64_t r = 0;
+    for (int i = 0; i < kChains; ++i) r ^= x[i] ^ y[i] ^ z[i];
+KERNEL_END((uint32_t)(r ^ (r >> 32)))
+
+// --- LDS: the broadcast read used for the multiplier limbs, and ds_bpermute ---------------------
+__global__ void __launch_bounds__(256) k_lds_bcast_b128(uint32_t* out, uint32_t seed) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[16 * 132];
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int i = threadIdx.x; i < 16 * 132; i += 256) lds[i] = seed + i;
+    __syncthreads();
+    const uint32_t* row = lds + (threadIdx.x >> 4) * 132;
+    uint32_t r = 0;
+    for (int it = 0; it < kIters / 4; ++it) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const uint4 v = *reinterpret_cast<const uint4*>(row + 4 * i);
+            r += v.x ^ v.y ^ v.z ^ v.w;
+            asm volatile("" : "+v"(r));
+        }
+    }
+    if (r == 0x12345678u) out[tid] = r;
+}
+DEF_U32_TEST(k_ds_bpermute, "ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)")
+
+// effective shader clock: s_memtime ticks (shader cycles) across a fixed VALU loop vs wall time
+__global__ void __launch_bounds__(256) k_clock(unsigned long long* ticks, uint32_t seed) {
+    uint32_t x = seed + threadIdx.x;
+    const unsigned long long t0 = clock64();
+    for (int it = 0; it < kIters * 8; ++it) asm volatile("v_add_u32 %0, %0, %0" : "+v"(x));
+    const unsigned long long t1 = clock64();
+    if (threadIdx.x == 0) ticks[blockIdx.x] = t1 - t0;
+    if (x == 0x12345678u) ticks[0] = x;
+}
+
+struct Test {
+    const char* name;
+    void (*fn)(uint32_t*, uint32_t);
+    double instr_per_iter;  // per lane per loop trip
+};
+
+int main() {
+    int dev = 0;
+    CK(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, dev));
+    const int cus = prop.multiProcessorCount;
+    const int blocks = cus * 8;  // 8 x 256 threads = 32 waves per CU
+    uint32_t* d = nullptr;
+    CK(hipMalloc((void**)&d, (size_t)blocks * 256 * 4));
+    std::vector<Test> tests = {
+        {"v_add_u32", k_add_u32, kChains},
+        {"v_mov_b32", k_mov_b32, kChains},
+        {"v_addc_co_u32", k_addc_chain, kChains},
+        {"v_add_co+v_addc_pair", k_add_co_addc_pair, 2.0 * kChains},
+        {"v_cndmask_b32", k_cndmask, kChains},
+        {"v_cndmask_b32_e64_sgpr", k_cndmask_sgpr, kChains},
+        {"v_and_b32", k_and_b32, kChains},
+        {"v_alignbit_b32", k_alignbit, kChains},
+        {"v_mad_u64_u32", k_mad_u64_u32, kChains},
+        {"v_mul_lo_u32", k_mul_lo_u32, kChains},
+        {"v_mul_hi_u32", k_mul_hi_u32, kChains},
+        {"v_mad_u32_u24", k_mad_u32_u24, kChains},
+        {"v_mul_hi_u32_u24", k_mul_hi_u32_u24, kChains},
+        {"v_fma_f32", k_fma_f32, kChains},
+        {"v_fma_f64", k_fma_f64, kChains},
+        {"v_lshl_add_u64", k_lshl_add_u64, kChains},
+        {"v_lshrrev_b64", k_lshrrev_b64, kChains},
+        {"v_mov_b32_dpp_row_shl1", k_dpp_row_shl1, kChains},
+        {"v_mov_b32_dpp_row_newbcast", k_dpp_newbcast, kChains},
+        {"ds_bpermute_b32", k_ds_bpermute, kChains},
+        {"ds_read_b128_row_broadcast", k_lds_bcast_b128, 32.0 / 4.0},
+        {"mix_mad+addc", k_mix_mad_addc, 2.0 * kChains},
+        {"mix_mad+addc+mov", k_mix_mad_addc_mov, 3.0 * kChains},
+    };
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0));
+    CK(hipEventCreate(&e1));
+    // effective clock under an all-CU VALU load
+    unsigned long long* dt = nullptr;
+    CK(hipMalloc((void**)&dt, (size_t)blocks * 8));
+    k_clock<<<blocks, 256>>>(dt, 1);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    k_clock<<<blocks, 256>>>(dt, 2);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float clk_ms = 0;
+    CK(hipEventElapsedTime(&clk_ms, e0, e1));
+    unsigned long long ticks0 = 0;
+    CK(hipMemcpy(&ticks0, dt, 8, hipMemcpyDeviceToHost));
+    // each wave issues kIters*8 dependent v_add; 8 waves per SIMD interleave, so the kernel lasts ~ticks0 cycles
+    printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, "
+           "\"clock_probe\": {\"s_memtime_ticks\": %llu, \"kernel_ms\": %.4f, \"ticks_per_us\": %.1f}, \"tests\": {",
+           prop.name, prop.gcnArchName, cus, prop.clockRate / 1000, ticks0, clk_ms, (double)ticks0 / (clk_ms * 1e3));
+    bool first = true;
+    for (const Test& t : tests) {
+        t.fn<<<blocks, 256>>>(d, 1);  // warm-up
+        CK(hipDeviceSynchronize());
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipEventRecord(e0));
+            t.fn<<<blocks, 256>>>(d, rep + 2);
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) best = ms;
+        }
+        const double lanes = (double)blocks * 256;
+        const double wave_instr = lanes / 64.0 * kIters * t.instr_per_iter;
+        const double lane_ops_per_s = lanes * kIters * t.instr_per_iter / (best * 1e-3);
+        // cycles a SIMD spends per wave-instruction, at the nominal clock
+        const double cyc = (double)cus * 4.0 * (prop.clockRate * 1e3) * (best * 1e-3) / wave_instr;
+        printf("%s\"%s\": {\"ms\": %.4f, \"lane_ops_per_s\": %.4e, \"cycles_per_wave_instr_per_simd\": %.3f}",
+               first ? "" : ", ", t.name, best, lane_ops_per_s, cyc);
+        first = false;
+    }
+    printf("}}\n");
+    CK(hipFree(d));
+    return 0;
+}

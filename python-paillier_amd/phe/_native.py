@@ -1,0 +1,248 @@
+"""ctypes binding of the C-ABI in include/phe_hip.h (lib/libphe_hip.so, hand-written HIP for gfx950).
+
+There is deliberately NO CPU fallback here: if the shared library is missing, or a call fails,
+an exception is raised.  Status codes map onto the exception types the reference raises
+(SURVEY.md 8(b) "Error conventions"): ENOINVERSE -> ZeroDivisionError (phe/util.py:96-102),
+EINVAL -> ValueError, EHIP -> RuntimeError.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libphe_hip.so")
+
+OK, EINVAL, EHIP, ENOINVERSE = 0, 1, 2, 3
+
+_lib = None
+
+
+class NativeLibraryMissing(ImportError):
+    pass
+
+
+def lib():
+    """Load lib/libphe_hip.so once; fail loudly if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeLibraryMissing(
+                "%s not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                "This package has no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        L.phe_hip_last_error.restype = ctypes.c_char_p
+        L.phe_hip_device_count.argtypes = [ctypes.POINTER(ci)]
+        L.phe_hip_ctx_create_public.argtypes = [vp, ci, ci, ctypes.POINTER(vp)]
+        L.phe_hip_ctx_create_private.argtypes = [vp, ci, vp, vp, vp, vp, vp, ci, ci, ctypes.POINTER(vp)]
+        L.phe_hip_ctx_destroy.argtypes = [vp]
+        L.phe_hip_ctx_destroy.restype = None
+        L.phe_hip_ctx_info.argtypes = [vp] + [ctypes.POINTER(ci)] * 6
+        L.phe_hip_ctx_set_blocks_per_cu.argtypes = [vp, ci]
+        L.phe_hip_encrypt.argtypes = [vp, vp, vp, vp, sz]
+        L.phe_hip_obfuscate.argtypes = [vp, vp, vp, vp, sz]
+        L.phe_hip_decrypt.argtypes = [vp, vp, vp, sz]
+        L.phe_hip_mulmod.argtypes = [vp, vp, vp, vp, sz]
+        L.phe_hip_powmod.argtypes = [vp, vp, vp, ci, vp, sz]
+        L.phe_hip_invert.argtypes = [vp, vp, vp, sz, ctypes.POINTER(sz)]
+        L.phe_hip_encrypt_dev.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.phe_hip_obfuscate_dev.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.phe_hip_decrypt_dev.argtypes = [vp, vp, vp, sz, vp]
+        L.phe_hip_mulmod_dev.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.phe_hip_powmod_dev.argtypes = [vp, vp, vp, ci, ci, vp, sz, vp]
+        L.phe_hip_malloc.argtypes = [vp, sz, ctypes.POINTER(vp)]
+        L.phe_hip_free.argtypes = [vp, vp]
+        L.phe_hip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+        L.phe_hip_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+        L.phe_hip_stream_sync.argtypes = [vp, vp]
+        L.phe_hip_selftest_prims.argtypes = [ci, vp]
+        _lib = L
+    return _lib
+
+
+EXPORTED_SYMBOLS = [
+    "phe_hip_last_error", "phe_hip_device_count", "phe_hip_ctx_create_public", "phe_hip_ctx_create_private",
+    "phe_hip_ctx_destroy", "phe_hip_ctx_info", "phe_hip_ctx_set_blocks_per_cu", "phe_hip_encrypt",
+    "phe_hip_obfuscate", "phe_hip_decrypt", "phe_hip_mulmod", "phe_hip_powmod", "phe_hip_invert",
+    "phe_hip_encrypt_dev", "phe_hip_obfuscate_dev", "phe_hip_decrypt_dev", "phe_hip_mulmod_dev",
+    "phe_hip_powmod_dev", "phe_hip_malloc", "phe_hip_free", "phe_hip_memcpy_h2d", "phe_hip_memcpy_d2h",
+    "phe_hip_stream_sync", "phe_hip_selftest_prims",
+]
+
+
+def _raise(rc, bad_index=None):
+    msg = lib().phe_hip_last_error().decode(errors="replace")
+    if rc == ENOINVERSE:
+        err = ZeroDivisionError(msg)
+        err.bad_index = bad_index
+        raise err
+    if rc == EINVAL:
+        raise ValueError(msg)
+    raise RuntimeError("HIP error: " + msg)
+
+
+def _check(rc):
+    if rc != OK:
+        _raise(rc)
+
+
+def int_to_limbs(x, limbs):
+    return np.frombuffer(int(x).to_bytes(4 * limbs, "little"), dtype=np.uint32).copy()
+
+
+def ints_to_limbs(xs, limbs):
+    nbytes = 4 * limbs
+    buf = bytearray(nbytes * len(xs))
+    for i, x in enumerate(xs):
+        buf[i * nbytes:(i + 1) * nbytes] = int(x).to_bytes(nbytes, "little")
+    return np.frombuffer(bytes(buf), dtype=np.uint32).reshape(len(xs), limbs).copy()
+
+
+def limbs_to_ints(arr):
+    arr = np.ascontiguousarray(arr, dtype=np.uint32)
+    if arr.ndim == 1:
+        arr = arr.reshape(1, -1)
+    nbytes = arr.shape[1] * 4
+    raw = arr.tobytes()
+    return [int.from_bytes(raw[i * nbytes:(i + 1) * nbytes], "little") for i in range(arr.shape[0])]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _rows(a, limbs, name):
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    if a.ndim != 2 or a.shape[1] != limbs:
+        raise ValueError("%s must have shape (batch, %d) uint32, got %r" % (name, limbs, a.shape))
+    return a
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    _check(lib().phe_hip_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def limbs_for_bits(bits):
+    return max(1, (bits + 31) // 32)
+
+
+class Context:
+    """One key on one device.  `n` (and optionally p, q, hp, hq, p_inverse) are Python ints."""
+
+    def __init__(self, n, p=None, q=None, hp=None, hq=None, p_inverse=None, device=0, n_limbs=None):
+        L = lib()
+        self.n = int(n)
+        self.n_limbs = n_limbs or limbs_for_bits(self.n.bit_length())
+        self.ct_limbs = 2 * self.n_limbs
+        self.device = device
+        self._h = ctypes.c_void_p(None)
+        n_arr = int_to_limbs(self.n, self.n_limbs)
+        if p is None:
+            _check(L.phe_hip_ctx_create_public(_ptr(n_arr), self.n_limbs, device, ctypes.byref(self._h)))
+            self.has_private = False
+        else:
+            pq = limbs_for_bits(max(int(p).bit_length(), int(q).bit_length()))
+            arrs = [int_to_limbs(v, pq) for v in (p, q, hp, hq, p_inverse)]
+            _check(L.phe_hip_ctx_create_private(_ptr(n_arr), self.n_limbs, *[_ptr(a) for a in arrs], pq, device,
+                                                ctypes.byref(self._h)))
+            self.has_private = True
+
+    def close(self):
+        if self._h and self._h.value:
+            lib().phe_hip_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        vals = [ctypes.c_int(0) for _ in range(6)]
+        _check(lib().phe_hip_ctx_info(self._h, *[ctypes.byref(v) for v in vals]))
+        keys = ["n_limbs", "ct_limbs", "lane_limbs_pub", "lane_limbs_priv", "rows_in_flight", "has_private"]
+        return dict(zip(keys, [v.value for v in vals]))
+
+    def set_blocks_per_cu(self, k):
+        _check(lib().phe_hip_ctx_set_blocks_per_cu(self._h, int(k)))
+
+    # ---- host-array entry points (numpy uint32, row-major (batch, limbs)) ----
+    def encrypt(self, m, r):
+        m = _rows(m, self.n_limbs, "m")
+        r = _rows(r, self.n_limbs, "r")
+        if m.shape[0] != r.shape[0]:
+            raise ValueError("m and r batch sizes differ")
+        c = np.empty((m.shape[0], self.ct_limbs), np.uint32)
+        _check(lib().phe_hip_encrypt(self._h, _ptr(m), _ptr(r), _ptr(c), m.shape[0]))
+        return c
+
+    def obfuscate(self, c_in, r):
+        c_in = _rows(c_in, self.ct_limbs, "c_in")
+        r = _rows(r, self.n_limbs, "r")
+        if c_in.shape[0] != r.shape[0]:
+            raise ValueError("c_in and r batch sizes differ")
+        c = np.empty_like(c_in)
+        _check(lib().phe_hip_obfuscate(self._h, _ptr(c_in), _ptr(r), _ptr(c), c_in.shape[0]))
+        return c
+
+    def decrypt(self, c):
+        c = _rows(c, self.ct_limbs, "c")
+        m = np.empty((c.shape[0], self.n_limbs), np.uint32)
+        _check(lib().phe_hip_decrypt(self._h, _ptr(c), _ptr(m), c.shape[0]))
+        return m
+
+    def mulmod(self, a, b):
+        a = _rows(a, self.ct_limbs, "a")
+        b = _rows(b, self.ct_limbs, "b")
+        if a.shape[0] != b.shape[0]:
+            raise ValueError("a and b batch sizes differ")
+        out = np.empty_like(a)
+        _check(lib().phe_hip_mulmod(self._h, _ptr(a), _ptr(b), _ptr(out), a.shape[0]))
+        return out
+
+    def powmod(self, base, exps):
+        base = _rows(base, self.ct_limbs, "base")
+        exps = np.ascontiguousarray(exps, dtype=np.uint32)
+        if exps.ndim != 2 or exps.shape[0] != base.shape[0]:
+            raise ValueError("exps must have shape (batch, exp_limbs)")
+        out = np.empty_like(base)
+        _check(lib().phe_hip_powmod(self._h, _ptr(base), _ptr(exps), exps.shape[1], _ptr(out), base.shape[0]))
+        return out
+
+    def invert(self, a):
+        a = _rows(a, self.ct_limbs, "a")
+        out = np.empty_like(a)
+        bad = ctypes.c_size_t(0)
+        rc = lib().phe_hip_invert(self._h, _ptr(a), _ptr(out), a.shape[0], ctypes.byref(bad))
+        if rc != OK:
+            _raise(rc, bad.value)
+        return out
+
+    # ---- device-pointer entry points (ints: device addresses; stream: hipStream_t as int) ----
+    def encrypt_dev(self, m_ptr, r_ptr, c_ptr, batch, stream=0):
+        _check(lib().phe_hip_encrypt_dev(self._h, m_ptr, r_ptr, c_ptr, batch, stream))
+
+    def obfuscate_dev(self, cin_ptr, r_ptr, cout_ptr, batch, stream=0):
+        _check(lib().phe_hip_obfuscate_dev(self._h, cin_ptr, r_ptr, cout_ptr, batch, stream))
+
+    def decrypt_dev(self, c_ptr, m_ptr, batch, stream=0):
+        _check(lib().phe_hip_decrypt_dev(self._h, c_ptr, m_ptr, batch, stream))
+
+    def mulmod_dev(self, a_ptr, b_ptr, out_ptr, batch, stream=0):
+        _check(lib().phe_hip_mulmod_dev(self._h, a_ptr, b_ptr, out_ptr, batch, stream))
+
+    def powmod_dev(self, base_ptr, exp_ptr, exp_limbs, max_exp_bits, out_ptr, batch, stream=0):
+        _check(lib().phe_hip_powmod_dev(self._h, base_ptr, exp_ptr, exp_limbs, max_exp_bits, out_ptr, batch, stream))
+
+    def sync(self, stream=0):
+        _check(lib().phe_hip_stream_sync(self._h, stream))
+
+
+def selftest_prims(device=0):
+    out = np.zeros(258, np.uint32)
+    _check(lib().phe_hip_selftest_prims(device, _ptr(out)))
+    return out

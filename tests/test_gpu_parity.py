@@ -1,0 +1,210 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C-ABI
+(lib/libphe_hip.so via phe._native) and is compared limb-for-limb with
+  * tests/golden/*.json  — values produced by the real reference (tests/golden/gen_golden.py),
+  * the libgmp oracle (oracle/) on seeded random batches,
+and, at sizes the CPU cannot check exhaustively, through size-independent properties
+(decrypt∘encrypt = id, homomorphism, inverse*self = 1).
+Nothing here reads /root/reference."""
+import random
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PKG, load_golden, load_kat
+
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+pytestmark = pytest.mark.gpu
+
+
+def H(x):
+    return int(x, 16)
+
+
+@pytest.fixture(scope="module")
+def native():
+    from phe import _native
+    assert _native.device_count() >= 1
+    return _native
+
+
+def make_ctx(native, g, private=True):
+    if private:
+        return native.Context(H(g["n"]), H(g["p"]), H(g["q"]), H(g["hp"]), H(g["hq"]), H(g["p_inverse"]),
+                              n_limbs=g["key_bits"] // 32)
+    return native.Context(H(g["n"]), n_limbs=g["key_bits"] // 32)
+
+
+def test_wave_primitives(native):
+    """The DPP row operations mean what csrc/wave_gfx950.h (and the CPU emulator) say they mean."""
+    out = native.selftest_prims(0)
+    lanes = np.arange(64)
+    down = np.where(lanes % 16 == 15, 0, lanes + 1 + 100)
+    up = np.where(lanes % 16 == 0, 0, lanes - 1 + 100)
+    bc = (lanes // 16) * 16 + 100
+    assert np.array_equal(out[0:64], down)
+    assert np.array_equal(out[64:128], up)
+    assert np.array_equal(out[128:192], bc)
+    assert np.array_equal(out[192:256], (lanes % 3 == 0).astype(np.uint32))
+    mask = sum(1 << int(l) for l in lanes if l % 3 == 0)
+    assert int(out[256]) | (int(out[257]) << 32) == mask
+
+
+def test_reference_kat(native):
+    k = load_kat()
+    ctx = native.Context(k["n"], k["p"], k["q"], k["hp"], k["hq"], k["p_inverse"])
+    c = ctx.encrypt(native.ints_to_limbs([k["m"], 1], 1), native.ints_to_limbs([k["r"], 1], 1))
+    assert native.limbs_to_ints(c) == [k["c"], k["encrypt_1_r_1"]]      # phe/tests/paillier_test.py:128-149
+    assert native.limbs_to_ints(ctx.decrypt(c)) == [k["m"], 1]
+
+
+@pytest.mark.parametrize("key_bits", [256, 1024, 2048, 3072])
+def test_golden_vectors(native, key_bits):
+    g = load_golden(key_bits)
+    s1, s2 = key_bits // 32, key_bits // 16
+    n_int = H(g["n"])
+    nsq = n_int * n_int
+    ctx = make_ctx(native, g)
+    L = native.ints_to_limbs
+    enc = g["raw_encrypt"]
+    c = ctx.encrypt(L([H(e["m"]) for e in enc], s1), L([H(e["r"]) for e in enc], s1))
+    assert native.limbs_to_ints(c) == [H(e["c"]) for e in enc]
+    dec = g["raw_decrypt"]
+    m = ctx.decrypt(L([H(e["c"]) for e in dec], s2))
+    assert native.limbs_to_ints(m) == [H(e["m"]) for e in dec]
+    obf = g["obfuscate"]
+    c2 = ctx.obfuscate(L([H(e["c_in"]) for e in obf], s2), L([H(e["r"]) for e in obf], s1))
+    assert native.limbs_to_ints(c2) == [H(e["c_out"]) for e in obf]
+    add = g["raw_add"]
+    out = ctx.mulmod(L([H(e["a"]) for e in add], s2), L([H(e["b"]) for e in add], s2))
+    assert native.limbs_to_ints(out) == [H(e["out"]) for e in add]
+    # _raw_mul, both branches, composed exactly like phe/paillier.py:745-751
+    max_int = H(g["max_int"])
+    pos = [e for e in g["raw_mul"] if H(e["s"]) < n_int - max_int]
+    neg = [e for e in g["raw_mul"] if H(e["s"]) >= n_int - max_int]
+    out = ctx.powmod(L([H(e["c"]) for e in pos], s2), L([H(e["s"]) for e in pos], s1))
+    assert native.limbs_to_ints(out) == [H(e["out"]) for e in pos]
+    inv = ctx.invert(L([H(e["c"]) for e in neg], s2))
+    assert native.limbs_to_ints(inv) == [pow(H(e["c"]), -1, nsq) for e in neg]
+    out = ctx.powmod(inv, L([n_int - H(e["s"]) for e in neg], s1))
+    assert native.limbs_to_ints(out) == [H(e["out"]) for e in neg]
+
+
+@pytest.mark.parametrize("key_bits,batch", [(1024, 300), (2048, 150), (3072, 40)])
+def test_random_batches_vs_gmp_oracle(native, c_oracle, key_bits, batch):
+    g = load_golden(key_bits)
+    s1, s2 = key_bits // 32, key_bits // 16
+    n_int = H(g["n"])
+    n = native.int_to_limbs(n_int, s1)
+    p, q = native.int_to_limbs(H(g["p"]), s1 // 2), native.int_to_limbs(H(g["q"]), s1 // 2)
+    ctx = make_ctx(native, g)
+    rng = random.Random(key_bits)
+    m = native.ints_to_limbs([rng.randrange(0, n_int) for _ in range(batch)], s1)
+    r = native.ints_to_limbs([rng.randrange(1, n_int) for _ in range(batch)], s1)
+    c = ctx.encrypt(m, r)
+    assert np.array_equal(c, c_oracle.encrypt(n, m, r, nthreads=8))
+    assert np.array_equal(ctx.decrypt(c), m)
+    junk = native.ints_to_limbs([rng.randrange(1, n_int * n_int) for _ in range(batch)], s2)
+    assert np.array_equal(ctx.decrypt(junk), c_oracle.decrypt(n, p, q, junk, nthreads=8))
+    assert np.array_equal(ctx.mulmod(c, junk), c_oracle.add(n, c, junk, nthreads=8))
+    scal = native.ints_to_limbs([rng.getrandbits(rng.choice([1, 8, 27, 56, 64, 130])) for _ in range(batch)], s1)
+    assert np.array_equal(ctx.powmod(c, scal), c_oracle.mul(n, c, scal, nthreads=8))
+    assert np.array_equal(ctx.obfuscate(junk, r), c_oracle.obfuscate(n, junk, r, nthreads=8))
+
+
+def test_ragged_and_empty_batches(native, c_oracle):
+    g = load_golden(1024)
+    n_int = H(g["n"])
+    n = native.int_to_limbs(n_int, 32)
+    ctx = make_ctx(native, g)
+    rng = random.Random(5)
+    assert ctx.encrypt(np.zeros((0, 32), np.uint32), np.zeros((0, 32), np.uint32)).shape == (0, 64)
+    assert ctx.decrypt(np.zeros((0, 64), np.uint32)).shape == (0, 32)
+    for batch in (1, 3, 15, 17, 63, 65, 257):
+        m = native.ints_to_limbs([rng.randrange(0, n_int) for _ in range(batch)], 32)
+        r = native.ints_to_limbs([rng.randrange(1, n_int) for _ in range(batch)], 32)
+        c = ctx.encrypt(m, r)
+        assert np.array_equal(c, c_oracle.encrypt(n, m, r, nthreads=4)), batch
+        assert np.array_equal(ctx.decrypt(c), m), batch
+
+
+def test_large_batch_properties(native, c_oracle):
+    """Config-2 shaped run scaled to the test budget: 2048-bit key, 2^15 elements; full-batch
+    round trip + additive homomorphism, strided sample against the libgmp oracle."""
+    g = load_golden(2048)
+    n_int = H(g["n"])
+    n = native.int_to_limbs(n_int, 64)
+    ctx = make_ctx(native, g)
+    B = 1 << 15
+    rs = np.random.Generator(np.random.PCG64(1234))
+    m = rs.integers(0, 1 << 32, size=(B, 64), dtype=np.uint32)
+    r = rs.integers(0, 1 << 32, size=(B, 64), dtype=np.uint32)
+    m[:, 63] = 0      # m < n: top limb cleared (n has 2048 bits)
+    r[:, 63] &= 0x3fffffff
+    r[:, 0] |= 1      # r != 0
+    c = ctx.encrypt(m, r)
+    assert np.array_equal(ctx.decrypt(c), m)
+    idx = np.arange(0, B, 257)
+    assert np.array_equal(c[idx], c_oracle.encrypt(n, m[idx], r[idx], nthreads=8))
+    # E(a)*E(b) decrypts to a+b mod n
+    half = B // 2
+    s = ctx.decrypt(ctx.mulmod(c[:half], c[half:]))
+    a_int = native.limbs_to_ints(m[:64]); b_int = native.limbs_to_ints(m[half:half + 64])
+    assert native.limbs_to_ints(s[:64]) == [(x + y) % n_int for x, y in zip(a_int, b_int)]
+    inv = ctx.invert(c[:1000])
+    one = ctx.mulmod(inv, c[:1000])
+    expect = np.zeros_like(one); expect[:, 0] = 1
+    assert np.array_equal(one, expect)
+
+
+def test_invert_reports_first_non_unit(native):
+    g = load_golden(256)
+    ctx = make_ctx(native, g, private=False)
+    n_int = H(g["n"])
+    vals = [H(e["c"]) for e in g["raw_encrypt"][:6]]
+    vals[4] = H(g["p"]) * 12345          # shares a factor with n^2
+    with pytest.raises(ZeroDivisionError) as ei:   # phe/util.py:96-102
+        ctx.invert(native.ints_to_limbs(vals, 16))
+    assert ei.value.bad_index == 4
+
+
+def test_decrypt_needs_private_key(native):
+    g = load_golden(256)
+    ctx = make_ctx(native, g, private=False)
+    with pytest.raises(ValueError):
+        ctx.decrypt(np.zeros((1, 16), np.uint32))
+
+
+def test_mismatched_private_key_rejected(native):
+    g = load_golden(256)
+    with pytest.raises(ValueError):   # phe/paillier.py:218-219
+        native.Context(H(g["n"]) + 2, H(g["p"]), H(g["q"]), H(g["hp"]), H(g["hq"]), H(g["p_inverse"]), n_limbs=8)
+
+
+@pytest.mark.parametrize("key_bits", [128, 512, 4096])
+def test_other_key_sizes_roundtrip(native, c_oracle, key_bits):
+    """Key widths the reference's own tests use (phe/tests/paillier_test.py:47-60) that have no fixture:
+    key material from the libgmp oracle's restatement of PaillierPrivateKey.__init__."""
+    rng = random.Random(key_bits)
+
+    def prime(bits):
+        while True:
+            cand = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+            if pow(2, cand - 1, cand) == 1 and pow(3, cand - 1, cand) == 1 and pow(5, cand - 1, cand) == 1:
+                return cand
+    while True:
+        p, q = prime(key_bits // 2), prime(key_bits // 2)
+        if p != q and (p * q).bit_length() == key_bits:
+            break
+    n_int = p * q
+    s1 = key_bits // 32
+    p, q, hp, hq, pinv = c_oracle.private_constants(n_int, p, q, s1, max(1, s1 // 2))
+    ctx = native.Context(n_int, p, q, hp, hq, pinv, n_limbs=s1)
+    batch = 24
+    m = native.ints_to_limbs([rng.randrange(0, n_int) for _ in range(batch)], s1)
+    r = native.ints_to_limbs([rng.randrange(1, n_int) for _ in range(batch)], s1)
+    c = ctx.encrypt(m, r)
+    assert np.array_equal(c, c_oracle.encrypt(native.int_to_limbs(n_int, s1), m, r, nthreads=8))
+    assert np.array_equal(ctx.decrypt(c), m)
