@@ -1,0 +1,118 @@
+"""Per-key engines: the only place where Python integers meet the C-ABI.
+
+An Engine owns one native Context (include/phe_hip.h) for one key on one GPU and exposes the five
+hot functions of the reference on *batches* of Python ints or uint32 limb arrays:
+
+    reference (scalar, phe/paillier.py)                  here (batched, HIP)
+    PaillierPublicKey.raw_encrypt      :102-139    ->    Engine.raw_encrypt
+    EncryptedNumber.obfuscate          :603-624    ->    Engine.obfuscate
+    PaillierPrivateKey.raw_decrypt     :328-374    ->    Engine.raw_decrypt
+    EncryptedNumber._raw_add           :705-719    ->    Engine.raw_add
+    EncryptedNumber._raw_mul           :721-751    ->    Engine.raw_mul   (both branches)
+
+There is no CPU implementation behind these: if lib/libphe_hip.so or a GPU is missing, they raise.
+"""
+import os
+import secrets
+
+import numpy as np
+
+from . import _native
+
+
+def default_device():
+    """One process per GPU: LOCAL_RANK picks the device unless PHE_HIP_DEVICE overrides it."""
+    for var in ("PHE_HIP_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            return int(v)
+    return 0
+
+
+def random_lt_n(n, count):
+    """`count` cryptographically random integers in [1, n) — bulk form of PaillierPublicKey.get_random_lt_n
+    (phe/paillier.py:141-143, random.SystemRandom().randrange(1, n)); same source (os.urandom), same
+    distribution (rejection sampling on bit_length(n-1) bits)."""
+    out = []
+    k = (n - 1).bit_length()
+    nbytes = (k + 7) // 8
+    mask = (1 << k) - 1
+    while len(out) < count:
+        need = count - len(out)
+        raw = secrets.token_bytes(nbytes * (need + need // 2 + 4))
+        for i in range(0, len(raw), nbytes):
+            v = int.from_bytes(raw[i:i + nbytes], "little") & mask
+            if 1 <= v < n:
+                out.append(v)
+                if len(out) == count:
+                    break
+    return out
+
+
+class Engine:
+    def __init__(self, n, p=None, q=None, hp=None, hq=None, p_inverse=None, device=None):
+        self.n = n
+        self.nsquare = n * n
+        self.max_int = n // 3 - 1
+        self.device = default_device() if device is None else device
+        self.ctx = _native.Context(n, p, q, hp, hq, p_inverse, device=self.device)
+        self.n_limbs = self.ctx.n_limbs
+        self.ct_limbs = self.ctx.ct_limbs
+
+    # ---- limb helpers -------------------------------------------------------------------------
+    def plain_limbs(self, ints):
+        return _native.ints_to_limbs(ints, self.n_limbs)
+
+    def cipher_limbs(self, ints):
+        return _native.ints_to_limbs(ints, self.ct_limbs)
+
+    @staticmethod
+    def to_ints(arr):
+        return _native.limbs_to_ints(arr)
+
+    def _as_plain(self, x):
+        return x if isinstance(x, np.ndarray) else self.plain_limbs(x)
+
+    def _as_cipher(self, x):
+        return x if isinstance(x, np.ndarray) else self.cipher_limbs(x)
+
+    # ---- the five hot functions (limb arrays in, limb arrays out) ------------------------------
+    def raw_encrypt(self, m, r):
+        """(1 + n*m) * r^n mod n^2 per row.  m is reduced mod n on the way in (value-identical to the
+        reference's `% nsquare`, which lets m = n, n+1 wrap to 0, 1: phe/tests/paillier_test.py:114-126)."""
+        if not isinstance(m, np.ndarray):
+            m = self.plain_limbs([v % self.n for v in m])
+        return self.ctx.encrypt(m, self._as_plain(r))
+
+    def obfuscate(self, c, r):
+        return self.ctx.obfuscate(self._as_cipher(c), self._as_plain(r))
+
+    def raw_decrypt(self, c):
+        return self.ctx.decrypt(self._as_cipher(c))
+
+    def raw_add(self, a, b):
+        return self.ctx.mulmod(self._as_cipher(a), self._as_cipher(b))
+
+    def raw_mul(self, c, scalars):
+        """Per row: powmod(c, s, n^2) if s < n - max_int, else powmod(invert(c, n^2), n - s, n^2) — the same
+        partition as phe/paillier.py:745-751 (the two branches give different ciphertext bits).
+        `scalars` are Python ints already validated to lie in [0, n)."""
+        c = self._as_cipher(c)
+        n, threshold = self.n, self.n - self.max_int
+        neg = [i for i, s in enumerate(scalars) if s >= threshold]
+        exps = [n - s if s >= threshold else s for s in scalars]
+        base = c
+        if neg:
+            base = c.copy()
+            idx = np.asarray(neg, dtype=np.int64)
+            base[idx] = self.ctx.invert(np.ascontiguousarray(c[idx]))
+        width = max(1, (max(e.bit_length() for e in exps) + 31) // 32) if exps else 1
+        return self.ctx.powmod(base, _native.ints_to_limbs(exps, width))
+
+    def powmod_n2(self, base, exps):
+        exps = list(exps)
+        width = max(1, (max(e.bit_length() for e in exps) + 31) // 32) if exps else 1
+        return self.ctx.powmod(self._as_cipher(base), _native.ints_to_limbs(exps, width))
+
+    def invert_n2(self, a):
+        return self.ctx.invert(self._as_cipher(a))

@@ -1,0 +1,294 @@
+"""Ciphertext containers.
+
+EncryptedNumber keeps the reference's scalar object API verbatim (phe/paillier.py:442-751: operators,
+lazy obfuscation state machine, exponent alignment, error types, even the name-mangled private fields
+the reference's tests poke at) but every bigint operation is a batch-of-one call into the GPU engine.
+
+EncryptedVector is the batched sibling the GPU actually wants: one (batch, ct_limbs) uint32 limb array
+plus per-element exponents and obfuscation flags; `+`, `*`, obfuscate(), decrease_exponent_to() are one
+kernel launch each over the whole vector, with the same per-element semantics as EncryptedNumber.
+"""
+import numpy as np
+
+from ._engine import random_lt_n
+from .codec import EncodedNumber
+
+
+class EncryptedNumber(object):
+    def __init__(self, public_key, ciphertext, exponent=0):
+        from .keys import PaillierPublicKey
+        self.public_key = public_key
+        self.__ciphertext = ciphertext
+        self.exponent = exponent
+        self.__is_obfuscated = False
+        if isinstance(ciphertext, EncryptedNumber):
+            raise TypeError('ciphertext should be an integer')
+        if not isinstance(self.public_key, PaillierPublicKey):
+            raise TypeError('public_key should be a PaillierPublicKey')
+
+    # ---- operators ------------------------------------------------------------------------------
+    def __add__(self, other):
+        if isinstance(other, EncryptedNumber):
+            return self._add_encrypted(other)
+        if isinstance(other, EncodedNumber):
+            return self._add_encoded(other)
+        return self._add_scalar(other)
+
+    def __radd__(self, other):
+        return self.__add__(other)
+
+    def __mul__(self, other):
+        if isinstance(other, EncryptedNumber):
+            raise NotImplementedError('Good luck with that...')
+        encoding = other if isinstance(other, EncodedNumber) else EncodedNumber.encode(self.public_key, other)
+        product = self._raw_mul(encoding.encoding)
+        return EncryptedNumber(self.public_key, product, self.exponent + encoding.exponent)
+
+    def __rmul__(self, other):
+        return self.__mul__(other)
+
+    def __sub__(self, other):
+        return self + (other * -1)
+
+    def __rsub__(self, other):
+        return other + (self * -1)
+
+    def __truediv__(self, scalar):
+        return self.__mul__(1 / scalar)
+
+    # ---- state ------------------------------------------------------------------------------------
+    def ciphertext(self, be_secure=True):
+        if be_secure and not self.__is_obfuscated:
+            self.obfuscate()
+        return self.__ciphertext
+
+    def decrease_exponent_to(self, new_exp):
+        if new_exp > self.exponent:
+            raise ValueError('New exponent %i should be more negative than old exponent %i' % (new_exp, self.exponent))
+        multiplied = self * pow(EncodedNumber.BASE, self.exponent - new_exp)
+        multiplied.exponent = new_exp
+        return multiplied
+
+    def obfuscate(self):
+        pk = self.public_key
+        eng = pk._get_engine()
+        r = pk.get_random_lt_n()
+        self.__ciphertext = eng.to_ints(eng.obfuscate([self.__ciphertext % pk.nsquare], [r]))[0]
+        self.__is_obfuscated = True
+
+    # ---- addition -----------------------------------------------------------------------------------
+    def _add_scalar(self, scalar):
+        encoded = EncodedNumber.encode(self.public_key, scalar, max_exponent=self.exponent)
+        return self._add_encoded(encoded)
+
+    def _add_encoded(self, encoded):
+        if self.public_key != encoded.public_key:
+            raise ValueError("Attempted to add numbers encoded against different public keys!")
+        a, b = self, encoded
+        if a.exponent > b.exponent:
+            a = self.decrease_exponent_to(b.exponent)
+        elif a.exponent < b.exponent:
+            b = b.decrease_exponent_to(a.exponent)
+        # E(b) with obfuscator 1 is 1 + n*b (phe/paillier.py:673): no exponentiation needed
+        encrypted_scalar = (a.public_key.n * b.encoding + 1) % a.public_key.nsquare
+        total = a._raw_add(a.ciphertext(False), encrypted_scalar)
+        return EncryptedNumber(a.public_key, total, a.exponent)
+
+    def _add_encrypted(self, other):
+        if self.public_key != other.public_key:
+            raise ValueError("Attempted to add numbers encrypted against different public keys!")
+        a, b = self, other
+        if a.exponent > b.exponent:
+            a = self.decrease_exponent_to(b.exponent)
+        elif a.exponent < b.exponent:
+            b = b.decrease_exponent_to(a.exponent)
+        total = a._raw_add(a.ciphertext(False), b.ciphertext(False))
+        return EncryptedNumber(a.public_key, total, a.exponent)
+
+    def _raw_add(self, e_a, e_b):
+        pk = self.public_key
+        eng = pk._get_engine()
+        return eng.to_ints(eng.raw_add([e_a % pk.nsquare], [e_b % pk.nsquare]))[0]
+
+    def _raw_mul(self, plaintext):
+        if not isinstance(plaintext, int):
+            raise TypeError('Expected ciphertext to be int, not %s' % type(plaintext))
+        pk = self.public_key
+        if plaintext < 0 or plaintext >= pk.n:
+            raise ValueError('Scalar out of bounds: %i' % plaintext)
+        eng = pk._get_engine()
+        return eng.to_ints(eng.raw_mul([self.ciphertext(False) % pk.nsquare], [plaintext]))[0]
+
+
+class EncryptedVector(object):
+    """A batch of Paillier ciphertexts under one public key, stored as little-endian uint32 limbs."""
+
+    def __init__(self, public_key, limbs, exponents, obfuscated=False):
+        self.public_key = public_key
+        self._limbs = np.ascontiguousarray(limbs, dtype=np.uint32)
+        self.exponents = list(exponents)
+        if self._limbs.ndim != 2 or self._limbs.shape[0] != len(self.exponents):
+            raise ValueError("limbs must be (batch, ct_limbs) with one exponent per row")
+        flags = obfuscated if isinstance(obfuscated, np.ndarray) else np.full(len(self.exponents), bool(obfuscated))
+        self._obfuscated = flags.astype(bool)
+
+    @classmethod
+    def from_numbers(cls, public_key, numbers):
+        numbers = list(numbers)
+        for x in numbers:
+            if not isinstance(x, EncryptedNumber):
+                raise TypeError('Expected encrypted_number to be an EncryptedNumber not: %s' % type(x))
+            if x.public_key != public_key:
+                raise ValueError('encrypted_number was encrypted against a different key!')
+        eng = public_key._get_engine()
+        limbs = eng.cipher_limbs([x.ciphertext(False) % public_key.nsquare for x in numbers])
+        flags = np.array([x._EncryptedNumber__is_obfuscated for x in numbers], dtype=bool)
+        return cls(public_key, limbs, [x.exponent for x in numbers], flags)
+
+    @classmethod
+    def from_ciphertexts(cls, public_key, ciphertexts, exponents=0):
+        ciphertexts = list(ciphertexts)
+        if isinstance(exponents, int):
+            exponents = [exponents] * len(ciphertexts)
+        eng = public_key._get_engine()
+        return cls(public_key, eng.cipher_limbs(ciphertexts), exponents)
+
+    def __len__(self):
+        return len(self.exponents)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return EncryptedVector(self.public_key, self._limbs[i], self.exponents[i], self._obfuscated[i])
+        eng = self.public_key._get_engine()
+        x = EncryptedNumber(self.public_key, eng.to_ints(self._limbs[i:i + 1])[0], self.exponents[i])
+        x._EncryptedNumber__is_obfuscated = bool(self._obfuscated[i])
+        return x
+
+    def to_numbers(self):
+        return [self[i] for i in range(len(self))]
+
+    # ---- state -----------------------------------------------------------------------------------------
+    def obfuscate(self, r_values=None):
+        """c_i <- c_i * r_i^n mod n^2 for the rows not yet obfuscated (all rows if r_values is given)."""
+        pk = self.public_key
+        eng = pk._get_engine()
+        rows = np.arange(len(self)) if r_values is not None else np.nonzero(~self._obfuscated)[0]
+        if len(rows):
+            r = list(r_values) if r_values is not None else random_lt_n(pk.n, len(rows))
+            self._limbs[rows] = eng.obfuscate(np.ascontiguousarray(self._limbs[rows]), r)
+            self._obfuscated[rows] = True
+        return self
+
+    def limbs(self, be_secure=True):
+        if be_secure:
+            self.obfuscate()
+        return self._limbs
+
+    def ciphertexts(self, be_secure=True):
+        return self.public_key._get_engine().to_ints(self.limbs(be_secure))
+
+    def decrease_exponent_to(self, new_exps):
+        """Per-element EncryptedNumber.decrease_exponent_to: rows whose exponent is above the target are
+        multiplied by BASE**delta (one variable-exponent modexp launch over those rows)."""
+        if isinstance(new_exps, int):
+            new_exps = [new_exps] * len(self)
+        new_exps = list(new_exps)
+        rows, scal = [], []
+        for i, (old, new) in enumerate(zip(self.exponents, new_exps)):
+            if new > old:
+                raise ValueError('New exponent %i should be more negative than old exponent %i' % (new, old))
+            if new < old:
+                rows.append(i)
+                scal.append(pow(EncodedNumber.BASE, old - new))
+        limbs = self._limbs.copy()
+        flags = self._obfuscated.copy()
+        if rows:
+            pk = self.public_key
+            if max(scal) >= pk.n:
+                raise ValueError('Scalar out of bounds: %i' % max(scal))
+            idx = np.asarray(rows)
+            limbs[idx] = pk._get_engine().raw_mul(np.ascontiguousarray(limbs[idx]), scal)
+            flags[idx] = False
+        return EncryptedVector(self.public_key, limbs, new_exps, flags)
+
+    # ---- arithmetic --------------------------------------------------------------------------------------
+    def _aligned(self, other_exps):
+        target = [min(a, b) for a, b in zip(self.exponents, other_exps)]
+        return self.decrease_exponent_to(target), target
+
+    def __add__(self, other):
+        pk = self.public_key
+        eng = pk._get_engine()
+        if isinstance(other, EncryptedVector):
+            if pk != other.public_key:
+                raise ValueError("Attempted to add numbers encrypted against different public keys!")
+            if len(other) != len(self):
+                raise ValueError("vector lengths differ")
+            a, target = self._aligned(other.exponents)
+            b = other.decrease_exponent_to(target)
+            return EncryptedVector(pk, eng.raw_add(a._limbs, b._limbs), target)
+        # plain operand(s): scalar broadcast or sequence; encode with max_exponent = own exponent per row
+        values = other if isinstance(other, (list, tuple, np.ndarray)) else [other] * len(self)
+        if len(values) != len(self):
+            raise ValueError("vector lengths differ")
+        values = values.tolist() if isinstance(values, np.ndarray) else values
+        encs, exps = [], []
+        for v, e in zip(values, self.exponents):
+            enc = v if isinstance(v, EncodedNumber) else EncodedNumber.encode(pk, v, max_exponent=e)
+            if enc.public_key != pk:
+                raise ValueError("Attempted to add numbers encoded against different public keys!")
+            encs.append(enc)
+            exps.append(enc.exponent)
+        a, target = self._aligned(exps)
+        nude = [(pk.n * enc.decrease_exponent_to(t).encoding + 1) % pk.nsquare for enc, t in zip(encs, target)]
+        return EncryptedVector(pk, eng.raw_add(a._limbs, nude), target)
+
+    __radd__ = __add__
+
+    def __mul__(self, other):
+        if isinstance(other, (EncryptedVector, EncryptedNumber)):
+            raise NotImplementedError('Good luck with that...')
+        pk = self.public_key
+        values = other if isinstance(other, (list, tuple, np.ndarray)) else [other] * len(self)
+        if len(values) != len(self):
+            raise ValueError("vector lengths differ")
+        if isinstance(values, np.ndarray) or not any(isinstance(v, EncodedNumber) for v in values):
+            encs, exps = EncodedNumber.encode_many(pk, values)
+        else:
+            pairs = [v if isinstance(v, EncodedNumber) else EncodedNumber.encode(pk, v) for v in values]
+            encs, exps = [e.encoding for e in pairs], [e.exponent for e in pairs]
+        limbs = pk._get_engine().raw_mul(self._limbs, encs)
+        return EncryptedVector(pk, limbs, [a + b for a, b in zip(self.exponents, exps)])
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return self * -1
+
+    def __sub__(self, other):
+        if isinstance(other, EncryptedVector):
+            return self + (other * -1)
+        if isinstance(other, (list, tuple, np.ndarray)):
+            return self + [-v for v in (other.tolist() if isinstance(other, np.ndarray) else other)]
+        return self + (-other)
+
+    def __truediv__(self, scalar):
+        return self * (1 / scalar)
+
+    def sum(self):
+        """Homomorphic sum of all elements -> EncryptedNumber (log2(batch) pairwise-product launches)."""
+        if len(self) == 0:
+            raise ValueError("empty vector")
+        pk = self.public_key
+        eng = pk._get_engine()
+        cur = self.decrease_exponent_to(min(self.exponents))
+        limbs, exp = cur._limbs, cur.exponents[0]
+        while limbs.shape[0] > 1:
+            half = limbs.shape[0] // 2
+            merged = eng.raw_add(np.ascontiguousarray(limbs[:half]), np.ascontiguousarray(limbs[half:2 * half]))
+            limbs = np.concatenate([merged, limbs[2 * half:]]) if limbs.shape[0] % 2 else merged
+        return EncryptedNumber(pk, eng.to_ints(limbs)[0], exp)
+
+    def dot(self, plain):
+        """sum_i self[i] * plain[i] -> EncryptedNumber (np.dot over ciphertexts, phe/tests/math_test.py:44-58)."""
+        return (self * plain).sum()

@@ -1,0 +1,129 @@
+"""Fixed-point codec between Python numbers and Paillier plaintexts (integers mod n).
+
+Behavioural mirror of the reference's phe/encoding.py (EncodedNumber.encode :110-199, decode :201-233,
+decrease_exponent_to :235-265) — same class name, attributes, results and exceptions — plus array forms
+(`encode_many` / `decode_many`) that feed the batched GPU entry points.  The codec itself is host-side
+integer bookkeeping; the heavy work it feeds is on the GPU.
+
+Representation: value = mantissa * BASE**exponent with mantissa stored mod n; residues <= max_int are
+non-negative, residues >= n - max_int are negative, the middle third flags overflow.
+"""
+import fractions
+import math
+import sys
+
+import numpy as np
+
+
+class EncodedNumber(object):
+    BASE = 16
+    LOG2_BASE = math.log(BASE, 2)
+    FLOAT_MANTISSA_BITS = sys.float_info.mant_dig
+
+    def __init__(self, public_key, encoding, exponent):
+        self.public_key = public_key
+        self.encoding = encoding
+        self.exponent = exponent
+
+    # ---- exponent selection (phe/encoding.py:160-183) ------------------------------------------
+    @classmethod
+    def _natural_exponent(cls, scalar, precision):
+        if precision is not None:
+            return math.floor(math.log(precision, cls.BASE))
+        if isinstance(scalar, int):
+            return 0
+        if isinstance(scalar, float):
+            lsb_power_of_two = math.frexp(scalar)[1] - cls.FLOAT_MANTISSA_BITS
+            return math.floor(lsb_power_of_two / cls.LOG2_BASE)
+        raise TypeError("Don't know the precision of type %s." % type(scalar))
+
+    @classmethod
+    def encode(cls, public_key, scalar, precision=None, max_exponent=None):
+        exponent = cls._natural_exponent(scalar, precision)
+        if max_exponent is not None:
+            exponent = min(max_exponent, exponent)
+        # exact rational arithmetic, then round-half-even like the reference (phe/encoding.py:191-192)
+        scaled = fractions.Fraction(scalar) * fractions.Fraction(cls.BASE) ** -exponent
+        int_rep = round(scaled)
+        if abs(int_rep) > public_key.max_int:
+            raise ValueError('Integer needs to be within +/- %d but got %d' % (public_key.max_int, int_rep))
+        return cls(public_key, int_rep % public_key.n, exponent)
+
+    def _signed_mantissa(self):
+        pk = self.public_key
+        if self.encoding >= pk.n:
+            raise ValueError('Attempted to decode corrupted number')
+        if self.encoding <= pk.max_int:
+            return self.encoding
+        if self.encoding >= pk.n - pk.max_int:
+            return self.encoding - pk.n
+        raise OverflowError('Overflow detected in decrypted number')
+
+    def decode(self):
+        mantissa = self._signed_mantissa()
+        if self.exponent >= 0:
+            return mantissa * self.BASE ** self.exponent
+        try:
+            return mantissa / self.BASE ** -self.exponent
+        except OverflowError as e:
+            raise OverflowError('decoded result too large for a float') from e
+
+    def decrease_exponent_to(self, new_exp):
+        if new_exp > self.exponent:
+            raise ValueError('New exponent %i should be more negative thanold exponent %i' % (new_exp, self.exponent))
+        factor = pow(self.BASE, self.exponent - new_exp)
+        return self.__class__(self.public_key, self.encoding * factor % self.public_key.n, new_exp)
+
+    # ---- array forms ------------------------------------------------------------------------------
+    @classmethod
+    def encode_many(cls, public_key, values, precision=None, max_exponent=None):
+        """Encode a sequence / numpy array.  Returns (encodings: list[int], exponents: list[int]).
+
+        dtype rules: float arrays follow the float rule per element (own exponent each),
+        integer arrays get exponent 0.  float64 arrays with BASE a power of two and no precision /
+        max_exponent take a vectorised path (exact: the mantissa shift is < log2(BASE) bits); anything
+        else goes through `encode` element by element."""
+        arr = values if isinstance(values, np.ndarray) else None
+        n, max_int = public_key.n, public_key.max_int
+        log2b = int(round(cls.LOG2_BASE))
+        pow2_base = (1 << log2b) == cls.BASE
+        if arr is not None and arr.dtype == np.float64 and precision is None and max_exponent is None and pow2_base:
+            if not np.all(np.isfinite(arr)):
+                raise ValueError("cannot encode inf / nan")
+            mant, e2 = np.frexp(arr)
+            lsb = e2.astype(np.int64) - cls.FLOAT_MANTISSA_BITS
+            exps = np.floor_divide(lsb, log2b)
+            shift = lsb - exps * log2b                       # 0 .. log2b-1
+            imant = np.ldexp(mant, cls.FLOAT_MANTISSA_BITS).astype(np.int64)   # exact: |mant| < 1, 53 bits
+            if log2b + cls.FLOAT_MANTISSA_BITS <= 62:
+                reps = (imant << shift).tolist()
+            else:
+                reps = [int(a) << int(s) for a, s in zip(imant.tolist(), shift.tolist())]
+            worst = max((abs(v) for v in reps), default=0)
+            if worst > max_int:
+                raise ValueError('Integer needs to be within +/- %d but got %d' % (max_int, worst))
+            return [v % n for v in reps], exps.tolist()
+        if arr is not None and arr.dtype.kind in "iu" and precision is None:
+            reps = arr.tolist()
+            exps = [0] * len(reps)
+            if max_exponent is not None and max_exponent < 0:
+                scale = cls.BASE ** -max_exponent
+                reps = [v * scale for v in reps]
+                exps = [max_exponent] * len(reps)
+            worst = max((abs(v) for v in reps), default=0)
+            if worst > max_int:
+                raise ValueError('Integer needs to be within +/- %d but got %d' % (max_int, worst))
+            return [v % n for v in reps], exps
+        seq = arr.tolist() if arr is not None else list(values)
+        encs, exps = [], []
+        for v in seq:
+            e = v if isinstance(v, EncodedNumber) else cls.encode(public_key, v, precision, max_exponent)
+            encs.append(e.encoding)
+            exps.append(e.exponent)
+        return encs, exps
+
+    @classmethod
+    def decode_many(cls, public_key, encodings, exponents):
+        """Inverse of encode_many: list of ints/floats, element-wise identical to
+        cls(public_key, enc, exp).decode()."""
+        return [cls(public_key, enc, exp).decode() for enc, exp in zip(encodings, exponents)]

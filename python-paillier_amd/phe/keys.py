@@ -1,0 +1,245 @@
+"""Key objects of the drop-in: same constructor signatures, attributes, equality/hash and error
+behaviour as the reference (phe/paillier.py:37-68 keypair generation, :71-194 PaillierPublicKey,
+:197-380 PaillierPrivateKey, :383-439 PaillierPrivateKeyring), with the arithmetic delegated to a
+per-key GPU Engine and batched siblings (`*_batch`) added next to every scalar method.
+
+Key generation and the once-per-key constants (p_inverse, hp, hq) are cold, host-side integer work
+(out of the hot path); everything per-ciphertext runs on the GPU.
+"""
+import random
+
+try:
+    from collections.abc import Mapping
+except ImportError:  # pragma: no cover
+    Mapping = dict
+
+import numpy as np
+
+from . import util
+from ._engine import Engine, random_lt_n
+from .codec import EncodedNumber
+
+DEFAULT_KEYSIZE = 3072
+
+
+def generate_paillier_keypair(private_keyring=None, n_length=DEFAULT_KEYSIZE):
+    """New (PaillierPublicKey, PaillierPrivateKey) with an n of exactly n_length bits (phe/paillier.py:37-68)."""
+    half = n_length // 2
+    while True:
+        p = util.getprimeover(half)
+        q = p
+        while q == p:
+            q = util.getprimeover(half)
+        n = p * q
+        if n.bit_length() == n_length:
+            break
+    public_key = PaillierPublicKey(n)
+    private_key = PaillierPrivateKey(public_key, p, q)
+    if private_keyring is not None:
+        private_keyring.add(private_key)
+    return public_key, private_key
+
+
+class PaillierPublicKey(object):
+    def __init__(self, n):
+        self.g = n + 1
+        self.n = n
+        self.nsquare = n * n
+        self.max_int = n // 3 - 1
+        self._engine = None
+
+    # one GPU context per key, created on first use (a private key shares its context with its public key)
+    def _get_engine(self):
+        if self._engine is None:
+            self._engine = Engine(self.n)
+        return self._engine
+
+    def __repr__(self):
+        return "<PaillierPublicKey {}>".format(hex(hash(self))[2:][:10])
+
+    def __eq__(self, other):
+        return self.n == other.n
+
+    def __hash__(self):
+        return hash(self.n)
+
+    def __getstate__(self):  # engines hold device handles; keys pickle as plain numbers
+        return {"n": self.n}
+
+    def __setstate__(self, state):
+        self.__init__(state["n"])
+
+    def get_random_lt_n(self):
+        return random.SystemRandom().randrange(1, self.n)
+
+    # ---- scalar API (batch of one on the GPU) ---------------------------------------------------
+    def raw_encrypt(self, plaintext, r_value=None):
+        if not isinstance(plaintext, int):
+            raise TypeError('Expected int type plaintext but got: %s' % type(plaintext))
+        r = r_value or self.get_random_lt_n()          # falsy r_value (None, 0) => random, as in the reference
+        return self.raw_encrypt_batch([plaintext], [r])[0]
+
+    def encrypt(self, value, precision=None, r_value=None):
+        encoding = value if isinstance(value, EncodedNumber) else EncodedNumber.encode(self, value, precision)
+        return self.encrypt_encoded(encoding, r_value)
+
+    def encrypt_encoded(self, encoding, r_value):
+        from .ciphertext import EncryptedNumber
+        if r_value is None:
+            # fresh obfuscator: one fused launch (1 + n*m) * r^n, flagged obfuscated like
+            # encrypt_encoded + obfuscate() in the reference (phe/paillier.py:189-193)
+            c = self.raw_encrypt(encoding.encoding, self.get_random_lt_n())
+            number = EncryptedNumber(self, c, encoding.exponent)
+            number._EncryptedNumber__is_obfuscated = True
+            return number
+        c = self.raw_encrypt(encoding.encoding, r_value or 1)   # r_value == 0 => obfuscator 1, not obfuscated
+        return EncryptedNumber(self, c, encoding.exponent)
+
+    # ---- batched API ------------------------------------------------------------------------------
+    def raw_encrypt_batch(self, plaintexts, r_values=None):
+        """List of ints -> list of int ciphertexts; r_values=None draws fresh obfuscators."""
+        plaintexts = list(plaintexts)
+        for m in plaintexts:
+            if not isinstance(m, int):
+                raise TypeError('Expected int type plaintext but got: %s' % type(m))
+        if r_values is None:
+            r_values = random_lt_n(self.n, len(plaintexts))
+        eng = self._get_engine()
+        return eng.to_ints(eng.raw_encrypt(plaintexts, list(r_values)))
+
+    def encrypt_batch(self, values, precision=None, r_values=None):
+        """Encode + encrypt a whole sequence / numpy array -> EncryptedVector (one kernel launch)."""
+        from .ciphertext import EncryptedVector
+        encs, exps = EncodedNumber.encode_many(self, values, precision)
+        eng = self._get_engine()
+        fresh = r_values is None
+        if fresh:
+            r_values = random_lt_n(self.n, len(encs))
+        limbs = eng.raw_encrypt(encs, list(r_values))
+        return EncryptedVector(self, limbs, exps, obfuscated=fresh)
+
+
+class PaillierPrivateKey(object):
+    def __init__(self, public_key, p, q):
+        if not p * q == public_key.n:
+            raise ValueError('given public key does not match the given p and q.')
+        if p == q:
+            raise ValueError('p and q have to be different')
+        self.public_key = public_key
+        self.p, self.q = (q, p) if q < p else (p, q)
+        self.psquare = self.p * self.p
+        self.qsquare = self.q * self.q
+        self.p_inverse = util.invert(self.p, self.q)
+        self.hp = self.h_function(self.p, self.psquare)
+        self.hq = self.h_function(self.q, self.qsquare)
+        self._engine = None
+
+    @staticmethod
+    def from_totient(public_key, totient):
+        p_plus_q = public_key.n - totient + 1
+        p_minus_q = util.isqrt(p_plus_q * p_plus_q - public_key.n * 4)
+        q = (p_plus_q - p_minus_q) // 2
+        p = p_plus_q - q
+        if not p * q == public_key.n:
+            raise ValueError('given public key and totient do not match.')
+        return PaillierPrivateKey(public_key, p, q)
+
+    def _get_engine(self):
+        if self._engine is None:
+            self._engine = Engine(self.public_key.n, self.p, self.q, self.hp, self.hq, self.p_inverse)
+            if self.public_key._engine is None:
+                self.public_key._engine = self._engine
+        return self._engine
+
+    def __repr__(self):
+        return "<PaillierPrivateKey for {}>".format(repr(self.public_key))
+
+    def __eq__(self, other):
+        return self.p == other.p and self.q == other.q
+
+    def __hash__(self):
+        return hash((self.p, self.q))
+
+    def __getstate__(self):
+        return {"n": self.public_key.n, "p": self.p, "q": self.q}
+
+    def __setstate__(self, state):
+        self.__init__(PaillierPublicKey(state["n"]), state["p"], state["q"])
+
+    # once-per-key helpers, host integers (phe/paillier.py:356-364)
+    def h_function(self, x, xsquare):
+        return util.invert(self.l_function(util.powmod(self.public_key.g, x - 1, xsquare), x), x)
+
+    def l_function(self, x, p):
+        return (x - 1) // p
+
+    def crt(self, mp, mq):
+        u = (mq - mp) * self.p_inverse % self.q
+        return mp + u * self.p
+
+    # ---- scalar API ---------------------------------------------------------------------------------
+    def raw_decrypt(self, ciphertext):
+        if not isinstance(ciphertext, int):
+            raise TypeError('Expected ciphertext to be an int, not: %s' % type(ciphertext))
+        return self.raw_decrypt_batch([ciphertext])[0]
+
+    def decrypt(self, encrypted_number):
+        return self.decrypt_encoded(encrypted_number).decode()
+
+    def decrypt_encoded(self, encrypted_number, Encoding=None):
+        from .ciphertext import EncryptedNumber
+        if not isinstance(encrypted_number, EncryptedNumber):
+            raise TypeError('Expected encrypted_number to be an EncryptedNumber not: %s' % type(encrypted_number))
+        if self.public_key != encrypted_number.public_key:
+            raise ValueError('encrypted_number was encrypted against a different key!')
+        if Encoding is None:
+            Encoding = EncodedNumber
+        encoded = self.raw_decrypt(encrypted_number.ciphertext(be_secure=False))
+        return Encoding(self.public_key, encoded, encrypted_number.exponent)
+
+    # ---- batched API ----------------------------------------------------------------------------------
+    def raw_decrypt_batch(self, ciphertexts):
+        ciphertexts = list(ciphertexts)
+        for c in ciphertexts:
+            if not isinstance(c, int):
+                raise TypeError('Expected ciphertext to be an int, not: %s' % type(c))
+        eng = self._get_engine()
+        # ciphertexts are residues mod n^2; reduce stray larger ints exactly like powmod would
+        return eng.to_ints(eng.raw_decrypt([c % self.public_key.nsquare for c in ciphertexts]))
+
+    def decrypt_batch(self, vector, Encoding=None):
+        """EncryptedVector (or list of EncryptedNumber) -> list of decoded ints/floats."""
+        from .ciphertext import EncryptedVector
+        if not isinstance(vector, EncryptedVector):
+            vector = EncryptedVector.from_numbers(self.public_key, vector)
+        if self.public_key != vector.public_key:
+            raise ValueError('encrypted_number was encrypted against a different key!')
+        eng = self._get_engine()
+        plain = eng.to_ints(eng.raw_decrypt(vector.limbs(be_secure=False)))
+        return (Encoding or EncodedNumber).decode_many(self.public_key, plain, vector.exponents)
+
+
+class PaillierPrivateKeyring(Mapping):
+    def __init__(self, private_keys=None):
+        private_keys = private_keys or []
+        self.__keyring = {k.public_key: k for k in private_keys}
+
+    def __getitem__(self, key):
+        return self.__keyring[key]
+
+    def __len__(self):
+        return len(self.__keyring)
+
+    def __iter__(self):
+        return iter(self.__keyring)
+
+    def __delitem__(self, public_key):
+        del self.__keyring[public_key]
+
+    def add(self, private_key):
+        if not isinstance(private_key, PaillierPrivateKey):
+            raise TypeError("private_key should be of type PaillierPrivateKey, not %s" % type(private_key))
+        self.__keyring[private_key.public_key] = private_key
+
+    def decrypt(self, encrypted_number):
+        return self.__keyring[encrypted_number.public_key].decrypt(encrypted_number)

@@ -1,0 +1,52 @@
+"""Multi-GPU sharding: one process per GPU, contiguous batch shards, no data-path collective.
+
+Every element of a Paillier batch is independent and the key constants are a few KiB, so the batch is cut into
+contiguous ranges `[rank*B/G, (rank+1)*B/G)`.  Each rank runs the ordinary single-GPU entry
+points on its shard.  The only exchange step that can be needed is the final concatenation of ciphertext
+shards on every device: `all_gather_rows` does it with one `all_gather_into_tensor` (RCCL over xGMI when the
+process group is "nccl"; the same code runs on "gloo" for the CPU tests).
+"""
+import numpy as np
+
+
+def shard_bounds(total, world_size, rank):
+    """Contiguous, balanced split: the first `total % world_size` ranks get one extra row."""
+    base, extra = divmod(total, world_size)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def shard_sizes(total, world_size):
+    return [shard_bounds(total, world_size, r)[1] - shard_bounds(total, world_size, r)[0] for r in range(world_size)]
+
+
+def my_shard(array, world_size, rank):
+    lo, hi = shard_bounds(len(array), world_size, rank)
+    return array[lo:hi]
+
+
+def all_gather_rows(local_rows, total_rows, group=None):
+    """Concatenate per-rank row blocks (torch tensor (rows_r, width), any integer dtype) into (total_rows, width)
+    on every rank.  Shards may differ by one row; they are padded to the largest shard for the collective."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    sizes = shard_sizes(total_rows, world)
+    width = local_rows.shape[1]
+    biggest = max(sizes)
+    padded = local_rows
+    if local_rows.shape[0] < biggest:
+        pad = torch.zeros((biggest - local_rows.shape[0], width), dtype=local_rows.dtype, device=local_rows.device)
+        padded = torch.cat([local_rows, pad])
+    out = torch.empty((world * biggest, width), dtype=local_rows.dtype, device=local_rows.device)
+    dist.all_gather_into_tensor(out, padded.contiguous(), group=group)
+    if all(s == biggest for s in sizes):
+        return out
+    return torch.cat([out[r * biggest:r * biggest + sizes[r]] for r in range(world)])
+
+
+def gather_ciphertexts(local_limbs, total_rows, group=None):
+    """numpy (rows_r, ct_limbs) uint32 -> numpy (total_rows, ct_limbs) uint32 on every rank (host tensors)."""
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(local_limbs).view(np.int32))
+    return all_gather_rows(t, total_rows, group).numpy().view(np.uint32)

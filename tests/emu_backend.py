@@ -1,0 +1,92 @@
+"""TEST INFRASTRUCTURE: an emulator-backed stand-in for phe._native.Context.
+
+Lets the host-side Python package (python-paillier_amd/phe) be exercised on a CPU-only box: the calls
+that would go through the C-ABI to the GPU are served by tests/emu/libphe_emu.so, i.e. by the same
+device algorithm headers compiled for the host on the fiber wave emulator.  Installed only by tests
+(monkeypatching phe._native.Context); the product has no such path.
+"""
+import numpy as np
+
+from emu_lib import Emu
+
+_emu = None
+
+
+def emu():
+    global _emu
+    if _emu is None:
+        _emu = Emu()
+    return _emu
+
+
+class EmuContext:
+    def __init__(self, n, p=None, q=None, hp=None, hq=None, p_inverse=None, device=0, n_limbs=None):
+        from phe import _native
+        self._native = _native
+        self.n = int(n)
+        self.n_limbs = n_limbs or _native.limbs_for_bits(self.n.bit_length())
+        self.ct_limbs = 2 * self.n_limbs
+        self.device = device
+        self.has_private = p is not None
+        self._n_arr = _native.int_to_limbs(self.n, self.n_limbs)
+        self._nsq_arr = _native.int_to_limbs(self.n * self.n, self.ct_limbs)
+        if self.has_private:
+            if p * q != n:
+                raise ValueError("given public key does not match the given p and q.")
+            pq = _native.limbs_for_bits(max(int(p).bit_length(), int(q).bit_length()))
+            self._key = [_native.int_to_limbs(v, pq) for v in (p, q, hp, hq, p_inverse)]
+
+    def close(self):
+        pass
+
+    def info(self):
+        return {"n_limbs": self.n_limbs, "ct_limbs": self.ct_limbs, "emulated": True}
+
+    def encrypt(self, m, r):
+        if m.shape[0] == 0:
+            return np.zeros((0, self.ct_limbs), np.uint32)
+        return emu().encrypt(self._n_arr, np.ascontiguousarray(m), np.ascontiguousarray(r))
+
+    def obfuscate(self, c_in, r):
+        if c_in.shape[0] == 0:
+            return c_in.copy()
+        return emu().obfuscate(self._n_arr, np.ascontiguousarray(c_in), np.ascontiguousarray(r))
+
+    def decrypt(self, c):
+        if not self.has_private:
+            raise ValueError("decrypt needs a private-key context")
+        if c.shape[0] == 0:
+            return np.zeros((0, self.n_limbs), np.uint32)
+        return emu().decrypt(*self._key, self.n_limbs, np.ascontiguousarray(c))
+
+    def mulmod(self, a, b):
+        if a.shape[0] == 0:
+            return a.copy()
+        return emu().mulmod(self._nsq_arr, np.ascontiguousarray(a), np.ascontiguousarray(b))
+
+    def powmod(self, base, exps):
+        if base.shape[0] == 0:
+            return base.copy()
+        return emu().powmod_var(self._nsq_arr, np.ascontiguousarray(base), np.ascontiguousarray(exps))
+
+    def invert(self, a):
+        # the product runs a mulmod product tree on the GPU plus one scalar inversion; the emulator
+        # backend takes the scalar inverses directly (the tree itself is covered by the GPU tests)
+        nsq = self.n * self.n
+        out = []
+        for i, v in enumerate(self._native.limbs_to_ints(a)):
+            try:
+                out.append(pow(v, -1, nsq))
+            except ValueError:
+                err = ZeroDivisionError("invert() no inverse exists")
+                err.bad_index = i
+                raise err
+        return self._native.ints_to_limbs(out, self.ct_limbs)
+
+
+def install(monkeypatch=None):
+    from phe import _native
+    if monkeypatch is not None:
+        monkeypatch.setattr(_native, "Context", EmuContext)
+    else:
+        _native.Context = EmuContext

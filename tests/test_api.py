@@ -1,0 +1,284 @@
+"""The drop-in `phe` API (python-paillier_amd/phe), exercised through both backends:
+
+  * backend "emu" (CPU, default run): phe._native.Context replaced by tests/emu_backend.EmuContext, i.e. the
+    device algorithm on the wave emulator — checks the host-side logic (encoding, exponent alignment,
+    obfuscation state machine, error types, batched containers) on a GPU-less box;
+  * backend "hip" (-m gpu): the real C-ABI / HIP kernels.
+
+Expected values come from tests/golden (real reference) and from the behaviours the reference's own
+tests pin (cited inline as phe/tests/paillier_test.py:<line>).
+"""
+import math
+import pickle
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PKG, load_golden, load_kat
+
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+import phe  # noqa: E402
+from phe import paillier  # noqa: E402
+
+
+def H(x):
+    return int(x, 16)
+
+
+@pytest.fixture(params=["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request, monkeypatch):
+    if request.param == "emu":
+        import emu_backend
+        emu_backend.install(monkeypatch)
+    return request.param
+
+
+@pytest.fixture
+def keys(backend):
+    g = load_golden(256)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["q"]), H(g["p"]))     # unordered on purpose
+    return g, pub, priv
+
+
+def test_public_names():
+    for name in ["EncodedNumber", "generate_paillier_keypair", "EncryptedNumber", "PaillierPrivateKey",
+                 "PaillierPublicKey", "PaillierPrivateKeyring", "util", "paillier", "encoding"]:
+        assert hasattr(phe, name)
+    assert paillier.DEFAULT_KEYSIZE == 3072
+
+
+def test_private_key_constants_match_reference():
+    g = load_golden(1024)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["q"]), H(g["p"]))
+    assert (priv.p, priv.q, priv.hp, priv.hq, priv.p_inverse) == tuple(H(g[k]) for k in ("p", "q", "hp", "hq", "p_inverse"))
+    assert priv == paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))       # paillier_test.py:82-86
+    with pytest.raises(ValueError):
+        paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]) + 2)
+    totient = (priv.p - 1) * (priv.q - 1)
+    assert paillier.PaillierPrivateKey.from_totient(pub, totient) == priv        # paillier_test.py:73-80
+    assert pickle.loads(pickle.dumps(priv)) == priv
+
+
+def test_encoding_matches_reference_fixture():
+    """encode() exponents / encodings against ciphertexts the real reference produced (host logic only)."""
+    for bits in (256, 1024):
+        g = load_golden(bits)
+        pub = paillier.PaillierPublicKey(H(g["n"]))
+        from oracle.paillier_oracle import PyPublic, PyPrivate
+        opub = PyPublic(pub.n)
+        opriv = PyPrivate(opub, H(g["p"]), H(g["q"]))
+        for e in g["encrypt_api"]:
+            value = eval(e["value"])
+            enc = phe.EncodedNumber.encode(pub, value)
+            assert enc.exponent == e["exponent"]
+            assert opub.raw_encrypt(enc.encoding, H(e["r"])) == H(e["c"])
+            back = phe.EncodedNumber(pub, opriv.raw_decrypt(H(e["c"])), e["exponent"]).decode()
+            assert repr(back) == e["decrypted"]
+
+
+def test_encode_many_equals_scalar_encode():
+    pub = paillier.PaillierPublicKey(H(load_golden(1024)["n"]))
+    rs = np.random.Generator(np.random.PCG64(3))
+    floats = np.concatenate([rs.standard_normal(200) * 10.0 ** rs.integers(-30, 30, 200), [0.0, -0.0, 5e-324, 1.5]])
+    encs, exps = phe.EncodedNumber.encode_many(pub, floats)
+    for v, a, b in zip(floats.tolist(), encs, exps):
+        s = phe.EncodedNumber.encode(pub, v)
+        assert (s.encoding, s.exponent) == (a, b)
+    ints = rs.integers(-2 ** 62, 2 ** 62, 100)
+    encs, exps = phe.EncodedNumber.encode_many(pub, ints)
+    assert exps == [0] * 100 and encs == [int(v) % pub.n for v in ints]
+    assert phe.EncodedNumber.decode_many(pub, encs, exps) == ints.tolist()
+    with pytest.raises(ValueError):
+        phe.EncodedNumber.encode_many(paillier.PaillierPublicKey(126869), np.array([1e9]))
+
+
+def test_encoded_number_errors():
+    pub = paillier.PaillierPublicKey(H(load_golden(256)["n"]))
+    with pytest.raises(TypeError):
+        phe.EncodedNumber.encode(pub, "1")
+    with pytest.raises(TypeError):
+        phe.EncodedNumber.encode(pub, np.int64(3))            # np.int64 is not int
+    with pytest.raises(ValueError):
+        phe.EncodedNumber.encode(pub, pub.max_int + 1)
+    with pytest.raises(OverflowError):
+        phe.EncodedNumber(pub, pub.max_int + 5, 0).decode()
+    with pytest.raises(ValueError):
+        phe.EncodedNumber(pub, pub.n, 0).decode()
+    e = phe.EncodedNumber.encode(pub, 1.5)
+    with pytest.raises(ValueError):
+        e.decrease_exponent_to(e.exponent + 1)
+    assert e.decrease_exponent_to(e.exponent - 3).decode() == 1.5
+
+
+def test_raw_kat(backend):
+    k = load_kat()
+    pub = paillier.PaillierPublicKey(k["n"])
+    priv = paillier.PaillierPrivateKey(pub, k["p"], k["q"])
+    assert pub.raw_encrypt(k["m"], k["r"]) == k["c"]                              # paillier_test.py:128-136
+    assert priv.raw_decrypt(k["c"]) == k["m"]
+    assert pub.encrypt(k["m"], r_value=k["r"]).ciphertext(False) == k["c"]        # :138-142
+    assert pub.encrypt(1, r_value=1).ciphertext(False) == k["encrypt_1_r_1"]      # :144-149
+    assert pub.encrypt(1).ciphertext(False) != k["encrypt_1_r_1"]                 # random r
+    with pytest.raises(TypeError):
+        pub.raw_encrypt("123")                                                    # :157-164
+    with pytest.raises(TypeError):
+        priv.raw_decrypt("935906717")
+
+
+def test_modulo_n_wrap(keys):
+    _, pub, priv = keys
+    for m, want in ((pub.n - 1, pub.n - 1), (pub.n, 0), (pub.n + 1, 1)):          # paillier_test.py:114-126
+        assert priv.raw_decrypt(pub.raw_encrypt(m)) == want
+
+
+def test_golden_api_vectors(keys):
+    g, pub, priv = keys
+    for e in g["encrypt_api"]:
+        value = eval(e["value"])
+        enc = pub.encrypt(value, r_value=H(e["r"]))
+        assert enc.ciphertext(False) == H(e["c"]) and enc.exponent == e["exponent"]
+        assert repr(priv.decrypt(enc)) == e["decrypted"]
+
+
+def test_obfuscation_state_machine(keys):
+    _, pub, priv = keys
+    a = pub.encrypt(3.25, r_value=12345)                   # explicit r: not flagged (paillier_test.py:1023-1039)
+    assert a._EncryptedNumber__is_obfuscated is False
+    c0 = a.ciphertext(be_secure=False)
+    c1 = a.ciphertext()                                    # obfuscates in place, once
+    assert a._EncryptedNumber__is_obfuscated is True and c1 != c0 and a.ciphertext() == c1
+    assert priv.decrypt(a) == 3.25
+    b = pub.encrypt(3.25)
+    assert b._EncryptedNumber__is_obfuscated is True
+    s = a + b
+    assert s._EncryptedNumber__is_obfuscated is False      # results of + and * are not obfuscated
+    assert (a * 2)._EncryptedNumber__is_obfuscated is False
+    z = pub.encrypt(7, r_value=0)
+    assert z.ciphertext(False) == (1 + pub.n * 7) % pub.nsquare and z._EncryptedNumber__is_obfuscated is False
+
+
+def test_homomorphic_arithmetic(keys):
+    _, pub, priv = keys
+    a, b = pub.encrypt(15), pub.encrypt(-1.125)
+    assert priv.decrypt(a + b) == 13.875
+    assert priv.decrypt(a + 5) == 20 and priv.decrypt(5 + a) == 20 and priv.decrypt(a + 0.5) == 15.5
+    assert priv.decrypt(a - b) == 16.125 and priv.decrypt(1 - a) == -14 and priv.decrypt(a - 20) == -5
+    assert priv.decrypt(a * 3) == 45 and priv.decrypt(-2 * a) == -30 and priv.decrypt(b * 0.5) == -0.5625
+    assert priv.decrypt(a / 4) == 3.75
+    assert priv.decrypt(a * 0) == 0
+    c = a * 1
+    assert c.ciphertext(False) == a.ciphertext(False)                                 # paillier_test.py:893-899
+    assert priv.decrypt(a + phe.EncodedNumber.encode(pub, 2.5)) == 17.5
+    assert priv.decrypt(a * phe.EncodedNumber.encode(pub, -2)) == -30
+    assert priv.decrypt(sum([a, b, a])) == 28.875                                     # __radd__ with 0
+    with pytest.raises(NotImplementedError):
+        a * b
+    before = (a.ciphertext(False), a.exponent)
+    _ = a + pub.encrypt(0.001)
+    assert (a.ciphertext(False), a.exponent) == before                                # operands untouched (:780-790)
+
+
+def test_exponent_alignment_and_decrease(keys):
+    _, pub, priv = keys
+    a = pub.encrypt(1.0 / 3)
+    b = pub.encrypt(2 ** 40)
+    s = a + b
+    assert s.exponent == min(a.exponent, b.exponent)
+    assert math.isclose(priv.decrypt(s), 2 ** 40 + 1.0 / 3, rel_tol=1e-15)
+    low = a.decrease_exponent_to(a.exponent - 5)
+    assert low.exponent == a.exponent - 5 and priv.decrypt(low) == priv.decrypt(a)
+    with pytest.raises(ValueError):
+        a.decrease_exponent_to(a.exponent + 1)
+
+
+def test_key_mismatch_and_type_errors(keys):
+    g, pub, priv = keys
+    g2 = load_golden(1024)
+    pub2 = paillier.PaillierPublicKey(H(g2["n"]))
+    priv2 = paillier.PaillierPrivateKey(pub2, H(g2["p"]), H(g2["q"]))
+    a = pub.encrypt(1, r_value=1)
+    with pytest.raises(ValueError):
+        priv2.decrypt(a)                                                              # paillier_test.py:468-473
+    with pytest.raises(TypeError):
+        priv.decrypt(a.ciphertext(False))
+    a2 = paillier.EncryptedNumber(pub2, 5, 0)
+    with pytest.raises(ValueError):
+        a + a2
+    with pytest.raises(ValueError):
+        a + phe.EncodedNumber.encode(pub2, 1)
+    with pytest.raises(ValueError):
+        a._raw_mul(pub.n)
+    with pytest.raises(ValueError):
+        a._raw_mul(-1)
+    with pytest.raises(TypeError):
+        a._raw_mul(1.5)
+    with pytest.raises(TypeError):
+        paillier.EncryptedNumber("key", 5)
+
+
+def test_overflow_detection(keys):
+    _, pub, priv = keys
+    big = pub.encrypt(pub.max_int)
+    with pytest.raises(OverflowError):
+        priv.decrypt(big + big)                                                       # paillier_test.py:608-635
+
+
+def test_keyring(keys):
+    _, pub, priv = keys
+    ring = paillier.PaillierPrivateKeyring()
+    ring.add(priv)
+    assert len(ring) == 1 and ring[pub] == priv
+    assert ring.decrypt(pub.encrypt(25, r_value=3)) == 25
+    with pytest.raises(TypeError):
+        ring.add(pub)
+    del ring[pub]
+    with pytest.raises(KeyError):
+        ring.decrypt(pub.encrypt(1, r_value=3))
+
+
+def test_numpy_interop(keys):
+    _, pub, priv = keys
+    vals = [0.5, -1.25, 3.0, 4.75]
+    enc = [pub.encrypt(v) for v in vals]
+    assert priv.decrypt(np.mean(enc)) == np.mean(vals)                                # math_test.py:26-42
+    w = [2.0, -1.0, 0.5, 4]
+    assert priv.decrypt(np.dot(enc, w)) == float(np.dot(vals, w))                     # math_test.py:44-58
+
+
+def test_encrypted_vector(keys):
+    g, pub, priv = keys
+    vals = np.array([0.5, -1.25, 3.0, 4.75, 1e-3, -7.0])
+    rs = [H(e["r"]) for e in g["raw_encrypt"][3:9]]
+    vec = pub.encrypt_batch(vals, r_values=rs)
+    singles = [pub.encrypt(float(v), r_value=r) for v, r in zip(vals, rs)]
+    assert vec.ciphertexts(be_secure=False) == [s.ciphertext(False) for s in singles]   # batch == scalar path, bit for bit
+    assert vec.exponents == [s.exponent for s in singles]
+    assert priv.decrypt_batch(vec) == vals.tolist()
+    assert priv.decrypt(vec[2]) == 3.0 and len(vec[1:3]) == 2
+    w = [2.0, -3.0, 0.5, 4, 1000.0, 0.25]
+    prod = vec * w
+    want = [priv.decrypt(s * x) for s, x in zip(singles, w)]
+    assert prod.ciphertexts(False) == [(s * x).ciphertext(False) for s, x in zip(singles, w)]
+    assert priv.decrypt_batch(prod) == want
+    other = pub.encrypt_batch(np.array([1.0, 2.0, 3.0, 4.0, 5.0, 6.0]), r_values=rs)
+    total = vec + other
+    assert total.ciphertexts(False) == [(a + b).ciphertext(False) for a, b in zip(singles, other.to_numbers())]
+    assert priv.decrypt_batch(vec + 1.5) == [v + 1.5 for v in vals.tolist()]
+    assert priv.decrypt_batch(vec - other) == [a - b for a, b in zip(vals.tolist(), [1.0, 2.0, 3.0, 4.0, 5.0, 6.0])]
+    assert math.isclose(priv.decrypt(vec.sum()), float(vals.sum()), rel_tol=1e-12)
+    assert math.isclose(priv.decrypt(vec.dot(w)), float(np.dot(vals, w)), rel_tol=1e-12)
+    fresh = pub.encrypt_batch([1, 2, 3])
+    assert all(fresh._obfuscated) and priv.decrypt_batch(fresh) == [1, 2, 3]
+    un = pub.encrypt_batch([1, 2, 3], r_values=[1, 1, 1])
+    before = un.ciphertexts(be_secure=False)
+    after = un.ciphertexts()                        # be_secure: obfuscates the whole vector once
+    assert before != after and all(un._obfuscated) and un.ciphertexts() == after
+    assert priv.decrypt_batch(un) == [1, 2, 3]
+    with pytest.raises(ValueError):
+        priv.decrypt_batch(paillier.EncryptedVector(paillier.PaillierPublicKey(H(load_golden(1024)["n"])),
+                                                    np.zeros((1, 64), np.uint32), [0]))

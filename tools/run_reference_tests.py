@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Run the reference's own unittest suites (read-only, from /root/reference/phe/tests) against the drop-in
+package in python-paillier_amd/, in the build container (no GPU): phe._native.Context is replaced by the
+emulator-backed stand-in from tests/emu_backend.py, and the default key size is lowered so the fiber
+emulator finishes in minutes.  Validation aid only; nothing is copied from the reference.
+
+usage: python tools/run_reference_tests.py [default_key_bits] [pytest args...]
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "python-paillier_amd"))
+
+import phe  # noqa: E402  (ours: must be first on sys.path)
+assert phe.__file__.startswith(os.path.join(ROOT, "python-paillier_amd")), phe.__file__
+import emu_backend  # noqa: E402
+from phe import keys  # noqa: E402
+
+emu_backend.install()
+bits = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 256
+keys.generate_paillier_keypair.__defaults__ = (None, bits)
+
+import pytest  # noqa: E402
+
+args = [a for a in sys.argv[1:] if not a.isdigit()] or [
+    "/root/reference/phe/tests/paillier_test.py", "/root/reference/phe/tests/math_test.py",
+    "/root/reference/phe/tests/util_test.py"]
+sys.exit(pytest.main(["--import-mode=importlib", "-p", "no:cacheprovider", "-q", "--no-header", "-rN"] + args))
