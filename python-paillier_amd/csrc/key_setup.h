@@ -128,44 +128,95 @@ inline Big inv_mod_pow2(const Big& a, int h) {
     return x;
 }
 
-// Everything mont_core.h needs for one modulus, padded to S = 16*L words.
-struct ModulusPack {
-    int L = 0, S = 0;
-    Big n, r1, r2, r3, aux;
-    uint32_t n0inv = 0;
-};
+// ---- radix-2^29 geometry -----------------------------------------------------------------------
+constexpr int kRadixBits = 29;
 
-inline int pick_L(int limbs) {
-    static const int kSupported[] = {1, 2, 3, 4, 6, 8, 12, 16};
-    for (int L : kSupported)
-        if (16 * L >= limbs) return L;
-    return 0;  // modulus too wide for the compiled kernels
+// a Big (32-bit limbs) -> `count` limbs of 29 bits
+inline std::vector<uint32_t> to_r29(const Big& a, int count) {
+    std::vector<uint32_t> r((size_t)count, 0u);
+    for (int j = 0; j < count; ++j) {
+        const int bit = kRadixBits * j;
+        const size_t q = (size_t)(bit >> 5);
+        const int o = bit & 31;
+        uint64_t w = q < a.size() ? a[q] : 0u;
+        if (q + 1 < a.size()) w |= (uint64_t)a[q + 1] << 32;
+        r[(size_t)j] = (uint32_t)(w >> o) & ((1u << kRadixBits) - 1u);
+    }
+    if (big_bits(a) > kRadixBits * count) throw std::invalid_argument("value does not fit the limb group");
+    return r;
 }
 
-// aux_src (optional, < N): aux = aux_src * R mod N.  min_limbs forces a minimum width (both CRT
-// halves of a private key share one L).
-inline ModulusPack build_modulus(const Big& N_any, const Big* aux_src, int min_limbs = 0) {
-    const int limbs = std::max((big_bits(N_any) + 31) / 32, min_limbs);
+// Limb-group geometry: G lanes x L limbs of 29 bits, S = G*L.  The compiled kernels exist for the
+// (G, L) pairs below; a modulus needs 29*S >= bits(N) + 4 (R = 2^(29 S) >= 16 N keeps products of
+// values in [0, 2N) inside [0, 2N)), and S must also cover the caller's 32-bit-word width.
+struct Geometry {
+    int G = 0, L = 0;
+    int S() const { return G * L; }
+};
+static const int kL16[] = {1, 2, 3, 5, 7, 9, 14, 18};
+static const int kL8[] = {5, 9, 14, 18};
+
+inline Geometry pick_geometry(int modulus_bits, int min_bits, int prefer_group) {
+    const int need_bits = std::max(modulus_bits + 4, min_bits);
+    const int need = (need_bits + kRadixBits - 1) / kRadixBits;
+    Geometry best;
+    if (prefer_group == 8) {
+        for (int L : kL8)
+            if (8 * L >= need && L <= 31) {
+                best.G = 8;
+                best.L = L;
+                return best;
+            }
+    }
+    for (int L : kL16)
+        if (16 * L >= need) {
+            best.G = 16;
+            best.L = L;
+            return best;
+        }
+    return best;  // G == 0: too wide for the compiled kernels
+}
+
+// Everything mont_core.h needs for one modulus: S limbs of 29 bits each, R = 2^(29 S).
+struct ModulusPack {
+    int G = 0, L = 0, S = 0;
+    int bits = 0;
+    std::vector<uint32_t> n, r1, r2, r3, aux;  // 29-bit limbs
+    uint32_t n0inv = 0;                        // -N^-1 mod 2^29
+};
+
+// aux_src (optional, < N): aux = aux_src * R mod N.  min_bits: width the group must also cover
+// (the caller's 32-bit-word rows; both CRT halves of a private key share one geometry).
+inline ModulusPack build_modulus(const Big& N_any, const Big* aux_src, int min_bits = 0, int prefer_group = 8) {
     ModulusPack m;
-    m.L = pick_L(limbs);
-    if (m.L == 0) throw std::invalid_argument("modulus wider than 8192 bits is not supported");
-    m.S = 16 * m.L;
-    m.n = big_resize(N_any, m.S);
-    if ((m.n[0] & 1u) == 0u) throw std::invalid_argument("modulus must be odd");
-    m.n0inv = neg_inv32(m.n[0]);
-    Big one((size_t)m.S, 0u);
+    m.bits = big_bits(N_any);
+    const Geometry geo = pick_geometry(m.bits, min_bits, prefer_group);
+    if (geo.G == 0) throw std::invalid_argument("modulus too wide for the compiled kernels (max 8344 bits)");
+    m.G = geo.G;
+    m.L = geo.L;
+    m.S = geo.S();
+    const int w32 = (m.bits + 31) / 32;
+    const Big N = big_resize(N_any, w32);
+    if ((N[0] & 1u) == 0u) throw std::invalid_argument("modulus must be odd");
+    Big one((size_t)w32, 0u);
     one[0] = 1;
-    if (big_cmp(one, m.n) >= 0) throw std::invalid_argument("modulus must be > 1");
-    m.r1 = big_shift_mod(one, 32 * m.S, m.n);
-    m.r2 = big_shift_mod(m.r1, 32 * m.S, m.n);
-    m.r3 = big_shift_mod(m.r2, 32 * m.S, m.n);
+    if (big_cmp(one, N) >= 0) throw std::invalid_argument("modulus must be > 1");
+    const int rbits = kRadixBits * m.S;
+    const Big r1 = big_shift_mod(one, rbits, N);
+    const Big r2 = big_shift_mod(r1, rbits, N);
+    const Big r3 = big_shift_mod(r2, rbits, N);
+    m.n = to_r29(N, m.S);
+    m.r1 = to_r29(r1, m.S);
+    m.r2 = to_r29(r2, m.S);
+    m.r3 = to_r29(r3, m.S);
     if (aux_src) {
-        Big a = big_resize(*aux_src, m.S);
-        if (big_cmp(a, m.n) >= 0) throw std::invalid_argument("aux value must be < modulus");
-        m.aux = big_shift_mod(a, 32 * m.S, m.n);
+        Big a = big_resize(*aux_src, w32);
+        if (big_cmp(a, N) >= 0) throw std::invalid_argument("aux value must be < modulus");
+        m.aux = to_r29(big_shift_mod(a, rbits, N), m.S);
     } else {
         m.aux.assign((size_t)m.S, 0u);
     }
+    m.n0inv = neg_inv32(N[0]) & ((1u << kRadixBits) - 1u);
     return m;
 }
 
@@ -267,19 +318,21 @@ inline TailPack build_tail(const Big& p_any, const Big& q_any, const Big& hp_any
 // Public-key side: modulus n^2, exponent n (phe/paillier.py:137, :622), aux = n*R for 1 + n*m.
 struct PublicPlan {
     int s1 = 0, s2 = 0;  // ABI widths: limbs of n / of a ciphertext (= 2*s1)
-    Big n;               // s1 limbs
+    Big n;               // s1 limbs (32-bit)
+    Big nsq32;           // n^2, s2 limbs (32-bit) — host-side scalar work of batched inversion
     ModulusPack nsq;
     Schedule exp_n;
 };
 
-inline PublicPlan build_public(const uint32_t* n, int n_limbs) {
+inline PublicPlan build_public(const uint32_t* n, int n_limbs, int prefer_group = 8) {
     PublicPlan P;
     P.s1 = n_limbs;
     P.s2 = 2 * n_limbs;
     P.n = big_from(n, n_limbs, n_limbs);
     if (big_bits(P.n) < 2) throw std::invalid_argument("n too small");
     Big nsq = big_mul(P.n, P.n);
-    P.nsq = build_modulus(nsq, &P.n);
+    P.nsq32 = big_resize(nsq, P.s2);
+    P.nsq = build_modulus(nsq, &P.n, 32 * P.s2, prefer_group);
     P.exp_n = build_schedule(P.n);
     return P;
 }
@@ -293,7 +346,7 @@ struct PrivatePlan {
 };
 
 inline PrivatePlan build_private(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const uint32_t* hq,
-                                 const uint32_t* p_inverse, int pq_limbs, int n_limbs) {
+                                 const uint32_t* p_inverse, int pq_limbs, int n_limbs, int prefer_group = 8) {
     PrivatePlan P;
     P.s1 = n_limbs;
     P.s2 = 2 * n_limbs;
@@ -301,10 +354,12 @@ inline PrivatePlan build_private(const uint32_t* p, const uint32_t* q, const uin
     P.tail = build_tail(bp, bq, big_from(hp, pq_limbs, pq_limbs), big_from(hq, pq_limbs, pq_limbs),
                         big_from(p_inverse, pq_limbs, pq_limbs));
     Big psq = big_mul(bp, bp), qsq = big_mul(bq, bq);
-    // the wide input c (s2 limbs) is split at S words, so S >= s1 is required
-    const int min_limbs = std::max(n_limbs, (big_bits(qsq) + 31) / 32);
-    P.psq = build_modulus(psq, nullptr, min_limbs);
-    P.qsq = build_modulus(qsq, nullptr, min_limbs);
+    // both halves share one geometry (sized for q^2, the larger); the wide input c (s2 32-bit words) is
+    // split at 2^(29 S), so 2*29*S must cover it
+    const int min_bits = std::max(big_bits(qsq) + 4, 16 * P.s2);
+    P.psq = build_modulus(psq, nullptr, min_bits, prefer_group);
+    P.qsq = build_modulus(qsq, nullptr, min_bits, prefer_group);
+    if (P.psq.L != P.qsq.L || P.psq.G != P.qsq.G) throw std::invalid_argument("p and q too unbalanced");
     Big one((size_t)pq_limbs, 0u);
     one[0] = 1;
     Big pm1 = bp, qm1 = bq;

@@ -1,4 +1,4 @@
-// mont_core.h — fixed-width multi-precision Montgomery arithmetic for one 16-lane limb group.
+// mont_core.h — carry-free radix-2^29 Montgomery arithmetic for one limb group of G lanes.
 //
 // Replaces, for whole batches, what the reference delegates to gmpy2/libgmp one scalar at a time:
 //   phe/util.py:38-50  powmod  -> modexp_uniform_body / modexp_var_body
@@ -7,196 +7,200 @@
 //   phe/paillier.py:102-139 raw_encrypt, :603-624 obfuscate, :328-354 raw_decrypt (the two CRT
 //   half-exponentiations; the L/CRT tail is decrypt_tail.h), :705-719 _raw_add, :721-751 _raw_mul.
 //
-// Number layout.  A modulus N < W^S (W = 2^32, S = 16*L limbs) is handled by one DPP row of 16
-// lanes; lane g keeps limbs [g*L, (g+1)*L) in VGPRs ("blocked" layout).  Four rows share a
-// wavefront and never interact.  Montgomery radix is R = W^S.
+// Why radix 2^29.  Calibration on gfx950 (csrc/microbench.hip, profiles/microbench_r01.json): a
+// v_mad_u64_u32 issues in ~4.8 cycles, but so does every instruction that touches a carry flag
+// (v_add_co / v_addc_co ~4.4), and a full-radix (2^32) CIOS needs ~1.1 of those per multiply.  With
+// 29-bit limbs held in 32-bit lanes the 58-bit products are summed directly in the 64-bit addend of
+// v_mad_u64_u32: a column accumulator absorbs 2 products per row for as many rows as it stays in a
+// lane (L <= 31 keeps it below 2^64), so the inner loop is multiply-accumulates only.  The price is
+// (ceil(bits/29)/ceil(bits/32))^2 ~ 1.27x more multiplies, a net ~1.5x fewer issue cycles.
 //
-// montmul() is word-serial CIOS: per limb a_i of the multiplier (broadcast-read from LDS, four
-// limbs per ds_read_b128)
-//     t += a_i * b            L  v_mad_u64_u32 + L+1 v_addc   (lane-local; carries between lanes
-//     m  = t_0 * (-N^-1)      1  v_mul_lo + 1 DPP row_newbcast  are parked in a per-lane overflow
-//     t += m * N              L  v_mad_u64_u32 + L+1 v_addc     word `th`, resolved once at the end)
-//     t >>= 32                1  DPP row_shl:1 + 2 adds
-// followed by one carry-lookahead across the row (two ballots + SALU mask arithmetic) and the
-// final conditional subtraction, so every result is the canonical residue in [0, N) — which is
-// what makes the GPU result bit-identical to gmpy2's.
+// Layout.  A modulus N with 29*S >= bits(N) + 4 (S = G*L limbs) is owned by a group of G lanes
+// (G = 16: one DPP row, G = 8: half a row); lane g keeps limbs [g*L, (g+1)*L).  R = 2^(29*S) >= 16 N.
 //
-// This header is written only against the `wave::` primitives (wave_gfx950.h on the device,
-// tests/emu/wave_emu.h for CPU tests) and is otherwise plain C++.
+// montmul (word-serial, per 29-bit digit a_i of the multiplier, broadcast-read from LDS):
+//     acc[k] += a_i * b[k]                      L  v_mad_u64_u32
+//     m = (acc[0] * -N^-1) mod 2^29 of lane 0   v_mul_lo, v_and, DPP broadcast
+//     acc[k] += m * n[k]                        L  v_mad_u64_u32
+//     shift by one limb: the low 29 bits of acc[0] (zero in lane 0) move to the top of the lane below
+//     (one DPP), the rest of acc[0] is added to acc[1]; accumulators rotate by renaming.
+// Values are kept in [0, 2N) between products (R >= 16N makes that closed under montmul) with limbs
+// "almost normalised" (< 2^29 + 2^8): one lane-local carry sweep and one neighbour hand-off per
+// product, no lane-to-lane ripple, no comparison.  Only a kernel's final result is made canonical
+// (full carry look-ahead over two ballots + conditional subtraction), which is what makes the output
+// bit-identical to gmpy2's canonical residues.
+//
+// Written only against the `wave::` primitives (wave_gfx950.h on the device,
+// tests/emu/wave_emu.h for CPU tests); otherwise plain C++.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
 
 namespace phe {
 
-constexpr int kRow = 16;     // lanes per limb group
-constexpr int kLdsPad = 4;   // words of padding after each row's LDS operand (keeps 16-B alignment)
+constexpr int kRadixBits = 29;
+constexpr uint32_t kLimbMask = (1u << kRadixBits) - 1u;
+constexpr int kLdsPad = 4;  // words of padding after each group's LDS operand (keeps 16-B alignment)
 
-constexpr uint64_t kRowLane0 = 0x0001000100010001ull;  // lane 0 of each of the 4 rows
-constexpr uint64_t kRowTop = 0x8000800080008000ull;    // lane 15 of each row
+template <int G>
+using Lanes = wave::Lanes<G>;
+
+template <int G>
+struct GroupMasks {
+    static constexpr uint64_t lane0 = (G == 16) ? 0x0001000100010001ull : 0x0101010101010101ull;
+    static constexpr uint64_t top = lane0 << (G - 1);
+};
 
 PHE_DEV uint32_t lane_bit(uint64_t mask, uint32_t lane) { return (uint32_t)(mask >> lane) & 1u; }
-PHE_DEV uint32_t row_top_bit(uint64_t mask, uint32_t lane) { return (uint32_t)(mask >> (lane | 15u)) & 1u; }
+template <int G>
+PHE_DEV uint32_t group_top_bit(uint64_t mask, uint32_t lane) { return (uint32_t)(mask >> (lane | (G - 1))) & 1u; }
 
-// Carry (or borrow) look-ahead across the 16 lanes of every row at once.
-//   gen  : lanes whose lane-local add produced a carry out
-//   prop : lanes that would pass an incoming carry on (all-ones sum / all-zero difference)
+// Carry (or borrow) look-ahead across the lanes of every group at once.
+//   gen  : lanes whose lane-local sweep produced a carry out
+//   prop : lanes that would pass an incoming carry on (all limbs 2^29-1 / all-zero difference)
 // gen and prop are disjoint by construction.  Returns the lanes that receive a carry-in;
-// out_top gets (at the top-lane bit of each row) whether the row as a whole carried out.
-PHE_DEV uint64_t row_carry_in(uint64_t gen, uint64_t prop, uint64_t& out_top) {
-    const uint64_t gs = (gen << 1) & ~kRowLane0;
-    const uint64_t pm = prop & ~kRowTop;  // the top lane must not ripple into the next row's field
+// out_top gets (at the top-lane bit of each group) whether the group as a whole carried out.
+template <int G>
+PHE_DEV uint64_t group_carry_in(uint64_t gen, uint64_t prop, uint64_t& out_top) {
+    const uint64_t gs = (gen << 1) & ~GroupMasks<G>::lane0;
+    const uint64_t pm = prop & ~GroupMasks<G>::top;  // a top lane must not ripple into the next group's field
     const uint64_t cin = (gs + pm) ^ pm;
-    out_top = (gen | (prop & cin)) & kRowTop;
+    out_top = (gen | (prop & cin)) & GroupMasks<G>::top;
     return cin;
 }
 
-// Finish a lane-local addition: `c` is this lane's carry out of its L limbs.  Propagates carries
-// lane to lane; returns (top-lane bits) the rows whose value overflowed W^S.
-template <int L>
-PHE_DEV uint64_t resolve_carries(uint32_t (&t)[L], uint32_t c, uint32_t lane) {
-    uint32_t ones = 0xffffffffu;
-#pragma unroll
-    for (int k = 0; k < L; ++k) ones &= t[k];
-    const uint64_t gen = wave::ballot(c != 0);
-    const uint64_t prop = wave::ballot(ones == 0xffffffffu);
-    uint64_t out_top;
-    const uint64_t cin = row_carry_in(gen, prop, out_top);
-    uint32_t ci = lane_bit(cin, lane);
-#pragma unroll
-    for (int k = 0; k < L; ++k) t[k] = wave::addc(t[k], 0u, ci, ci);
-    return out_top;
-}
-
-// t <- t - N if t (plus the overflow bit ov_top) >= N.  Requires value < 2N.
-template <int L>
-PHE_DEV void cond_sub(uint32_t (&t)[L], const uint32_t (&n)[L], uint64_t ov_top, uint32_t lane) {
-    uint32_t d[L];
-    uint32_t bo = 0, nz = 0;
+// ---- normalisation ---------------------------------------------------------------------------
+// 64-bit column sums -> almost-normalised 32-bit limbs (< 2^29 + 2^8), value unchanged.
+template <int G, int L>
+PHE_DEV void normalize_partial(uint32_t (&t)[L], const uint64_t (&acc)[L], const Lanes<G>& ln) {
+    uint64_t carry = 0;
 #pragma unroll
     for (int k = 0; k < L; ++k) {
-        d[k] = wave::subb(t[k], n[k], bo, bo);
+        const uint64_t v = acc[k] + carry;
+        t[k] = (uint32_t)v & kLimbMask;
+        carry = v >> kRadixBits;
+    }
+    // the lane's carry (< 2^36) belongs to limb 0 of the lane above; the top lane's is 0 (value < R)
+    const uint32_t inc_lo = wave::grp_up1<G>((uint32_t)carry, ln);
+    const uint32_t inc_hi = wave::grp_up1<G>((uint32_t)(carry >> 32), ln);
+    const uint64_t v = (uint64_t)t[0] + (((uint64_t)inc_hi << 32) | inc_lo);
+    t[0] = (uint32_t)v & kLimbMask;
+    const uint32_t c2 = (uint32_t)(v >> kRadixBits);  // < 2^8
+    if constexpr (L > 1) {
+        t[1] += c2;
+    } else {
+        t[0] += wave::grp_up1<G>(c2, ln);
+    }
+}
+
+// almost-normalised -> canonical limbs (< 2^29) with all lane-to-lane carries resolved
+template <int G, int L>
+PHE_DEV void normalize_full(uint32_t (&t)[L], const Lanes<G>& ln) {
+    uint32_t c = 0, ones = kLimbMask;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        const uint32_t v = t[k] + c;
+        t[k] = v & kLimbMask;
+        c = v >> kRadixBits;
+        ones &= t[k];
+    }
+    const uint64_t gen = wave::ballot(c != 0);
+    const uint64_t prop = wave::ballot(ones == kLimbMask);
+    uint64_t out_top;
+    const uint64_t cin = group_carry_in<G>(gen, prop, out_top);
+    uint32_t ci = lane_bit(cin, ln.lane);
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        const uint32_t v = t[k] + ci;
+        t[k] = v & kLimbMask;
+        ci = v >> kRadixBits;
+    }
+}
+
+// canonical t <- t - N if t >= N
+template <int G, int L>
+PHE_DEV void cond_sub(uint32_t (&t)[L], const uint32_t (&n)[L], const Lanes<G>& ln) {
+    uint32_t d[L];
+    uint32_t br = 0, nz = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        const uint32_t v = t[k] - n[k] - br;  // in (-2^29, 2^29): the sign bit is the borrow
+        br = v >> 31;
+        d[k] = v & kLimbMask;
         nz |= d[k];
     }
-    const uint64_t gen = wave::ballot(bo != 0);
+    const uint64_t gen = wave::ballot(br != 0);
     const uint64_t prop = wave::ballot(nz == 0);
     uint64_t out_top;
-    const uint64_t bin = row_carry_in(gen, prop, out_top);
-    const uint64_t take = ov_top | (~out_top & kRowTop);  // t >= N: overflowed, or no final borrow
-    uint32_t bi = lane_bit(bin, lane);
-    const uint32_t sel = row_top_bit(take, lane);
+    const uint64_t bin = group_carry_in<G>(gen, prop, out_top);
+    const uint64_t take = ~out_top & GroupMasks<G>::top;  // no final borrow: t >= N
+    uint32_t bi = lane_bit(bin, ln.lane);
+    const uint32_t sel = group_top_bit<G>(take, ln.lane);
 #pragma unroll
     for (int k = 0; k < L; ++k) {
-        d[k] = wave::subb(d[k], 0u, bi, bi);
-        t[k] = sel ? d[k] : t[k];
+        const uint32_t v = d[k] - bi;
+        bi = v >> 31;
+        t[k] = sel ? (v & kLimbMask) : t[k];
     }
 }
 
-// (a + b) mod N for a, b < N
-template <int L>
-PHE_DEV void modadd(uint32_t (&out)[L], const uint32_t (&a)[L], const uint32_t (&b)[L],
-                    const uint32_t (&n)[L], uint32_t lane) {
-    uint32_t t[L];
-    uint32_t c = 0;
-#pragma unroll
-    for (int k = 0; k < L; ++k) t[k] = wave::addc(a[k], b[k], c, c);
-    const uint64_t ov = resolve_carries<L>(t, c, lane);
-    cond_sub<L>(t, n, ov, lane);
-#pragma unroll
-    for (int k = 0; k < L; ++k) out[k] = t[k];
+// value in [0, 3N), almost-normalised  ->  the canonical residue in [0, N)
+template <int G, int L>
+PHE_DEV void canonicalize(uint32_t (&t)[L], const uint32_t (&n)[L], const Lanes<G>& ln) {
+    normalize_full<G, L>(t, ln);
+    cond_sub<G, L>(t, n, ln);
+    cond_sub<G, L>(t, n, ln);
 }
 
-// t += 1 (value stays < W^S by the caller's guarantee)
-template <int L>
-PHE_DEV void add_one(uint32_t (&t)[L], uint32_t lane) {
-    uint32_t c = ((lane & 15u) == 0u) ? 1u : 0u;
+// ---- the product ---------------------------------------------------------------------------------
+// out = a * b * R^-1 (mod N), out < 2N almost-normalised.
+//   a : the group's S digits in LDS (almost-normalised, value < R);  b : registers, value < 2N
+//   (any a*b < R*N is fine: a < R with b < N, or both < 2N).
+template <int G, int L>
+PHE_DEV void montmul(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[L], const uint32_t (&n)[L],
+                     uint32_t n0inv, const Lanes<G>& ln) {
+    constexpr int S = G * L;
+    uint64_t acc[L];
 #pragma unroll
-    for (int k = 0; k < L; ++k) t[k] = wave::addc(t[k], 0u, c, c);
-    (void)resolve_carries<L>(t, c, lane);
-}
-
-// One CIOS row: t = (t + a_i*b + m*N) / W with the lane-local overflow kept in th (thh is the
-// transient second overflow word; it is 0 on entry and exit).
-template <int L>
-PHE_DEV void mont_row(uint32_t (&t)[L], uint32_t& th, uint32_t ai, const uint32_t (&b)[L],
-                      const uint32_t (&n)[L], uint32_t n0inv) {
-    uint64_t p[L];
-    uint32_t c, thh;
-    // t += a_i * b
-#pragma unroll
-    for (int k = 0; k < L; ++k) p[k] = wave::mad(ai, b[k], t[k]);
-    // quotient digit from the row's least significant word (lane 0, limb 0)
-    const uint32_t m = wave::row_bcast0((uint32_t)p[0] * n0inv);
-    t[0] = (uint32_t)p[0];
-    c = 0;
-#pragma unroll
-    for (int k = 1; k < L; ++k) t[k] = wave::addc((uint32_t)p[k], (uint32_t)(p[k - 1] >> 32), c, c);
-    th = wave::addc(th, (uint32_t)(p[L - 1] >> 32), c, c);
-    thh = c;
-    // t += m * N, written one limb down (the /W of this row)
-#pragma unroll
-    for (int k = 0; k < L; ++k) p[k] = wave::mad(m, n[k], t[k]);
-    const uint32_t w0 = (uint32_t)p[0];  // lane 0: zero by construction; lane g>0: goes to lane g-1
-    c = 0;
-#pragma unroll
-    for (int k = 1; k < L; ++k) t[k - 1] = wave::addc((uint32_t)p[k], (uint32_t)(p[k - 1] >> 32), c, c);
-    const uint32_t top = wave::addc(th, (uint32_t)(p[L - 1] >> 32), c, c);
-    thh += c;
-    const uint32_t recv = wave::row_down1(w0);
-    t[L - 1] = wave::addc(top, recv, 0u, c);
-    th = thh + c;
-}
-
-// out = a * b * R^-1 mod N.   a: the row's S-limb multiplier in LDS (standard little-endian
-// order), any value < R;  b < N in registers;  out in [0, N).
-template <int L>
-PHE_DEV void montmul(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[L],
-                     const uint32_t (&n)[L], uint32_t n0inv, uint32_t lane) {
-    constexpr int S = kRow * L;
-    uint32_t t[L];
-    uint32_t th = 0;
-#pragma unroll
-    for (int k = 0; k < L; ++k) t[k] = 0;
+    for (int k = 0; k < L; ++k) acc[k] = 0;
 #pragma unroll 1
-    for (int i = 0; i < S; i += 4) {
-        const uint32_t a0 = a[i], a1 = a[i + 1], a2 = a[i + 2], a3 = a[i + 3];
-        mont_row<L>(t, th, a0, b, n, n0inv);
-        mont_row<L>(t, th, a1, b, n, n0inv);
-        mont_row<L>(t, th, a2, b, n, n0inv);
-        mont_row<L>(t, th, a3, b, n, n0inv);
+    for (int i = 0; i < S; i += L) {
+        // L digits per trip: the accumulators rotate by one slot per digit and are back in place after L
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const uint32_t ai = a[i + j];
+#pragma unroll
+            for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(ai, b[k], acc[(k + j) % L]);
+            const uint32_t m = wave::grp_bcast0<G>(((uint32_t)acc[j] * n0inv) & kLimbMask, ln);
+#pragma unroll
+            for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(m, n[k], acc[(k + j) % L]);
+            const uint64_t low = acc[j];  // logical limb 0 (= 0 mod 2^29 in lane 0)
+            const uint32_t recv = wave::grp_down1<G>((uint32_t)low & kLimbMask, ln);
+            if constexpr (L > 1) {
+                acc[(j + 1) % L] += low >> kRadixBits;
+                acc[j] = recv;  // becomes logical limb L-1
+            } else {
+                acc[0] = (low >> kRadixBits) + recv;
+            }
+        }
     }
-    // hand each lane's overflow word to the next lane, then resolve
-    const uint32_t inc = wave::row_up1(th);
-    uint32_t c;
-    t[0] = wave::addc(t[0], inc, 0u, c);
-#pragma unroll
-    for (int k = 1; k < L; ++k) t[k] = wave::addc(t[k], 0u, c, c);
-    uint64_t ov = resolve_carries<L>(t, c, lane);
-    ov |= wave::ballot(th != 0) & kRowTop;  // the top lane's own overflow word is bit 32*S
-    cond_sub<L>(t, n, ov, lane);
-#pragma unroll
-    for (int k = 0; k < L; ++k) out[k] = t[k];
+    normalize_partial<G, L>(out, acc, ln);
 }
 
-// ---- operand movement ----------------------------------------------------------------------
-// lane's L limbs of a `limbs`-word little-endian number at p, zero-extended to S words
+// ---- operand movement --------------------------------------------------------------------------------
+// 29-bit limbs [first_limb + g*L, +L) of the little-endian 32-bit-word number at p (limbs32 words)
 template <int L>
-PHE_DEV void load_limbs(uint32_t (&x)[L], const uint32_t* p, int limbs, uint32_t g) {
+PHE_DEV void load_u32_as_r29(uint32_t (&x)[L], const uint32_t* p, int limbs32, int first_limb, uint32_t g) {
 #pragma unroll
     for (int k = 0; k < L; ++k) {
-        const int idx = (int)g * L + k;
-        x[k] = (idx < limbs) ? p[idx] : 0u;
+        const int bit = kRadixBits * (first_limb + (int)g * L + k);
+        const int q = bit >> 5, o = bit & 31;
+        const uint64_t w0 = (q < limbs32) ? p[q] : 0u;
+        const uint64_t w1 = (q + 1 < limbs32) ? p[q + 1] : 0u;
+        x[k] = (uint32_t)(((w1 << 32) | w0) >> o) & kLimbMask;
     }
 }
-template <int L>
-PHE_DEV void store_limbs(uint32_t* p, const uint32_t (&x)[L], int limbs, uint32_t g) {
-#pragma unroll
-    for (int k = 0; k < L; ++k) {
-        const int idx = (int)g * L + k;
-        if (idx < limbs) p[idx] = x[k];
-    }
-}
-// full-width (S words) row, e.g. window-table entries and per-modulus constants
+// full-width (S words) row of 29-bit limbs: window-table entries and per-modulus constants
 template <int L>
 PHE_DEV void load_row(uint32_t (&x)[L], const uint32_t* p, uint32_t g) {
 #pragma unroll
@@ -207,7 +211,7 @@ PHE_DEV void store_row(uint32_t* p, const uint32_t (&x)[L], uint32_t g) {
 #pragma unroll
     for (int k = 0; k < L; ++k) p[g * L + k] = x[k];
 }
-// publish a value as the row's LDS multiplier operand
+// publish a value as the group's LDS multiplier operand
 template <int L>
 PHE_DEV void lds_put(uint32_t* row, const uint32_t (&x)[L], uint32_t g) {
     wave::lds_fence();
@@ -215,22 +219,42 @@ PHE_DEV void lds_put(uint32_t* row, const uint32_t (&x)[L], uint32_t g) {
     for (int k = 0; k < L; ++k) row[g * L + k] = x[k];
     wave::lds_fence();
 }
+// canonical 29-bit limbs -> little-endian 32-bit words at p (limbs32 words), repacked through LDS so
+// that consecutive lanes store consecutive words
+template <int G, int L>
+PHE_DEV void store_r29_as_u32(uint32_t* p, int limbs32, const uint32_t (&t)[L], uint32_t* row, uint32_t g,
+                              bool live) {
+    constexpr int S = G * L;
+    lds_put<L>(row, t, g);
+    if (live) {
+        for (int j = (int)g; j < limbs32; j += G) {
+            const int bit = 32 * j;
+            const int q = bit / kRadixBits, o = bit - q * kRadixBits;
+            uint64_t v = (q < S) ? row[q] : 0u;
+            if (q + 1 < S) v |= (uint64_t)row[q + 1] << kRadixBits;
+            if (q + 2 < S) v |= (uint64_t)row[q + 2] << (2 * kRadixBits);
+            p[j] = (uint32_t)(v >> o);
+        }
+    }
+    wave::lds_fence();
+}
 
-// ---- per-modulus constants (device pointers, S = 16*L words each) ---------------------------
+// ---- per-modulus constants (device pointers, S = G*L words of 29-bit limbs each) ------------------------
 struct ModConsts {
     const uint32_t* n;    // N
     const uint32_t* r1;   // R   mod N  (Montgomery one)
     const uint32_t* r2;   // R^2 mod N
-    const uint32_t* r3;   // R^3 mod N  (folds the high half of a 2S-word input)
+    const uint32_t* r3;   // R^3 mod N  (folds the part of a wide input above 2^(29*S))
     const uint32_t* aux;  // encrypt: n*R mod n^2, so montmul(m, aux) = n*m
-    uint32_t n0inv;       // -N^-1 mod 2^32
+    uint32_t n0inv;       // -N^-1 mod 2^29
 };
 
 enum : int { kModeEncrypt = 0, kModeObfuscate = 1, kModeHalfDecrypt = 2, kModePow = 3 };
 
 // Batch-uniform exponent (encrypt/obfuscate: e = n;  decrypt halves: e = p-1, q-1).
 // The host turns e into a sliding-window schedule; every op word is (squarings << 8) | (idx+1)
-// where idx selects the odd power base^(2*idx+1) from the row's table (0 = no multiply).
+// where idx selects the odd power base^(2*idx+1) from the group's table (0 = no multiply).
+// All user-visible numbers (base, post, out) are little-endian 32-bit-word rows.
 struct UniformArgs {
     ModConsts mod;
     const uint32_t* sched;
@@ -243,54 +267,61 @@ struct UniformArgs {
     int post_limbs;
     uint32_t* out;  // (batch, out_limbs)
     int out_limbs;
-    uint32_t* table;  // scratch: total_rows * tbl_entries * S words
+    uint32_t* table;  // scratch: total_groups * tbl_entries * S words
     uint64_t batch;
 };
 
-template <int L, int MODE>
-PHE_DEV void modexp_uniform_body(const UniformArgs& A, uint32_t* lds_row, uint32_t row_slot,
-                                 uint32_t total_rows, uint32_t lane) {
-    constexpr int S = kRow * L;
-    const uint32_t g = lane & 15u;
+template <int G, int L, int MODE>
+PHE_DEV void modexp_uniform_body(const UniformArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots,
+                                 uint32_t lane) {
+    constexpr int S = G * L;
+    const Lanes<G> ln(lane);
+    const uint32_t g = ln.g;
     const uint32_t n0inv = A.mod.n0inv;
     uint32_t n[L];
     load_row<L>(n, A.mod.n, g);
-    uint32_t* tbl = A.table + (size_t)row_slot * (size_t)A.tbl_entries * S;
-
-    // the wave iterates while any of its rows has work; an idle row recomputes the last item
-    // harmlessly (all 64 lanes stay converged through the DPP/ballot steps of montmul)
-    const uint64_t n_iter = (A.batch + total_rows - 1) / total_rows;
+    uint32_t* tbl = A.table + (size_t)slot * (size_t)A.tbl_entries * S;
+    // the wave iterates while any of its groups has work; an idle group recomputes the last item
+    // harmlessly (all 64 lanes stay converged through the DPP/ballot steps)
+    const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
     for (uint64_t it = 0; it < n_iter; ++it) {
-        uint64_t item = row_slot + it * (uint64_t)total_rows;
+        uint64_t item = slot + it * (uint64_t)total_slots;
         const bool live = item < A.batch;
         if (!live) item = A.batch - 1;
         uint32_t acc[L], tmp[L], cst[L];
-        // ---- base -> Montgomery form -------------------------------------------------------
+        // ---- base -> Montgomery form -----------------------------------------------------------
         const uint32_t* bp = A.base + item * (uint64_t)A.base_limbs;
-        load_limbs<L>(tmp, bp, A.base_limbs < S ? A.base_limbs : S, g);
+        load_u32_as_r29<L>(tmp, bp, A.base_limbs, 0, g);
         lds_put<L>(lds_row, tmp, g);
         load_row<L>(cst, A.mod.r2, g);
-        montmul<L>(acc, lds_row, cst, n, n0inv, lane);
+        montmul<G, L>(acc, lds_row, cst, n, n0inv, ln);
         if (MODE == kModeHalfDecrypt) {
-            // c = lo + hi*W^S  ->  c*R = lo*R + hi*R^2  (mod N)
-            load_limbs<L>(tmp, bp + S, A.base_limbs - S, g);
+            // c = lo + hi*2^(29S)  ->  c*R = lo*R + hi*R^2; the sum (< 4N) is brought back below 2N by a
+            // product with R mod N
+            load_u32_as_r29<L>(tmp, bp, A.base_limbs, S, g);
             lds_put<L>(lds_row, tmp, g);
             load_row<L>(cst, A.mod.r3, g);
-            montmul<L>(tmp, lds_row, cst, n, n0inv, lane);
-            modadd<L>(acc, acc, tmp, n, lane);
+            montmul<G, L>(tmp, lds_row, cst, n, n0inv, ln);
+            uint64_t sum[L];
+#pragma unroll
+            for (int k = 0; k < L; ++k) sum[k] = (uint64_t)acc[k] + tmp[k];
+            normalize_partial<G, L>(tmp, sum, ln);
+            lds_put<L>(lds_row, tmp, g);
+            load_row<L>(cst, A.mod.r1, g);
+            montmul<G, L>(acc, lds_row, cst, n, n0inv, ln);
         }
-        // ---- odd powers base^1, base^3, ... in Montgomery form ------------------------------
+        // ---- odd powers base^1, base^3, ... in Montgomery form ----------------------------------
         store_row<L>(tbl, acc, g);
         if (A.tbl_entries > 1) {
             lds_put<L>(lds_row, acc, g);
-            montmul<L>(cst, lds_row, acc, n, n0inv, lane);  // base^2
+            montmul<G, L>(cst, lds_row, acc, n, n0inv, ln);  // base^2
             for (int j = 1; j < A.tbl_entries; ++j) {
                 lds_put<L>(lds_row, acc, g);
-                montmul<L>(acc, lds_row, cst, n, n0inv, lane);
+                montmul<G, L>(acc, lds_row, cst, n, n0inv, ln);
                 store_row<L>(tbl + (size_t)j * S, acc, g);
             }
         }
-        // ---- left-to-right sliding window --------------------------------------------------
+        // ---- left-to-right sliding window ------------------------------------------------------
         load_row<L>(acc, tbl + (size_t)A.first_idx * S, g);
         for (int op = 0; op < A.n_ops; ++op) {
             const uint32_t w = A.sched[op];
@@ -298,38 +329,39 @@ PHE_DEV void modexp_uniform_body(const UniformArgs& A, uint32_t* lds_row, uint32
             const int sel = (int)(w & 0xffu);
             for (int s = 0; s < nsq; ++s) {
                 lds_put<L>(lds_row, acc, g);
-                montmul<L>(acc, lds_row, acc, n, n0inv, lane);
+                montmul<G, L>(acc, lds_row, acc, n, n0inv, ln);
             }
             if (sel) {
                 lds_put<L>(lds_row, acc, g);
                 load_row<L>(tmp, tbl + (size_t)(sel - 1) * S, g);
-                montmul<L>(acc, lds_row, tmp, n, n0inv, lane);
+                montmul<G, L>(acc, lds_row, tmp, n, n0inv, ln);
             }
         }
-        // ---- leave Montgomery form (fused with the op's final multiply) ---------------------
+        // ---- leave Montgomery form (fused with the op's final multiply) -------------------------
         if (MODE == kModeEncrypt) {
             // nude ciphertext 1 + n*m (phe/paillier.py:134; the :125-130 branch is value-identical)
-            load_limbs<L>(tmp, A.post + item * (uint64_t)A.post_limbs, A.post_limbs, g);
+            load_u32_as_r29<L>(tmp, A.post + item * (uint64_t)A.post_limbs, A.post_limbs, 0, g);
             lds_put<L>(lds_row, tmp, g);
             load_row<L>(cst, A.mod.aux, g);
-            montmul<L>(tmp, lds_row, cst, n, n0inv, lane);  // n*m mod n^2  (<= n^2 - n)
-            add_one<L>(tmp, lane);
+            montmul<G, L>(tmp, lds_row, cst, n, n0inv, ln);  // n*m (mod n^2), < 2N
+            if (g == 0u) tmp[0] += 1u;
         } else if (MODE == kModeObfuscate) {
-            load_limbs<L>(tmp, A.post + item * (uint64_t)A.post_limbs, A.post_limbs, g);
+            load_u32_as_r29<L>(tmp, A.post + item * (uint64_t)A.post_limbs, A.post_limbs, 0, g);
         } else {
 #pragma unroll
             for (int k = 0; k < L; ++k) tmp[k] = (g == 0u && k == 0) ? 1u : 0u;
         }
-        // acc = x*R, tmp = y (standard form)  ->  montmul = x*y mod N, standard form
+        // acc = x*R, tmp = y (plain)  ->  montmul = x*y mod N, plain
         lds_put<L>(lds_row, tmp, g);
-        montmul<L>(acc, lds_row, acc, n, n0inv, lane);
-        if (live) store_limbs<L>(A.out + item * (uint64_t)A.out_limbs, acc, A.out_limbs, g);
+        montmul<G, L>(acc, lds_row, acc, n, n0inv, ln);
+        canonicalize<G, L>(acc, n, ln);
+        store_r29_as_u32<G, L>(A.out + item * (uint64_t)A.out_limbs, A.out_limbs, acc, lds_row, g, live);
     }
 }
 
 // Per-element exponents (phe/paillier.py:751 powmod(c, scalar, n^2); :749 with the inverted base).
-// Fixed 2^w-ary windows over the batch-wide maximum bit length: every row runs the same
-// schedule (no divergence between the four rows of a wave); the digit only picks the table entry.
+// Fixed 2^w-ary windows over the batch-wide maximum bit length: every group runs the same
+// schedule (no divergence inside a wave); the digit only picks the table entry.
 struct VarArgs {
     ModConsts mod;
     const uint32_t* base;  // (batch, base_limbs), values < N
@@ -340,7 +372,7 @@ struct VarArgs {
     int n_windows;   // ceil(max_bits / w), >= 1
     uint32_t* out;
     int out_limbs;
-    uint32_t* table;  // scratch: total_rows * 2^w * S words
+    uint32_t* table;  // scratch: total_groups * 2^w * S words
     uint64_t batch;
 };
 
@@ -352,26 +384,27 @@ PHE_DEV uint32_t exp_digit(const uint32_t* e, int exp_limbs, int bitpos, int w) 
     return (uint32_t)(v >> sh) & ((1u << w) - 1u);
 }
 
-template <int L>
-PHE_DEV void modexp_var_body(const VarArgs& A, uint32_t* lds_row, uint32_t row_slot,
-                             uint32_t total_rows, uint32_t lane) {
-    constexpr int S = kRow * L;
-    const uint32_t g = lane & 15u;
+template <int G, int L>
+PHE_DEV void modexp_var_body(const VarArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots,
+                             uint32_t lane) {
+    constexpr int S = G * L;
+    const Lanes<G> ln(lane);
+    const uint32_t g = ln.g;
     const uint32_t n0inv = A.mod.n0inv;
     const int tbl_entries = 1 << A.window;
     uint32_t n[L];
     load_row<L>(n, A.mod.n, g);
-    uint32_t* tbl = A.table + (size_t)row_slot * (size_t)tbl_entries * S;
-    const uint64_t n_iter = (A.batch + total_rows - 1) / total_rows;
+    uint32_t* tbl = A.table + (size_t)slot * (size_t)tbl_entries * S;
+    const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
     for (uint64_t it = 0; it < n_iter; ++it) {
-        uint64_t item = row_slot + it * (uint64_t)total_rows;
+        uint64_t item = slot + it * (uint64_t)total_slots;
         const bool live = item < A.batch;
         if (!live) item = A.batch - 1;
         uint32_t acc[L], tmp[L], xm[L];
-        load_limbs<L>(tmp, A.base + item * (uint64_t)A.base_limbs, A.base_limbs, g);
+        load_u32_as_r29<L>(tmp, A.base + item * (uint64_t)A.base_limbs, A.base_limbs, 0, g);
         lds_put<L>(lds_row, tmp, g);
         load_row<L>(xm, A.mod.r2, g);
-        montmul<L>(xm, lds_row, xm, n, n0inv, lane);  // base*R
+        montmul<G, L>(xm, lds_row, xm, n, n0inv, ln);  // base*R
         // table: base^0 .. base^(2^w - 1)
         load_row<L>(acc, A.mod.r1, g);
         store_row<L>(tbl, acc, g);
@@ -380,7 +413,7 @@ PHE_DEV void modexp_var_body(const VarArgs& A, uint32_t* lds_row, uint32_t row_s
         for (int k = 0; k < L; ++k) acc[k] = xm[k];
         for (int j = 2; j < tbl_entries; ++j) {
             lds_put<L>(lds_row, acc, g);
-            montmul<L>(acc, lds_row, xm, n, n0inv, lane);
+            montmul<G, L>(acc, lds_row, xm, n, n0inv, ln);
             store_row<L>(tbl + (size_t)j * S, acc, g);
         }
         const uint32_t* e = A.exps + item * (uint64_t)A.exp_limbs;
@@ -389,20 +422,21 @@ PHE_DEV void modexp_var_body(const VarArgs& A, uint32_t* lds_row, uint32_t row_s
         for (int wi = A.n_windows - 2; wi >= 0; --wi) {
             for (int s = 0; s < A.window; ++s) {
                 lds_put<L>(lds_row, acc, g);
-                montmul<L>(acc, lds_row, acc, n, n0inv, lane);
+                montmul<G, L>(acc, lds_row, acc, n, n0inv, ln);
             }
             d = exp_digit(e, A.exp_limbs, wi * A.window, A.window);
-            if (wave::ballot(d != 0) != 0) {  // wave-uniform: skip when all four rows have a zero digit
+            if (wave::ballot(d != 0) != 0) {  // wave-uniform: skip when every group has a zero digit
                 lds_put<L>(lds_row, acc, g);
                 load_row<L>(tmp, tbl + (size_t)d * S, g);
-                montmul<L>(acc, lds_row, tmp, n, n0inv, lane);
+                montmul<G, L>(acc, lds_row, tmp, n, n0inv, ln);
             }
         }
 #pragma unroll
         for (int k = 0; k < L; ++k) tmp[k] = (g == 0u && k == 0) ? 1u : 0u;
         lds_put<L>(lds_row, tmp, g);
-        montmul<L>(acc, lds_row, acc, n, n0inv, lane);
-        if (live) store_limbs<L>(A.out + item * (uint64_t)A.out_limbs, acc, A.out_limbs, g);
+        montmul<G, L>(acc, lds_row, acc, n, n0inv, ln);
+        canonicalize<G, L>(acc, n, ln);
+        store_r29_as_u32<G, L>(A.out + item * (uint64_t)A.out_limbs, A.out_limbs, acc, lds_row, g, live);
     }
 }
 
@@ -413,32 +447,33 @@ struct MulArgs {
     const uint32_t* a;
     const uint32_t* b;
     uint32_t* out;
-    size_t a_stride, b_stride, out_stride;  // words between consecutive rows
-    int limbs;                              // words per number
+    size_t a_stride, b_stride, out_stride;  // 32-bit words between consecutive rows
+    int limbs;                              // 32-bit words per number
     uint64_t batch;
 };
 
-template <int L>
-PHE_DEV void mulmod_body(const MulArgs& A, uint32_t* lds_row, uint32_t row_slot, uint32_t total_rows,
-                         uint32_t lane) {
-    const uint32_t g = lane & 15u;
+template <int G, int L>
+PHE_DEV void mulmod_body(const MulArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots, uint32_t lane) {
+    const Lanes<G> ln(lane);
+    const uint32_t g = ln.g;
     const uint32_t n0inv = A.mod.n0inv;
     uint32_t n[L], r2[L];
     load_row<L>(n, A.mod.n, g);
     load_row<L>(r2, A.mod.r2, g);
-    const uint64_t n_iter = (A.batch + total_rows - 1) / total_rows;
+    const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
     for (uint64_t it = 0; it < n_iter; ++it) {
-        uint64_t item = row_slot + it * (uint64_t)total_rows;
+        uint64_t item = slot + it * (uint64_t)total_slots;
         const bool live = item < A.batch;
         if (!live) item = A.batch - 1;
         uint32_t x[L], y[L];
-        load_limbs<L>(x, A.a + item * A.a_stride, A.limbs, g);
-        load_limbs<L>(y, A.b + item * A.b_stride, A.limbs, g);
+        load_u32_as_r29<L>(x, A.a + item * A.a_stride, A.limbs, 0, g);
+        load_u32_as_r29<L>(y, A.b + item * A.b_stride, A.limbs, 0, g);
         lds_put<L>(lds_row, x, g);
-        montmul<L>(x, lds_row, y, n, n0inv, lane);   // a*b/R
+        montmul<G, L>(x, lds_row, y, n, n0inv, ln);   // a*b/R
         lds_put<L>(lds_row, x, g);
-        montmul<L>(x, lds_row, r2, n, n0inv, lane);  // a*b
-        if (live) store_limbs<L>(A.out + item * A.out_stride, x, A.limbs, g);
+        montmul<G, L>(x, lds_row, r2, n, n0inv, ln);  // a*b
+        canonicalize<G, L>(x, n, ln);
+        store_r29_as_u32<G, L>(A.out + item * A.out_stride, A.limbs, x, lds_row, g, live);
     }
 }
 

@@ -31,34 +31,33 @@ using host::Big;
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-constexpr int kBlock = 256;               // threads per workgroup
-constexpr int kRowsPerBlock = kBlock / 16;  // limb groups per workgroup
+constexpr int kBlock = 256;  // threads per workgroup = 4 wavefronts = 256/G limb groups
 
-template <int L, int MODE>
+template <int G, int L, int MODE>
 __global__ void __launch_bounds__(kBlock) k_modexp_uniform(UniformArgs A) {
-    constexpr int S = 16 * L;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kRowsPerBlock * (S + kLdsPad)];
-    const uint32_t row = threadIdx.x >> 4;
-    modexp_uniform_body<L, MODE>(A, lds + row * (S + kLdsPad), blockIdx.x * kRowsPerBlock + row,
-                                 gridDim.x * kRowsPerBlock, threadIdx.x & 63u);
+    constexpr int S = G * L, kGroups = kBlock / G;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kGroups * (S + kLdsPad)];
+    const uint32_t grp = threadIdx.x / G;
+    modexp_uniform_body<G, L, MODE>(A, lds + grp * (S + kLdsPad), blockIdx.x * kGroups + grp, gridDim.x * kGroups,
+                                    threadIdx.x & 63u);
 }
 
-template <int L>
+template <int G, int L>
 __global__ void __launch_bounds__(kBlock) k_modexp_var(VarArgs A) {
-    constexpr int S = 16 * L;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kRowsPerBlock * (S + kLdsPad)];
-    const uint32_t row = threadIdx.x >> 4;
-    modexp_var_body<L>(A, lds + row * (S + kLdsPad), blockIdx.x * kRowsPerBlock + row,
-                       gridDim.x * kRowsPerBlock, threadIdx.x & 63u);
+    constexpr int S = G * L, kGroups = kBlock / G;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kGroups * (S + kLdsPad)];
+    const uint32_t grp = threadIdx.x / G;
+    modexp_var_body<G, L>(A, lds + grp * (S + kLdsPad), blockIdx.x * kGroups + grp, gridDim.x * kGroups,
+                          threadIdx.x & 63u);
 }
 
-template <int L>
+template <int G, int L>
 __global__ void __launch_bounds__(kBlock) k_mulmod(MulArgs A) {
-    constexpr int S = 16 * L;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kRowsPerBlock * (S + kLdsPad)];
-    const uint32_t row = threadIdx.x >> 4;
-    mulmod_body<L>(A, lds + row * (S + kLdsPad), blockIdx.x * kRowsPerBlock + row,
-                   gridDim.x * kRowsPerBlock, threadIdx.x & 63u);
+    constexpr int S = G * L, kGroups = kBlock / G;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[kGroups * (S + kLdsPad)];
+    const uint32_t grp = threadIdx.x / G;
+    mulmod_body<G, L>(A, lds + grp * (S + kLdsPad), blockIdx.x * kGroups + grp, gridDim.x * kGroups,
+                      threadIdx.x & 63u);
 }
 
 constexpr int kTailBlock = 64;
@@ -72,12 +71,17 @@ __global__ void __launch_bounds__(kTailBlock) k_decrypt_tail(TailArgs A) {
 
 __global__ void k_selftest_prims(uint32_t* out) {
     const uint32_t lane = threadIdx.x & 63u;
-    out[lane] = wave::row_down1(lane + 100u);
-    out[64 + lane] = wave::row_up1(lane + 100u);
-    out[128 + lane] = wave::row_bcast0(lane + 100u);
+    const wave::Lanes<16> l16(lane);
+    const wave::Lanes<8> l8(lane);
+    out[lane] = wave::grp_down1<16>(lane + 100u, l16);
+    out[64 + lane] = wave::grp_up1<16>(lane + 100u, l16);
+    out[128 + lane] = wave::grp_bcast0<16>(lane + 100u, l16);
     const uint64_t b = wave::ballot((lane % 3u) == 0u);
     out[192 + lane] = (uint32_t)(b >> lane) & 1u;
     if (lane < 2) out[256 + lane] = (uint32_t)(b >> (32 * lane));
+    out[258 + lane] = wave::grp_down1<8>(lane + 100u, l8);
+    out[322 + lane] = wave::grp_up1<8>(lane + 100u, l8);
+    out[386 + lane] = wave::grp_bcast0<8>(lane + 100u, l8);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -96,7 +100,7 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 struct DevModulus {  // device copies of a host::ModulusPack
-    int L = 0, S = 0;
+    int G = 0, L = 0, S = 0;
     uint32_t* blob = nullptr;  // n | r1 | r2 | r3 | aux
     ModConsts c{};
 };
@@ -113,6 +117,7 @@ struct phe_hip_ctx {
     int device = 0;
     int n_cus = 256;
     int blocks_per_cu = 2;
+    int prefer_group = 8;  // lanes per limb group when the key size offers both (PHE_HIP_GROUP=16 overrides)
     bool has_private = false;
     host::PublicPlan pub;
     host::PrivatePlan priv;
@@ -130,12 +135,13 @@ struct phe_hip_ctx {
 };
 
 static int upload_modulus(const host::ModulusPack& m, DevModulus& d) {
+    d.G = m.G;
     d.L = m.L;
     d.S = m.S;
     const size_t words = (size_t)5 * m.S;
     HIP_TRY(hipMalloc((void**)&d.blob, words * 4));
     std::vector<uint32_t> h(words);
-    const Big* parts[5] = {&m.n, &m.r1, &m.r2, &m.r3, &m.aux};
+    const std::vector<uint32_t>* parts[5] = {&m.n, &m.r1, &m.r2, &m.r3, &m.aux};
     for (int i = 0; i < 5; ++i) memcpy(h.data() + (size_t)i * m.S, parts[i]->data(), (size_t)m.S * 4);
     HIP_TRY(hipMemcpy(d.blob, h.data(), words * 4, hipMemcpyHostToDevice));
     d.c.n = d.blob;
@@ -185,47 +191,56 @@ static int ensure_words(uint32_t** buf, size_t* have, size_t need) {
     return PHE_HIP_OK;
 }
 
-static int grid_blocks(const phe_hip_ctx* ctx, size_t batch) {
-    const size_t want = (batch + kRowsPerBlock - 1) / kRowsPerBlock;
-    const size_t cap = (size_t)ctx->n_cus * (size_t)ctx->blocks_per_cu;
+static int grid_blocks(const phe_hip_ctx* ctx, size_t batch, int G, int max_blocks_per_cu = 0) {
+    const size_t groups = (size_t)(kBlock / G);
+    const size_t want = (batch + groups - 1) / groups;
+    const size_t cap = (size_t)ctx->n_cus * (size_t)(max_blocks_per_cu ? max_blocks_per_cu : ctx->blocks_per_cu);
     return (int)std::max<size_t>(1, std::min(want, cap));
 }
 
-#define DISPATCH_L(L_, CALL)                                                             \
-    switch (L_) {                                                                        \
-        case 1: { constexpr int LL = 1; CALL; break; }                                   \
-        case 2: { constexpr int LL = 2; CALL; break; }                                   \
-        case 3: { constexpr int LL = 3; CALL; break; }                                   \
-        case 4: { constexpr int LL = 4; CALL; break; }                                   \
-        case 6: { constexpr int LL = 6; CALL; break; }                                   \
-        case 8: { constexpr int LL = 8; CALL; break; }                                   \
-        case 12: { constexpr int LL = 12; CALL; break; }                                 \
-        case 16: { constexpr int LL = 16; CALL; break; }                                 \
-        default: return fail(PHE_HIP_EINVAL, "unsupported limbs-per-lane");              \
-    }
+// the (G, L) pairs key_setup.h:pick_geometry can return
+#define DISPATCH_GL(G_, L_, CALL)                                                              \
+    do {                                                                                       \
+        const int key_ = (G_) * 100 + (L_);                                                    \
+        switch (key_) {                                                                        \
+            case 1601: { constexpr int GG = 16, LL = 1; CALL; break; }                         \
+            case 1602: { constexpr int GG = 16, LL = 2; CALL; break; }                         \
+            case 1603: { constexpr int GG = 16, LL = 3; CALL; break; }                         \
+            case 1605: { constexpr int GG = 16, LL = 5; CALL; break; }                         \
+            case 1607: { constexpr int GG = 16, LL = 7; CALL; break; }                         \
+            case 1609: { constexpr int GG = 16, LL = 9; CALL; break; }                         \
+            case 1614: { constexpr int GG = 16, LL = 14; CALL; break; }                        \
+            case 1618: { constexpr int GG = 16, LL = 18; CALL; break; }                        \
+            case 805: { constexpr int GG = 8, LL = 5; CALL; break; }                           \
+            case 809: { constexpr int GG = 8, LL = 9; CALL; break; }                           \
+            case 814: { constexpr int GG = 8, LL = 14; CALL; break; }                          \
+            case 818: { constexpr int GG = 8, LL = 18; CALL; break; }                          \
+            default: return fail(PHE_HIP_EINVAL, "unsupported limb-group geometry");           \
+        }                                                                                      \
+    } while (0)
 
 // ------------------------------------------------------------------------------------------------
 // launches (device pointers)
 // ------------------------------------------------------------------------------------------------
-template <int L, int MODE>
+template <int G, int L, int MODE>
 static void go_uniform(int blocks, hipStream_t st, const UniformArgs& A) {
-    k_modexp_uniform<L, MODE><<<dim3(blocks), dim3(kBlock), 0, st>>>(A);
+    k_modexp_uniform<G, L, MODE><<<dim3(blocks), dim3(kBlock), 0, st>>>(A);
 }
-template <int L>
+template <int G, int L>
 static void go_var(int blocks, hipStream_t st, const VarArgs& A) {
-    k_modexp_var<L><<<dim3(blocks), dim3(kBlock), 0, st>>>(A);
+    k_modexp_var<G, L><<<dim3(blocks), dim3(kBlock), 0, st>>>(A);
 }
-template <int L>
+template <int G, int L>
 static void go_mul(int blocks, hipStream_t st, const MulArgs& A) {
-    k_mulmod<L><<<dim3(blocks), dim3(kBlock), 0, st>>>(A);
+    k_mulmod<G, L><<<dim3(blocks), dim3(kBlock), 0, st>>>(A);
 }
 
 template <int MODE>
 static int launch_uniform(phe_hip_ctx* ctx, const DevModulus& M, const DevSchedule& E, const uint32_t* base,
                           int base_limbs, const uint32_t* post, int post_limbs, uint32_t* out, int out_limbs,
                           size_t batch, hipStream_t stream) {
-    const int blocks = grid_blocks(ctx, batch);
-    const size_t rows = (size_t)blocks * kRowsPerBlock;
+    const int blocks = grid_blocks(ctx, batch, M.G);
+    const size_t rows = (size_t)blocks * (size_t)(kBlock / M.G);
     int rc = ensure_words(&ctx->table, &ctx->table_words, rows * (size_t)E.tbl_entries * M.S);
     if (rc) return rc;
     UniformArgs A;
@@ -242,7 +257,7 @@ static int launch_uniform(phe_hip_ctx* ctx, const DevModulus& M, const DevSchedu
     A.out_limbs = out_limbs;
     A.table = ctx->table;
     A.batch = batch;
-    DISPATCH_L(M.L, (go_uniform<LL, MODE>(blocks, stream, A)));
+    DISPATCH_GL(M.G, M.L, (go_uniform<GG, LL, MODE>(blocks, stream, A)));
     HIP_TRY(hipGetLastError());
     return PHE_HIP_OK;
 }
@@ -261,12 +276,12 @@ static int launch_var(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* bas
     A.out = out;
     A.out_limbs = out_limbs;
     A.batch = batch;
-    const int blocks = grid_blocks(ctx, batch);
-    const size_t rows = (size_t)blocks * kRowsPerBlock;
+    const int blocks = grid_blocks(ctx, batch, M.G);
+    const size_t rows = (size_t)blocks * (size_t)(kBlock / M.G);
     int rc = ensure_words(&ctx->table, &ctx->table_words, rows * ((size_t)1 << A.window) * M.S);
     if (rc) return rc;
     A.table = ctx->table;
-    DISPATCH_L(M.L, (go_var<LL>(blocks, stream, A)));
+    DISPATCH_GL(M.G, M.L, (go_var<GG, LL>(blocks, stream, A)));
     HIP_TRY(hipGetLastError());
     return PHE_HIP_OK;
 }
@@ -284,10 +299,9 @@ static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, 
     A.out_stride = out_stride;
     A.limbs = limbs;
     A.batch = batch;
-    // memory-light kernel: let every CU hold as many groups as the batch offers (cap 8 blocks/CU)
-    const size_t want = (batch + kRowsPerBlock - 1) / kRowsPerBlock;
-    const int blocks = (int)std::max<size_t>(1, std::min(want, (size_t)ctx->n_cus * 8));
-    DISPATCH_L(M.L, (go_mul<LL>(blocks, stream, A)));
+    // no table scratch here: let every CU hold as many groups as the batch offers (cap 8 blocks/CU)
+    const int blocks = grid_blocks(ctx, batch, M.G, 8);
+    DISPATCH_GL(M.G, M.L, (go_mul<GG, LL>(blocks, stream, A)));
     HIP_TRY(hipGetLastError());
     return PHE_HIP_OK;
 }
@@ -322,8 +336,12 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
         const int v = atoi(e);
         if (v >= 1 && v <= 8) ctx->blocks_per_cu = v;
     }
+    if (const char* e = getenv("PHE_HIP_GROUP")) {
+        const int v = atoi(e);
+        if (v == 8 || v == 16) ctx->prefer_group = v;
+    }
     try {
-        ctx->pub = host::build_public(n, n_limbs);
+        ctx->pub = host::build_public(n, n_limbs, ctx->prefer_group);
     } catch (const std::exception& ex) {
         return fail(PHE_HIP_EINVAL, ex.what());
     }
@@ -353,7 +371,7 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
     int rc = ctx_common(ctx, n, n_limbs, device);
     if (!rc) {
         try {
-            ctx->priv = host::build_private(p, q, hp, hq, p_inverse, pq_limbs, n_limbs);
+            ctx->priv = host::build_private(p, q, hp, hq, p_inverse, pq_limbs, n_limbs, ctx->prefer_group);
             // p*q == n, like phe/paillier.py:218-219
             Big prod = host::big_mul(ctx->priv.tail.p, ctx->priv.tail.q);
             Big nn = host::big_from(n, n_limbs, (int)prod.size() > n_limbs ? (int)prod.size() : n_limbs);
@@ -401,9 +419,10 @@ int phe_hip_ctx_info(const phe_hip_ctx* ctx, int* n_limbs, int* ct_limbs, int* l
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
     if (n_limbs) *n_limbs = ctx->pub.s1;
     if (ct_limbs) *ct_limbs = ctx->pub.s2;
-    if (lane_limbs_pub) *lane_limbs_pub = ctx->pub.nsq.L;
-    if (lane_limbs_priv) *lane_limbs_priv = ctx->has_private ? ctx->priv.psq.L : 0;
-    if (rows_in_flight) *rows_in_flight = ctx->n_cus * ctx->blocks_per_cu * kRowsPerBlock;
+    // geometry is reported as G*100 + L (e.g. 818 = groups of 8 lanes x 18 limbs of 29 bits)
+    if (lane_limbs_pub) *lane_limbs_pub = ctx->pub.nsq.G * 100 + ctx->pub.nsq.L;
+    if (lane_limbs_priv) *lane_limbs_priv = ctx->has_private ? ctx->priv.psq.G * 100 + ctx->priv.psq.L : 0;
+    if (rows_in_flight) *rows_in_flight = ctx->n_cus * ctx->blocks_per_cu * (kBlock / ctx->pub.nsq.G);
     if (has_private) *has_private = ctx->has_private ? 1 : 0;
     return PHE_HIP_OK;
 }
@@ -441,7 +460,8 @@ int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t
     if (batch == 0) return PHE_HIP_OK;
     if (!c || !m) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
-    const int S = ctx->d_psq.S;
+    // x_p, x_q rows in 32-bit words; only their low h words are read by the tail
+    const int S = (std::max(ctx->priv.psq.bits, ctx->priv.qsq.bits) + 31) / 32;
     int rc = ensure_words(&ctx->scratch, &ctx->scratch_words, (size_t)2 * batch * S);
     if (rc) return rc;
     uint32_t* xp = ctx->scratch;
@@ -649,7 +669,7 @@ int phe_hip_invert(phe_hip_ctx* ctx, const uint32_t* a, uint32_t* out, size_t ba
         if (cnt[k] & 1) HIP_TRY(hipMemcpyAsync(dst + pairs * w, src + (cnt[k] - 1) * w, w * 4, hipMemcpyDeviceToDevice, nullptr));
     }
     // one scalar inversion of the root on the host
-    Big root(w), N = host::big_from(ctx->pub.nsq.n.data(), s2, s2), rinv;  // n^2 < W^s2
+    Big root(w), N = ctx->pub.nsq32, rinv;
     HIP_TRY(hipMemcpy(root.data(), prod + off.back() * w, w * 4, hipMemcpyDeviceToHost));
     bool reduced_ok = host::big_cmp(root, N) < 0;
     if (!reduced_ok || !host_invert(root, N, rinv)) {
@@ -720,10 +740,10 @@ int phe_hip_selftest_prims(int device, uint32_t* out) {
     if (!out) return fail(PHE_HIP_EINVAL, "null out");
     HIP_TRY(hipSetDevice(device));
     uint32_t* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, 258 * 4));
+    HIP_TRY(hipMalloc((void**)&d, 450 * 4));
     k_selftest_prims<<<dim3(1), dim3(64), 0, nullptr>>>(d);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, d, 258 * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, d, 450 * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(d));
     return PHE_HIP_OK;
 }

@@ -1,13 +1,14 @@
 // wave_gfx950.h — the CDNA4 (gfx950) wavefront primitives the multi-precision core is written against.
 //
-// A 64-lane wavefront is used as four independent 16-lane DPP rows; each row ("limb group")
-// owns one big number whose limbs are blocked across the row's lanes (lane g of the row holds
-// limbs [g*L, (g+1)*L)).  Every cross-lane movement the Montgomery core needs is a single-
+// A 64-lane wavefront is used as independent limb groups of G = 16 lanes (one DPP row) or G = 8
+// lanes (half a row); each group owns one big number whose limbs are blocked across its lanes
+// (lane g of the group holds limbs [g*L, (g+1)*L)).  Every cross-lane movement the Montgomery core needs is a single-
 // instruction DPP row operation; nothing here touches LDS or memory:
 //
-//   row_down1  v_mov_b32_dpp row_shl:1   bound_ctrl:0   lane g <- lane g+1   (top lane <- 0)
-//   row_up1    v_mov_b32_dpp row_shr:1   bound_ctrl:0   lane g <- lane g-1   (lane 0  <- 0)
-//   row_bcast0 v_mov_b32_dpp row_newbcast:0             lane g <- lane 0 of its row
+//   grp_down1  v_mov_b32_dpp row_shl:1   bound_ctrl:0   lane g <- lane g+1   (top lane <- 0)
+//   grp_up1    v_mov_b32_dpp row_shr:1   bound_ctrl:0   lane g <- lane g-1   (lane 0  <- 0)
+//   grp_bcast0 v_mov_b32_dpp row_newbcast:0             lane g <- lane 0 of its group
+// (groups of 8 lanes add one v_and / a second DPP; see the templates below)
 //
 // tests/emu/wave_emu.h provides the same names on the host (fibers) so tests can run
 // mont_core.h on the CPU; tests/test_gpu_prims.py checks these semantics on the real GPU.
@@ -20,21 +21,53 @@
 
 namespace wave {
 
-constexpr int kRow = 16;  // lanes per limb group (= one DPP row)
+constexpr int kRow = 16;  // lanes of one DPP row
 
 PHE_DEV uint32_t lane_id() { return __lane_id(); }
 
-// lane g <- lane g+1 within the 16-lane row; the row's top lane receives 0
-PHE_DEV uint32_t row_down1(uint32_t x) {
+// Per-lane constants of a limb group of G lanes (G = 16: one DPP row; G = 8: half a row).
+template <int G>
+struct Lanes {
+    uint32_t lane;      // 0..63
+    uint32_t g;         // position inside the group, 0..G-1
+    uint32_t not_top;   // all-ones unless this is the group's top lane    (G = 8 only)
+    uint32_t not_low;   // all-ones unless this is the group's lane 0      (G = 8 only)
+    PHE_DEV explicit Lanes(uint32_t lane_) : lane(lane_), g(lane_ & (G - 1)) {
+        not_top = (g == G - 1) ? 0u : 0xffffffffu;
+        not_low = (g == 0) ? 0u : 0xffffffffu;
+    }
+};
+
+PHE_DEV uint32_t dpp_row_shl1(uint32_t x) {  // lane i <- lane i+1 in the 16-lane row, lane 15 <- 0
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x101 /*row_shl:1*/, 0xf, 0xf, true);
 }
-// lane g <- lane g-1 within the 16-lane row; the row's lane 0 receives 0
-PHE_DEV uint32_t row_up1(uint32_t x) {
+PHE_DEV uint32_t dpp_row_shr1(uint32_t x) {  // lane i <- lane i-1 in the 16-lane row, lane 0 <- 0
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /*row_shr:1*/, 0xf, 0xf, true);
 }
-// every lane <- lane 0 of its own row
-PHE_DEV uint32_t row_bcast0(uint32_t x) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 /*row_newbcast:0*/, 0xf, 0xf, true);
+
+// lane g <- lane g+1 of its group; the group's top lane receives 0
+template <int G>
+PHE_DEV uint32_t grp_down1(uint32_t x, const Lanes<G>& l) {
+    if constexpr (G == 16) return dpp_row_shl1(x);
+    else return dpp_row_shl1(x) & l.not_top;
+}
+// lane g <- lane g-1 of its group; the group's lane 0 receives 0
+template <int G>
+PHE_DEV uint32_t grp_up1(uint32_t x, const Lanes<G>& l) {
+    if constexpr (G == 16) return dpp_row_shr1(x);
+    else return dpp_row_shr1(x) & l.not_low;
+}
+// every lane <- lane 0 of its group
+template <int G>
+PHE_DEV uint32_t grp_bcast0(uint32_t x, const Lanes<G>&) {
+    if constexpr (G == 16) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 /*row_newbcast:0*/, 0xf, 0xf, true);
+    } else {
+        // quad_perm:[0,0,0,0] puts lanes 0,4,8,12 into their quads; row_shr:4 restricted to banks 1 and 3
+        // then copies quad 0 -> quad 1 and quad 2 -> quad 3, i.e. lanes 0 and 8 to their 8-lane groups
+        const int q = __builtin_amdgcn_update_dpp(0, (int)x, 0x00 /*quad_perm:[0,0,0,0]*/, 0xf, 0xf, true);
+        return (uint32_t)__builtin_amdgcn_update_dpp(q, q, 0x114 /*row_shr:4*/, 0xf, 0xa, false);
+    }
 }
 // 64-bit lane mask of a per-lane predicate (SGPR pair)
 PHE_DEV uint64_t ballot(bool p) { return __ballot(p); }
@@ -47,20 +80,8 @@ PHE_DEV void lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// 32x32+32 -> 64 multiply-add: v_mad_u64_u32 (cannot overflow: (2^32-1)^2 + 2^32-1 < 2^64)
-PHE_DEV uint64_t mad(uint32_t a, uint32_t b, uint32_t c) { return (uint64_t)a * b + c; }
-// add/sub with carry chains: v_add_co_u32 / v_addc_co_u32 / v_sub_co_u32 / v_subb_co_u32
-PHE_DEV uint32_t addc(uint32_t a, uint32_t b, uint32_t cin, uint32_t& cout) {
-    unsigned co;
-    uint32_t r = __builtin_addc(a, b, cin, &co);
-    cout = co;
-    return r;
-}
-PHE_DEV uint32_t subb(uint32_t a, uint32_t b, uint32_t bin, uint32_t& bout) {
-    unsigned bo;
-    uint32_t r = __builtin_subc(a, b, bin, &bo);
-    bout = bo;
-    return r;
-}
+// 32x32+64 -> 64 multiply-accumulate: v_mad_u64_u32 with a full 64-bit addend.  The radix-2^29 core
+// keeps every accumulator below 2^64 by construction, so the carry-out is never needed.
+PHE_DEV uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
 
 }  // namespace wave

@@ -243,6 +243,6 @@ class Context:
 
 
 def selftest_prims(device=0):
-    out = np.zeros(258, np.uint32)
+    out = np.zeros(450, np.uint32)
     _check(lib().phe_hip_selftest_prims(device, _ptr(out)))
     return out

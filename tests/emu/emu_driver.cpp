@@ -20,17 +20,21 @@ using host::Big;
 
 static thread_local std::string g_err;
 
-#define DISPATCH_L(L_, CALL)                                   \
-    switch (L_) {                                              \
-        case 1: { constexpr int LL = 1; CALL; break; }         \
-        case 2: { constexpr int LL = 2; CALL; break; }         \
-        case 3: { constexpr int LL = 3; CALL; break; }         \
-        case 4: { constexpr int LL = 4; CALL; break; }         \
-        case 6: { constexpr int LL = 6; CALL; break; }         \
-        case 8: { constexpr int LL = 8; CALL; break; }         \
-        case 12: { constexpr int LL = 12; CALL; break; }       \
-        case 16: { constexpr int LL = 16; CALL; break; }       \
-        default: throw std::invalid_argument("unsupported L"); \
+#define DISPATCH_GL(G_, L_, CALL)                                                     \
+    switch ((G_) * 100 + (L_)) {                                                      \
+        case 1601: { constexpr int GG = 16, LL = 1; CALL; break; }                    \
+        case 1602: { constexpr int GG = 16, LL = 2; CALL; break; }                    \
+        case 1603: { constexpr int GG = 16, LL = 3; CALL; break; }                    \
+        case 1605: { constexpr int GG = 16, LL = 5; CALL; break; }                    \
+        case 1607: { constexpr int GG = 16, LL = 7; CALL; break; }                    \
+        case 1609: { constexpr int GG = 16, LL = 9; CALL; break; }                    \
+        case 1614: { constexpr int GG = 16, LL = 14; CALL; break; }                   \
+        case 1618: { constexpr int GG = 16, LL = 18; CALL; break; }                   \
+        case 805: { constexpr int GG = 8, LL = 5; CALL; break; }                      \
+        case 809: { constexpr int GG = 8, LL = 9; CALL; break; }                      \
+        case 814: { constexpr int GG = 8, LL = 14; CALL; break; }                     \
+        case 818: { constexpr int GG = 8, LL = 18; CALL; break; }                     \
+        default: throw std::invalid_argument("unsupported geometry");                 \
     }
 
 static ModConsts consts_of(const host::ModulusPack& m) {
@@ -40,76 +44,85 @@ static ModConsts consts_of(const host::ModulusPack& m) {
     return c;
 }
 
-// number of emulated waves: enough rows for the batch, capped (rows loop over items like the GPU grid)
-static int waves_for(uint64_t B, int cap = 2) {
-    int w = (int)((B + 3) / 4);
+// number of emulated waves: enough groups for the batch, capped (groups stride over items like the GPU grid)
+static int waves_for(uint64_t B, int G, int cap = 2) {
+    const int per_wave = 64 / G;
+    int w = (int)((B + per_wave - 1) / per_wave);
     return w < 1 ? 1 : (w > cap ? cap : w);
 }
 
-template <int L, int MODE>
-static void run_uniform(UniformArgs A, int n_waves) {
-    constexpr int S = 16 * L;
-    const uint32_t total_rows = 4u * (uint32_t)n_waves;
-    std::vector<uint32_t> table((size_t)total_rows * (size_t)A.tbl_entries * S);
+template <int G, int L, int MODE>
+static void run_uniform(UniformArgs A) {
+    constexpr int S = G * L, kPer = 64 / G;
+    const int n_waves = waves_for(A.batch, G);
+    const uint32_t total = (uint32_t)(kPer * n_waves);
+    std::vector<uint32_t> table((size_t)total * (size_t)A.tbl_entries * S);
     A.table = table.data();
     for (int w = 0; w < n_waves; ++w) {
-        std::vector<uint32_t> lds(4 * (S + kLdsPad));
+        std::vector<uint32_t> lds(kPer * (S + kLdsPad));
         wave::run_wave([&](uint32_t lane) {
-            const uint32_t row = lane >> 4;
-            modexp_uniform_body<L, MODE>(A, lds.data() + row * (S + kLdsPad), (uint32_t)w * 4u + row, total_rows, lane);
+            const uint32_t grp = lane / G;
+            modexp_uniform_body<G, L, MODE>(A, lds.data() + grp * (S + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
         });
     }
 }
 
-template <int L>
-static void run_var(VarArgs A, int n_waves) {
-    constexpr int S = 16 * L;
-    const uint32_t total_rows = 4u * (uint32_t)n_waves;
-    std::vector<uint32_t> table((size_t)total_rows * ((size_t)1 << A.window) * S);
+template <int G, int L>
+static void run_var(VarArgs A) {
+    constexpr int S = G * L, kPer = 64 / G;
+    const int n_waves = waves_for(A.batch, G);
+    const uint32_t total = (uint32_t)(kPer * n_waves);
+    std::vector<uint32_t> table((size_t)total * ((size_t)1 << A.window) * S);
     A.table = table.data();
     for (int w = 0; w < n_waves; ++w) {
-        std::vector<uint32_t> lds(4 * (S + kLdsPad));
+        std::vector<uint32_t> lds(kPer * (S + kLdsPad));
         wave::run_wave([&](uint32_t lane) {
-            const uint32_t row = lane >> 4;
-            modexp_var_body<L>(A, lds.data() + row * (S + kLdsPad), (uint32_t)w * 4u + row, total_rows, lane);
+            const uint32_t grp = lane / G;
+            modexp_var_body<G, L>(A, lds.data() + grp * (S + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
         });
     }
 }
 
-template <int L>
-static void run_mul(MulArgs A, int n_waves) {
-    constexpr int S = 16 * L;
-    const uint32_t total_rows = 4u * (uint32_t)n_waves;
+template <int G, int L>
+static void run_mul(MulArgs A) {
+    constexpr int S = G * L, kPer = 64 / G;
+    const int n_waves = waves_for(A.batch, G);
+    const uint32_t total = (uint32_t)(kPer * n_waves);
     for (int w = 0; w < n_waves; ++w) {
-        std::vector<uint32_t> lds(4 * (S + kLdsPad));
+        std::vector<uint32_t> lds(kPer * (S + kLdsPad));
         wave::run_wave([&](uint32_t lane) {
-            const uint32_t row = lane >> 4;
-            mulmod_body<L>(A, lds.data() + row * (S + kLdsPad), (uint32_t)w * 4u + row, total_rows, lane);
+            const uint32_t grp = lane / G;
+            mulmod_body<G, L>(A, lds.data() + grp * (S + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
         });
     }
 }
+
+static int g_prefer_group = 8;
 
 extern "C" {
 
 const char* emu_last_error() { return g_err.c_str(); }
 
-// four independent products a[r]*b[r]*R^-1 mod n, one per DPP row; all arrays are 16*L words per row
-int emu_montmul(int L, const uint32_t* a, const uint32_t* b, const uint32_t* n, uint32_t* out) {
+void emu_set_group(int g) { g_prefer_group = (g == 16) ? 16 : 8; }
+
+// 64/G independent products a[r]*b[r]*R^-1 (mod N), one per limb group.  All arrays hold 29-bit limbs,
+// G*L words per number; a < R, b < 2N; the result is < 2N, almost-normalised (limbs < 2^29 + 2^8).
+int emu_montmul(int G, int L, const uint32_t* a, const uint32_t* b, const uint32_t* n, uint32_t n0inv, uint32_t* out) {
     try {
-        DISPATCH_L(L, ({
-            constexpr int S = 16 * LL;
-            std::vector<uint32_t> lds(4 * (S + kLdsPad));
-            const uint32_t n0inv = host::neg_inv32(n[0]);
+        DISPATCH_GL(G, L, ({
+            constexpr int S = GG * LL, kPer = 64 / GG;
+            std::vector<uint32_t> lds(kPer * (S + kLdsPad));
             wave::run_wave([&](uint32_t lane) {
-                const uint32_t row = lane >> 4, g = lane & 15;
-                uint32_t* lrow = lds.data() + row * (S + kLdsPad);
+                const Lanes<GG> ln(lane);
+                const uint32_t grp = lane / GG, g = ln.g;
+                uint32_t* lrow = lds.data() + grp * (S + kLdsPad);
                 uint32_t x[LL], y[LL], nn[LL], r[LL];
-                load_row<LL>(x, a + row * S, g);
-                load_row<LL>(y, b + row * S, g);
+                load_row<LL>(x, a + grp * S, g);
+                load_row<LL>(y, b + grp * S, g);
                 load_row<LL>(nn, n, g);
                 lds_put<LL>(lrow, x, g);
-                montmul<LL>(r, lrow, y, nn, n0inv, lane);
-                store_row<LL>(out + row * S, r, g);
+                montmul<GG, LL>(r, lrow, y, nn, n0inv, ln);
+                store_row<LL>(out + grp * S, r, g);
             });
         }));
         return 0;
@@ -121,7 +134,7 @@ int emu_encrypt(const uint32_t* n, int n_limbs, const uint32_t* m, const uint32_
                 uint32_t* c_out, uint64_t B) {
     try {
         if (B == 0) return 0;
-        host::PublicPlan P = host::build_public(n, n_limbs);
+        host::PublicPlan P = host::build_public(n, n_limbs, g_prefer_group);
         UniformArgs A;
         memset(&A, 0, sizeof A);
         A.mod = consts_of(P.nsq);
@@ -130,9 +143,8 @@ int emu_encrypt(const uint32_t* n, int n_limbs, const uint32_t* m, const uint32_
         A.base = r; A.base_limbs = P.s1;
         A.post = c_in ? c_in : m; A.post_limbs = c_in ? P.s2 : P.s1;
         A.out = c_out; A.out_limbs = P.s2; A.batch = B;
-        const int nw = waves_for(B);
-        if (c_in) { DISPATCH_L(P.nsq.L, (run_uniform<LL, kModeObfuscate>(A, nw))); }
-        else { DISPATCH_L(P.nsq.L, (run_uniform<LL, kModeEncrypt>(A, nw))); }
+        if (c_in) { DISPATCH_GL(P.nsq.G, P.nsq.L, (run_uniform<GG, LL, kModeObfuscate>(A))); }
+        else { DISPATCH_GL(P.nsq.G, P.nsq.L, (run_uniform<GG, LL, kModeEncrypt>(A))); }
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
@@ -142,10 +154,9 @@ int emu_decrypt(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const 
                 uint64_t B) {
     try {
         if (B == 0) return 0;
-        host::PrivatePlan P = host::build_private(p, q, hp, hq, p_inverse, pq_limbs, n_limbs);
-        const int S = P.psq.S;
+        host::PrivatePlan P = host::build_private(p, q, hp, hq, p_inverse, pq_limbs, n_limbs, g_prefer_group);
+        const int S = (std::max(P.psq.bits, P.qsq.bits) + 31) / 32;
         std::vector<uint32_t> xp((size_t)B * S), xq((size_t)B * S);
-        const int nw = waves_for(B);
         for (int half = 0; half < 2; ++half) {
             const host::ModulusPack& M = half ? P.qsq : P.psq;
             const host::Schedule& E = half ? P.exp_q : P.exp_p;
@@ -156,7 +167,7 @@ int emu_decrypt(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const 
             A.first_idx = E.first_idx; A.tbl_entries = E.tbl_entries;
             A.base = c; A.base_limbs = P.s2;
             A.out = half ? xq.data() : xp.data(); A.out_limbs = S; A.batch = B;
-            DISPATCH_L(M.L, (run_uniform<LL, kModeHalfDecrypt>(A, nw)));
+            DISPATCH_GL(M.G, M.L, (run_uniform<GG, LL, kModeHalfDecrypt>(A)));
         }
         TailArgs T;
         memset(&T, 0, sizeof T);
@@ -178,12 +189,12 @@ int emu_decrypt(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const 
 int emu_mulmod(const uint32_t* N, int limbs, const uint32_t* a, const uint32_t* b, uint32_t* out, uint64_t B) {
     try {
         if (B == 0) return 0;
-        host::ModulusPack M = host::build_modulus(host::big_from(N, limbs, limbs), nullptr);
+        host::ModulusPack M = host::build_modulus(host::big_from(N, limbs, limbs), nullptr, 32 * limbs, g_prefer_group);
         MulArgs A;
         memset(&A, 0, sizeof A);
         A.mod = consts_of(M); A.a = a; A.b = b; A.limbs = limbs; A.out = out; A.batch = B;
         A.a_stride = A.b_stride = A.out_stride = (size_t)limbs;
-        DISPATCH_L(M.L, (run_mul<LL>(A, waves_for(B))));
+        DISPATCH_GL(M.G, M.L, (run_mul<GG, LL>(A)));
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
@@ -193,7 +204,7 @@ int emu_powmod_var(const uint32_t* N, int limbs, const uint32_t* base, const uin
                    uint32_t* out, uint64_t B) {
     try {
         if (B == 0) return 0;
-        host::ModulusPack M = host::build_modulus(host::big_from(N, limbs, limbs), nullptr);
+        host::ModulusPack M = host::build_modulus(host::big_from(N, limbs, limbs), nullptr, 32 * limbs, g_prefer_group);
         int max_bits = 0;
         for (uint64_t i = 0; i < B; ++i) {
             Big e = host::big_from(exps + i * exp_limbs, exp_limbs, exp_limbs);
@@ -205,19 +216,19 @@ int emu_powmod_var(const uint32_t* N, int limbs, const uint32_t* base, const uin
         A.window = host::pick_window(max_bits);
         A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
         A.out = out; A.out_limbs = limbs; A.batch = B;
-        DISPATCH_L(M.L, (run_var<LL>(A, waves_for(B))));
+        DISPATCH_GL(M.G, M.L, (run_var<GG, LL>(A)));
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
-// key-setup introspection: which = 0:n 1:r1 2:r2 3:r3 4:aux (S words each); returns S, L in *L_out
-int emu_public_constants(const uint32_t* n, int n_limbs, int which, uint32_t* out, int* L_out, uint32_t* n0inv,
+// key-setup introspection: which = 0:n 1:r1 2:r2 3:r3 4:aux (S words of 29-bit limbs each); returns S
+int emu_public_constants(const uint32_t* n, int n_limbs, int which, uint32_t* out, int* GL_out, uint32_t* n0inv,
                          int* sched_info /* window, tbl_entries, first_idx, n_ops, squarings, multiplies */) {
     try {
-        host::PublicPlan P = host::build_public(n, n_limbs);
-        const Big* src[] = {&P.nsq.n, &P.nsq.r1, &P.nsq.r2, &P.nsq.r3, &P.nsq.aux};
+        host::PublicPlan P = host::build_public(n, n_limbs, g_prefer_group);
+        const std::vector<uint32_t>* src[] = {&P.nsq.n, &P.nsq.r1, &P.nsq.r2, &P.nsq.r3, &P.nsq.aux};
         memcpy(out, src[which]->data(), sizeof(uint32_t) * (size_t)P.nsq.S);
-        *L_out = P.nsq.L;
+        GL_out[0] = P.nsq.G; GL_out[1] = P.nsq.L;
         *n0inv = P.nsq.n0inv;
         sched_info[0] = P.exp_n.window; sched_info[1] = P.exp_n.tbl_entries; sched_info[2] = P.exp_n.first_idx;
         sched_info[3] = (int)P.exp_n.ops.size(); sched_info[4] = P.exp_n.squarings; sched_info[5] = P.exp_n.multiplies;

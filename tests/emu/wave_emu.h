@@ -96,14 +96,25 @@ inline uint32_t exchange(uint32_t x, F src_of) {
     return src < 0 ? 0u : e->box[ph][src];
 }
 
-inline uint32_t row_down1(uint32_t x) {
-    return exchange(x, [](int l) { return (l & 15) == 15 ? -1 : l + 1; });
+template <int G>
+struct Lanes {
+    uint32_t lane, g, not_top, not_low;
+    explicit Lanes(uint32_t lane_) : lane(lane_), g(lane_ & (G - 1)) {
+        not_top = (g == G - 1) ? 0u : 0xffffffffu;
+        not_low = (g == 0) ? 0u : 0xffffffffu;
+    }
+};
+template <int G>
+inline uint32_t grp_down1(uint32_t x, const Lanes<G>&) {
+    return exchange(x, [](int l) { return (l & (G - 1)) == G - 1 ? -1 : l + 1; });
 }
-inline uint32_t row_up1(uint32_t x) {
-    return exchange(x, [](int l) { return (l & 15) == 0 ? -1 : l - 1; });
+template <int G>
+inline uint32_t grp_up1(uint32_t x, const Lanes<G>&) {
+    return exchange(x, [](int l) { return (l & (G - 1)) == 0 ? -1 : l - 1; });
 }
-inline uint32_t row_bcast0(uint32_t x) {
-    return exchange(x, [](int l) { return l & ~15; });
+template <int G>
+inline uint32_t grp_bcast0(uint32_t x, const Lanes<G>&) {
+    return exchange(x, [](int l) { return l & ~(G - 1); });
 }
 inline uint64_t ballot(bool p) {
     Emu* e = emu();
@@ -121,16 +132,6 @@ inline void lds_fence() {
     yield_all();
 }
 
-inline uint64_t mad(uint32_t a, uint32_t b, uint32_t c) { return (uint64_t)a * b + c; }
-inline uint32_t addc(uint32_t a, uint32_t b, uint32_t cin, uint32_t& cout) {
-    const uint64_t s = (uint64_t)a + b + cin;
-    cout = (uint32_t)(s >> 32);
-    return (uint32_t)s;
-}
-inline uint32_t subb(uint32_t a, uint32_t b, uint32_t bin, uint32_t& bout) {
-    const uint64_t d = (uint64_t)a - b - bin;
-    bout = (uint32_t)(d >> 63);
-    return (uint32_t)d;
-}
+inline uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
 
 }  // namespace wave

@@ -25,9 +25,13 @@ class Emu:
         if rc != 0:
             raise RuntimeError(self.L.emu_last_error().decode())
 
-    def montmul(self, L, a, b, n):
-        out = np.zeros((4, 16 * L), np.uint32)
-        self._ck(self.L.emu_montmul(L, P(a), P(b), P(n), P(out)))
+    def set_group(self, g):
+        self.L.emu_set_group(int(g))
+
+    def montmul(self, G, L, a, b, n, n0inv):
+        """a, b: (64/G, G*L) arrays of 29-bit limbs; n: (G*L,) limbs."""
+        out = np.zeros((64 // G, G * L), np.uint32)
+        self._ck(self.L.emu_montmul(G, L, P(a), P(b), P(n), ctypes.c_uint32(n0inv), P(out)))
         return out
 
     def encrypt(self, n, m, r):
@@ -62,15 +66,25 @@ class Emu:
     def public_constants(self, n):
         s1 = n.shape[0]
         res = {}
-        L = ctypes.c_int(0)
+        GL = (ctypes.c_int * 2)()
         n0 = ctypes.c_uint32(0)
         info = (ctypes.c_int * 6)()
         for which, name in enumerate(["n", "r1", "r2", "r3", "aux"]):
             buf = np.zeros(1024, np.uint32)
-            S = self.L.emu_public_constants(P(n), s1, which, P(buf), ctypes.byref(L), ctypes.byref(n0), info)
+            S = self.L.emu_public_constants(P(n), s1, which, P(buf), GL, ctypes.byref(n0), info)
             if S < 0:
                 raise RuntimeError(self.L.emu_last_error().decode())
             res[name] = buf[:S].copy()
-        res.update(L=L.value, S=S, n0inv=n0.value, window=info[0], tbl_entries=info[1], first_idx=info[2],
+        res.update(G=GL[0], L=GL[1], S=S, n0inv=n0.value, window=info[0], tbl_entries=info[1], first_idx=info[2],
                    n_ops=info[3], squarings=info[4], multiplies=info[5])
         return res
+
+
+def to_r29(x, count):
+    """Python int -> `count` limbs of 29 bits (numpy uint32)."""
+    return np.array([(x >> (29 * j)) & ((1 << 29) - 1) for j in range(count)], dtype=np.uint32)
+
+
+def from_r29(limbs):
+    """limbs (possibly not normalised) -> Python int."""
+    return sum(int(v) << (29 * j) for j, v in enumerate(np.asarray(limbs).tolist()))

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden, load_kat
-from emu_lib import Emu
+from emu_lib import Emu, from_r29, to_r29
 from oracle.paillier_oracle import int_to_limbs, ints_to_limbs, limbs_to_int, limbs_to_ints
 
 
@@ -20,34 +20,44 @@ def emu():
     return Emu()
 
 
-@pytest.mark.parametrize("L", [1, 2, 3, 4, 6, 8, 12, 16])
-def test_montmul_rows(emu, L):
-    rng = random.Random(100 + L)
-    S = 16 * L
-    R = 1 << (32 * S)
-    moduli = [rng.getrandbits(32 * S) | 1 | (1 << (32 * S - 1)),  # full width
-              (R - 1 - 2 * rng.getrandbits(20)) | 1,             # just below R: exercises the overflow bit
-              126869 ** 2,                                        # tiny modulus in a wide container
-              (1 << (32 * S - 1)) + 1]
+GEOMETRIES = [(16, 1), (16, 2), (16, 3), (16, 5), (16, 7), (16, 9), (16, 14), (16, 18), (8, 5), (8, 9), (8, 14), (8, 18)]
+
+
+@pytest.mark.parametrize("G,L", GEOMETRIES)
+def test_montmul_groups(emu, G, L):
+    """One radix-2^29 Montgomery product per limb group: result == a*b/R (mod N), < 2N, limbs < 2^29 + 2^8."""
+    rng = random.Random(100 * G + L)
+    S = G * L
+    R = 1 << (29 * S)
+    per = 64 // G
+    top = 29 * S - 4                                            # largest modulus this geometry accepts
+    moduli = [rng.getrandbits(top) | 1 | (1 << (top - 1)),      # widest
+              (1 << top) - 1,                                   # all-ones limbs: every carry path
+              126869 ** 2,                                      # tiny modulus in a wide container
+              (1 << (top - 1)) + 1]
     for N in moduli:
-        a = [rng.randrange(0, R) for _ in range(4)]
-        b = [rng.randrange(0, N) for _ in range(4)]
-        a[0], b[0], a[1], b[2] = R - 1, N - 1, 0, 0
-        got = limbs_to_ints(emu.montmul(L, ints_to_limbs(a, S), ints_to_limbs(b, S), int_to_limbs(N, S)))
+        n0inv = (-pow(N, -1, 1 << 29)) % (1 << 29)
+        a = [rng.randrange(0, R) for _ in range(per)]           # multiplier: any value below R
+        b = [rng.randrange(0, N) for _ in range(per)]
+        a[0], b[0] = R - 1, N - 1
+        a[1], b[per - 1] = 0, 0
+        aa = np.stack([to_r29(x, S) for x in a])
+        bb = np.stack([to_r29(x, S) for x in b])
+        out = emu.montmul(G, L, aa, bb, to_r29(N, S), n0inv)
         rinv = pow(R, -1, N)
-        assert got == [x * y * rinv % N for x, y in zip(a, b)]
-
-
-def test_carry_chains_all_ones(emu):
-    # products engineered so lane sums are all-ones words and carries ripple across every lane
-    L, S = 2, 32
-    R = 1 << (32 * S)
-    N = R - 1  # odd, every limb 0xffffffff
-    a = [R - 1, R - 2, 1, (1 << 512) - 1]
-    b = [N - 1, N - 1, N - 1, N - 2]
-    got = limbs_to_ints(emu.montmul(L, ints_to_limbs(a, S), ints_to_limbs(b, S), int_to_limbs(N, S)))
-    rinv = pow(R, -1, N)
-    assert got == [x * y * rinv % N for x, y in zip(a, b)]
+        for x, y, limbs in zip(a, b, out):
+            v = from_r29(limbs)
+            assert v % N == x * y * rinv % N
+            assert v < 2 * N and int(limbs.max()) < (1 << 29) + (1 << 8)
+        # both operands in [N, 2N) and almost-normalised digits: the lazy-reduction invariant is closed
+        a2 = [N + rng.randrange(0, N) for _ in range(per)]
+        b2 = [N + rng.randrange(0, N) for _ in range(per)]
+        bb2 = np.stack([to_r29(x, S) for x in b2])
+        aa2 = np.stack([to_r29(x, S) for x in a2])
+        out = emu.montmul(G, L, aa2, bb2, to_r29(N, S), n0inv)
+        for x, y, limbs in zip(a2, b2, out):
+            v = from_r29(limbs)
+            assert v % N == x * y * rinv % N and v < 2 * N
 
 
 @pytest.mark.parametrize("key_bits", [256, 1024])
@@ -55,19 +65,22 @@ def test_public_constants(emu, key_bits):
     g = load_golden(key_bits)
     n = H(g["n"])
     s1 = key_bits // 32
-    k = emu.public_constants(int_to_limbs(n, s1))
-    S = k["S"]
-    N = n * n
-    R = 1 << (32 * S)
-    assert S >= 2 * s1 and S == 16 * k["L"]
-    assert limbs_to_int(k["n"]) == N
-    assert limbs_to_int(k["r1"]) == R % N
-    assert limbs_to_int(k["r2"]) == R * R % N
-    assert limbs_to_int(k["r3"]) == R * R * R % N
-    assert limbs_to_int(k["aux"]) == n * R % N
-    assert (k["n0inv"] * N + 1) % (1 << 32) == 0
-    # schedule cost vs the canonical E(t) = t + t/6 + 16 of SURVEY.md 8(d)
-    assert k["squarings"] <= key_bits and k["multiplies"] <= key_bits // 5 + 2
+    for group in (8, 16):
+        emu.set_group(group)
+        k = emu.public_constants(int_to_limbs(n, s1))
+        S = k["S"]
+        N = n * n
+        R = 1 << (29 * S)
+        assert S == k["G"] * k["L"] and 29 * S >= N.bit_length() + 4 and 29 * S >= 64 * s1
+        assert from_r29(k["n"]) == N
+        assert from_r29(k["r1"]) == R % N
+        assert from_r29(k["r2"]) == R * R % N
+        assert from_r29(k["r3"]) == R * R * R % N
+        assert from_r29(k["aux"]) == n * R % N
+        assert (k["n0inv"] * N + 1) % (1 << 29) == 0
+        # schedule cost vs the canonical E(t) = t + t/6 + 16 of SURVEY.md 8(d)
+        assert k["squarings"] <= key_bits and k["multiplies"] <= key_bits // 5 + 2
+    emu.set_group(8)
 
 
 def test_reference_kat(emu):
@@ -80,8 +93,10 @@ def test_reference_kat(emu):
     assert limbs_to_ints(m) == [k["m"], 1]
 
 
-@pytest.mark.parametrize("key_bits,count", [(256, None), (1024, 5), (2048, 2)])
-def test_golden_through_emulator(emu, key_bits, count):
+@pytest.mark.parametrize("key_bits,count,group", [(256, None, 16), (256, None, 8), (1024, 5, 8), (1024, 3, 16),
+                                                  (2048, 2, 8)])
+def test_golden_through_emulator(emu, key_bits, count, group):
+    emu.set_group(group)
     g = load_golden(key_bits)
     s1, s2, h = key_bits // 32, key_bits // 16, key_bits // 64
     n = int_to_limbs(H(g["n"]), s1)

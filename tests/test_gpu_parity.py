@@ -38,15 +38,16 @@ def make_ctx(native, g, private=True):
 
 
 def test_wave_primitives(native):
-    """The DPP row operations mean what csrc/wave_gfx950.h (and the CPU emulator) say they mean."""
+    """The DPP group operations mean what csrc/wave_gfx950.h (and the CPU emulator) say they mean."""
     out = native.selftest_prims(0)
     lanes = np.arange(64)
-    down = np.where(lanes % 16 == 15, 0, lanes + 1 + 100)
-    up = np.where(lanes % 16 == 0, 0, lanes - 1 + 100)
-    bc = (lanes // 16) * 16 + 100
-    assert np.array_equal(out[0:64], down)
-    assert np.array_equal(out[64:128], up)
-    assert np.array_equal(out[128:192], bc)
+    for G, base in ((16, 0), (8, 258)):
+        down = np.where(lanes % G == G - 1, 0, lanes + 1 + 100)
+        up = np.where(lanes % G == 0, 0, lanes - 1 + 100)
+        bc = (lanes // G) * G + 100
+        assert np.array_equal(out[base:base + 64], down), G
+        assert np.array_equal(out[base + 64:base + 128], up), G
+        assert np.array_equal(out[base + 128:base + 192], bc), G
     assert np.array_equal(out[192:256], (lanes % 3 == 0).astype(np.uint32))
     mask = sum(1 << int(l) for l in lanes if l % 3 == 0)
     assert int(out[256]) | (int(out[257]) << 32) == mask
