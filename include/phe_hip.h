@@ -61,12 +61,14 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
 
 void phe_hip_ctx_destroy(phe_hip_ctx* ctx);
 
-/* Geometry chosen for this key: limbs-per-lane of the n^2 kernels and of the p^2/q^2 kernels,
- * and the number of 16-lane limb groups one launch keeps in flight. Any pointer may be NULL. */
+/* Geometry chosen for this key, encoded G*100 + L (lanes per limb group, 29-bit limbs per lane) for the n^2
+ * kernels and for the p^2/q^2 kernels, and the number of limb groups one launch keeps in flight.
+ * Any pointer may be NULL. */
 int phe_hip_ctx_info(const phe_hip_ctx* ctx, int* n_limbs, int* ct_limbs, int* lanes_limbs_pub,
                      int* lane_limbs_priv, int* rows_in_flight, int* has_private);
 
-/* Tuning: workgroups (256 threads = 16 limb groups) resident per CU for the modexp kernels. */
+/* Tuning: workgroups (256 threads) resident per CU for the modexp kernels; 0 = ask the HIP occupancy API
+ * per kernel (the default). */
 int phe_hip_ctx_set_blocks_per_cu(phe_hip_ctx* ctx, int blocks_per_cu);
 
 /* ---- the hot path, host buffers ------------------------------------------------------------ */

@@ -116,7 +116,7 @@ struct DevTail {
 struct phe_hip_ctx {
     int device = 0;
     int n_cus = 256;
-    int blocks_per_cu = 2;
+    int blocks_per_cu = 0;  // 0 = ask the occupancy API per kernel (PHE_HIP_BLOCKS_PER_CU / set_blocks_per_cu override)
     int prefer_group = 8;  // lanes per limb group when the key size offers both (PHE_HIP_GROUP=16 overrides)
     bool has_private = false;
     host::PublicPlan pub;
@@ -191,10 +191,10 @@ static int ensure_words(uint32_t** buf, size_t* have, size_t need) {
     return PHE_HIP_OK;
 }
 
-static int grid_blocks(const phe_hip_ctx* ctx, size_t batch, int G, int max_blocks_per_cu = 0) {
+static int grid_blocks(const phe_hip_ctx* ctx, size_t batch, int G, int blocks_per_cu) {
     const size_t groups = (size_t)(kBlock / G);
     const size_t want = (batch + groups - 1) / groups;
-    const size_t cap = (size_t)ctx->n_cus * (size_t)(max_blocks_per_cu ? max_blocks_per_cu : ctx->blocks_per_cu);
+    const size_t cap = (size_t)ctx->n_cus * (size_t)std::max(1, blocks_per_cu);
     return (int)std::max<size_t>(1, std::min(want, cap));
 }
 
@@ -222,6 +222,24 @@ static int grid_blocks(const phe_hip_ctx* ctx, size_t batch, int G, int max_bloc
 // ------------------------------------------------------------------------------------------------
 // launches (device pointers)
 // ------------------------------------------------------------------------------------------------
+// Resident workgroups per CU for a kernel (VGPR/LDS-limited), asked once per instantiation.  The modexp
+// kernels size their grid to the residency so that the window tables stay per resident group.
+static int query_resident_blocks(const void* kernel) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, 0) != hipSuccess || nb < 1) nb = 2;
+    return std::min(nb, 4);
+}
+template <int G, int L, int MODE>
+static int occ_uniform() {
+    static const int cached = query_resident_blocks((const void*)k_modexp_uniform<G, L, MODE>);
+    return cached;
+}
+template <int G, int L>
+static int occ_var() {
+    static const int cached = query_resident_blocks((const void*)k_modexp_var<G, L>);
+    return cached;
+}
+
 template <int G, int L, int MODE>
 static void go_uniform(int blocks, hipStream_t st, const UniformArgs& A) {
     k_modexp_uniform<G, L, MODE><<<dim3(blocks), dim3(kBlock), 0, st>>>(A);
@@ -239,7 +257,9 @@ template <int MODE>
 static int launch_uniform(phe_hip_ctx* ctx, const DevModulus& M, const DevSchedule& E, const uint32_t* base,
                           int base_limbs, const uint32_t* post, int post_limbs, uint32_t* out, int out_limbs,
                           size_t batch, hipStream_t stream) {
-    const int blocks = grid_blocks(ctx, batch, M.G);
+    int per_cu = ctx->blocks_per_cu;
+    if (per_cu == 0) DISPATCH_GL(M.G, M.L, (per_cu = occ_uniform<GG, LL, MODE>()));
+    const int blocks = grid_blocks(ctx, batch, M.G, per_cu);
     const size_t rows = (size_t)blocks * (size_t)(kBlock / M.G);
     int rc = ensure_words(&ctx->table, &ctx->table_words, rows * (size_t)E.tbl_entries * M.S);
     if (rc) return rc;
@@ -276,7 +296,9 @@ static int launch_var(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* bas
     A.out = out;
     A.out_limbs = out_limbs;
     A.batch = batch;
-    const int blocks = grid_blocks(ctx, batch, M.G);
+    int per_cu = ctx->blocks_per_cu;
+    if (per_cu == 0) DISPATCH_GL(M.G, M.L, (per_cu = occ_var<GG, LL>()));
+    const int blocks = grid_blocks(ctx, batch, M.G, per_cu);
     const size_t rows = (size_t)blocks * (size_t)(kBlock / M.G);
     int rc = ensure_words(&ctx->table, &ctx->table_words, rows * ((size_t)1 << A.window) * M.S);
     if (rc) return rc;
@@ -422,14 +444,14 @@ int phe_hip_ctx_info(const phe_hip_ctx* ctx, int* n_limbs, int* ct_limbs, int* l
     // geometry is reported as G*100 + L (e.g. 818 = groups of 8 lanes x 18 limbs of 29 bits)
     if (lane_limbs_pub) *lane_limbs_pub = ctx->pub.nsq.G * 100 + ctx->pub.nsq.L;
     if (lane_limbs_priv) *lane_limbs_priv = ctx->has_private ? ctx->priv.psq.G * 100 + ctx->priv.psq.L : 0;
-    if (rows_in_flight) *rows_in_flight = ctx->n_cus * ctx->blocks_per_cu * (kBlock / ctx->pub.nsq.G);
+    if (rows_in_flight) *rows_in_flight = ctx->n_cus * std::max(1, ctx->blocks_per_cu ? ctx->blocks_per_cu : 2) * (kBlock / ctx->pub.nsq.G);
     if (has_private) *has_private = ctx->has_private ? 1 : 0;
     return PHE_HIP_OK;
 }
 
 int phe_hip_ctx_set_blocks_per_cu(phe_hip_ctx* ctx, int blocks_per_cu) {
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
-    if (blocks_per_cu < 1 || blocks_per_cu > 8) return fail(PHE_HIP_EINVAL, "blocks_per_cu must be in 1..8");
+    if (blocks_per_cu < 0 || blocks_per_cu > 8) return fail(PHE_HIP_EINVAL, "blocks_per_cu must be in 0..8 (0 = automatic)");
     ctx->blocks_per_cu = blocks_per_cu;
     return PHE_HIP_OK;
 }

