@@ -113,10 +113,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run (also with 1 rank)
     torch.cuda.set_device(local_rank)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
 
     with open(os.path.join(ROOT, "tests", "golden", "paillier_%d.json" % args.key_bits)) as f:
@@ -149,7 +151,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     def timed(step_fn, steps):
@@ -163,7 +165,7 @@ def main():
             b.record()
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
@@ -218,7 +220,8 @@ def main():
     if rank == 0:
         enc_mac, dec_mac = mac32_counts(args.key_bits)
         peak, sustained, peak_src = valu_peak_mac32()
-        traffic_unit, traffic_src = measured_traffic_per_unit("k_modexp_uniform<8,encrypt>") if args.key_bits == 2048 else (None, None)
+        traffic_unit, traffic_src = measured_traffic_per_unit("k_modexp_uniform<8,18,encrypt>") if (
+            args.key_bits == 2048 and ctx.info()["lane_limbs_pub"] == 818) else (None, None)
         enc_kernel_s = sum(enc_launch_ms) / len(enc_launch_ms) * 1e-3
         dec_kernel_s = sum(dec_launch_ms) / len(dec_launch_ms) * 1e-3
         achieved = enc_mac * B / enc_kernel_s
@@ -226,7 +229,7 @@ def main():
         out = {
             "metric": METRIC, "value": value, "unit": "encrypts/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": enc_dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (v_mad_u64_u32, 64-bit accumulate)",
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32 (29-bit limbs, v_mad_u64_u32 with 64-bit accumulate)",
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d-bit key, %d-plaintext batch per GPU, raw_encrypt then raw_decrypt, "
                                    "operands resident in HBM" % (args.key_bits, B),
@@ -236,7 +239,7 @@ def main():
                         "ms_per_step": dec_dt / args.steps * 1e3},
             "bit_exact": {"roundtrip_full_batch": roundtrip_ok, "strided_sample_vs_gmp_oracle": sample_ok},
             "roofline": {
-                "bound": "valu_int32", "kernel": "k_modexp_uniform<L=%d, encrypt>" % ctx.info()["lane_limbs_pub"],
+                "bound": "valu_int32", "kernel": "k_modexp_uniform<G=%d, L=%d, encrypt> (radix 2^29)" % divmod(ctx.info()["lane_limbs_pub"], 100),
                 "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": achieved / peak,
                 "traffic": (traffic_unit * B) if traffic_unit else None,
                 "traffic_note": ("HBM+MALL bytes per launch = %.0f B/encrypt (PMC FETCH_SIZE x2 + WRITE_SIZE, %s) x batch; "
@@ -255,7 +258,7 @@ def main():
             out["speedup_vs_cpu_all_cores"] = {"encrypt": value / cpu["value"],
                                                "decrypt": out["decrypt"]["value"] / cpu["decrypts_per_s"]}
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if not roundtrip_ok or sample_ok is False:

@@ -112,11 +112,20 @@ int phe_hip_mulmod_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, u
 int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, int max_exp_bits,
                        uint32_t* out, size_t batch, void* stream);
 
+/* phe_hip_invert on device buffers.  Synchronises `stream` internally (the root of the product tree makes one
+ * round trip to the host); results are complete on return. */
+int phe_hip_invert_dev(phe_hip_ctx* ctx, const uint32_t* a, uint32_t* out, size_t batch, size_t* bad_index, void* stream);
+/* out[i] = mask[i] ? b[i] : a[i] for rows of `limbs` words; mask is one byte per row (device).  Used to keep the
+ * branch select of _raw_mul (phe/paillier.py:745-751: inverted base for scalars >= n - max_int) on the device. */
+int phe_hip_select_rows_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, const uint8_t* mask, uint32_t* out,
+                            int limbs, size_t batch, void* stream);
+
 /* ---- device memory helpers for hosts without a tensor library ------------------------------- */
 int phe_hip_malloc(phe_hip_ctx* ctx, size_t bytes, void** dptr);
 int phe_hip_free(phe_hip_ctx* ctx, void* dptr);
 int phe_hip_memcpy_h2d(phe_hip_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 int phe_hip_memcpy_d2h(phe_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+int phe_hip_memcpy_d2d(phe_hip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 int phe_hip_stream_sync(phe_hip_ctx* ctx, void* stream);
 
 /* ---- diagnostics ----------------------------------------------------------------------------- */

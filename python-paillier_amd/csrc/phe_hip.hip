@@ -69,6 +69,16 @@ __global__ void __launch_bounds__(kTailBlock) k_decrypt_tail(TailArgs A) {
     decrypt_tail_one(A, ws, item);
 }
 
+// out[i] = mask[i] ? b[i] : a[i], rows of `limbs` 32-bit words (the branch select of _raw_mul, phe/paillier.py:745-751)
+__global__ void __launch_bounds__(256) k_select_rows(const uint32_t* a, const uint32_t* b, const uint8_t* mask,
+                                                     uint32_t* out, int limbs, uint64_t batch) {
+    const uint64_t total = batch * (uint64_t)limbs;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t row = i / (uint64_t)limbs;
+        out[i] = mask[row] ? b[i] : a[i];
+    }
+}
+
 __global__ void k_selftest_prims(uint32_t* out) {
     const uint32_t lane = threadIdx.x & 63u;
     const wave::Lanes<16> l16(lane);
@@ -659,11 +669,9 @@ static bool host_invert(const Big& a_in, const Big& N, Big& out) {
     return true;
 }
 
-int phe_hip_invert(phe_hip_ctx* ctx, const uint32_t* a, uint32_t* out, size_t batch, size_t* bad_index) {
-    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
-    if (batch == 0) return PHE_HIP_OK;
-    if (!a || !out) return fail(PHE_HIP_EINVAL, "null buffer");
-    if (int rc = bind_device(ctx)) return rc;
+// a_is_device/out_is_device pick the copy kinds; the trees live in stage[0] (products) and stage[1] (inverses).
+static int invert_impl(phe_hip_ctx* ctx, const uint32_t* a, bool a_is_device, uint32_t* out, bool out_is_device,
+                       size_t batch, size_t* bad_index, hipStream_t st) {
     const int s2 = ctx->pub.s2;
     const size_t w = (size_t)s2;
     const DevModulus& M = ctx->d_nsq;
@@ -673,31 +681,31 @@ int phe_hip_invert(phe_hip_ctx* ctx, const uint32_t* a, uint32_t* out, size_t ba
     std::vector<size_t> off(cnt.size());
     size_t total = 0;
     for (size_t k = 0; k < cnt.size(); ++k) { off[k] = total; total += cnt[k]; }
-    // prod tree in stage[0], inverse tree in stage[1]
     int rc = stage_in(ctx, 0, nullptr, total * w);
     if (!rc) rc = stage_in(ctx, 1, nullptr, total * w);
     if (rc) return rc;
     uint32_t* prod = ctx->stage[0];
     uint32_t* inv = ctx->stage[1];
-    HIP_TRY(hipMemcpy(prod, a, batch * w * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(prod, a, batch * w * 4, a_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     for (size_t k = 0; k + 1 < cnt.size(); ++k) {
         const size_t pairs = cnt[k] / 2;
         uint32_t* src = prod + off[k] * w;
         uint32_t* dst = prod + off[k + 1] * w;
         if (pairs) {
-            rc = launch_mul(ctx, M, src, 2 * w, src + w, 2 * w, dst, w, s2, pairs, nullptr);
+            rc = launch_mul(ctx, M, src, 2 * w, src + w, 2 * w, dst, w, s2, pairs, st);
             if (rc) return rc;
         }
-        if (cnt[k] & 1) HIP_TRY(hipMemcpyAsync(dst + pairs * w, src + (cnt[k] - 1) * w, w * 4, hipMemcpyDeviceToDevice, nullptr));
+        if (cnt[k] & 1) HIP_TRY(hipMemcpyAsync(dst + pairs * w, src + (cnt[k] - 1) * w, w * 4, hipMemcpyDeviceToDevice, st));
     }
     // one scalar inversion of the root on the host
     Big root(w), N = ctx->pub.nsq32, rinv;
-    HIP_TRY(hipMemcpy(root.data(), prod + off.back() * w, w * 4, hipMemcpyDeviceToHost));
-    bool reduced_ok = host::big_cmp(root, N) < 0;
+    HIP_TRY(hipMemcpyAsync(root.data(), prod + off.back() * w, w * 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const bool reduced_ok = host::big_cmp(root, N) < 0;
     if (!reduced_ok || !host_invert(root, N, rinv)) {
         // slow path only on failure: find the first row that is not a unit (or not reduced)
         std::vector<uint32_t> h(batch * w);
-        memcpy(h.data(), a, batch * w * 4);
+        HIP_TRY(hipMemcpy(h.data(), prod, batch * w * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < batch; ++i) {
             Big x(h.begin() + (long)(i * w), h.begin() + (long)((i + 1) * w)), tmp;
             Big xr = host::big_cmp(x, N) < 0 ? x : host::big_mod(x, N);
@@ -708,7 +716,7 @@ int phe_hip_invert(phe_hip_ctx* ctx, const uint32_t* a, uint32_t* out, size_t ba
         }
         return fail(PHE_HIP_EINVAL, "inversion failed although every element is a unit (operands must be < n^2)");
     }
-    HIP_TRY(hipMemcpy(inv + off.back() * w, rinv.data(), w * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(inv + off.back() * w, rinv.data(), w * 4, hipMemcpyHostToDevice, st));
     for (size_t k = cnt.size() - 1; k-- > 0;) {
         const size_t pairs = cnt[k] / 2;
         uint32_t* p = prod + off[k] * w;
@@ -716,13 +724,43 @@ int phe_hip_invert(phe_hip_ctx* ctx, const uint32_t* a, uint32_t* out, size_t ba
         uint32_t* dn = inv + off[k] * w;
         if (pairs) {
             // inv[2i] = up[i] * prod[2i+1];  inv[2i+1] = up[i] * prod[2i]
-            rc = launch_mul(ctx, M, up, w, p + w, 2 * w, dn, 2 * w, s2, pairs, nullptr);
-            if (!rc) rc = launch_mul(ctx, M, up, w, p, 2 * w, dn + w, 2 * w, s2, pairs, nullptr);
+            rc = launch_mul(ctx, M, up, w, p + w, 2 * w, dn, 2 * w, s2, pairs, st);
+            if (!rc) rc = launch_mul(ctx, M, up, w, p, 2 * w, dn + w, 2 * w, s2, pairs, st);
             if (rc) return rc;
         }
-        if (cnt[k] & 1) HIP_TRY(hipMemcpyAsync(dn + (cnt[k] - 1) * w, up + pairs * w, w * 4, hipMemcpyDeviceToDevice, nullptr));
+        if (cnt[k] & 1) HIP_TRY(hipMemcpyAsync(dn + (cnt[k] - 1) * w, up + pairs * w, w * 4, hipMemcpyDeviceToDevice, st));
     }
-    HIP_TRY(hipMemcpy(out, inv, batch * w * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpyAsync(out, inv, batch * w * 4, out_is_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));  // rinv (host) was an async source; results are complete on return
+    return PHE_HIP_OK;
+}
+
+int phe_hip_invert(phe_hip_ctx* ctx, const uint32_t* a, uint32_t* out, size_t batch, size_t* bad_index) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!a || !out) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    return invert_impl(ctx, a, false, out, false, batch, bad_index, nullptr);
+}
+
+int phe_hip_invert_dev(phe_hip_ctx* ctx, const uint32_t* a, uint32_t* out, size_t batch, size_t* bad_index, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!a || !out) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    return invert_impl(ctx, a, true, out, true, batch, bad_index, (hipStream_t)stream);
+}
+
+int phe_hip_select_rows_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, const uint8_t* mask, uint32_t* out,
+                            int limbs, size_t batch, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!a || !b || !mask || !out || limbs < 1) return fail(PHE_HIP_EINVAL, "null buffer / limbs");
+    if (int rc = bind_device(ctx)) return rc;
+    const size_t total = batch * (size_t)limbs;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)ctx->n_cus * 8);
+    k_select_rows<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(a, b, mask, out, limbs, (uint64_t)batch);
+    HIP_TRY(hipGetLastError());
     return PHE_HIP_OK;
 }
 
@@ -749,6 +787,12 @@ int phe_hip_memcpy_d2h(phe_hip_ctx* ctx, void* dst_host, const void* src_dev, si
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
     if (int rc = bind_device(ctx)) return rc;
     HIP_TRY(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return PHE_HIP_OK;
+}
+int phe_hip_memcpy_d2d(phe_hip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (int rc = bind_device(ctx)) return rc;
+    HIP_TRY(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return PHE_HIP_OK;
 }
 int phe_hip_stream_sync(phe_hip_ctx* ctx, void* stream) {

@@ -18,6 +18,7 @@ import secrets
 import numpy as np
 
 from . import _native
+from ._device import DeviceArray
 
 
 def default_device():
@@ -116,3 +117,63 @@ class Engine:
 
     def invert_n2(self, a):
         return self.ctx.invert(self._as_cipher(a))
+
+    # ---- the same five functions on device-resident arrays (DeviceArray in, DeviceArray out) --------------
+    def upload_plain(self, ints_or_limbs):
+        return DeviceArray.from_host(self.ctx, self._as_plain(ints_or_limbs))
+
+    def upload_cipher(self, ints_or_limbs):
+        return DeviceArray.from_host(self.ctx, self._as_cipher(ints_or_limbs))
+
+    def raw_encrypt_dev(self, m, r):
+        m = self.upload_plain([v % self.n for v in m] if not isinstance(m, np.ndarray) else m)
+        r = self.upload_plain(r)
+        out = DeviceArray(self.ctx, m.rows, self.ct_limbs)
+        self.ctx.encrypt_dev(m.ptr, r.ptr, out.ptr, m.rows)
+        self.ctx.sync()
+        return out
+
+    def obfuscate_dev(self, c, r):
+        r = self.upload_plain(r)
+        out = DeviceArray(self.ctx, c.rows, self.ct_limbs)
+        self.ctx.obfuscate_dev(c.ptr, r.ptr, out.ptr, c.rows)
+        self.ctx.sync()
+        return out
+
+    def raw_decrypt_dev(self, c):
+        out = DeviceArray(self.ctx, c.rows, self.n_limbs)
+        self.ctx.decrypt_dev(c.ptr, out.ptr, c.rows)
+        self.ctx.sync()
+        return out.to_host()
+
+    def raw_add_dev(self, a, b):
+        out = DeviceArray(self.ctx, a.rows, self.ct_limbs)
+        self.ctx.mulmod_dev(a.ptr, b.ptr, out.ptr, a.rows)
+        self.ctx.sync()
+        return out
+
+    def powmod_dev(self, base, exps):
+        exps = list(exps)
+        bits = max(1, max(e.bit_length() for e in exps))
+        width = (bits + 31) // 32
+        e = DeviceArray.from_host(self.ctx, _native.ints_to_limbs(exps, width))
+        out = DeviceArray(self.ctx, base.rows, self.ct_limbs)
+        self.ctx.powmod_dev(base.ptr, e.ptr, width, bits, out.ptr, base.rows)
+        self.ctx.sync()
+        return out
+
+    def raw_mul_dev(self, c, scalars):
+        """Engine.raw_mul with the ciphertexts staying in HBM: the inverse branch (phe/paillier.py:745-749) is taken
+        by inverting the whole vector on the device (3 modmuls per row) and selecting per row."""
+        n, threshold = self.n, self.n - self.max_int
+        neg = np.fromiter((s >= threshold for s in scalars), dtype=np.uint8, count=len(scalars))
+        exps = [n - s if s >= threshold else s for s in scalars]
+        base = c
+        if neg.any():
+            inv = DeviceArray(self.ctx, c.rows, self.ct_limbs)
+            self.ctx.invert_dev(c.ptr, inv.ptr, c.rows)
+            mask = DeviceArray.from_host(self.ctx, neg, dtype=np.uint8)
+            base = DeviceArray(self.ctx, c.rows, self.ct_limbs)
+            self.ctx.select_rows_dev(c.ptr, inv.ptr, mask.ptr, base.ptr, self.ct_limbs, c.rows)
+            self.ctx.sync()
+        return self.powmod_dev(base, exps)

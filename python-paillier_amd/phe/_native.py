@@ -56,6 +56,9 @@ def lib():
         L.phe_hip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
         L.phe_hip_memcpy_d2h.argtypes = [vp, vp, vp, sz]
         L.phe_hip_stream_sync.argtypes = [vp, vp]
+        L.phe_hip_memcpy_d2d.argtypes = [vp, vp, vp, sz, vp]
+        L.phe_hip_invert_dev.argtypes = [vp, vp, vp, sz, ctypes.POINTER(sz), vp]
+        L.phe_hip_select_rows_dev.argtypes = [vp, vp, vp, vp, vp, ci, sz, vp]
         L.phe_hip_selftest_prims.argtypes = [ci, vp]
         _lib = L
     return _lib
@@ -67,7 +70,8 @@ EXPORTED_SYMBOLS = [
     "phe_hip_obfuscate", "phe_hip_decrypt", "phe_hip_mulmod", "phe_hip_powmod", "phe_hip_invert",
     "phe_hip_encrypt_dev", "phe_hip_obfuscate_dev", "phe_hip_decrypt_dev", "phe_hip_mulmod_dev",
     "phe_hip_powmod_dev", "phe_hip_malloc", "phe_hip_free", "phe_hip_memcpy_h2d", "phe_hip_memcpy_d2h",
-    "phe_hip_stream_sync", "phe_hip_selftest_prims",
+    "phe_hip_stream_sync", "phe_hip_selftest_prims", "phe_hip_memcpy_d2d", "phe_hip_invert_dev",
+    "phe_hip_select_rows_dev",
 ]
 
 
@@ -238,8 +242,37 @@ class Context:
     def powmod_dev(self, base_ptr, exp_ptr, exp_limbs, max_exp_bits, out_ptr, batch, stream=0):
         _check(lib().phe_hip_powmod_dev(self._h, base_ptr, exp_ptr, exp_limbs, max_exp_bits, out_ptr, batch, stream))
 
+    def invert_dev(self, a_ptr, out_ptr, batch, stream=0):
+        bad = ctypes.c_size_t(0)
+        rc = lib().phe_hip_invert_dev(self._h, a_ptr, out_ptr, batch, ctypes.byref(bad), stream)
+        if rc != OK:
+            _raise(rc, bad.value)
+
+    def select_rows_dev(self, a_ptr, b_ptr, mask_ptr, out_ptr, limbs, batch, stream=0):
+        _check(lib().phe_hip_select_rows_dev(self._h, a_ptr, b_ptr, mask_ptr, out_ptr, limbs, batch, stream))
+
     def sync(self, stream=0):
         _check(lib().phe_hip_stream_sync(self._h, stream))
+
+    # ---- raw device memory (for hosts without a tensor library) ----
+    def malloc(self, nbytes):
+        p = ctypes.c_void_p(None)
+        _check(lib().phe_hip_malloc(self._h, nbytes, ctypes.byref(p)))
+        return p.value
+
+    def free(self, ptr):
+        if self._h and self._h.value:
+            _check(lib().phe_hip_free(self._h, ptr))
+
+    def h2d(self, dst_ptr, arr):
+        arr = np.ascontiguousarray(arr)
+        _check(lib().phe_hip_memcpy_h2d(self._h, dst_ptr, _ptr(arr), arr.nbytes))
+
+    def d2h(self, arr, src_ptr):
+        _check(lib().phe_hip_memcpy_d2h(self._h, _ptr(arr), src_ptr, arr.nbytes))
+
+    def d2d(self, dst_ptr, src_ptr, nbytes, stream=0):
+        _check(lib().phe_hip_memcpy_d2d(self._h, dst_ptr, src_ptr, nbytes, stream))
 
 
 def selftest_prims(device=0):

@@ -10,6 +10,7 @@ kernel launch each over the whole vector, with the same per-element semantics as
 """
 import numpy as np
 
+from ._device import DeviceArray
 from ._engine import random_lt_n
 from .codec import EncodedNumber
 
@@ -121,17 +122,22 @@ class EncryptedNumber(object):
 
 
 class EncryptedVector(object):
-    """A batch of Paillier ciphertexts under one public key, stored as little-endian uint32 limbs."""
+    """A batch of Paillier ciphertexts under one public key, stored as little-endian uint32 limbs — either a
+    host numpy array or a device-resident DeviceArray (`device=True` / `.to_device()`), in which case every
+    operation below runs on HBM-resident operands and only plaintext-sized data crosses PCIe."""
 
     def __init__(self, public_key, limbs, exponents, obfuscated=False):
         self.public_key = public_key
-        self._limbs = np.ascontiguousarray(limbs, dtype=np.uint32)
+        self.on_device = isinstance(limbs, DeviceArray)
+        self._limbs = limbs if self.on_device else np.ascontiguousarray(limbs, dtype=np.uint32)
         self.exponents = list(exponents)
-        if self._limbs.ndim != 2 or self._limbs.shape[0] != len(self.exponents):
+        shape = self._limbs.shape
+        if len(shape) != 2 or shape[0] != len(self.exponents):
             raise ValueError("limbs must be (batch, ct_limbs) with one exponent per row")
         flags = obfuscated if isinstance(obfuscated, np.ndarray) else np.full(len(self.exponents), bool(obfuscated))
         self._obfuscated = flags.astype(bool)
 
+    # ---- construction / movement -------------------------------------------------------------------------
     @classmethod
     def from_numbers(cls, public_key, numbers):
         numbers = list(numbers)
@@ -153,19 +159,40 @@ class EncryptedVector(object):
         eng = public_key._get_engine()
         return cls(public_key, eng.cipher_limbs(ciphertexts), exponents)
 
+    def to_device(self):
+        if self.on_device:
+            return self
+        eng = self.public_key._get_engine()
+        return EncryptedVector(self.public_key, eng.upload_cipher(self._limbs), self.exponents, self._obfuscated.copy())
+
+    def to_host(self):
+        if not self.on_device:
+            return self
+        return EncryptedVector(self.public_key, self._limbs.to_host(), self.exponents, self._obfuscated.copy())
+
+    def _like(self, limbs, exponents, obfuscated=False):
+        return EncryptedVector(self.public_key, limbs, exponents, obfuscated)
+
     def __len__(self):
         return len(self.exponents)
 
     def __getitem__(self, i):
         if isinstance(i, slice):
-            return EncryptedVector(self.public_key, self._limbs[i], self.exponents[i], self._obfuscated[i])
+            lo, hi, step = i.indices(len(self))
+            if self.on_device and step == 1:
+                return self._like(self._limbs.rows_view(lo, hi), self.exponents[i], self._obfuscated[i])
+            host = self._limbs.to_host() if self.on_device else self._limbs
+            return self._like(host[i], self.exponents[i], self._obfuscated[i])
+        i = range(len(self))[i]
+        row = self._limbs.rows_view(i, i + 1).to_host() if self.on_device else self._limbs[i:i + 1]
         eng = self.public_key._get_engine()
-        x = EncryptedNumber(self.public_key, eng.to_ints(self._limbs[i:i + 1])[0], self.exponents[i])
+        x = EncryptedNumber(self.public_key, eng.to_ints(row)[0], self.exponents[i])
         x._EncryptedNumber__is_obfuscated = bool(self._obfuscated[i])
         return x
 
     def to_numbers(self):
-        return [self[i] for i in range(len(self))]
+        host = self.to_host()
+        return [host[i] for i in range(len(self))]
 
     # ---- state -----------------------------------------------------------------------------------------
     def obfuscate(self, r_values=None):
@@ -173,10 +200,18 @@ class EncryptedVector(object):
         pk = self.public_key
         eng = pk._get_engine()
         rows = np.arange(len(self)) if r_values is not None else np.nonzero(~self._obfuscated)[0]
-        if len(rows):
-            r = list(r_values) if r_values is not None else random_lt_n(pk.n, len(rows))
+        if len(rows) == 0:
+            return self
+        r = list(r_values) if r_values is not None else random_lt_n(pk.n, len(rows))
+        if self.on_device:
+            # one launch over the whole vector; rows that need nothing get r = 1 (c * 1^n = c)
+            full = [1] * len(self)
+            for idx, rv in zip(rows.tolist(), r):
+                full[idx] = rv
+            self._limbs = eng.obfuscate_dev(self._limbs, full)
+        else:
             self._limbs[rows] = eng.obfuscate(np.ascontiguousarray(self._limbs[rows]), r)
-            self._obfuscated[rows] = True
+        self._obfuscated[rows] = True
         return self
 
     def limbs(self, be_secure=True):
@@ -185,11 +220,12 @@ class EncryptedVector(object):
         return self._limbs
 
     def ciphertexts(self, be_secure=True):
-        return self.public_key._get_engine().to_ints(self.limbs(be_secure))
+        limbs = self.limbs(be_secure)
+        return self.public_key._get_engine().to_ints(limbs.to_host() if self.on_device else limbs)
 
     def decrease_exponent_to(self, new_exps):
         """Per-element EncryptedNumber.decrease_exponent_to: rows whose exponent is above the target are
-        multiplied by BASE**delta (one variable-exponent modexp launch over those rows)."""
+        multiplied by BASE**delta (one variable-exponent modexp launch)."""
         if isinstance(new_exps, int):
             new_exps = [new_exps] * len(self)
         new_exps = list(new_exps)
@@ -200,33 +236,50 @@ class EncryptedVector(object):
             if new < old:
                 rows.append(i)
                 scal.append(pow(EncodedNumber.BASE, old - new))
-        limbs = self._limbs.copy()
         flags = self._obfuscated.copy()
-        if rows:
-            pk = self.public_key
-            if max(scal) >= pk.n:
-                raise ValueError('Scalar out of bounds: %i' % max(scal))
-            idx = np.asarray(rows)
-            limbs[idx] = pk._get_engine().raw_mul(np.ascontiguousarray(limbs[idx]), scal)
-            flags[idx] = False
-        return EncryptedVector(self.public_key, limbs, new_exps, flags)
+        if not rows:
+            limbs = self._limbs if self.on_device else self._limbs.copy()
+            return self._like(limbs, new_exps, flags)
+        pk = self.public_key
+        if max(scal) >= pk.n:
+            raise ValueError('Scalar out of bounds: %i' % max(scal))
+        idx = np.asarray(rows)
+        flags[idx] = False
+        eng = pk._get_engine()
+        if self.on_device:
+            # whole-vector launch: untouched rows are raised to the power 1 (c^1 = c, still canonical)
+            exps = [1] * len(self)
+            for i, sc in zip(rows, scal):
+                exps[i] = sc
+            return self._like(eng.powmod_dev(self._limbs, exps), new_exps, flags)
+        limbs = self._limbs.copy()
+        limbs[idx] = eng.raw_mul(np.ascontiguousarray(limbs[idx]), scal)
+        return self._like(limbs, new_exps, flags)
 
     # ---- arithmetic --------------------------------------------------------------------------------------
     def _aligned(self, other_exps):
         target = [min(a, b) for a, b in zip(self.exponents, other_exps)]
         return self.decrease_exponent_to(target), target
 
+    def _raw_add(self, a_limbs, b):
+        eng = self.public_key._get_engine()
+        if self.on_device:
+            b_dev = b if isinstance(b, DeviceArray) else eng.upload_cipher(b)
+            return eng.raw_add_dev(a_limbs, b_dev)
+        return eng.raw_add(a_limbs, b.to_host() if isinstance(b, DeviceArray) else b)
+
     def __add__(self, other):
         pk = self.public_key
-        eng = pk._get_engine()
         if isinstance(other, EncryptedVector):
             if pk != other.public_key:
                 raise ValueError("Attempted to add numbers encrypted against different public keys!")
             if len(other) != len(self):
                 raise ValueError("vector lengths differ")
+            if other.on_device != self.on_device:
+                other = other.to_device() if self.on_device else other.to_host()
             a, target = self._aligned(other.exponents)
             b = other.decrease_exponent_to(target)
-            return EncryptedVector(pk, eng.raw_add(a._limbs, b._limbs), target)
+            return self._like(self._raw_add(a._limbs, b._limbs), target)
         # plain operand(s): scalar broadcast or sequence; encode with max_exponent = own exponent per row
         values = other if isinstance(other, (list, tuple, np.ndarray)) else [other] * len(self)
         if len(values) != len(self):
@@ -241,7 +294,7 @@ class EncryptedVector(object):
             exps.append(enc.exponent)
         a, target = self._aligned(exps)
         nude = [(pk.n * enc.decrease_exponent_to(t).encoding + 1) % pk.nsquare for enc, t in zip(encs, target)]
-        return EncryptedVector(pk, eng.raw_add(a._limbs, nude), target)
+        return self._like(self._raw_add(a._limbs, pk._get_engine().cipher_limbs(nude)), target)
 
     __radd__ = __add__
 
@@ -257,8 +310,9 @@ class EncryptedVector(object):
         else:
             pairs = [v if isinstance(v, EncodedNumber) else EncodedNumber.encode(pk, v) for v in values]
             encs, exps = [e.encoding for e in pairs], [e.exponent for e in pairs]
-        limbs = pk._get_engine().raw_mul(self._limbs, encs)
-        return EncryptedVector(pk, limbs, [a + b for a, b in zip(self.exponents, exps)])
+        eng = pk._get_engine()
+        limbs = eng.raw_mul_dev(self._limbs, encs) if self.on_device else eng.raw_mul(self._limbs, encs)
+        return self._like(limbs, [a + b for a, b in zip(self.exponents, exps)])
 
     __rmul__ = __mul__
 
@@ -276,13 +330,26 @@ class EncryptedVector(object):
         return self * (1 / scalar)
 
     def sum(self):
-        """Homomorphic sum of all elements -> EncryptedNumber (log2(batch) pairwise-product launches)."""
+        """Homomorphic sum of all elements -> EncryptedNumber (log2(batch) pairwise-product launches; on a
+        device-resident vector the halves are views, nothing is copied or moved across PCIe)."""
         if len(self) == 0:
             raise ValueError("empty vector")
         pk = self.public_key
         eng = pk._get_engine()
         cur = self.decrease_exponent_to(min(self.exponents))
         limbs, exp = cur._limbs, cur.exponents[0]
+        if self.on_device:
+            while limbs.rows > 1:
+                half = limbs.rows // 2
+                merged = eng.raw_add_dev(limbs.rows_view(0, half), limbs.rows_view(half, 2 * half))
+                if limbs.rows % 2:
+                    grown = DeviceArray(eng.ctx, half + 1, limbs.cols)
+                    eng.ctx.d2d(grown.ptr, merged.ptr, merged.nbytes)
+                    eng.ctx.d2d(grown.ptr + merged.nbytes, limbs.rows_view(2 * half, 2 * half + 1).ptr, limbs.cols * 4)
+                    eng.ctx.sync()
+                    merged = grown
+                limbs = merged
+            return EncryptedNumber(pk, eng.to_ints(limbs.to_host())[0], exp)
         while limbs.shape[0] > 1:
             half = limbs.shape[0] // 2
             merged = eng.raw_add(np.ascontiguousarray(limbs[:half]), np.ascontiguousarray(limbs[half:2 * half]))

@@ -107,15 +107,19 @@ class PaillierPublicKey(object):
         eng = self._get_engine()
         return eng.to_ints(eng.raw_encrypt(plaintexts, list(r_values)))
 
-    def encrypt_batch(self, values, precision=None, r_values=None):
-        """Encode + encrypt a whole sequence / numpy array -> EncryptedVector (one kernel launch)."""
+    def encrypt_batch(self, values, precision=None, r_values=None, device=False):
+        """Encode + encrypt a whole sequence / numpy array -> EncryptedVector (one kernel launch).
+        device=True keeps the ciphertexts resident in HBM for later homomorphic operations."""
         from .ciphertext import EncryptedVector
         encs, exps = EncodedNumber.encode_many(self, values, precision)
         eng = self._get_engine()
         fresh = r_values is None
         if fresh:
             r_values = random_lt_n(self.n, len(encs))
-        limbs = eng.raw_encrypt(encs, list(r_values))
+        if device:
+            limbs = eng.raw_encrypt_dev(encs, list(r_values))
+        else:
+            limbs = eng.raw_encrypt(encs, list(r_values))
         return EncryptedVector(self, limbs, exps, obfuscated=fresh)
 
 
@@ -215,7 +219,10 @@ class PaillierPrivateKey(object):
         if self.public_key != vector.public_key:
             raise ValueError('encrypted_number was encrypted against a different key!')
         eng = self._get_engine()
-        plain = eng.to_ints(eng.raw_decrypt(vector.limbs(be_secure=False)))
+        if vector.on_device:     # device pointers are valid across contexts of the same GPU
+            plain = eng.to_ints(eng.raw_decrypt_dev(vector.limbs(be_secure=False)))
+        else:
+            plain = eng.to_ints(eng.raw_decrypt(vector.limbs(be_secure=False)))
         return (Encoding or EncodedNumber).decode_many(self.public_key, plain, vector.exponents)
 
 

@@ -282,3 +282,44 @@ def test_encrypted_vector(keys):
     with pytest.raises(ValueError):
         priv.decrypt_batch(paillier.EncryptedVector(paillier.PaillierPublicKey(H(load_golden(1024)["n"])),
                                                     np.zeros((1, 64), np.uint32), [0]))
+
+
+@pytest.mark.gpu
+def test_device_resident_vector_matches_host_vector():
+    """EncryptedVector(device=True): every op stays in HBM and gives the same ciphertext bits as the host-array path
+    (which in turn equals the scalar path, test_encrypted_vector)."""
+    g = load_golden(1024)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    rs_np = np.random.Generator(np.random.PCG64(11))
+    vals = rs_np.standard_normal(37) * 10.0 ** rs_np.integers(-3, 6, 37)
+    vals[5] = 0.0
+    rs = [int(x) + 2 for x in rs_np.integers(0, 2 ** 62, 37)]
+    host = pub.encrypt_batch(vals, r_values=rs)
+    dev = pub.encrypt_batch(vals, r_values=rs, device=True)
+    assert dev.on_device and not host.on_device
+    assert dev.ciphertexts(False) == host.ciphertexts(False)
+    w = rs_np.standard_normal(37)                        # ~half negative: exercises invert + select on the device
+    w[3], w[4] = 0.0, 1.0
+    assert (dev * w).ciphertexts(False) == (host * w).ciphertexts(False)
+    ints = [int(x) for x in rs_np.integers(-1000, 1000, 37)]
+    assert (dev * ints).ciphertexts(False) == (host * ints).ciphertexts(False)
+    other_h = pub.encrypt_batch(np.arange(37, dtype=np.float64) * 0.5, r_values=rs)
+    other_d = other_h.to_device()
+    assert (dev + other_d).ciphertexts(False) == (host + other_h).ciphertexts(False)     # mixed exponents: alignment on device
+    assert (dev + other_h).ciphertexts(False) == (host + other_h).ciphertexts(False)     # host operand is uploaded
+    assert (dev + 2.5).ciphertexts(False) == (host + 2.5).ciphertexts(False)
+    assert (dev - other_d).ciphertexts(False) == (host - other_h).ciphertexts(False)
+    assert priv.decrypt_batch(dev) == priv.decrypt_batch(host) == vals.tolist()
+    assert dev.sum().ciphertext(False) == host.sum().ciphertext(False)
+    assert dev.dot(w).ciphertext(False) == host.dot(w).ciphertext(False)
+    assert math.isclose(priv.decrypt(dev.dot(w)), float(np.dot(vals, w)), rel_tol=1e-9)
+    assert dev[3:9].ciphertexts(False) == host[3:9].ciphertexts(False)
+    assert dev[7].ciphertext(False) == host[7].ciphertext(False)
+    fresh = pub.encrypt_batch(vals[:5], device=True)
+    assert all(fresh._obfuscated) and priv.decrypt_batch(fresh) == vals[:5].tolist()
+    un = pub.encrypt_batch([1, 2, 3], r_values=[1, 1, 1], device=True)
+    before = un.ciphertexts(False)
+    after = un.ciphertexts()                              # be_secure -> obfuscate_dev over the vector
+    assert before != after and all(un._obfuscated) and priv.decrypt_batch(un) == [1, 2, 3]
+    assert dev.to_host().ciphertexts(False) == host.ciphertexts(False)
