@@ -132,6 +132,12 @@ struct phe_hip_ctx {
     host::PublicPlan pub;
     host::PrivatePlan priv;
     DevModulus d_nsq, d_psq, d_qsq;
+    // latency geometry: small batches cannot fill the GPU, so they use 16-lane groups (half the limbs per
+    // lane => about half the time per product) when the key size offers both
+    bool has_lat_pub = false, has_lat_priv = false;
+    host::PublicPlan pub_lat;
+    host::PrivatePlan priv_lat;
+    DevModulus d_nsq_lat, d_psq_lat, d_qsq_lat;
     DevSchedule d_exp_n, d_exp_p, d_exp_q;
     DevTail d_tail;
     // grow-only device scratch
@@ -338,6 +344,12 @@ static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, 
     return PHE_HIP_OK;
 }
 
+// batches at or below this many elements run on the latency geometry (one 16-lane group per SIMD wave slot)
+static bool small_batch(const phe_hip_ctx* ctx, size_t batch) { return batch <= (size_t)ctx->n_cus * 16; }
+static const DevModulus& pick_nsq(const phe_hip_ctx* ctx, size_t batch) {
+    return (ctx->has_lat_pub && small_batch(ctx, batch)) ? ctx->d_nsq_lat : ctx->d_nsq;
+}
+
 static int check_ctx(const phe_hip_ctx* ctx) {
     if (!ctx) return fail(PHE_HIP_EINVAL, "null context");
     return PHE_HIP_OK;
@@ -379,6 +391,15 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
     }
     int rc = upload_modulus(ctx->pub.nsq, ctx->d_nsq);
     if (!rc) rc = upload_schedule(ctx->pub.exp_n, ctx->d_exp_n);
+    if (!rc && ctx->pub.nsq.G == 8 && !getenv("PHE_HIP_GROUP")) {
+        try {
+            ctx->pub_lat = host::build_public(n, n_limbs, 16);
+            rc = upload_modulus(ctx->pub_lat.nsq, ctx->d_nsq_lat);
+            ctx->has_lat_pub = (rc == PHE_HIP_OK);
+        } catch (const std::exception& ex) {
+            rc = fail(PHE_HIP_EINVAL, ex.what());
+        }
+    }
     return rc;
 }
 
@@ -415,6 +436,16 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
     }
     if (!rc) rc = upload_modulus(ctx->priv.psq, ctx->d_psq);
     if (!rc) rc = upload_modulus(ctx->priv.qsq, ctx->d_qsq);
+    if (!rc && ctx->priv.psq.G == 8 && !getenv("PHE_HIP_GROUP")) {
+        try {
+            ctx->priv_lat = host::build_private(p, q, hp, hq, p_inverse, pq_limbs, n_limbs, 16);
+            rc = upload_modulus(ctx->priv_lat.psq, ctx->d_psq_lat);
+            if (!rc) rc = upload_modulus(ctx->priv_lat.qsq, ctx->d_qsq_lat);
+            ctx->has_lat_priv = (rc == PHE_HIP_OK);
+        } catch (const std::exception& ex) {
+            rc = fail(PHE_HIP_EINVAL, ex.what());
+        }
+    }
     if (!rc) rc = upload_schedule(ctx->priv.exp_p, ctx->d_exp_p);
     if (!rc) rc = upload_schedule(ctx->priv.exp_q, ctx->d_exp_q);
     if (!rc) rc = upload_tail(ctx->priv.tail, ctx->d_tail);
@@ -438,7 +469,8 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
 void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    uint32_t* bufs[] = {ctx->d_nsq.blob, ctx->d_psq.blob, ctx->d_qsq.blob, ctx->d_exp_n.ops, ctx->d_exp_p.ops,
+    uint32_t* bufs[] = {ctx->d_nsq_lat.blob, ctx->d_psq_lat.blob, ctx->d_qsq_lat.blob,
+                        ctx->d_nsq.blob, ctx->d_psq.blob, ctx->d_qsq.blob, ctx->d_exp_n.ops, ctx->d_exp_p.ops,
                         ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->scratch, ctx->stage[0], ctx->stage[1],
                         ctx->stage[2]};
     for (uint32_t* b : bufs)
@@ -472,7 +504,7 @@ int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, 
     if (batch == 0) return PHE_HIP_OK;
     if (!m || !r || !c) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
-    return launch_uniform<kModeEncrypt>(ctx, ctx->d_nsq, ctx->d_exp_n, r, ctx->pub.s1, m, ctx->pub.s1, c, ctx->pub.s2,
+    return launch_uniform<kModeEncrypt>(ctx, pick_nsq(ctx, batch), ctx->d_exp_n, r, ctx->pub.s1, m, ctx->pub.s1, c, ctx->pub.s2,
                                         batch, (hipStream_t)stream);
 }
 
@@ -482,7 +514,7 @@ int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t
     if (batch == 0) return PHE_HIP_OK;
     if (!c_in || !r || !c_out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
-    return launch_uniform<kModeObfuscate>(ctx, ctx->d_nsq, ctx->d_exp_n, r, ctx->pub.s1, c_in, ctx->pub.s2, c_out,
+    return launch_uniform<kModeObfuscate>(ctx, pick_nsq(ctx, batch), ctx->d_exp_n, r, ctx->pub.s1, c_in, ctx->pub.s2, c_out,
                                           ctx->pub.s2, batch, (hipStream_t)stream);
 }
 
@@ -499,9 +531,12 @@ int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t
     uint32_t* xp = ctx->scratch;
     uint32_t* xq = ctx->scratch + batch * (size_t)S;
     hipStream_t st = (hipStream_t)stream;
-    rc = launch_uniform<kModeHalfDecrypt>(ctx, ctx->d_psq, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0, xp, S, batch, st);
+    const bool lat = ctx->has_lat_priv && small_batch(ctx, batch);
+    rc = launch_uniform<kModeHalfDecrypt>(ctx, lat ? ctx->d_psq_lat : ctx->d_psq, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0,
+                                          xp, S, batch, st);
     if (rc) return rc;
-    rc = launch_uniform<kModeHalfDecrypt>(ctx, ctx->d_qsq, ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0, xq, S, batch, st);
+    rc = launch_uniform<kModeHalfDecrypt>(ctx, lat ? ctx->d_qsq_lat : ctx->d_qsq, ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0,
+                                          xq, S, batch, st);
     if (rc) return rc;
     TailArgs T;
     T.k = ctx->d_tail.k;
@@ -524,7 +559,7 @@ int phe_hip_mulmod_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, u
     if (!a || !b || !out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
     const size_t s2 = (size_t)ctx->pub.s2;
-    return launch_mul(ctx, ctx->d_nsq, a, s2, b, s2, out, s2, ctx->pub.s2, batch, (hipStream_t)stream);
+    return launch_mul(ctx, pick_nsq(ctx, batch), a, s2, b, s2, out, s2, ctx->pub.s2, batch, (hipStream_t)stream);
 }
 
 int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, int max_exp_bits,
@@ -534,7 +569,7 @@ int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e
     if (!base || !e || !out || exp_limbs < 1) return fail(PHE_HIP_EINVAL, "null buffer / exp_limbs");
     if (max_exp_bits <= 0 || max_exp_bits > 32 * exp_limbs) max_exp_bits = 32 * exp_limbs;
     if (int rc = bind_device(ctx)) return rc;
-    return launch_var(ctx, ctx->d_nsq, base, ctx->pub.s2, e, exp_limbs, max_exp_bits, out, ctx->pub.s2, batch,
+    return launch_var(ctx, pick_nsq(ctx, batch), base, ctx->pub.s2, e, exp_limbs, max_exp_bits, out, ctx->pub.s2, batch,
                       (hipStream_t)stream);
 }
 

@@ -356,6 +356,24 @@ class EncryptedVector(object):
             limbs = np.concatenate([merged, limbs[2 * half:]]) if limbs.shape[0] % 2 else merged
         return EncryptedNumber(pk, eng.to_ints(limbs)[0], exp)
 
+    # ---- bulk wire format (docs/serialisation.rst:24-43 of the reference) ----------------------------------
+    def to_json(self, be_secure=True):
+        """{"public_key": {"n": ...}, "values": [[str(ciphertext), exponent], ...]} — the reference's documented
+        vector format; like EncryptedNumber.ciphertext() the rows are obfuscated first unless be_secure=False
+        (one launch over the vector instead of one modexp per element)."""
+        import json
+        return json.dumps({"public_key": {"n": self.public_key.n},
+                           "values": [[str(c), e] for c, e in zip(self.ciphertexts(be_secure), self.exponents)]})
+
+    @classmethod
+    def from_json(cls, text, device=False):
+        import json
+        from .keys import PaillierPublicKey
+        doc = json.loads(text)
+        public_key = PaillierPublicKey(n=int(doc["public_key"]["n"]))
+        vec = cls.from_ciphertexts(public_key, [int(v[0]) for v in doc["values"]], [int(v[1]) for v in doc["values"]])
+        return vec.to_device() if device else vec
+
     def dot(self, plain):
         """sum_i self[i] * plain[i] -> EncryptedNumber (np.dot over ciphertexts, phe/tests/math_test.py:44-58)."""
         return (self * plain).sum()

@@ -282,6 +282,16 @@ def test_encrypted_vector(keys):
     with pytest.raises(ValueError):
         priv.decrypt_batch(paillier.EncryptedVector(paillier.PaillierPublicKey(H(load_golden(1024)["n"])),
                                                     np.zeros((1, 64), np.uint32), [0]))
+    # the reference's documented JSON vector format (docs/serialisation.rst:24-43)
+    import json
+    text = vec.to_json(be_secure=False)
+    doc = json.loads(text)
+    assert int(doc["public_key"]["n"]) == pub.n
+    assert [(int(c), e) for c, e in doc["values"]] == list(zip(vec.ciphertexts(False), vec.exponents))
+    back = paillier.EncryptedVector.from_json(text)
+    assert back.public_key == pub and priv.decrypt_batch(back) == vals.tolist()
+    singles_rec = [paillier.EncryptedNumber(back.public_key, int(c), int(e)) for c, e in doc["values"]]   # the doc's recipe
+    assert [priv.decrypt(x) for x in singles_rec] == vals.tolist()
 
 
 @pytest.mark.gpu

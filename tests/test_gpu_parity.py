@@ -61,8 +61,19 @@ def test_reference_kat(native):
     assert native.limbs_to_ints(ctx.decrypt(c)) == [k["m"], 1]
 
 
+@pytest.fixture(params=["auto", "8", "16"])
+def group(request, monkeypatch):
+    """Limb-group width: 'auto' = 8-lane groups for large batches, 16-lane groups for small ones; '8' / '16'
+    force one geometry for every batch size (PHE_HIP_GROUP is read when a context is created)."""
+    if request.param == "auto":
+        monkeypatch.delenv("PHE_HIP_GROUP", raising=False)
+    else:
+        monkeypatch.setenv("PHE_HIP_GROUP", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("key_bits", [256, 1024, 2048, 3072])
-def test_golden_vectors(native, key_bits):
+def test_golden_vectors(native, key_bits, group):
     g = load_golden(key_bits)
     s1, s2 = key_bits // 32, key_bits // 16
     n_int = H(g["n"])
@@ -94,7 +105,7 @@ def test_golden_vectors(native, key_bits):
 
 
 @pytest.mark.parametrize("key_bits,batch", [(1024, 300), (2048, 150), (3072, 40)])
-def test_random_batches_vs_gmp_oracle(native, c_oracle, key_bits, batch):
+def test_random_batches_vs_gmp_oracle(native, c_oracle, key_bits, batch, group):
     g = load_golden(key_bits)
     s1, s2 = key_bits // 32, key_bits // 16
     n_int = H(g["n"])
