@@ -155,25 +155,32 @@ struct Geometry {
 };
 static const int kL16[] = {1, 2, 3, 5, 7, 9, 14, 18};
 static const int kL8[] = {5, 9, 14, 18};
+static const int kL4[] = {9, 18};
 
+// prefer_group: 0 = automatic (least padding, then fewest lanes = most limbs per lane, which amortises the
+// per-digit DPP/quotient work best); 4 / 8 / 16 = the narrowest group allowed (wider ones are the fallback).
 inline Geometry pick_geometry(int modulus_bits, int min_bits, int prefer_group) {
     const int need_bits = std::max(modulus_bits + 4, min_bits);
     const int need = (need_bits + kRadixBits - 1) / kRadixBits;
     Geometry best;
-    if (prefer_group == 8) {
-        for (int L : kL8)
-            if (8 * L >= need && L <= 31) {
-                best.G = 8;
-                best.L = L;
-                return best;
-            }
-    }
-    for (int L : kL16)
-        if (16 * L >= need) {
-            best.G = 16;
+    auto consider = [&](int G, int L) {
+        const int S = G * L;
+        if (S < need) return;
+        if (best.G == 0 || S < best.S() || (S == best.S() && L > best.L)) {
+            best.G = G;
             best.L = L;
-            return best;
         }
+    };
+    if (prefer_group != 16) {
+        const int narrowest = prefer_group == 0 ? 4 : prefer_group;
+        if (narrowest <= 4)
+            for (int L : kL4) consider(4, L);
+        if (narrowest <= 8)
+            for (int L : kL8) consider(8, L);
+    }
+    // 16-lane groups: the only choice in latency mode, a competitor in automatic mode, the fallback otherwise
+    if (prefer_group == 16 || prefer_group == 0 || best.G == 0)
+        for (int L : kL16) consider(16, L);
     return best;  // G == 0: too wide for the compiled kernels
 }
 
@@ -187,7 +194,7 @@ struct ModulusPack {
 
 // aux_src (optional, < N): aux = aux_src * R mod N.  min_bits: width the group must also cover
 // (the caller's 32-bit-word rows; both CRT halves of a private key share one geometry).
-inline ModulusPack build_modulus(const Big& N_any, const Big* aux_src, int min_bits = 0, int prefer_group = 8) {
+inline ModulusPack build_modulus(const Big& N_any, const Big* aux_src, int min_bits = 0, int prefer_group = 0) {
     ModulusPack m;
     m.bits = big_bits(N_any);
     const Geometry geo = pick_geometry(m.bits, min_bits, prefer_group);
@@ -324,7 +331,7 @@ struct PublicPlan {
     Schedule exp_n;
 };
 
-inline PublicPlan build_public(const uint32_t* n, int n_limbs, int prefer_group = 8) {
+inline PublicPlan build_public(const uint32_t* n, int n_limbs, int prefer_group = 0) {
     PublicPlan P;
     P.s1 = n_limbs;
     P.s2 = 2 * n_limbs;
@@ -346,7 +353,7 @@ struct PrivatePlan {
 };
 
 inline PrivatePlan build_private(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const uint32_t* hq,
-                                 const uint32_t* p_inverse, int pq_limbs, int n_limbs, int prefer_group = 8) {
+                                 const uint32_t* p_inverse, int pq_limbs, int n_limbs, int prefer_group = 0) {
     PrivatePlan P;
     P.s1 = n_limbs;
     P.s2 = 2 * n_limbs;

@@ -16,7 +16,7 @@
 // (ceil(bits/29)/ceil(bits/32))^2 ~ 1.27x more multiplies, a net ~1.5x fewer issue cycles.
 //
 // Layout.  A modulus N with 29*S >= bits(N) + 4 (S = G*L limbs) is owned by a group of G lanes
-// (G = 16: one DPP row, G = 8: half a row); lane g keeps limbs [g*L, (g+1)*L).  R = 2^(29*S) >= 16 N.
+// (G = 16: one DPP row, G = 8: half a row, G = 4: one quad); lane g keeps limbs [g*L, (g+1)*L).  R = 2^(29*S) >= 16 N.
 //
 // montmul (word-serial, per 29-bit digit a_i of the multiplier, broadcast-read from LDS):
 //     acc[k] += a_i * b[k]                      L  v_mad_u64_u32
@@ -47,7 +47,7 @@ using Lanes = wave::Lanes<G>;
 
 template <int G>
 struct GroupMasks {
-    static constexpr uint64_t lane0 = (G == 16) ? 0x0001000100010001ull : 0x0101010101010101ull;
+    static constexpr uint64_t lane0 = (G == 16) ? 0x0001000100010001ull : (G == 8) ? 0x0101010101010101ull : 0x1111111111111111ull;
     static constexpr uint64_t top = lane0 << (G - 1);
 };
 
@@ -91,6 +91,19 @@ PHE_DEV void normalize_partial(uint32_t (&t)[L], const uint64_t (&acc)[L], const
     } else {
         t[0] += wave::grp_up1<G>(c2, ln);
     }
+}
+
+// t += u for two almost-normalised numbers; the sum is almost-normalised again (32-bit arithmetic only)
+template <int G, int L>
+PHE_DEV void add_normalize(uint32_t (&t)[L], const uint32_t (&u)[L], const Lanes<G>& ln) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        const uint32_t v = t[k] + u[k] + carry;  // < 2^31
+        t[k] = v & kLimbMask;
+        carry = v >> kRadixBits;                 // <= 3
+    }
+    t[0] += wave::grp_up1<G>(carry, ln);         // the top lane's carry is 0 (value < R)
 }
 
 // almost-normalised -> canonical limbs (< 2^29) with all lane-to-lane carries resolved
@@ -302,10 +315,7 @@ PHE_DEV void modexp_uniform_body(const UniformArgs& A, uint32_t* lds_row, uint32
             lds_put<L>(lds_row, tmp, g);
             load_row<L>(cst, A.mod.r3, g);
             montmul<G, L>(tmp, lds_row, cst, n, n0inv, ln);
-            uint64_t sum[L];
-#pragma unroll
-            for (int k = 0; k < L; ++k) sum[k] = (uint64_t)acc[k] + tmp[k];
-            normalize_partial<G, L>(tmp, sum, ln);
+            add_normalize<G, L>(tmp, acc, ln);  // tmp += acc, limbs brought back below 2^29 + 2^8
             lds_put<L>(lds_row, tmp, g);
             load_row<L>(cst, A.mod.r1, g);
             montmul<G, L>(acc, lds_row, cst, n, n0inv, ln);

@@ -33,8 +33,10 @@ using host::Big;
 // ------------------------------------------------------------------------------------------------
 constexpr int kBlock = 256;  // threads per workgroup = 4 wavefronts = 256/G limb groups
 
+// (the half-decrypt prologue keeps a few more operands alive; asking for 2 waves per SIMD there makes the
+//  compiler park them in scratch outside the hot loop instead of dropping the kernel to 1 wave per SIMD)
 template <int G, int L, int MODE>
-__global__ void __launch_bounds__(kBlock) k_modexp_uniform(UniformArgs A) {
+__global__ void __launch_bounds__(kBlock, (MODE == kModeHalfDecrypt && L >= 14) ? 2 : 1) k_modexp_uniform(UniformArgs A) {
     constexpr int S = G * L, kGroups = kBlock / G;
     __shared__ __attribute__((aligned(16))) uint32_t lds[kGroups * (S + kLdsPad)];
     const uint32_t grp = threadIdx.x / G;
@@ -92,6 +94,10 @@ __global__ void k_selftest_prims(uint32_t* out) {
     out[258 + lane] = wave::grp_down1<8>(lane + 100u, l8);
     out[322 + lane] = wave::grp_up1<8>(lane + 100u, l8);
     out[386 + lane] = wave::grp_bcast0<8>(lane + 100u, l8);
+    const wave::Lanes<4> l4(lane);
+    out[450 + lane] = wave::grp_down1<4>(lane + 100u, l4);
+    out[514 + lane] = wave::grp_up1<4>(lane + 100u, l4);
+    out[578 + lane] = wave::grp_bcast0<4>(lane + 100u, l4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -127,7 +133,7 @@ struct phe_hip_ctx {
     int device = 0;
     int n_cus = 256;
     int blocks_per_cu = 0;  // 0 = ask the occupancy API per kernel (PHE_HIP_BLOCKS_PER_CU / set_blocks_per_cu override)
-    int prefer_group = 8;  // lanes per limb group when the key size offers both (PHE_HIP_GROUP=16 overrides)
+    int prefer_group = 0;  // 0 = automatic geometry; PHE_HIP_GROUP=4|8|16 sets the narrowest limb group allowed
     bool has_private = false;
     host::PublicPlan pub;
     host::PrivatePlan priv;
@@ -227,6 +233,8 @@ static int grid_blocks(const phe_hip_ctx* ctx, size_t batch, int G, int blocks_p
             case 1609: { constexpr int GG = 16, LL = 9; CALL; break; }                         \
             case 1614: { constexpr int GG = 16, LL = 14; CALL; break; }                        \
             case 1618: { constexpr int GG = 16, LL = 18; CALL; break; }                        \
+            case 409: { constexpr int GG = 4, LL = 9; CALL; break; }                           \
+            case 418: { constexpr int GG = 4, LL = 18; CALL; break; }                          \
             case 805: { constexpr int GG = 8, LL = 5; CALL; break; }                           \
             case 809: { constexpr int GG = 8, LL = 9; CALL; break; }                           \
             case 814: { constexpr int GG = 8, LL = 14; CALL; break; }                          \
@@ -382,7 +390,7 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
     }
     if (const char* e = getenv("PHE_HIP_GROUP")) {
         const int v = atoi(e);
-        if (v == 8 || v == 16) ctx->prefer_group = v;
+        if (v == 4 || v == 8 || v == 16) ctx->prefer_group = v;
     }
     try {
         ctx->pub = host::build_public(n, n_limbs, ctx->prefer_group);
@@ -391,7 +399,7 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
     }
     int rc = upload_modulus(ctx->pub.nsq, ctx->d_nsq);
     if (!rc) rc = upload_schedule(ctx->pub.exp_n, ctx->d_exp_n);
-    if (!rc && ctx->pub.nsq.G == 8 && !getenv("PHE_HIP_GROUP")) {
+    if (!rc && ctx->pub.nsq.G < 16 && !getenv("PHE_HIP_GROUP")) {
         try {
             ctx->pub_lat = host::build_public(n, n_limbs, 16);
             rc = upload_modulus(ctx->pub_lat.nsq, ctx->d_nsq_lat);
@@ -436,7 +444,7 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
     }
     if (!rc) rc = upload_modulus(ctx->priv.psq, ctx->d_psq);
     if (!rc) rc = upload_modulus(ctx->priv.qsq, ctx->d_qsq);
-    if (!rc && ctx->priv.psq.G == 8 && !getenv("PHE_HIP_GROUP")) {
+    if (!rc && ctx->priv.psq.G < 16 && !getenv("PHE_HIP_GROUP")) {
         try {
             ctx->priv_lat = host::build_private(p, q, hp, hq, p_inverse, pq_limbs, n_limbs, 16);
             rc = upload_modulus(ctx->priv_lat.psq, ctx->d_psq_lat);
@@ -841,10 +849,10 @@ int phe_hip_selftest_prims(int device, uint32_t* out) {
     if (!out) return fail(PHE_HIP_EINVAL, "null out");
     HIP_TRY(hipSetDevice(device));
     uint32_t* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, 450 * 4));
+    HIP_TRY(hipMalloc((void**)&d, 642 * 4));
     k_selftest_prims<<<dim3(1), dim3(64), 0, nullptr>>>(d);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, d, 450 * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, d, 642 * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(d));
     return PHE_HIP_OK;
 }

@@ -1,7 +1,7 @@
 // wave_gfx950.h — the CDNA4 (gfx950) wavefront primitives the multi-precision core is written against.
 //
-// A 64-lane wavefront is used as independent limb groups of G = 16 lanes (one DPP row) or G = 8
-// lanes (half a row); each group owns one big number whose limbs are blocked across its lanes
+// A 64-lane wavefront is used as independent limb groups of G = 16 lanes (one DPP row), G = 8 lanes
+// (half a row) or G = 4 lanes (one quad); each group owns one big number whose limbs are blocked across its lanes
 // (lane g of the group holds limbs [g*L, (g+1)*L)).  Every cross-lane movement the Montgomery core needs is a single-
 // instruction DPP row operation; nothing here touches LDS or memory:
 //
@@ -25,13 +25,13 @@ constexpr int kRow = 16;  // lanes of one DPP row
 
 PHE_DEV uint32_t lane_id() { return __lane_id(); }
 
-// Per-lane constants of a limb group of G lanes (G = 16: one DPP row; G = 8: half a row).
+// Per-lane constants of a limb group of G lanes (G = 16: one DPP row; G = 8: half a row; G = 4: one quad).
 template <int G>
 struct Lanes {
     uint32_t lane;      // 0..63
     uint32_t g;         // position inside the group, 0..G-1
-    uint32_t not_top;   // all-ones unless this is the group's top lane    (G = 8 only)
-    uint32_t not_low;   // all-ones unless this is the group's lane 0      (G = 8 only)
+    uint32_t not_top;   // all-ones unless this is the group's top lane    (G < 16 only)
+    uint32_t not_low;   // all-ones unless this is the group's lane 0      (G < 16 only)
     PHE_DEV explicit Lanes(uint32_t lane_) : lane(lane_), g(lane_ & (G - 1)) {
         not_top = (g == G - 1) ? 0u : 0xffffffffu;
         not_low = (g == 0) ? 0u : 0xffffffffu;
@@ -49,19 +49,23 @@ PHE_DEV uint32_t dpp_row_shr1(uint32_t x) {  // lane i <- lane i-1 in the 16-lan
 template <int G>
 PHE_DEV uint32_t grp_down1(uint32_t x, const Lanes<G>& l) {
     if constexpr (G == 16) return dpp_row_shl1(x);
-    else return dpp_row_shl1(x) & l.not_top;
+    else if constexpr (G == 8) return dpp_row_shl1(x) & l.not_top;
+    else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9 /*quad_perm:[1,2,3,3]*/, 0xf, 0xf, true) & l.not_top;
 }
 // lane g <- lane g-1 of its group; the group's lane 0 receives 0
 template <int G>
 PHE_DEV uint32_t grp_up1(uint32_t x, const Lanes<G>& l) {
     if constexpr (G == 16) return dpp_row_shr1(x);
-    else return dpp_row_shr1(x) & l.not_low;
+    else if constexpr (G == 8) return dpp_row_shr1(x) & l.not_low;
+    else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x90 /*quad_perm:[0,0,1,2]*/, 0xf, 0xf, true) & l.not_low;
 }
 // every lane <- lane 0 of its group
 template <int G>
 PHE_DEV uint32_t grp_bcast0(uint32_t x, const Lanes<G>&) {
     if constexpr (G == 16) {
         return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 /*row_newbcast:0*/, 0xf, 0xf, true);
+    } else if constexpr (G == 4) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x00 /*quad_perm:[0,0,0,0]*/, 0xf, 0xf, true);
     } else {
         // quad_perm:[0,0,0,0] puts lanes 0,4,8,12 into their quads; row_shr:4 restricted to banks 1 and 3
         // then copies quad 0 -> quad 1 and quad 2 -> quad 3, i.e. lanes 0 and 8 to their 8-lane groups

@@ -30,6 +30,8 @@ static thread_local std::string g_err;
         case 1609: { constexpr int GG = 16, LL = 9; CALL; break; }                    \
         case 1614: { constexpr int GG = 16, LL = 14; CALL; break; }                   \
         case 1618: { constexpr int GG = 16, LL = 18; CALL; break; }                   \
+        case 409: { constexpr int GG = 4, LL = 9; CALL; break; }                      \
+        case 418: { constexpr int GG = 4, LL = 18; CALL; break; }                     \
         case 805: { constexpr int GG = 8, LL = 5; CALL; break; }                      \
         case 809: { constexpr int GG = 8, LL = 9; CALL; break; }                      \
         case 814: { constexpr int GG = 8, LL = 14; CALL; break; }                     \
@@ -97,13 +99,13 @@ static void run_mul(MulArgs A) {
     }
 }
 
-static int g_prefer_group = 8;
+static int g_prefer_group = 0;
 
 extern "C" {
 
 const char* emu_last_error() { return g_err.c_str(); }
 
-void emu_set_group(int g) { g_prefer_group = (g == 16) ? 16 : 8; }
+void emu_set_group(int g) { g_prefer_group = (g == 4 || g == 8 || g == 16) ? g : 0; }
 
 // 64/G independent products a[r]*b[r]*R^-1 (mod N), one per limb group.  All arrays hold 29-bit limbs,
 // G*L words per number; a < R, b < 2N; the result is < 2N, almost-normalised (limbs < 2^29 + 2^8).
