@@ -31,22 +31,39 @@ def default_device():
 
 
 def random_lt_n(n, count):
-    """`count` cryptographically random integers in [1, n) — bulk form of PaillierPublicKey.get_random_lt_n
-    (phe/paillier.py:141-143, random.SystemRandom().randrange(1, n)); same source (os.urandom), same
-    distribution (rejection sampling on bit_length(n-1) bits)."""
-    out = []
+    """`count` cryptographically random integers in [1, n) as Python ints (see random_lt_n_limbs)."""
+    limbs = (n.bit_length() + 31) // 32
+    return _native.limbs_to_ints(random_lt_n_limbs(n, count, limbs)) if count else []
+
+
+def random_lt_n_limbs(n, count, limbs):
+    """`count` cryptographically random integers in [1, n) as a (count, limbs) uint32 array — the bulk form of
+    PaillierPublicKey.get_random_lt_n (phe/paillier.py:141-143, random.SystemRandom().randrange(1, n)): same
+    source (os.urandom), same distribution (rejection sampling on bit_length(n-1) bits), vectorised with numpy."""
     k = (n - 1).bit_length()
-    nbytes = (k + 7) // 8
-    mask = (1 << k) - 1
-    while len(out) < count:
-        need = count - len(out)
-        raw = secrets.token_bytes(nbytes * (need + need // 2 + 4))
-        for i in range(0, len(raw), nbytes):
-            v = int.from_bytes(raw[i:i + nbytes], "little") & mask
-            if 1 <= v < n:
-                out.append(v)
-                if len(out) == count:
-                    break
+    top_limb, top_bits = (k - 1) // 32, k - 32 * ((k - 1) // 32)
+    top_mask = np.uint32((1 << top_bits) - 1) if top_bits < 32 else np.uint32(0xffffffff)
+    n_arr = _native.int_to_limbs(n, limbs)
+    out = np.frombuffer(bytearray(secrets.token_bytes(count * limbs * 4)), dtype=np.uint32).reshape(count, limbs)
+    rows = np.arange(count)
+    while len(rows):
+        out[rows, top_limb] &= top_mask
+        if top_limb + 1 < limbs:
+            out[rows, top_limb + 1:] = 0
+        # rows that are >= n (lexicographic compare from the most significant limb down) or zero are redrawn
+        lt = np.zeros(len(rows), dtype=bool)
+        undecided = np.ones(len(rows), dtype=bool)
+        for j in range(top_limb, -1, -1):
+            col = out[rows, j]
+            lt |= undecided & (col < n_arr[j])
+            undecided &= (col == n_arr[j])
+            if not undecided.any():
+                break
+        bad = ~lt
+        bad[lt] = ~out[rows[lt]].any(axis=1) if len(rows) < count else ~out.any(axis=1)[lt]
+        rows = rows[bad]
+        if len(rows):
+            out[rows] = np.frombuffer(secrets.token_bytes(len(rows) * limbs * 4), dtype=np.uint32).reshape(len(rows), limbs)
     return out
 
 

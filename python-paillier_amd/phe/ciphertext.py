@@ -11,7 +11,7 @@ kernel launch each over the whole vector, with the same per-element semantics as
 import numpy as np
 
 from ._device import DeviceArray
-from ._engine import random_lt_n
+from ._engine import random_lt_n, random_lt_n_limbs
 from .codec import EncodedNumber
 
 

@@ -16,7 +16,7 @@ except ImportError:  # pragma: no cover
 import numpy as np
 
 from . import util
-from ._engine import Engine, random_lt_n
+from ._engine import Engine, random_lt_n, random_lt_n_limbs
 from .codec import EncodedNumber
 
 DEFAULT_KEYSIZE = 3072
@@ -114,12 +114,8 @@ class PaillierPublicKey(object):
         encs, exps = EncodedNumber.encode_many(self, values, precision)
         eng = self._get_engine()
         fresh = r_values is None
-        if fresh:
-            r_values = random_lt_n(self.n, len(encs))
-        if device:
-            limbs = eng.raw_encrypt_dev(encs, list(r_values))
-        else:
-            limbs = eng.raw_encrypt(encs, list(r_values))
+        r = random_lt_n_limbs(self.n, len(encs), eng.n_limbs) if fresh else list(r_values)
+        limbs = eng.raw_encrypt_dev(encs, r) if device else eng.raw_encrypt(encs, r)
         return EncryptedVector(self, limbs, exps, obfuscated=fresh)
 
 

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""API-level throughput of the drop-in package (what a Python user gets, including encoding, random obfuscators,
+int<->limb conversion and PCIe): encrypt_batch / vector ops / decrypt_batch on float64 arrays, 2048-bit key."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "python-paillier_amd"))
+import phe as paillier  # noqa: E402
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 17
+g = json.load(open(os.path.join(ROOT, "tests", "golden", "paillier_2048.json")))
+pub = paillier.PaillierPublicKey(int(g["n"], 16))
+priv = paillier.PaillierPrivateKey(pub, int(g["p"], 16), int(g["q"], 16))
+rng = np.random.default_rng(5)
+x, w = rng.random(B), rng.standard_normal(B)
+pub.encrypt_batch(x[:64], device=True)          # context creation / first-launch costs out of the timings
+res = {"batch": B}
+
+
+def timed(name, fn):
+    t0 = time.perf_counter()
+    out = fn()
+    res[name] = {"seconds": time.perf_counter() - t0}
+    res[name]["per_s"] = B / res[name]["seconds"]
+    return out
+
+
+vec = timed("encrypt_batch(float64, device=True)", lambda: pub.encrypt_batch(x, device=True))
+prod = timed("vec * float64 array (device)", lambda: vec * w)
+tot = timed("vec + vec (device)", lambda: vec + prod)
+dot = timed("vec.dot(w) (device)", lambda: vec.dot(w))
+back = timed("decrypt_batch (device vector)", lambda: priv.decrypt_batch(vec))
+hvec = timed("encrypt_batch(float64, host arrays)", lambda: pub.encrypt_batch(x))
+timed("decrypt_batch (host vector)", lambda: priv.decrypt_batch(hvec))
+res["checks"] = {"roundtrip": back == x.tolist(), "dot_close": bool(abs(priv.decrypt(dot) - float(x @ w)) < 1e-6 * B)}
+print(json.dumps(res))
