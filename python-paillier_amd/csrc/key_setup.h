@@ -154,8 +154,8 @@ struct Geometry {
     int S() const { return G * L; }
 };
 static const int kL16[] = {1, 2, 3, 5, 7, 9, 14, 18};
-static const int kL8[] = {5, 9, 14, 18};
-static const int kL4[] = {9, 18};
+static const int kL8[] = {5, 9, 14, 18, 27};
+static const int kL4[] = {9, 18, 36};
 
 // prefer_group: 0 = automatic (least padding, then fewest lanes = most limbs per lane, which amortises the
 // per-digit DPP/quotient work best); 4 / 8 / 16 = the narrowest group allowed (wider ones are the fallback).

@@ -36,7 +36,7 @@ constexpr int kBlock = 256;  // threads per workgroup = 4 wavefronts = 256/G lim
 // (the half-decrypt prologue keeps a few more operands alive; asking for 2 waves per SIMD there makes the
 //  compiler park them in scratch outside the hot loop instead of dropping the kernel to 1 wave per SIMD)
 template <int G, int L, int MODE>
-__global__ void __launch_bounds__(kBlock, (MODE == kModeHalfDecrypt && L >= 14) ? 2 : 1) k_modexp_uniform(UniformArgs A) {
+__global__ void __launch_bounds__(kBlock, ((MODE == kModeHalfDecrypt && L >= 14) || L >= 27) ? 2 : 1) k_modexp_uniform(UniformArgs A) {
     constexpr int S = G * L, kGroups = kBlock / G;
     __shared__ __attribute__((aligned(16))) uint32_t lds[kGroups * (S + kLdsPad)];
     const uint32_t grp = threadIdx.x / G;
@@ -45,7 +45,7 @@ __global__ void __launch_bounds__(kBlock, (MODE == kModeHalfDecrypt && L >= 14) 
 }
 
 template <int G, int L>
-__global__ void __launch_bounds__(kBlock) k_modexp_var(VarArgs A) {
+__global__ void __launch_bounds__(kBlock, L >= 27 ? 2 : 1) k_modexp_var(VarArgs A) {
     constexpr int S = G * L, kGroups = kBlock / G;
     __shared__ __attribute__((aligned(16))) uint32_t lds[kGroups * (S + kLdsPad)];
     const uint32_t grp = threadIdx.x / G;
@@ -235,6 +235,8 @@ static int grid_blocks(const phe_hip_ctx* ctx, size_t batch, int G, int blocks_p
             case 1618: { constexpr int GG = 16, LL = 18; CALL; break; }                        \
             case 409: { constexpr int GG = 4, LL = 9; CALL; break; }                           \
             case 418: { constexpr int GG = 4, LL = 18; CALL; break; }                          \
+            case 436: { constexpr int GG = 4, LL = 36; CALL; break; }                          \
+            case 827: { constexpr int GG = 8, LL = 27; CALL; break; }                          \
             case 805: { constexpr int GG = 8, LL = 5; CALL; break; }                           \
             case 809: { constexpr int GG = 8, LL = 9; CALL; break; }                           \
             case 814: { constexpr int GG = 8, LL = 14; CALL; break; }                          \
@@ -246,6 +248,18 @@ static int grid_blocks(const phe_hip_ctx* ctx, size_t batch, int G, int blocks_p
 // ------------------------------------------------------------------------------------------------
 // launches (device pointers)
 // ------------------------------------------------------------------------------------------------
+// The constants of a modulus are rows of S = G*L limbs in global limb order, so two geometries with the same S
+// can share them.  The 4x36 split only pays in the uniform-exponent kernel (whose loops fit 256 VGPRs); the
+// per-element-exponent and mulmod kernels keep more operands alive and run the same numbers as 8x18.
+static void light_geometry(const DevModulus& M, int& G, int& L) {
+    G = M.G;
+    L = M.L;
+    if (G == 4 && L == 36) {
+        G = 8;
+        L = 18;
+    }
+}
+
 // Resident workgroups per CU for a kernel (VGPR/LDS-limited), asked once per instantiation.  The modexp
 // kernels size their grid to the residency so that the window tables stay per resident group.
 static int query_resident_blocks(const void* kernel) {
@@ -320,14 +334,16 @@ static int launch_var(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* bas
     A.out = out;
     A.out_limbs = out_limbs;
     A.batch = batch;
+    int G, L;
+    light_geometry(M, G, L);
     int per_cu = ctx->blocks_per_cu;
-    if (per_cu == 0) DISPATCH_GL(M.G, M.L, (per_cu = occ_var<GG, LL>()));
-    const int blocks = grid_blocks(ctx, batch, M.G, per_cu);
-    const size_t rows = (size_t)blocks * (size_t)(kBlock / M.G);
+    if (per_cu == 0) DISPATCH_GL(G, L, (per_cu = occ_var<GG, LL>()));
+    const int blocks = grid_blocks(ctx, batch, G, per_cu);
+    const size_t rows = (size_t)blocks * (size_t)(kBlock / G);
     int rc = ensure_words(&ctx->table, &ctx->table_words, rows * ((size_t)1 << A.window) * M.S);
     if (rc) return rc;
     A.table = ctx->table;
-    DISPATCH_GL(M.G, M.L, (go_var<GG, LL>(blocks, stream, A)));
+    DISPATCH_GL(G, L, (go_var<GG, LL>(blocks, stream, A)));
     HIP_TRY(hipGetLastError());
     return PHE_HIP_OK;
 }
@@ -346,8 +362,10 @@ static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, 
     A.limbs = limbs;
     A.batch = batch;
     // no table scratch here: let every CU hold as many groups as the batch offers (cap 8 blocks/CU)
-    const int blocks = grid_blocks(ctx, batch, M.G, 8);
-    DISPATCH_GL(M.G, M.L, (go_mul<GG, LL>(blocks, stream, A)));
+    int G, L;
+    light_geometry(M, G, L);
+    const int blocks = grid_blocks(ctx, batch, G, 8);
+    DISPATCH_GL(G, L, (go_mul<GG, LL>(blocks, stream, A)));
     HIP_TRY(hipGetLastError());
     return PHE_HIP_OK;
 }

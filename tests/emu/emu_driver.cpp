@@ -32,6 +32,8 @@ static thread_local std::string g_err;
         case 1618: { constexpr int GG = 16, LL = 18; CALL; break; }                   \
         case 409: { constexpr int GG = 4, LL = 9; CALL; break; }                      \
         case 418: { constexpr int GG = 4, LL = 18; CALL; break; }                     \
+        case 436: { constexpr int GG = 4, LL = 36; CALL; break; }                     \
+        case 827: { constexpr int GG = 8, LL = 27; CALL; break; }                     \
         case 805: { constexpr int GG = 8, LL = 5; CALL; break; }                      \
         case 809: { constexpr int GG = 8, LL = 9; CALL; break; }                      \
         case 814: { constexpr int GG = 8, LL = 14; CALL; break; }                     \

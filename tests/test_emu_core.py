@@ -21,7 +21,7 @@ def emu():
 
 
 GEOMETRIES = [(16, 1), (16, 2), (16, 3), (16, 5), (16, 7), (16, 9), (16, 14), (16, 18), (8, 5), (8, 9), (8, 14), (8, 18),
-              (4, 9), (4, 18)]
+              (4, 9), (4, 18), (4, 36), (8, 27)]
 
 
 @pytest.mark.parametrize("G,L", GEOMETRIES)

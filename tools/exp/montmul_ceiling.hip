@@ -26,6 +26,7 @@ void run(const char* name, int cus) {
     constexpr int S = G * L, kGroups = 256 / G;
     const int reps = 2000;
     for (int bpc = 1; bpc <= 4; ++bpc) {
+        if (L > 18 && bpc > 2) break;
         const int blocks = cus * bpc;
         std::vector<uint32_t> h((size_t)blocks * kGroups * S, 0x0abcdef1u & 0x1fffffffu), n(S, 0x1ffffffdu);
         n[0] = 0x1ffffffbu | 1u;
@@ -51,5 +52,8 @@ int main() {
     run<4, 18>("sq<4,18>", p.multiProcessorCount);
     run<8, 9>("sq<8,9>", p.multiProcessorCount);
     run<16, 9>("sq<16,9>", p.multiProcessorCount);
+    run<4, 36>("sq<4,36>", p.multiProcessorCount);
+    run<8, 27>("sq<8,27>", p.multiProcessorCount);
+    run<16, 14>("sq<16,14>", p.multiProcessorCount);
     return 0;
 }
