@@ -220,8 +220,8 @@ def main():
     if rank == 0:
         enc_mac, dec_mac = mac32_counts(args.key_bits)
         peak, sustained, peak_src = valu_peak_mac32()
-        traffic_unit, traffic_src = measured_traffic_per_unit("k_modexp_uniform<8,18,encrypt>") if (
-            args.key_bits == 2048 and ctx.info()["lane_limbs_pub"] == 818) else (None, None)
+        traffic_unit, traffic_src = measured_traffic_per_unit("k_modexp_uniform<4,36,encrypt>") if (
+            args.key_bits == 2048 and ctx.info()["lane_limbs_pub"] == 436) else (None, None)
         enc_kernel_s = sum(enc_launch_ms) / len(enc_launch_ms) * 1e-3
         dec_kernel_s = sum(dec_launch_ms) / len(dec_launch_ms) * 1e-3
         achieved = enc_mac * B / enc_kernel_s
