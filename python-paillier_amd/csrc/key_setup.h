@@ -155,24 +155,33 @@ struct Geometry {
 };
 static const int kL16[] = {1, 2, 3, 5, 7, 9, 14, 18};
 static const int kL8[] = {5, 9, 14, 18, 27};
-static const int kL4[] = {9, 18, 36};
+static const int kL4[] = {9, 18, 27, 36};
+static const int kL2[] = {18, 36};
 
 // prefer_group: 0 = automatic (least padding, then fewest lanes = most limbs per lane, which amortises the
-// per-digit DPP/quotient work best); 4 / 8 / 16 = the narrowest group allowed (wider ones are the fallback).
-inline Geometry pick_geometry(int modulus_bits, int min_bits, int prefer_group) {
+// per-digit DPP/quotient work best); 2 / 4 / 8 / 16 = the narrowest group allowed (wider ones are the fallback).
+// Limbs per lane up to this many keep every 64-bit column accumulator below 2^64 for ANY operands:
+// an accumulator stays in a lane for L digits and takes two products < 2^58 (+ almost-normalisation slack) per
+// digit, so 2L * 2^58 < 2^64 needs L <= 31.  Larger L is only used after accumulators_fit() has checked the
+// actual modulus.
+constexpr int kMaxUnconditionalL = 31;
+
+inline Geometry pick_geometry(int modulus_bits, int min_bits, int prefer_group, int max_L = 1 << 30) {
     const int need_bits = std::max(modulus_bits + 4, min_bits);
     const int need = (need_bits + kRadixBits - 1) / kRadixBits;
     Geometry best;
     auto consider = [&](int G, int L) {
         const int S = G * L;
-        if (S < need) return;
+        if (S < need || L > max_L) return;
         if (best.G == 0 || S < best.S() || (S == best.S() && L > best.L)) {
             best.G = G;
             best.L = L;
         }
     };
     if (prefer_group != 16) {
-        const int narrowest = prefer_group == 0 ? 4 : prefer_group;
+        const int narrowest = prefer_group == 0 ? 2 : prefer_group;
+        if (narrowest <= 2)
+            for (int L : kL2) consider(2, L);
         if (narrowest <= 4)
             for (int L : kL4) consider(4, L);
         if (narrowest <= 8)
@@ -182,6 +191,22 @@ inline Geometry pick_geometry(int modulus_bits, int min_bits, int prefer_group) 
     if (prefer_group == 16 || prefer_group == 0 || best.G == 0)
         for (int L : kL16) consider(16, L);
     return best;  // G == 0: too wide for the compiled kernels
+}
+
+// Worst-case value of a column accumulator of mont_core.h:montmul for the modulus limbs `n29` split into lanes
+// of L limbs: it enters a lane below 2^29, takes a_i*b[k] (both digits almost-normalised, < 2^29 + 2^8) and
+// m*n[k] (m < 2^29) at each of the lane's L positions, and once the carry of the limb below (< 2^35).
+inline bool accumulators_fit(const std::vector<uint32_t>& n29, int L) {
+    const unsigned __int128 limit = (unsigned __int128)1 << 64;
+    const unsigned __int128 digit = ((unsigned __int128)1 << 29) + 256;
+    // entry value + carry of the limb below + the carry added by the final normalisation sweep, with margin
+    const unsigned __int128 fixed = ((unsigned __int128)1 << 29) + ((unsigned __int128)1 << 37) + (unsigned __int128)L * digit * digit;
+    for (size_t lane = 0; lane + (size_t)L <= n29.size(); lane += (size_t)L) {
+        unsigned __int128 sum = 0;
+        for (int k = 0; k < L; ++k) sum += n29[lane + (size_t)k];
+        if (fixed + sum * (((unsigned __int128)1 << 29) - 1) >= limit) return false;
+    }
+    return true;
 }
 
 // Everything mont_core.h needs for one modulus: S limbs of 29 bits each, R = 2^(29 S).
@@ -197,12 +222,17 @@ struct ModulusPack {
 inline ModulusPack build_modulus(const Big& N_any, const Big* aux_src, int min_bits = 0, int prefer_group = 0) {
     ModulusPack m;
     m.bits = big_bits(N_any);
-    const Geometry geo = pick_geometry(m.bits, min_bits, prefer_group);
+    const int w32 = (m.bits + 31) / 32;
+    Geometry geo = pick_geometry(m.bits, min_bits, prefer_group);
     if (geo.G == 0) throw std::invalid_argument("modulus too wide for the compiled kernels (max 8344 bits)");
+    if (geo.L > kMaxUnconditionalL && !accumulators_fit(to_r29(big_resize(N_any, w32), geo.S()), geo.L)) {
+        // this modulus has a lane of unusually large limbs (probability ~1e-9 for a random one): stay at L <= 31
+        geo = pick_geometry(m.bits, min_bits, prefer_group, kMaxUnconditionalL);
+        if (geo.G == 0) throw std::invalid_argument("modulus too wide for the compiled kernels (max 8344 bits)");
+    }
     m.G = geo.G;
     m.L = geo.L;
     m.S = geo.S();
-    const int w32 = (m.bits + 31) / 32;
     const Big N = big_resize(N_any, w32);
     if ((N[0] & 1u) == 0u) throw std::invalid_argument("modulus must be odd");
     Big one((size_t)w32, 0u);

@@ -12,7 +12,8 @@
 // (v_add_co / v_addc_co ~4.4), and a full-radix (2^32) CIOS needs ~1.1 of those per multiply.  With
 // 29-bit limbs held in 32-bit lanes the 58-bit products are summed directly in the 64-bit addend of
 // v_mad_u64_u32: a column accumulator absorbs 2 products per row for as many rows as it stays in a
-// lane (L <= 31 keeps it below 2^64), so the inner loop is multiply-accumulates only.  The price is
+// lane (L <= 31 keeps it below 2^64 for any operands; L = 36 is used only for moduli that
+// key_setup.h:accumulators_fit() has checked), so the inner loop is multiply-accumulates only.  The price is
 // (ceil(bits/29)/ceil(bits/32))^2 ~ 1.27x more multiplies, a net ~1.5x fewer issue cycles.
 //
 // Layout.  A modulus N with 29*S >= bits(N) + 4 (S = G*L limbs) is owned by a group of G lanes
@@ -47,7 +48,10 @@ using Lanes = wave::Lanes<G>;
 
 template <int G>
 struct GroupMasks {
-    static constexpr uint64_t lane0 = (G == 16) ? 0x0001000100010001ull : (G == 8) ? 0x0101010101010101ull : 0x1111111111111111ull;
+    static constexpr uint64_t lane0 = (G == 16) ? 0x0001000100010001ull
+                                      : (G == 8) ? 0x0101010101010101ull
+                                      : (G == 4) ? 0x1111111111111111ull
+                                                 : 0x5555555555555555ull;
     static constexpr uint64_t top = lane0 << (G - 1);
 };
 

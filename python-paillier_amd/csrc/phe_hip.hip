@@ -98,6 +98,10 @@ __global__ void k_selftest_prims(uint32_t* out) {
     out[450 + lane] = wave::grp_down1<4>(lane + 100u, l4);
     out[514 + lane] = wave::grp_up1<4>(lane + 100u, l4);
     out[578 + lane] = wave::grp_bcast0<4>(lane + 100u, l4);
+    const wave::Lanes<2> l2(lane);
+    out[642 + lane] = wave::grp_down1<2>(lane + 100u, l2);
+    out[706 + lane] = wave::grp_up1<2>(lane + 100u, l2);
+    out[770 + lane] = wave::grp_bcast0<2>(lane + 100u, l2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -233,7 +237,10 @@ static int grid_blocks(const phe_hip_ctx* ctx, size_t batch, int G, int blocks_p
             case 1609: { constexpr int GG = 16, LL = 9; CALL; break; }                         \
             case 1614: { constexpr int GG = 16, LL = 14; CALL; break; }                        \
             case 1618: { constexpr int GG = 16, LL = 18; CALL; break; }                        \
+            case 218: { constexpr int GG = 2, LL = 18; CALL; break; }                          \
+            case 236: { constexpr int GG = 2, LL = 36; CALL; break; }                          \
             case 409: { constexpr int GG = 4, LL = 9; CALL; break; }                           \
+            case 427: { constexpr int GG = 4, LL = 27; CALL; break; }                          \
             case 418: { constexpr int GG = 4, LL = 18; CALL; break; }                          \
             case 436: { constexpr int GG = 4, LL = 36; CALL; break; }                          \
             case 827: { constexpr int GG = 8, LL = 27; CALL; break; }                          \
@@ -254,8 +261,11 @@ static int grid_blocks(const phe_hip_ctx* ctx, size_t batch, int G, int blocks_p
 static void light_geometry(const DevModulus& M, int& G, int& L) {
     G = M.G;
     L = M.L;
-    if (G == 4 && L == 36) {
+    if (G == 4 && L == 36) {         // 144 limbs
         G = 8;
+        L = 18;
+    } else if (G == 2 && L == 36) {  // 72 limbs
+        G = 4;
         L = 18;
     }
 }
@@ -408,7 +418,7 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
     }
     if (const char* e = getenv("PHE_HIP_GROUP")) {
         const int v = atoi(e);
-        if (v == 4 || v == 8 || v == 16) ctx->prefer_group = v;
+        if (v == 2 || v == 4 || v == 8 || v == 16) ctx->prefer_group = v;
     }
     try {
         ctx->pub = host::build_public(n, n_limbs, ctx->prefer_group);
@@ -867,10 +877,10 @@ int phe_hip_selftest_prims(int device, uint32_t* out) {
     if (!out) return fail(PHE_HIP_EINVAL, "null out");
     HIP_TRY(hipSetDevice(device));
     uint32_t* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, 642 * 4));
+    HIP_TRY(hipMalloc((void**)&d, 834 * 4));
     k_selftest_prims<<<dim3(1), dim3(64), 0, nullptr>>>(d);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, d, 642 * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, d, 834 * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(d));
     return PHE_HIP_OK;
 }

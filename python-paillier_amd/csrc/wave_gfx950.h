@@ -1,7 +1,7 @@
 // wave_gfx950.h — the CDNA4 (gfx950) wavefront primitives the multi-precision core is written against.
 //
 // A 64-lane wavefront is used as independent limb groups of G = 16 lanes (one DPP row), G = 8 lanes
-// (half a row) or G = 4 lanes (one quad); each group owns one big number whose limbs are blocked across its lanes
+// (half a row), G = 4 lanes (one quad) or G = 2 lanes (half a quad); each group owns one big number whose limbs are blocked across its lanes
 // (lane g of the group holds limbs [g*L, (g+1)*L)).  Every cross-lane movement the Montgomery core needs is a single-
 // instruction DPP row operation; nothing here touches LDS or memory:
 //
@@ -25,7 +25,8 @@ constexpr int kRow = 16;  // lanes of one DPP row
 
 PHE_DEV uint32_t lane_id() { return __lane_id(); }
 
-// Per-lane constants of a limb group of G lanes (G = 16: one DPP row; G = 8: half a row; G = 4: one quad).
+// Per-lane constants of a limb group of G lanes (G = 16: one DPP row; G = 8: half a row; G = 4: one quad;
+// G = 2: half a quad).
 template <int G>
 struct Lanes {
     uint32_t lane;      // 0..63
@@ -50,14 +51,16 @@ template <int G>
 PHE_DEV uint32_t grp_down1(uint32_t x, const Lanes<G>& l) {
     if constexpr (G == 16) return dpp_row_shl1(x);
     else if constexpr (G == 8) return dpp_row_shl1(x) & l.not_top;
-    else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9 /*quad_perm:[1,2,3,3]*/, 0xf, 0xf, true) & l.not_top;
+    else if constexpr (G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9 /*quad_perm:[1,2,3,3]*/, 0xf, 0xf, true) & l.not_top;
+    else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF5 /*quad_perm:[1,1,3,3]*/, 0xf, 0xf, true) & l.not_top;
 }
 // lane g <- lane g-1 of its group; the group's lane 0 receives 0
 template <int G>
 PHE_DEV uint32_t grp_up1(uint32_t x, const Lanes<G>& l) {
     if constexpr (G == 16) return dpp_row_shr1(x);
     else if constexpr (G == 8) return dpp_row_shr1(x) & l.not_low;
-    else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x90 /*quad_perm:[0,0,1,2]*/, 0xf, 0xf, true) & l.not_low;
+    else if constexpr (G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x90 /*quad_perm:[0,0,1,2]*/, 0xf, 0xf, true) & l.not_low;
+    else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xA0 /*quad_perm:[0,0,2,2]*/, 0xf, 0xf, true) & l.not_low;
 }
 // every lane <- lane 0 of its group
 template <int G>
@@ -66,6 +69,8 @@ PHE_DEV uint32_t grp_bcast0(uint32_t x, const Lanes<G>&) {
         return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 /*row_newbcast:0*/, 0xf, 0xf, true);
     } else if constexpr (G == 4) {
         return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x00 /*quad_perm:[0,0,0,0]*/, 0xf, 0xf, true);
+    } else if constexpr (G == 2) {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xA0 /*quad_perm:[0,0,2,2]*/, 0xf, 0xf, true);
     } else {
         // quad_perm:[0,0,0,0] puts lanes 0,4,8,12 into their quads; row_shr:4 restricted to banks 1 and 3
         // then copies quad 0 -> quad 1 and quad 2 -> quad 3, i.e. lanes 0 and 8 to their 8-lane groups

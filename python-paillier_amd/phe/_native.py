@@ -276,6 +276,6 @@ class Context:
 
 
 def selftest_prims(device=0):
-    out = np.zeros(642, np.uint32)
+    out = np.zeros(834, np.uint32)
     _check(lib().phe_hip_selftest_prims(device, _ptr(out)))
     return out

@@ -30,7 +30,10 @@ static thread_local std::string g_err;
         case 1609: { constexpr int GG = 16, LL = 9; CALL; break; }                    \
         case 1614: { constexpr int GG = 16, LL = 14; CALL; break; }                   \
         case 1618: { constexpr int GG = 16, LL = 18; CALL; break; }                   \
+        case 218: { constexpr int GG = 2, LL = 18; CALL; break; }                     \
+        case 236: { constexpr int GG = 2, LL = 36; CALL; break; }                     \
         case 409: { constexpr int GG = 4, LL = 9; CALL; break; }                      \
+        case 427: { constexpr int GG = 4, LL = 27; CALL; break; }                     \
         case 418: { constexpr int GG = 4, LL = 18; CALL; break; }                     \
         case 436: { constexpr int GG = 4, LL = 36; CALL; break; }                     \
         case 827: { constexpr int GG = 8, LL = 27; CALL; break; }                     \
@@ -107,7 +110,7 @@ extern "C" {
 
 const char* emu_last_error() { return g_err.c_str(); }
 
-void emu_set_group(int g) { g_prefer_group = (g == 4 || g == 8 || g == 16) ? g : 0; }
+void emu_set_group(int g) { g_prefer_group = (g == 2 || g == 4 || g == 8 || g == 16) ? g : 0; }
 
 // 64/G independent products a[r]*b[r]*R^-1 (mod N), one per limb group.  All arrays hold 29-bit limbs,
 // G*L words per number; a < R, b < 2N; the result is < 2N, almost-normalised (limbs < 2^29 + 2^8).
@@ -221,6 +224,15 @@ int emu_powmod_var(const uint32_t* N, int limbs, const uint32_t* base, const uin
         A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
         A.out = out; A.out_limbs = limbs; A.batch = B;
         DISPATCH_GL(M.G, M.L, (run_var<GG, LL>(A)));
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// geometry key_setup.h picks for an arbitrary odd modulus given as `limbs` 32-bit words: GL_out = {G, L}
+int emu_modulus_geometry(const uint32_t* N, int limbs, int* GL_out) {
+    try {
+        host::ModulusPack M = host::build_modulus(host::big_from(N, limbs, limbs), nullptr, 32 * limbs, g_prefer_group);
+        GL_out[0] = M.G; GL_out[1] = M.L;
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }

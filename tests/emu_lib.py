@@ -63,6 +63,11 @@ class Emu:
                                        ctypes.c_uint64(base.shape[0])))
         return out
 
+    def modulus_geometry(self, N):
+        GL = (ctypes.c_int * 2)()
+        self._ck(self.L.emu_modulus_geometry(P(N), N.shape[0], GL))
+        return GL[0], GL[1]
+
     def public_constants(self, n):
         s1 = n.shape[0]
         res = {}

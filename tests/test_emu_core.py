@@ -21,7 +21,7 @@ def emu():
 
 
 GEOMETRIES = [(16, 1), (16, 2), (16, 3), (16, 5), (16, 7), (16, 9), (16, 14), (16, 18), (8, 5), (8, 9), (8, 14), (8, 18),
-              (4, 9), (4, 18), (4, 36), (8, 27)]
+              (4, 9), (4, 18), (4, 36), (8, 27), (4, 27), (2, 18), (2, 36)]
 
 
 @pytest.mark.parametrize("G,L", GEOMETRIES)
@@ -33,9 +33,10 @@ def test_montmul_groups(emu, G, L):
     per = 64 // G
     top = 29 * S - 4                                            # largest modulus this geometry accepts
     moduli = [rng.getrandbits(top) | 1 | (1 << (top - 1)),      # widest
-              (1 << top) - 1,                                   # all-ones limbs: every carry path
               126869 ** 2,                                      # tiny modulus in a wide container
               (1 << (top - 1)) + 1]
+    if L <= 31:
+        moduli.append((1 << top) - 1)     # all-ones limbs: every carry path (L > 31 is never chosen for such a modulus)
     for N in moduli:
         n0inv = (-pow(N, -1, 1 << 29)) % (1 << 29)
         a = [rng.randrange(0, R) for _ in range(per)]           # multiplier: any value below R
@@ -61,12 +62,32 @@ def test_montmul_groups(emu, G, L):
             assert v % N == x * y * rinv % N and v < 2 * N
 
 
+def test_dense_modulus_falls_back_to_unconditionally_safe_geometry(emu):
+    """L = 36 keeps the 64-bit column sums below 2^64 only if no lane of the modulus is unusually dense;
+    key_setup.h checks that per modulus and otherwise stays at L <= 31 — and the result is still exact."""
+    emu.set_group(0)
+    rng = random.Random(36)
+    dense = (1 << 4090) - 1 - (rng.getrandbits(64) << 1)         # ~every 29-bit limb at its maximum
+    typical = rng.getrandbits(4090) | 1 | (1 << 4089)
+    assert emu.modulus_geometry(int_to_limbs(typical, 128)) == (4, 36)
+    G, L = emu.modulus_geometry(int_to_limbs(dense, 128))
+    assert L <= 31 and G * L >= 142
+    a = [dense - 1, dense - 2, rng.randrange(dense), 1]
+    b = [dense - 1, dense - 3, rng.randrange(dense), dense - 1]
+    got = emu.mulmod(int_to_limbs(dense, 128), ints_to_limbs(a, 128), ints_to_limbs(b, 128))
+    assert limbs_to_ints(got) == [x * y % dense for x, y in zip(a, b)]
+    # the same worst-case operands under a typical modulus, on the 4x36 split
+    a = [typical - 1, typical - 2, (1 << 4089) - 1, rng.randrange(typical)]
+    got = emu.mulmod(int_to_limbs(typical, 128), ints_to_limbs(a, 128), ints_to_limbs(a, 128))
+    assert limbs_to_ints(got) == [x * x % typical for x in a]
+
+
 @pytest.mark.parametrize("key_bits", [256, 1024])
 def test_public_constants(emu, key_bits):
     g = load_golden(key_bits)
     n = H(g["n"])
     s1 = key_bits // 32
-    for group in (0, 4, 8, 16):
+    for group in (0, 2, 4, 8, 16):
         emu.set_group(group)
         k = emu.public_constants(int_to_limbs(n, s1))
         S = k["S"]
@@ -95,7 +116,7 @@ def test_reference_kat(emu):
 
 
 @pytest.mark.parametrize("key_bits,count,group", [(256, None, 16), (256, None, 8), (1024, 5, 0), (1024, 3, 16),
-                                                  (1024, 3, 4), (2048, 2, 0)])
+                                                  (1024, 3, 4), (1024, 3, 2), (2048, 2, 0)])
 def test_golden_through_emulator(emu, key_bits, count, group):
     emu.set_group(group)
     g = load_golden(key_bits)

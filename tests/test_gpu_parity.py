@@ -41,7 +41,7 @@ def test_wave_primitives(native):
     """The DPP group operations mean what csrc/wave_gfx950.h (and the CPU emulator) say they mean."""
     out = native.selftest_prims(0)
     lanes = np.arange(64)
-    for G, base in ((16, 0), (8, 258), (4, 450)):
+    for G, base in ((16, 0), (8, 258), (4, 450), (2, 642)):
         down = np.where(lanes % G == G - 1, 0, lanes + 1 + 100)
         up = np.where(lanes % G == 0, 0, lanes - 1 + 100)
         bc = (lanes // G) * G + 100
@@ -61,7 +61,7 @@ def test_reference_kat(native):
     assert native.limbs_to_ints(ctx.decrypt(c)) == [k["m"], 1]
 
 
-@pytest.fixture(params=["auto", "4", "8", "16"])
+@pytest.fixture(params=["auto", "2", "4", "8", "16"])
 def group(request, monkeypatch):
     """Limb-group width: 'auto' = 8-lane groups for large batches, 16-lane groups for small ones; '8' / '16'
     force one geometry for every batch size (PHE_HIP_GROUP is read when a context is created)."""
