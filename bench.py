@@ -249,7 +249,9 @@ def main():
                 "peak_source": "256 CUs x 4 SIMD x 64 lanes x 2.4 GHz / 4 cycles per v_mad_u64_u32 (half-rate, calibrated)",
                 "peak_sustained_microbench": (sustained / 1e12) if sustained else None, "microbench": peak_src,
                 "hbm_algorithmic_GBps": (2 * s1 + s2) * 4 * B / enc_kernel_s / 1e9, "hbm_peak_GBps": 8000.0,
-                "decrypt": {"achieved": dec_mac * B / dec_kernel_s / 1e12, "frac": dec_mac * B / dec_kernel_s / peak,
+                "decrypt": {"kernel": "2 x k_modexp_uniform<G=%d, L=%d, half_decrypt> + k_decrypt_tail" % divmod(
+                                ctx.info()["lane_limbs_priv"], 100),
+                            "achieved": dec_mac * B / dec_kernel_s / 1e12, "frac": dec_mac * B / dec_kernel_s / peak,
                             "mac32_per_decrypt": dec_mac, "launch_ms_avg": dec_kernel_s * 1e3},
             },
             "cpu_baseline": cpu,

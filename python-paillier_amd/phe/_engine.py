@@ -92,7 +92,9 @@ class Engine:
         return x if isinstance(x, np.ndarray) else self.plain_limbs(x)
 
     def _as_cipher(self, x):
-        return x if isinstance(x, np.ndarray) else self.cipher_limbs(x)
+        # Python ints are reduced mod n^2 on the way in (the reference's mulmod/powmod accept any int and
+        # reduce implicitly; the kernels want residues)
+        return x if isinstance(x, np.ndarray) else self.cipher_limbs([v % self.nsquare for v in x])
 
     # ---- the five hot functions (limb arrays in, limb arrays out) ------------------------------
     def raw_encrypt(self, m, r):
