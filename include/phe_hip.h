@@ -90,6 +90,11 @@ int phe_hip_decrypt(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t bat
  * (= phe.util.mulmod, phe/util.py:53-64).  a, b, out: (batch, ct_limbs); b < n^2. */
 int phe_hip_mulmod(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t batch);
 
+/* out[i] = c[i] * (1 + n*m[i]) mod n^2      — adding a plaintext to a ciphertext: EncryptedNumber._add_encoded,
+ * phe/paillier.py:673-675 (raw_encrypt(m, r_value=1) followed by _raw_add).  c, out: (batch, ct_limbs);
+ * m: (batch, n_limbs), any value < 2^(32*n_limbs) (reduced mod n like raw_encrypt does). */
+int phe_hip_add_plain(phe_hip_ctx* ctx, const uint32_t* c, const uint32_t* m, uint32_t* out, size_t batch);
+
 /* out[i] = base[i]^e[i] mod n^2             — the powmod of EncryptedNumber._raw_mul,
  * phe/paillier.py:749/:751 (= phe.util.powmod, phe/util.py:38-50).  base: (batch, ct_limbs) < n^2;
  * e: (batch, exp_limbs).  The negative-scalar branch (:745-749) is composed by the host from
@@ -108,6 +113,7 @@ int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, 
 int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t* r, uint32_t* c_out, size_t batch, void* stream);
 int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t batch, void* stream);
 int phe_hip_mulmod_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t batch, void* stream);
+int phe_hip_add_plain_dev(phe_hip_ctx* ctx, const uint32_t* c, const uint32_t* m, uint32_t* out, size_t batch, void* stream);
 /* max_exp_bits: upper bound on the bit length of every e[i] (0 = 32*exp_limbs) */
 int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, int max_exp_bits,
                        uint32_t* out, size_t batch, void* stream);

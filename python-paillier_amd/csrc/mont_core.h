@@ -463,6 +463,9 @@ struct MulArgs {
     uint32_t* out;
     size_t a_stride, b_stride, out_stride;  // 32-bit words between consecutive rows
     int limbs;                              // 32-bit words per number
+    int b_plain_limbs;                      // 0: b is a residue mod N.  > 0: b is a plaintext m of that many words and
+                                            // the product is taken with 1 + n*m — E(a) * g^m, the "add a plaintext" of
+                                            // EncryptedNumber._add_encoded (phe/paillier.py:673-675); needs mod.aux
     uint64_t batch;
 };
 
@@ -481,7 +484,16 @@ PHE_DEV void mulmod_body(const MulArgs& A, uint32_t* lds_row, uint32_t slot, uin
         if (!live) item = A.batch - 1;
         uint32_t x[L], y[L];
         load_u32_as_r29<L>(x, A.a + item * A.a_stride, A.limbs, 0, g);
-        load_u32_as_r29<L>(y, A.b + item * A.b_stride, A.limbs, 0, g);
+        if (A.b_plain_limbs > 0) {
+            // nude ciphertext of the plaintext: 1 + n*m (mod n^2), value < 2N
+            load_u32_as_r29<L>(y, A.b + item * A.b_stride, A.b_plain_limbs, 0, g);
+            lds_put<L>(lds_row, y, g);
+            load_row<L>(y, A.mod.aux, g);
+            montmul<G, L>(y, lds_row, y, n, n0inv, ln);
+            if (g == 0u) y[0] += 1u;
+        } else {
+            load_u32_as_r29<L>(y, A.b + item * A.b_stride, A.limbs, 0, g);
+        }
         lds_put<L>(lds_row, x, g);
         montmul<G, L>(x, lds_row, y, n, n0inv, ln);   // a*b/R
         lds_put<L>(lds_row, x, g);

@@ -360,8 +360,9 @@ static int launch_var(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* bas
 
 static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, size_t a_stride, const uint32_t* b,
                       size_t b_stride, uint32_t* out, size_t out_stride, int limbs, size_t batch,
-                      hipStream_t stream) {
+                      hipStream_t stream, int b_plain_limbs = 0) {
     MulArgs A;
+    A.b_plain_limbs = b_plain_limbs;
     A.mod = M.c;
     A.a = a;
     A.b = b;
@@ -598,6 +599,15 @@ int phe_hip_mulmod_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, u
     return launch_mul(ctx, pick_nsq(ctx, batch), a, s2, b, s2, out, s2, ctx->pub.s2, batch, (hipStream_t)stream);
 }
 
+int phe_hip_add_plain_dev(phe_hip_ctx* ctx, const uint32_t* c, const uint32_t* m, uint32_t* out, size_t batch, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!c || !m || !out) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    const size_t s1 = (size_t)ctx->pub.s1, s2 = (size_t)ctx->pub.s2;
+    return launch_mul(ctx, pick_nsq(ctx, batch), c, s2, m, s1, out, s2, ctx->pub.s2, batch, (hipStream_t)stream, ctx->pub.s1);
+}
+
 int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, int max_exp_bits,
                        uint32_t* out, size_t batch, void* stream) {
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
@@ -671,6 +681,21 @@ int phe_hip_mulmod(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, uint3
     if (!rc) rc = stage_in(ctx, 1, b, batch * s2);
     if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
     if (!rc) rc = phe_hip_mulmod_dev(ctx, ctx->stage[0], ctx->stage[1], ctx->stage[2], batch, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));
+    return PHE_HIP_OK;
+}
+
+int phe_hip_add_plain(phe_hip_ctx* ctx, const uint32_t* c, const uint32_t* m, uint32_t* out, size_t batch) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!c || !m || !out) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    const size_t s1 = (size_t)ctx->pub.s1, s2 = (size_t)ctx->pub.s2;
+    int rc = stage_in(ctx, 0, c, batch * s2);
+    if (!rc) rc = stage_in(ctx, 1, m, batch * s1);
+    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
+    if (!rc) rc = phe_hip_add_plain_dev(ctx, ctx->stage[0], ctx->stage[1], ctx->stage[2], batch, nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));
     return PHE_HIP_OK;

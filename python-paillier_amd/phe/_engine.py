@@ -113,6 +113,12 @@ class Engine:
     def raw_add(self, a, b):
         return self.ctx.mulmod(self._as_cipher(a), self._as_cipher(b))
 
+    def add_plain(self, c, plaintexts):
+        """c * (1 + n*m) mod n^2 per row: E(a) + b for a plaintext encoding b (phe/paillier.py:673-675)."""
+        if not isinstance(plaintexts, np.ndarray):
+            plaintexts = self.plain_limbs([v % self.n for v in plaintexts])
+        return self.ctx.add_plain(self._as_cipher(c), plaintexts)
+
     def raw_mul(self, c, scalars):
         """Per row: powmod(c, s, n^2) if s < n - max_int, else powmod(invert(c, n^2), n - s, n^2) — the same
         partition as phe/paillier.py:745-751 (the two branches give different ciphertext bits).
@@ -168,6 +174,13 @@ class Engine:
     def raw_add_dev(self, a, b):
         out = DeviceArray(self.ctx, a.rows, self.ct_limbs)
         self.ctx.mulmod_dev(a.ptr, b.ptr, out.ptr, a.rows)
+        self.ctx.sync()
+        return out
+
+    def add_plain_dev(self, c, plaintexts):
+        m = self.upload_plain([v % self.n for v in plaintexts] if not isinstance(plaintexts, np.ndarray) else plaintexts)
+        out = DeviceArray(self.ctx, c.rows, self.ct_limbs)
+        self.ctx.add_plain_dev(c.ptr, m.ptr, out.ptr, c.rows)
         self.ctx.sync()
         return out
 

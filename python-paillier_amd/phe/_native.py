@@ -45,6 +45,8 @@ def lib():
         L.phe_hip_decrypt.argtypes = [vp, vp, vp, sz]
         L.phe_hip_mulmod.argtypes = [vp, vp, vp, vp, sz]
         L.phe_hip_powmod.argtypes = [vp, vp, vp, ci, vp, sz]
+        L.phe_hip_add_plain.argtypes = [vp, vp, vp, vp, sz]
+        L.phe_hip_add_plain_dev.argtypes = [vp, vp, vp, vp, sz, vp]
         L.phe_hip_invert.argtypes = [vp, vp, vp, sz, ctypes.POINTER(sz)]
         L.phe_hip_encrypt_dev.argtypes = [vp, vp, vp, vp, sz, vp]
         L.phe_hip_obfuscate_dev.argtypes = [vp, vp, vp, vp, sz, vp]
@@ -71,7 +73,7 @@ EXPORTED_SYMBOLS = [
     "phe_hip_encrypt_dev", "phe_hip_obfuscate_dev", "phe_hip_decrypt_dev", "phe_hip_mulmod_dev",
     "phe_hip_powmod_dev", "phe_hip_malloc", "phe_hip_free", "phe_hip_memcpy_h2d", "phe_hip_memcpy_d2h",
     "phe_hip_stream_sync", "phe_hip_selftest_prims", "phe_hip_memcpy_d2d", "phe_hip_invert_dev",
-    "phe_hip_select_rows_dev",
+    "phe_hip_select_rows_dev", "phe_hip_add_plain", "phe_hip_add_plain_dev",
 ]
 
 
@@ -208,6 +210,15 @@ class Context:
         _check(lib().phe_hip_mulmod(self._h, _ptr(a), _ptr(b), _ptr(out), a.shape[0]))
         return out
 
+    def add_plain(self, c, m):
+        c = _rows(c, self.ct_limbs, "c")
+        m = _rows(m, self.n_limbs, "m")
+        if c.shape[0] != m.shape[0]:
+            raise ValueError("c and m batch sizes differ")
+        out = np.empty_like(c)
+        _check(lib().phe_hip_add_plain(self._h, _ptr(c), _ptr(m), _ptr(out), c.shape[0]))
+        return out
+
     def powmod(self, base, exps):
         base = _rows(base, self.ct_limbs, "base")
         exps = np.ascontiguousarray(exps, dtype=np.uint32)
@@ -238,6 +249,9 @@ class Context:
 
     def mulmod_dev(self, a_ptr, b_ptr, out_ptr, batch, stream=0):
         _check(lib().phe_hip_mulmod_dev(self._h, a_ptr, b_ptr, out_ptr, batch, stream))
+
+    def add_plain_dev(self, c_ptr, m_ptr, out_ptr, batch, stream=0):
+        _check(lib().phe_hip_add_plain_dev(self._h, c_ptr, m_ptr, out_ptr, batch, stream))
 
     def powmod_dev(self, base_ptr, exp_ptr, exp_limbs, max_exp_bits, out_ptr, batch, stream=0):
         _check(lib().phe_hip_powmod_dev(self._h, base_ptr, exp_ptr, exp_limbs, max_exp_bits, out_ptr, batch, stream))

@@ -90,10 +90,11 @@ class EncryptedNumber(object):
             a = self.decrease_exponent_to(b.exponent)
         elif a.exponent < b.exponent:
             b = b.decrease_exponent_to(a.exponent)
-        # E(b) with obfuscator 1 is 1 + n*b (phe/paillier.py:673): no exponentiation needed
-        encrypted_scalar = (a.public_key.n * b.encoding + 1) % a.public_key.nsquare
-        total = a._raw_add(a.ciphertext(False), encrypted_scalar)
-        return EncryptedNumber(a.public_key, total, a.exponent)
+        # E(b) with obfuscator 1 is 1 + n*b (phe/paillier.py:673): formed and multiplied in on the GPU
+        pk = a.public_key
+        eng = pk._get_engine()
+        total = eng.to_ints(eng.add_plain([a.ciphertext(False)], [b.encoding]))[0]
+        return EncryptedNumber(pk, total, a.exponent)
 
     def _add_encrypted(self, other):
         if self.public_key != other.public_key:
@@ -293,8 +294,10 @@ class EncryptedVector(object):
             encs.append(enc)
             exps.append(enc.exponent)
         a, target = self._aligned(exps)
-        nude = [(pk.n * enc.decrease_exponent_to(t).encoding + 1) % pk.nsquare for enc, t in zip(encs, target)]
-        return self._like(self._raw_add(a._limbs, pk._get_engine().cipher_limbs(nude)), target)
+        plain = [enc.decrease_exponent_to(t).encoding for enc, t in zip(encs, target)]
+        eng = pk._get_engine()
+        limbs = eng.add_plain_dev(a._limbs, plain) if self.on_device else eng.add_plain(a._limbs, plain)
+        return self._like(limbs, target)
 
     __radd__ = __add__
 

@@ -206,6 +206,20 @@ int emu_mulmod(const uint32_t* N, int limbs, const uint32_t* a, const uint32_t* 
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
+// out = c * (1 + n*m) mod n^2 (the add-a-plaintext entry)
+int emu_add_plain(const uint32_t* n, int n_limbs, const uint32_t* c, const uint32_t* m, uint32_t* out, uint64_t B) {
+    try {
+        if (B == 0) return 0;
+        host::PublicPlan P = host::build_public(n, n_limbs, g_prefer_group);
+        MulArgs A;
+        memset(&A, 0, sizeof A);
+        A.mod = consts_of(P.nsq); A.a = c; A.b = m; A.out = out; A.limbs = P.s2; A.batch = B;
+        A.a_stride = A.out_stride = (size_t)P.s2; A.b_stride = (size_t)P.s1; A.b_plain_limbs = P.s1;
+        DISPATCH_GL(P.nsq.G, P.nsq.L, (run_mul<GG, LL>(A)));
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
 // out = base^exp mod N with per-row exponents
 int emu_powmod_var(const uint32_t* N, int limbs, const uint32_t* base, const uint32_t* exps, int exp_limbs,
                    uint32_t* out, uint64_t B) {

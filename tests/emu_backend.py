@@ -64,6 +64,11 @@ class EmuContext:
             return a.copy()
         return emu().mulmod(self._nsq_arr, np.ascontiguousarray(a), np.ascontiguousarray(b))
 
+    def add_plain(self, c, m):
+        if c.shape[0] == 0:
+            return c.copy()
+        return emu().add_plain(self._n_arr, np.ascontiguousarray(c), np.ascontiguousarray(m))
+
     def powmod(self, base, exps):
         if base.shape[0] == 0:
             return base.copy()

@@ -57,6 +57,11 @@ class Emu:
         self._ck(self.L.emu_mulmod(P(N), N.shape[0], P(a), P(b), P(out), ctypes.c_uint64(a.shape[0])))
         return out
 
+    def add_plain(self, n, c, m):
+        out = np.zeros_like(c)
+        self._ck(self.L.emu_add_plain(P(n), n.shape[0], P(c), P(m), P(out), ctypes.c_uint64(c.shape[0])))
+        return out
+
     def powmod_var(self, N, base, exps):
         out = np.zeros_like(base)
         self._ck(self.L.emu_powmod_var(P(N), N.shape[0], P(base), P(exps), exps.shape[1], P(out),

@@ -124,6 +124,9 @@ def test_random_batches_vs_gmp_oracle(native, c_oracle, key_bits, batch, group):
     scal = native.ints_to_limbs([rng.getrandbits(rng.choice([1, 8, 27, 56, 64, 130])) for _ in range(batch)], s1)
     assert np.array_equal(ctx.powmod(c, scal), c_oracle.mul(n, c, scal, nthreads=8))
     assert np.array_equal(ctx.obfuscate(junk, r), c_oracle.obfuscate(n, junk, r, nthreads=8))
+    # adding a plaintext = multiplying by its nude ciphertext 1 + n*m = raw_encrypt(m, r_value=1) (phe/paillier.py:673-675)
+    ones = np.zeros_like(r); ones[:, 0] = 1
+    assert np.array_equal(ctx.add_plain(c, m), c_oracle.add(n, c, c_oracle.encrypt(n, m, ones, nthreads=8), nthreads=8))
 
 
 def test_ragged_and_empty_batches(native, c_oracle):
