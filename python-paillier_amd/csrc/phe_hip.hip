@@ -1,11 +1,13 @@
 // phe_hip.hip — gfx950 kernels and the C-ABI (include/phe_hip.h) of the batched Paillier engine.
 //
 // Kernels (all hand-written for CDNA4; the arithmetic lives in mont_core.h / decrypt_tail.h):
-//   k_modexp_uniform<L, MODE>  batch-uniform exponent: encrypt / obfuscate (e = n, mod n^2) and the
-//                              two CRT halves of decrypt (e = p-1 mod p^2, e = q-1 mod q^2)
-//   k_modexp_var<L>            per-element exponent (powmod of _raw_mul)
-//   k_mulmod<L>                a*b mod n^2 (_raw_add, and the product tree of batched inversion)
-//   k_decrypt_tail             L-function, *hp, CRT recombination, one ciphertext per thread
+//   k_modexp_uniform<G, L, MODE>  batch-uniform exponent: encrypt / obfuscate (e = n, mod n^2) and the
+//                                 two CRT halves of decrypt (e = p-1 mod p^2, e = q-1 mod q^2)
+//   k_modexp_var<G, L>            per-element exponent (powmod of _raw_mul)
+//   k_mulmod<G, L>                a*b mod n^2 (_raw_add, add-plaintext, the product tree of batched inversion)
+//     (these three live in group_kernels.inc, instantiated by kernels_g*.hip, one TU per group width)
+//   k_decrypt_tail                L-function, *hp, CRT recombination, one ciphertext per thread
+//   k_select_rows                 per-row select between two ciphertext arrays
 // Launch geometry: 256-thread workgroups = 4 wavefronts = 16 limb groups; the grid is sized to the
 // resident capacity (CUs x blocks_per_cu) and each limb group strides over the batch, so the
 // window tables (one per resident limb group) stay L2/MALL-resident regardless of batch size.
@@ -31,36 +33,63 @@ using host::Big;
 // ------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------
-constexpr int kBlock = 256;  // threads per workgroup = 4 wavefronts = 256/G limb groups
+constexpr int kBlock = 256;  // threads per workgroup = 4 wavefronts = 256/G limb groups (same constant as group_kernels.inc)
 
-// (the half-decrypt prologue keeps a few more operands alive; asking for 2 waves per SIMD there makes the
-//  compiler park them in scratch outside the hot loop instead of dropping the kernel to 1 wave per SIMD)
-template <int G, int L, int MODE>
-__global__ void __launch_bounds__(kBlock, ((MODE == kModeHalfDecrypt && L >= 14) || L >= 27) ? 2 : 1) k_modexp_uniform(UniformArgs A) {
-    constexpr int S = G * L, kGroups = kBlock / G;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kGroups * (S + kLdsPad)];
-    const uint32_t grp = threadIdx.x / G;
-    modexp_uniform_body<G, L, MODE>(A, lds + grp * (S + kLdsPad), blockIdx.x * kGroups + grp, gridDim.x * kGroups,
-                                    threadIdx.x & 63u);
-}
+// The limb-group kernels live in kernels_g*.hip (compiled in parallel); every part answers -1 for an L it
+// does not hold.
+namespace phe {
+#define PHE_DECLARE_PART(P)                                                                       \
+    namespace P {                                                                                 \
+    int occ_uniform(int L, int mode);                                                             \
+    int launch_uniform(int L, int mode, int blocks, hipStream_t st, const UniformArgs& A);        \
+    int occ_var(int L);                                                                           \
+    int launch_var(int L, int blocks, hipStream_t st, const VarArgs& A);                          \
+    int launch_mul(int L, int blocks, hipStream_t st, const MulArgs& A);                          \
+    }
+PHE_DECLARE_PART(g2a)
+PHE_DECLARE_PART(g2b)
+PHE_DECLARE_PART(g4a)
+PHE_DECLARE_PART(g4b)
+PHE_DECLARE_PART(g4c)
+PHE_DECLARE_PART(g8a)
+PHE_DECLARE_PART(g8b)
+PHE_DECLARE_PART(g8c)
+PHE_DECLARE_PART(g16a)
+PHE_DECLARE_PART(g16b)
+#undef PHE_DECLARE_PART
+}  // namespace phe
 
-template <int G, int L>
-__global__ void __launch_bounds__(kBlock, L >= 27 ? 2 : 1) k_modexp_var(VarArgs A) {
-    constexpr int S = G * L, kGroups = kBlock / G;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kGroups * (S + kLdsPad)];
-    const uint32_t grp = threadIdx.x / G;
-    modexp_var_body<G, L>(A, lds + grp * (S + kLdsPad), blockIdx.x * kGroups + grp, gridDim.x * kGroups,
-                          threadIdx.x & 63u);
-}
+struct KernelPart {
+    int G;
+    int (*occ_uniform)(int, int);
+    int (*launch_uniform)(int, int, int, hipStream_t, const UniformArgs&);
+    int (*occ_var)(int);
+    int (*launch_var)(int, int, hipStream_t, const VarArgs&);
+    int (*launch_mul)(int, int, hipStream_t, const MulArgs&);
+};
+static const KernelPart kParts[] = {
+    {2, phe::g2a::occ_uniform, phe::g2a::launch_uniform, phe::g2a::occ_var, phe::g2a::launch_var, phe::g2a::launch_mul},
+    {2, phe::g2b::occ_uniform, phe::g2b::launch_uniform, phe::g2b::occ_var, phe::g2b::launch_var, phe::g2b::launch_mul},
+    {4, phe::g4a::occ_uniform, phe::g4a::launch_uniform, phe::g4a::occ_var, phe::g4a::launch_var, phe::g4a::launch_mul},
+    {4, phe::g4b::occ_uniform, phe::g4b::launch_uniform, phe::g4b::occ_var, phe::g4b::launch_var, phe::g4b::launch_mul},
+    {4, phe::g4c::occ_uniform, phe::g4c::launch_uniform, phe::g4c::occ_var, phe::g4c::launch_var, phe::g4c::launch_mul},
+    {8, phe::g8a::occ_uniform, phe::g8a::launch_uniform, phe::g8a::occ_var, phe::g8a::launch_var, phe::g8a::launch_mul},
+    {8, phe::g8b::occ_uniform, phe::g8b::launch_uniform, phe::g8b::occ_var, phe::g8b::launch_var, phe::g8b::launch_mul},
+    {8, phe::g8c::occ_uniform, phe::g8c::launch_uniform, phe::g8c::occ_var, phe::g8c::launch_var, phe::g8c::launch_mul},
+    {16, phe::g16a::occ_uniform, phe::g16a::launch_uniform, phe::g16a::occ_var, phe::g16a::launch_var, phe::g16a::launch_mul},
+    {16, phe::g16b::occ_uniform, phe::g16b::launch_uniform, phe::g16b::occ_var, phe::g16b::launch_var, phe::g16b::launch_mul},
+};
 
-template <int G, int L>
-__global__ void __launch_bounds__(kBlock) k_mulmod(MulArgs A) {
-    constexpr int S = G * L, kGroups = kBlock / G;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[kGroups * (S + kLdsPad)];
-    const uint32_t grp = threadIdx.x / G;
-    mulmod_body<G, L>(A, lds + grp * (S + kLdsPad), blockIdx.x * kGroups + grp, gridDim.x * kGroups,
-                      threadIdx.x & 63u);
-}
+// first part of group width G_ that holds the requested L (its call returns >= 0); -1 if none does
+#define PHE_BY_GROUP(G_, CALL2)                       \
+    [&]() -> int {                                    \
+        for (const KernelPart& part_ : kParts) {      \
+            if (part_.G != (G_)) continue;            \
+            const int r_ = part_.CALL2;               \
+            if (r_ >= 0) return r_;                   \
+        }                                             \
+        return -1;                                    \
+    }()
 
 constexpr int kTailBlock = 64;
 __global__ void __launch_bounds__(kTailBlock) k_decrypt_tail(TailArgs A) {
@@ -224,34 +253,6 @@ static int grid_blocks(const phe_hip_ctx* ctx, size_t batch, int G, int blocks_p
     return (int)std::max<size_t>(1, std::min(want, cap));
 }
 
-// the (G, L) pairs key_setup.h:pick_geometry can return
-#define DISPATCH_GL(G_, L_, CALL)                                                              \
-    do {                                                                                       \
-        const int key_ = (G_) * 100 + (L_);                                                    \
-        switch (key_) {                                                                        \
-            case 1601: { constexpr int GG = 16, LL = 1; CALL; break; }                         \
-            case 1602: { constexpr int GG = 16, LL = 2; CALL; break; }                         \
-            case 1603: { constexpr int GG = 16, LL = 3; CALL; break; }                         \
-            case 1605: { constexpr int GG = 16, LL = 5; CALL; break; }                         \
-            case 1607: { constexpr int GG = 16, LL = 7; CALL; break; }                         \
-            case 1609: { constexpr int GG = 16, LL = 9; CALL; break; }                         \
-            case 1614: { constexpr int GG = 16, LL = 14; CALL; break; }                        \
-            case 1618: { constexpr int GG = 16, LL = 18; CALL; break; }                        \
-            case 218: { constexpr int GG = 2, LL = 18; CALL; break; }                          \
-            case 236: { constexpr int GG = 2, LL = 36; CALL; break; }                          \
-            case 409: { constexpr int GG = 4, LL = 9; CALL; break; }                           \
-            case 427: { constexpr int GG = 4, LL = 27; CALL; break; }                          \
-            case 418: { constexpr int GG = 4, LL = 18; CALL; break; }                          \
-            case 436: { constexpr int GG = 4, LL = 36; CALL; break; }                          \
-            case 827: { constexpr int GG = 8, LL = 27; CALL; break; }                          \
-            case 805: { constexpr int GG = 8, LL = 5; CALL; break; }                           \
-            case 809: { constexpr int GG = 8, LL = 9; CALL; break; }                           \
-            case 814: { constexpr int GG = 8, LL = 14; CALL; break; }                          \
-            case 818: { constexpr int GG = 8, LL = 18; CALL; break; }                          \
-            default: return fail(PHE_HIP_EINVAL, "unsupported limb-group geometry");           \
-        }                                                                                      \
-    } while (0)
-
 // ------------------------------------------------------------------------------------------------
 // launches (device pointers)
 // ------------------------------------------------------------------------------------------------
@@ -272,41 +273,13 @@ static void light_geometry(const DevModulus& M, int& G, int& L) {
 
 // Resident workgroups per CU for a kernel (VGPR/LDS-limited), asked once per instantiation.  The modexp
 // kernels size their grid to the residency so that the window tables stay per resident group.
-static int query_resident_blocks(const void* kernel) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, kBlock, 0) != hipSuccess || nb < 1) nb = 2;
-    return std::min(nb, 4);
-}
-template <int G, int L, int MODE>
-static int occ_uniform() {
-    static const int cached = query_resident_blocks((const void*)k_modexp_uniform<G, L, MODE>);
-    return cached;
-}
-template <int G, int L>
-static int occ_var() {
-    static const int cached = query_resident_blocks((const void*)k_modexp_var<G, L>);
-    return cached;
-}
-
-template <int G, int L, int MODE>
-static void go_uniform(int blocks, hipStream_t st, const UniformArgs& A) {
-    k_modexp_uniform<G, L, MODE><<<dim3(blocks), dim3(kBlock), 0, st>>>(A);
-}
-template <int G, int L>
-static void go_var(int blocks, hipStream_t st, const VarArgs& A) {
-    k_modexp_var<G, L><<<dim3(blocks), dim3(kBlock), 0, st>>>(A);
-}
-template <int G, int L>
-static void go_mul(int blocks, hipStream_t st, const MulArgs& A) {
-    k_mulmod<G, L><<<dim3(blocks), dim3(kBlock), 0, st>>>(A);
-}
-
 template <int MODE>
 static int launch_uniform(phe_hip_ctx* ctx, const DevModulus& M, const DevSchedule& E, const uint32_t* base,
                           int base_limbs, const uint32_t* post, int post_limbs, uint32_t* out, int out_limbs,
                           size_t batch, hipStream_t stream) {
     int per_cu = ctx->blocks_per_cu;
-    if (per_cu == 0) DISPATCH_GL(M.G, M.L, (per_cu = occ_uniform<GG, LL, MODE>()));
+    if (per_cu == 0) per_cu = PHE_BY_GROUP(M.G, occ_uniform(M.L, MODE));
+    if (per_cu < 0) return fail(PHE_HIP_EINVAL, "unsupported limb-group geometry");
     const int blocks = grid_blocks(ctx, batch, M.G, per_cu);
     const size_t rows = (size_t)blocks * (size_t)(kBlock / M.G);
     int rc = ensure_words(&ctx->table, &ctx->table_words, rows * (size_t)E.tbl_entries * M.S);
@@ -325,7 +298,8 @@ static int launch_uniform(phe_hip_ctx* ctx, const DevModulus& M, const DevSchedu
     A.out_limbs = out_limbs;
     A.table = ctx->table;
     A.batch = batch;
-    DISPATCH_GL(M.G, M.L, (go_uniform<GG, LL, MODE>(blocks, stream, A)));
+    if (PHE_BY_GROUP(M.G, launch_uniform(M.L, MODE, blocks, stream, A)) < 0)
+        return fail(PHE_HIP_EINVAL, "unsupported limb-group geometry");
     HIP_TRY(hipGetLastError());
     return PHE_HIP_OK;
 }
@@ -347,13 +321,14 @@ static int launch_var(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* bas
     int G, L;
     light_geometry(M, G, L);
     int per_cu = ctx->blocks_per_cu;
-    if (per_cu == 0) DISPATCH_GL(G, L, (per_cu = occ_var<GG, LL>()));
+    if (per_cu == 0) per_cu = PHE_BY_GROUP(G, occ_var(L));
+    if (per_cu < 0) return fail(PHE_HIP_EINVAL, "unsupported limb-group geometry");
     const int blocks = grid_blocks(ctx, batch, G, per_cu);
     const size_t rows = (size_t)blocks * (size_t)(kBlock / G);
     int rc = ensure_words(&ctx->table, &ctx->table_words, rows * ((size_t)1 << A.window) * M.S);
     if (rc) return rc;
     A.table = ctx->table;
-    DISPATCH_GL(G, L, (go_var<GG, LL>(blocks, stream, A)));
+    if (PHE_BY_GROUP(G, launch_var(L, blocks, stream, A)) < 0) return fail(PHE_HIP_EINVAL, "unsupported limb-group geometry");
     HIP_TRY(hipGetLastError());
     return PHE_HIP_OK;
 }
@@ -376,7 +351,7 @@ static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, 
     int G, L;
     light_geometry(M, G, L);
     const int blocks = grid_blocks(ctx, batch, G, 8);
-    DISPATCH_GL(G, L, (go_mul<GG, LL>(blocks, stream, A)));
+    if (PHE_BY_GROUP(G, launch_mul(L, blocks, stream, A)) < 0) return fail(PHE_HIP_EINVAL, "unsupported limb-group geometry");
     HIP_TRY(hipGetLastError());
     return PHE_HIP_OK;
 }
