@@ -128,6 +128,40 @@ inline Big inv_mod_pow2(const Big& a, int h) {
     return x;
 }
 
+// a = q*n + r by binary long division (cold path); q has a.size() limbs, r has n.size() limbs
+inline void big_divmod(const Big& a, const Big& n, Big& q, Big& r) {
+    const size_t w = n.size();
+    Big rem(w + 1, 0u), nn(n);
+    nn.push_back(0u);
+    q.assign(a.size(), 0u);
+    for (int bit = big_bits(a) - 1; bit >= 0; --bit) {
+        uint32_t top = (a[(size_t)(bit >> 5)] >> (bit & 31)) & 1u;
+        for (size_t i = 0; i <= w; ++i) {
+            const uint32_t v = rem[i];
+            rem[i] = (v << 1) | top;
+            top = v >> 31;
+        }
+        if (big_cmp(rem, nn) >= 0) {
+            big_sub_inplace(rem, nn);
+            q[(size_t)(bit >> 5)] |= 1u << (bit & 31);
+        }
+    }
+    rem.resize(w);
+    r = rem;
+}
+// a >> k
+inline Big big_shr(const Big& a, int k) {
+    Big r(a.size(), 0u);
+    const size_t ws = (size_t)(k >> 5);
+    const int bs = k & 31;
+    for (size_t i = 0; i + ws < a.size(); ++i) {
+        uint64_t v = a[i + ws];
+        if (i + ws + 1 < a.size()) v |= (uint64_t)a[i + ws + 1] << 32;
+        r[i] = (uint32_t)(v >> bs);
+    }
+    return r;
+}
+
 // ---- radix-2^29 geometry -----------------------------------------------------------------------
 constexpr int kRadixBits = 29;
 
@@ -257,6 +291,114 @@ inline ModulusPack build_modulus(const Big& N_any, const Big* aux_src, int min_b
     return m;
 }
 
+// ---- split-modulus ("n-adic") arithmetic: constants of csrc/split_core.h -----------------------------------
+// Work modulo n^2 is done on pairs (X0, X1), x = X0*beta + X1*n (mod n^2), beta = R^-1 mod n^2, with half-width
+// Montgomery passes modulo n only: R = 2^(29 H) >= 16 n, H = G*L limbs.  The widest pass adds three products per
+// digit to a column accumulator, so 3L * 2^58 < 2^64 bounds L by 21.
+static const int kS16[] = {1, 2, 3, 5, 7, 9, 14, 18};
+static const int kS8[] = {7, 9, 14, 18};
+static const int kS4[] = {9, 14, 18};
+static const int kS2[] = {9, 18};
+constexpr int kMaxSplitL = 21;
+
+inline Geometry pick_geometry_split(int n_bits, int prefer_group) {
+    const int need = (n_bits + 4 + kRadixBits - 1) / kRadixBits;
+    Geometry best;
+    auto consider = [&](int G, int L) {
+        const int S = G * L;
+        if (S < need) return;
+        if (best.G == 0 || S < best.S() || (S == best.S() && L > best.L)) {
+            best.G = G;
+            best.L = L;
+        }
+    };
+    if (prefer_group != 16) {
+        const int narrowest = prefer_group == 0 ? 2 : prefer_group;
+        if (narrowest <= 2)
+            for (int L : kS2) consider(2, L);
+        if (narrowest <= 4)
+            for (int L : kS4) consider(4, L);
+        if (narrowest <= 8)
+            for (int L : kS8) consider(8, L);
+    }
+    if (prefer_group == 16 || prefer_group == 0 || best.G == 0)
+        for (int L : kS16) consider(16, L);
+    return best;  // G == 0: no compiled split kernel covers this width
+}
+
+struct SplitPack {
+    int G = 0, L = 0, H = 0;  // H = G*L limbs of 29 bits cover n (+4 bits)
+    int bits = 0;             // bits of n
+    int chunks = 0;           // conv rows available: inputs of up to chunks*29*H bits
+    std::vector<uint32_t> n, gam, r1, r2;  // H limbs each: n, -R^-1 mod n, R mod n, R^2 mod n
+    std::vector<uint32_t> e;               // rep_1(1) = E0 | E1                       (2H)
+    std::vector<uint32_t> conv;            // chunk j: D0_j | D1'_j = rep_2(R^j)        (chunks * 2H)
+    std::vector<uint32_t> nsq;             // n^2, 2H limbs
+    uint32_t n0inv = 0;                    // -n^-1 mod 2^29
+};
+
+// max_input_bits: widest number that will be converted into the pair representation (a ciphertext).
+inline SplitPack build_split(const Big& n_any, int max_input_bits, int prefer_group = 0) {
+    SplitPack P;
+    P.bits = big_bits(n_any);
+    const int w = (P.bits + 31) / 32;
+    const Geometry geo = pick_geometry_split(P.bits, prefer_group);
+    if (geo.G == 0) return P;  // caller falls back to the full-width kernels
+    P.G = geo.G;
+    P.L = geo.L;
+    P.H = geo.S();
+    const Big n = big_resize(n_any, w);
+    if ((n[0] & 1u) == 0u) throw std::invalid_argument("modulus must be odd");
+    const int rbits = kRadixBits * P.H;
+    P.chunks = std::max(1, (max_input_bits + rbits - 1) / rbits);
+    Big nsq = big_resize(big_mul(n, n), 2 * w);
+    // rho = R^-1 mod n = (1 + n * (-n^-1 mod R)) / R
+    const int rw = (rbits + 31) / 32;
+    Big ninv = inv_mod_pow2(big_resize(n, std::max(rw, w)), std::max(rw, w));  // n^-1 mod 2^(32 rw')
+    Big nprime(ninv.size(), 0u);
+    big_sub_inplace(nprime, ninv);  // -n^-1
+    for (size_t i = 0; i < nprime.size(); ++i) {  // mod 2^rbits
+        const int lo = 32 * (int)i;
+        if (lo >= rbits) nprime[i] = 0u;
+        else if (lo + 32 > rbits) nprime[i] &= (1u << (rbits - lo)) - 1u;
+    }
+    Big prod = big_mul(n, nprime);
+    Big one_p(prod.size(), 0u);
+    one_p[0] = 1;
+    big_add_inplace(prod, one_p);
+    Big rho = big_resize(big_shr(prod, rbits), w);
+    Big gam = n;
+    big_sub_inplace(gam, rho);
+    Big one((size_t)w, 0u);
+    one[0] = 1;
+    const Big r1 = big_shift_mod(one, rbits, n);
+    const Big r2 = big_shift_mod(r1, rbits, n);
+    P.n = to_r29(n, P.H);
+    P.gam = to_r29(gam, P.H);
+    P.r1 = to_r29(r1, P.H);
+    P.r2 = to_r29(r2, P.H);
+    P.nsq = to_r29(nsq, 2 * P.H);
+    P.n0inv = neg_inv32(n[0]) & ((1u << kRadixBits) - 1u);
+    // K*R^j = z0 + z1*n (mod n^2)  ->  (z0, z1*rho mod n); Z is handed in as R^j*K mod n^2
+    auto pair_of = [&](const Big& Z, std::vector<uint32_t>& out) {
+        Big q, r;
+        big_divmod(Z, n, q, r);
+        Big z1rho = big_mod(big_mul(big_resize(q, w), rho), n);
+        const std::vector<uint32_t> a = to_r29(r, P.H), b = to_r29(z1rho, P.H);
+        out.insert(out.end(), a.begin(), a.end());
+        out.insert(out.end(), b.begin(), b.end());
+    };
+    Big one2((size_t)(2 * w), 0u);
+    one2[0] = 1;
+    Big Z = big_shift_mod(one2, rbits, nsq);  // R mod n^2
+    pair_of(Z, P.e);
+    for (int j = 0; j < P.chunks; ++j) {
+        Z = big_shift_mod(Z, rbits, nsq);  // R^(j+2) mod n^2
+        pair_of(Z, P.conv);
+    }
+    return P;
+}
+
 // Left-to-right sliding-window schedule for a batch-uniform exponent e > 0.
 // Table entry idx holds base^(2*idx+1).  Op word = (squarings << 8) | (idx + 1); idx+1 == 0 means
 // squarings only.  first_idx is the entry the accumulator is initialised from.
@@ -358,6 +500,7 @@ struct PublicPlan {
     Big n;               // s1 limbs (32-bit)
     Big nsq32;           // n^2, s2 limbs (32-bit) — host-side scalar work of batched inversion
     ModulusPack nsq;
+    SplitPack nsplit;    // pair arithmetic modulo n for encrypt / obfuscate (G == 0: not available)
     Schedule exp_n;
 };
 
@@ -370,6 +513,7 @@ inline PublicPlan build_public(const uint32_t* n, int n_limbs, int prefer_group 
     Big nsq = big_mul(P.n, P.n);
     P.nsq32 = big_resize(nsq, P.s2);
     P.nsq = build_modulus(nsq, &P.n, 32 * P.s2, prefer_group);
+    P.nsplit = build_split(P.n, 32 * P.s2, prefer_group);
     P.exp_n = build_schedule(P.n);
     return P;
 }
@@ -378,6 +522,7 @@ inline PublicPlan build_public(const uint32_t* n, int n_limbs, int prefer_group 
 struct PrivatePlan {
     int s1 = 0, s2 = 0;
     ModulusPack psq, qsq;  // same L
+    SplitPack psplit, qsplit;  // pair arithmetic modulo p / q for the two CRT half-exponentiations
     Schedule exp_p, exp_q;
     TailPack tail;
 };
@@ -397,6 +542,8 @@ inline PrivatePlan build_private(const uint32_t* p, const uint32_t* q, const uin
     P.psq = build_modulus(psq, nullptr, min_bits, prefer_group);
     P.qsq = build_modulus(qsq, nullptr, min_bits, prefer_group);
     if (P.psq.L != P.qsq.L || P.psq.G != P.qsq.G) throw std::invalid_argument("p and q too unbalanced");
+    P.psplit = build_split(bp, 32 * P.s2, prefer_group);
+    P.qsplit = build_split(bq, 32 * P.s2, prefer_group);
     Big one((size_t)pq_limbs, 0u);
     one[0] = 1;
     Big pm1 = bp, qm1 = bq;

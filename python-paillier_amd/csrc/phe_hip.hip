@@ -3,6 +3,9 @@
 // Kernels (all hand-written for CDNA4; the arithmetic lives in mont_core.h / decrypt_tail.h):
 //   k_modexp_uniform<G, L, MODE>  batch-uniform exponent: encrypt / obfuscate (e = n, mod n^2) and the
 //                                 two CRT halves of decrypt (e = p-1 mod p^2, e = q-1 mod q^2)
+//   k_modexp_split<G, L, MODE>    the same three jobs on the split-modulus pair representation (split_core.h):
+//                                 half-width passes modulo n / p / q, ~1/3 fewer multiply-adds; the default engine
+//                                 (PHE_HIP_ENGINE=full selects k_modexp_uniform instead)
 //   k_modexp_var<G, L>            per-element exponent (powmod of _raw_mul)
 //   k_mulmod<G, L>                a*b mod n^2 (_raw_add, add-plaintext, the product tree of batched inversion)
 //     (these three live in group_kernels.inc, instantiated by kernels_g*.hip, one TU per group width)
@@ -23,6 +26,7 @@
 // clang-format off
 #include "wave_gfx950.h"
 #include "mont_core.h"
+#include "split_core.h"
 #include "decrypt_tail.h"
 #include "key_setup.h"
 // clang-format on
@@ -57,6 +61,22 @@ PHE_DECLARE_PART(g8c)
 PHE_DECLARE_PART(g16a)
 PHE_DECLARE_PART(g16b)
 #undef PHE_DECLARE_PART
+#define PHE_DECLARE_SPLIT_PART(P)                                                                 \
+    namespace P {                                                                                 \
+    int occ_split(int L, int mode);                                                               \
+    int launch_split(int L, int mode, int blocks, hipStream_t st, const SplitArgs& A);            \
+    }
+PHE_DECLARE_SPLIT_PART(s2a)
+PHE_DECLARE_SPLIT_PART(s2b)
+PHE_DECLARE_SPLIT_PART(s4a)
+PHE_DECLARE_SPLIT_PART(s4b)
+PHE_DECLARE_SPLIT_PART(s8a)
+PHE_DECLARE_SPLIT_PART(s8b)
+PHE_DECLARE_SPLIT_PART(s8c)
+PHE_DECLARE_SPLIT_PART(s16a)
+PHE_DECLARE_SPLIT_PART(s16b)
+PHE_DECLARE_SPLIT_PART(s16c)
+#undef PHE_DECLARE_SPLIT_PART
 }  // namespace phe
 
 struct KernelPart {
@@ -79,6 +99,28 @@ static const KernelPart kParts[] = {
     {16, phe::g16a::occ_uniform, phe::g16a::launch_uniform, phe::g16a::occ_var, phe::g16a::launch_var, phe::g16a::launch_mul},
     {16, phe::g16b::occ_uniform, phe::g16b::launch_uniform, phe::g16b::occ_var, phe::g16b::launch_var, phe::g16b::launch_mul},
 };
+
+struct SplitPart {
+    int G;
+    int (*occ_split)(int, int);
+    int (*launch_split)(int, int, int, hipStream_t, const SplitArgs&);
+};
+static const SplitPart kSplitParts[] = {
+    {2, phe::s2a::occ_split, phe::s2a::launch_split},    {2, phe::s2b::occ_split, phe::s2b::launch_split},
+    {4, phe::s4a::occ_split, phe::s4a::launch_split},    {4, phe::s4b::occ_split, phe::s4b::launch_split},
+    {8, phe::s8a::occ_split, phe::s8a::launch_split},    {8, phe::s8b::occ_split, phe::s8b::launch_split},
+    {8, phe::s8c::occ_split, phe::s8c::launch_split},    {16, phe::s16a::occ_split, phe::s16a::launch_split},
+    {16, phe::s16b::occ_split, phe::s16b::launch_split}, {16, phe::s16c::occ_split, phe::s16c::launch_split},
+};
+#define PHE_SPLIT_BY_GROUP(G_, CALL2)                 \
+    [&]() -> int {                                    \
+        for (const SplitPart& part_ : kSplitParts) {  \
+            if (part_.G != (G_)) continue;            \
+            const int r_ = part_.CALL2;               \
+            if (r_ >= 0) return r_;                   \
+        }                                             \
+        return -1;                                    \
+    }()
 
 // first part of group width G_ that holds the requested L (its call returns >= 0); -1 if none does
 #define PHE_BY_GROUP(G_, CALL2)                       \
@@ -153,6 +195,11 @@ struct DevModulus {  // device copies of a host::ModulusPack
     uint32_t* blob = nullptr;  // n | r1 | r2 | r3 | aux
     ModConsts c{};
 };
+struct DevSplit {  // device copies of a host::SplitPack
+    int G = 0, L = 0, H = 0;  // G == 0: no split kernel for this modulus
+    uint32_t* blob = nullptr;  // n | gam | r1 | r2 | e | nsq | conv
+    SplitConsts c{};
+};
 struct DevSchedule {
     uint32_t* ops = nullptr;
     int n_ops = 0, first_idx = 0, tbl_entries = 1;
@@ -171,6 +218,8 @@ struct phe_hip_ctx {
     host::PublicPlan pub;
     host::PrivatePlan priv;
     DevModulus d_nsq, d_psq, d_qsq;
+    bool use_split = true;  // PHE_HIP_ENGINE=full: keep the uniform-exponent jobs on the full-width kernels
+    DevSplit d_nsplit, d_psplit, d_qsplit, d_nsplit_lat, d_psplit_lat, d_qsplit_lat;
     // latency geometry: small batches cannot fill the GPU, so they use 16-lane groups (half the limbs per
     // lane => about half the time per product) when the key size offers both
     bool has_lat_pub = false, has_lat_priv = false;
@@ -204,6 +253,32 @@ static int upload_modulus(const host::ModulusPack& m, DevModulus& d) {
     d.c.r2 = d.blob + 2 * m.S;
     d.c.r3 = d.blob + 3 * m.S;
     d.c.aux = d.blob + 4 * m.S;
+    d.c.n0inv = m.n0inv;
+    return PHE_HIP_OK;
+}
+static int upload_split(const host::SplitPack& m, DevSplit& d) {
+    d.G = m.G;
+    d.L = m.L;
+    d.H = m.H;
+    if (m.G == 0) return PHE_HIP_OK;
+    const size_t H = (size_t)m.H;
+    std::vector<uint32_t> h;
+    const std::vector<uint32_t>* parts[7] = {&m.n, &m.gam, &m.r1, &m.r2, &m.e, &m.nsq, &m.conv};
+    size_t off[7];
+    for (int i = 0; i < 7; ++i) {
+        off[i] = h.size();
+        h.insert(h.end(), parts[i]->begin(), parts[i]->end());
+    }
+    HIP_TRY(hipMalloc((void**)&d.blob, h.size() * 4));
+    HIP_TRY(hipMemcpy(d.blob, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    (void)H;
+    d.c.n = d.blob + off[0];
+    d.c.gam = d.blob + off[1];
+    d.c.r1 = d.blob + off[2];
+    d.c.r2 = d.blob + off[3];
+    d.c.e = d.blob + off[4];
+    d.c.nsq = d.blob + off[5];
+    d.c.conv = d.blob + off[6];
     d.c.n0inv = m.n0inv;
     return PHE_HIP_OK;
 }
@@ -304,6 +379,41 @@ static int launch_uniform(phe_hip_ctx* ctx, const DevModulus& M, const DevSchedu
     return PHE_HIP_OK;
 }
 
+static int chunks_for(int limbs32, int H) { return std::max(1, (32 * limbs32 + 29 * H - 1) / (29 * H)); }
+
+template <int MODE>
+static int launch_split(phe_hip_ctx* ctx, const DevSplit& M, const DevSchedule& E, const uint32_t* base, int base_limbs,
+                        const uint32_t* post, int post_limbs, uint32_t* out, int out_limbs, size_t batch,
+                        hipStream_t stream) {
+    int per_cu = ctx->blocks_per_cu;
+    if (per_cu == 0) per_cu = PHE_SPLIT_BY_GROUP(M.G, occ_split(M.L, MODE));
+    if (per_cu < 0) return fail(PHE_HIP_EINVAL, "unsupported split geometry");
+    const int blocks = grid_blocks(ctx, batch, M.G, per_cu);
+    const size_t rows = (size_t)blocks * (size_t)(kBlock / M.G);
+    int rc = ensure_words(&ctx->table, &ctx->table_words, rows * (size_t)E.tbl_entries * 2 * M.H);
+    if (rc) return rc;
+    SplitArgs A;
+    A.mod = M.c;
+    A.sched = E.ops;
+    A.n_ops = E.n_ops;
+    A.first_idx = E.first_idx;
+    A.tbl_entries = E.tbl_entries;
+    A.base = base;
+    A.base_limbs = base_limbs;
+    A.base_chunks = chunks_for(base_limbs, M.H);
+    A.post = post;
+    A.post_limbs = post_limbs;
+    A.post_chunks = chunks_for(post_limbs, M.H);
+    A.out = out;
+    A.out_limbs = out_limbs;
+    A.table = ctx->table;
+    A.batch = batch;
+    if (PHE_SPLIT_BY_GROUP(M.G, launch_split(M.L, MODE, blocks, stream, A)) < 0)
+        return fail(PHE_HIP_EINVAL, "unsupported split geometry");
+    HIP_TRY(hipGetLastError());
+    return PHE_HIP_OK;
+}
+
 static int launch_var(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* base, int base_limbs,
                       const uint32_t* e, int exp_limbs, int max_bits, uint32_t* out, int out_limbs, size_t batch,
                       hipStream_t stream) {
@@ -362,6 +472,10 @@ static const DevModulus& pick_nsq(const phe_hip_ctx* ctx, size_t batch) {
     return (ctx->has_lat_pub && small_batch(ctx, batch)) ? ctx->d_nsq_lat : ctx->d_nsq;
 }
 
+static const DevSplit& pick_nsplit(const phe_hip_ctx* ctx, size_t batch) {
+    return (ctx->has_lat_pub && small_batch(ctx, batch)) ? ctx->d_nsplit_lat : ctx->d_nsplit;
+}
+
 static int check_ctx(const phe_hip_ctx* ctx) {
     if (!ctx) return fail(PHE_HIP_EINVAL, "null context");
     return PHE_HIP_OK;
@@ -392,6 +506,7 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
         const int v = atoi(e);
         if (v >= 1 && v <= 8) ctx->blocks_per_cu = v;
     }
+    if (const char* e = getenv("PHE_HIP_ENGINE")) ctx->use_split = (strcmp(e, "full") != 0);
     if (const char* e = getenv("PHE_HIP_GROUP")) {
         const int v = atoi(e);
         if (v == 2 || v == 4 || v == 8 || v == 16) ctx->prefer_group = v;
@@ -402,11 +517,13 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
         return fail(PHE_HIP_EINVAL, ex.what());
     }
     int rc = upload_modulus(ctx->pub.nsq, ctx->d_nsq);
+    if (!rc) rc = upload_split(ctx->pub.nsplit, ctx->d_nsplit);
     if (!rc) rc = upload_schedule(ctx->pub.exp_n, ctx->d_exp_n);
     if (!rc && ctx->pub.nsq.G < 16 && !getenv("PHE_HIP_GROUP")) {
         try {
             ctx->pub_lat = host::build_public(n, n_limbs, 16);
             rc = upload_modulus(ctx->pub_lat.nsq, ctx->d_nsq_lat);
+            if (!rc) rc = upload_split(ctx->pub_lat.nsplit, ctx->d_nsplit_lat);
             ctx->has_lat_pub = (rc == PHE_HIP_OK);
         } catch (const std::exception& ex) {
             rc = fail(PHE_HIP_EINVAL, ex.what());
@@ -448,11 +565,15 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
     }
     if (!rc) rc = upload_modulus(ctx->priv.psq, ctx->d_psq);
     if (!rc) rc = upload_modulus(ctx->priv.qsq, ctx->d_qsq);
+    if (!rc) rc = upload_split(ctx->priv.psplit, ctx->d_psplit);
+    if (!rc) rc = upload_split(ctx->priv.qsplit, ctx->d_qsplit);
     if (!rc && ctx->priv.psq.G < 16 && !getenv("PHE_HIP_GROUP")) {
         try {
             ctx->priv_lat = host::build_private(p, q, hp, hq, p_inverse, pq_limbs, n_limbs, 16);
             rc = upload_modulus(ctx->priv_lat.psq, ctx->d_psq_lat);
             if (!rc) rc = upload_modulus(ctx->priv_lat.qsq, ctx->d_qsq_lat);
+            if (!rc) rc = upload_split(ctx->priv_lat.psplit, ctx->d_psplit_lat);
+            if (!rc) rc = upload_split(ctx->priv_lat.qsplit, ctx->d_qsplit_lat);
             ctx->has_lat_priv = (rc == PHE_HIP_OK);
         } catch (const std::exception& ex) {
             rc = fail(PHE_HIP_EINVAL, ex.what());
@@ -481,7 +602,9 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
 void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    uint32_t* bufs[] = {ctx->d_nsq_lat.blob, ctx->d_psq_lat.blob, ctx->d_qsq_lat.blob,
+    uint32_t* bufs[] = {ctx->d_nsplit.blob, ctx->d_psplit.blob, ctx->d_qsplit.blob, ctx->d_nsplit_lat.blob,
+                        ctx->d_psplit_lat.blob, ctx->d_qsplit_lat.blob,
+                        ctx->d_nsq_lat.blob, ctx->d_psq_lat.blob, ctx->d_qsq_lat.blob,
                         ctx->d_nsq.blob, ctx->d_psq.blob, ctx->d_qsq.blob, ctx->d_exp_n.ops, ctx->d_exp_p.ops,
                         ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->scratch, ctx->stage[0], ctx->stage[1],
                         ctx->stage[2]};
@@ -496,8 +619,12 @@ int phe_hip_ctx_info(const phe_hip_ctx* ctx, int* n_limbs, int* ct_limbs, int* l
     if (n_limbs) *n_limbs = ctx->pub.s1;
     if (ct_limbs) *ct_limbs = ctx->pub.s2;
     // geometry is reported as G*100 + L (e.g. 818 = groups of 8 lanes x 18 limbs of 29 bits)
-    if (lane_limbs_pub) *lane_limbs_pub = ctx->pub.nsq.G * 100 + ctx->pub.nsq.L;
-    if (lane_limbs_priv) *lane_limbs_priv = ctx->has_private ? ctx->priv.psq.G * 100 + ctx->priv.psq.L : 0;
+    // (the geometry of the uniform-exponent kernels in use: split-modulus halves when that engine is on)
+    const bool sp_pub = ctx->use_split && ctx->pub.nsplit.G, sp_priv = ctx->use_split && ctx->priv.psplit.G;
+    if (lane_limbs_pub) *lane_limbs_pub = sp_pub ? ctx->pub.nsplit.G * 100 + ctx->pub.nsplit.L : ctx->pub.nsq.G * 100 + ctx->pub.nsq.L;
+    if (lane_limbs_priv)
+        *lane_limbs_priv = !ctx->has_private ? 0 : sp_priv ? ctx->priv.psplit.G * 100 + ctx->priv.psplit.L
+                                                           : ctx->priv.psq.G * 100 + ctx->priv.psq.L;
     if (rows_in_flight) *rows_in_flight = ctx->n_cus * std::max(1, ctx->blocks_per_cu ? ctx->blocks_per_cu : 2) * (kBlock / ctx->pub.nsq.G);
     if (has_private) *has_private = ctx->has_private ? 1 : 0;
     return PHE_HIP_OK;
@@ -516,6 +643,9 @@ int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, 
     if (batch == 0) return PHE_HIP_OK;
     if (!m || !r || !c) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
+    if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G)
+        return launch_split<kModeEncrypt>(ctx, sp, ctx->d_exp_n, r, ctx->pub.s1, m, ctx->pub.s1, c, ctx->pub.s2, batch,
+                                          (hipStream_t)stream);
     return launch_uniform<kModeEncrypt>(ctx, pick_nsq(ctx, batch), ctx->d_exp_n, r, ctx->pub.s1, m, ctx->pub.s1, c, ctx->pub.s2,
                                         batch, (hipStream_t)stream);
 }
@@ -526,6 +656,9 @@ int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t
     if (batch == 0) return PHE_HIP_OK;
     if (!c_in || !r || !c_out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
+    if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G)
+        return launch_split<kModeObfuscate>(ctx, sp, ctx->d_exp_n, r, ctx->pub.s1, c_in, ctx->pub.s2, c_out, ctx->pub.s2,
+                                            batch, (hipStream_t)stream);
     return launch_uniform<kModeObfuscate>(ctx, pick_nsq(ctx, batch), ctx->d_exp_n, r, ctx->pub.s1, c_in, ctx->pub.s2, c_out,
                                           ctx->pub.s2, batch, (hipStream_t)stream);
 }
@@ -544,11 +677,19 @@ int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t
     uint32_t* xq = ctx->scratch + batch * (size_t)S;
     hipStream_t st = (hipStream_t)stream;
     const bool lat = ctx->has_lat_priv && small_batch(ctx, batch);
-    rc = launch_uniform<kModeHalfDecrypt>(ctx, lat ? ctx->d_psq_lat : ctx->d_psq, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0,
-                                          xp, S, batch, st);
+    const DevSplit& sp_p = lat ? ctx->d_psplit_lat : ctx->d_psplit;
+    const DevSplit& sp_q = lat ? ctx->d_qsplit_lat : ctx->d_qsplit;
+    if (ctx->use_split && sp_p.G)
+        rc = launch_split<kModeHalfDecrypt>(ctx, sp_p, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0, xp, S, batch, st);
+    else
+        rc = launch_uniform<kModeHalfDecrypt>(ctx, lat ? ctx->d_psq_lat : ctx->d_psq, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0,
+                                              xp, S, batch, st);
     if (rc) return rc;
-    rc = launch_uniform<kModeHalfDecrypt>(ctx, lat ? ctx->d_qsq_lat : ctx->d_qsq, ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0,
-                                          xq, S, batch, st);
+    if (ctx->use_split && sp_q.G)
+        rc = launch_split<kModeHalfDecrypt>(ctx, sp_q, ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0, xq, S, batch, st);
+    else
+        rc = launch_uniform<kModeHalfDecrypt>(ctx, lat ? ctx->d_qsq_lat : ctx->d_qsq, ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0,
+                                              xq, S, batch, st);
     if (rc) return rc;
     TailArgs T;
     T.k = ctx->d_tail.k;

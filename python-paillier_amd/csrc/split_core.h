@@ -1,0 +1,426 @@
+// split_core.h — arithmetic modulo n^2 on pairs of half-width numbers ("n-adic" split of the modulus).
+//
+// The moduli of Paillier are squares: n^2 for encrypt/obfuscate (phe/paillier.py:137, :622 powmod(r, n, nsquare)),
+// p^2 and q^2 for the CRT halves of decrypt (:347, :351).  mont_core.h treats them as opaque 2k-bit moduli; here
+// an element x of Z/n^2 is kept as a pair (X0, X1) of numbers modulo n with
+//
+//        x = X0 * beta + X1 * n   (mod n^2),      beta = R^-1 mod n^2,  R = 2^(29 H) >= 16 n,
+//
+// and every product needs half-width Montgomery passes modulo n only.  With MQ a Montgomery product that also
+// keeps its quotient m (X0*Y0 + m*n = u*R exactly) and gamma = -R^-1 mod n:
+//
+//     x*y :  (u, m) = MQ(X0, Y0)                       X0' = u
+//            X1' = MAC2(X0, Y1; m, gamma) + MONT(X1, Y0)          MAC2(a,b;m,g) = (a*b + m*g) * R^-1 mod n
+//     x^2 :  (u, m) = MQ(X0, X0),   X1' = MAC2(X0, 2*X1; m, gamma)
+//
+// (X0*Y0*beta^2 = u*beta - m*beta^2*n because R*beta = 1, and (X0*Y1 + X1*Y0)*beta - m*beta^2 is exactly the
+// Montgomery reduction of X0*Y1 + X1*Y0 + m*gamma.)  In units of one half-width pass (H digits x L multiply-adds
+// per lane) a squaring costs 2 + 3 = 5 and a product 2 + 3 + 2 = 7, against 8 for either on the full-width modulus:
+// the exponentiations of encrypt and decrypt are ~85 % squarings, so ~1/3 of the multiply-adds disappear.
+// tools/exp/split_model.py checks the algebra and the lazy-reduction bounds below with plain integers.
+//
+// Lazy bounds (R >= 16 n): X0 < 2n, X1 < 5n are closed under both operations; sums made while converting inputs
+// stay below R.  Limbs are almost-normalised (< 2^29 + 2^8) exactly as in mont_core.h, and a column accumulator
+// takes at most three products per digit for L digits: L <= 21 keeps it below 2^64 for any operands.
+//
+// Conversions happen once per element: in  — x = sum_j x_j R^j with x_j < R is sum_j (x_j (*) rep_2(R^j)), where
+// x (*) (D0, D1') = (u, MAC2(x, D1'; m, gamma)) with (u, m) = MQ(x, D0);  out — X0*beta = u - m*beta*n with
+// (u, m) = MQ(X0, 1), so  x*(1 + n*mp) = u + n*t,  t = X1 + MONT(m, n-1) + mp*u  (mod n), made canonical.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mont_core.h"
+
+namespace phe {
+
+// per-modulus constants (device pointers; H = G*L words of 29-bit limbs per row)
+struct SplitConsts {
+    const uint32_t* n;     // n
+    const uint32_t* gam;   // -R^-1 mod n
+    const uint32_t* r1;    // R mod n
+    const uint32_t* r2;    // R^2 mod n
+    const uint32_t* e;     // rep_1(1): E0 | E1
+    const uint32_t* conv;  // chunk j: D0_j | D1'_j
+    const uint32_t* nsq;   // n^2, 2H limbs
+    uint32_t n0inv;        // -n^-1 mod 2^29
+};
+
+// Same contract as UniformArgs (mont_core.h): batch-uniform exponent given as a sliding-window schedule,
+// all user-visible numbers are little-endian 32-bit-word rows.
+struct SplitArgs {
+    SplitConsts mod;
+    const uint32_t* sched;
+    int n_ops;
+    int first_idx;
+    int tbl_entries;
+    const uint32_t* base;  // (batch, base_limbs): r | wide c
+    int base_limbs;
+    int base_chunks;       // ceil(32*base_limbs / (29 H))
+    const uint32_t* post;  // encrypt: m (batch, post_limbs); obfuscate: c_in (batch, post_limbs)
+    int post_limbs;
+    int post_chunks;
+    uint32_t* out;  // (batch, out_limbs)
+    int out_limbs;
+    uint32_t* table;  // scratch: total_groups * tbl_entries * 2H words
+    uint64_t batch;
+};
+
+// ---- the three passes ------------------------------------------------------------------------------------
+// out = (a*b + m*n) / R with the quotient digits m_i stored to m_row (LDS, H words); a: H digits in LDS.
+template <int G, int L>
+PHE_DEV void montmul_q(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[L], uint32_t* m_row,
+                       const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln) {
+    constexpr int H = G * L;
+    uint64_t acc[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) acc[k] = 0;
+#pragma unroll 1
+    for (int i = 0; i < H; i += L) {
+        uint32_t mq[L];
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const uint32_t ai = a[i + j];
+#pragma unroll
+            for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(ai, b[k], acc[(k + j) % L]);
+            const uint32_t m = wave::grp_bcast0<G>(((uint32_t)acc[j] * n0inv) & kLimbMask, ln);
+            mq[j] = m;
+#pragma unroll
+            for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(m, n[k], acc[(k + j) % L]);
+            const uint64_t low = acc[j];
+            const uint32_t recv = wave::grp_down1<G>((uint32_t)low & kLimbMask, ln);
+            if constexpr (L > 1) {
+                acc[(j + 1) % L] += low >> kRadixBits;
+                acc[j] = recv;
+            } else {
+                acc[0] = (low >> kRadixBits) + recv;
+            }
+        }
+        if (ln.g == 0u) {
+#pragma unroll
+            for (int j = 0; j < L; ++j) m_row[i + j] = mq[j];
+        }
+    }
+    normalize_partial<G, L>(out, acc, ln);
+}
+
+// out = (a*b + m*g + m2*n) / R;  a and m: H digits each in LDS
+template <int G, int L>
+PHE_DEV void montmac2(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[L], const uint32_t* m_row,
+                      const uint32_t (&gm)[L], const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln) {
+    constexpr int H = G * L;
+    uint64_t acc[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) acc[k] = 0;
+#pragma unroll 1
+    for (int i = 0; i < H; i += L) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const uint32_t ai = a[i + j];
+            const uint32_t mi = m_row[i + j];
+#pragma unroll
+            for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(ai, b[k], acc[(k + j) % L]);
+#pragma unroll
+            for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(mi, gm[k], acc[(k + j) % L]);
+            const uint32_t m2 = wave::grp_bcast0<G>(((uint32_t)acc[j] * n0inv) & kLimbMask, ln);
+#pragma unroll
+            for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(m2, n[k], acc[(k + j) % L]);
+            const uint64_t low = acc[j];
+            const uint32_t recv = wave::grp_down1<G>((uint32_t)low & kLimbMask, ln);
+            if constexpr (L > 1) {
+                acc[(j + 1) % L] += low >> kRadixBits;
+                acc[j] = recv;
+            } else {
+                acc[0] = (low >> kRadixBits) + recv;
+            }
+        }
+    }
+    normalize_partial<G, L>(out, acc, ln);
+}
+
+// plain product: a*b + addend = hi*R + lo.  a: H digits in LDS; lo: H canonical digits stored to lo_row (LDS);
+// hi: almost-normalised.
+template <int G, int L>
+PHE_DEV void mul_wide(uint32_t (&hi)[L], const uint32_t* a, const uint32_t (&b)[L], const uint32_t (&addend)[L],
+                      uint32_t* lo_row, const Lanes<G>& ln) {
+    constexpr int H = G * L;
+    uint64_t acc[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) acc[k] = addend[k];
+#pragma unroll 1
+    for (int i = 0; i < H; i += L) {
+        uint32_t dq[L];
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const uint32_t ai = a[i + j];
+#pragma unroll
+            for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(ai, b[k], acc[(k + j) % L]);
+            const uint64_t low = acc[j];
+            const uint32_t digit = (uint32_t)low & kLimbMask;  // final in lane 0: every lower column is done
+            dq[j] = digit;
+            const uint32_t recv = wave::grp_down1<G>(digit, ln);
+            if constexpr (L > 1) {
+                acc[(j + 1) % L] += low >> kRadixBits;
+                acc[j] = recv;
+            } else {
+                acc[0] = (low >> kRadixBits) + recv;
+            }
+        }
+        if (ln.g == 0u) {
+#pragma unroll
+            for (int j = 0; j < L; ++j) lo_row[i + j] = dq[j];
+        }
+    }
+    normalize_partial<G, L>(hi, acc, ln);
+}
+
+// ---- pair operations ------------------------------------------------------------------------------------------
+template <int G, int L>
+struct SplitLane {  // what every pass needs, loaded once per kernel
+    uint32_t n[L], gam[L];
+    uint32_t n0inv;
+    uint32_t* row_a;  // H words: multiplier digits
+    uint32_t* row_m;  // H words: quotient digits
+};
+
+template <int G, int L>
+PHE_DEV void split_square(uint32_t (&X0)[L], uint32_t (&X1)[L], const SplitLane<G, L>& K, const Lanes<G>& ln) {
+    uint32_t u[L], d[L];
+    lds_put<L>(K.row_a, X0, ln.g);
+    montmul_q<G, L>(u, K.row_a, X0, K.row_m, K.n, K.n0inv, ln);
+#pragma unroll
+    for (int k = 0; k < L; ++k) d[k] = X1[k];
+    add_normalize<G, L>(d, X1, ln);  // 2*X1
+    wave::lds_fence();
+    montmac2<G, L>(X1, K.row_a, d, K.row_m, K.gam, K.n, K.n0inv, ln);
+#pragma unroll
+    for (int k = 0; k < L; ++k) X0[k] = u[k];
+}
+
+template <int G, int L>
+PHE_DEV void split_mul(uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t (&Y0)[L], const uint32_t (&Y1)[L],
+                       const SplitLane<G, L>& K, const Lanes<G>& ln) {
+    uint32_t u[L], t[L];
+    lds_put<L>(K.row_a, X0, ln.g);
+    montmul_q<G, L>(u, K.row_a, Y0, K.row_m, K.n, K.n0inv, ln);
+    wave::lds_fence();
+    montmac2<G, L>(t, K.row_a, Y1, K.row_m, K.gam, K.n, K.n0inv, ln);
+    lds_put<L>(K.row_a, X1, ln.g);
+    montmul<G, L>(X1, K.row_a, Y0, K.n, K.n0inv, ln);
+    add_normalize<G, L>(X1, t, ln);
+#pragma unroll
+    for (int k = 0; k < L; ++k) X0[k] = u[k];
+}
+
+// the number in the 32-bit-word row src -> pair representation
+template <int G, int L>
+PHE_DEV void split_conv(uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t* src, int limbs32, int chunks,
+                        const SplitConsts& C, const SplitLane<G, L>& K, const Lanes<G>& ln) {
+    constexpr int H = G * L;
+    uint32_t tmp[L], cst[L], u[L], t[L];
+    for (int j = 0; j < chunks; ++j) {
+        load_u32_as_r29<L>(tmp, src, limbs32, j * H, ln.g);
+        lds_put<L>(K.row_a, tmp, ln.g);
+        load_row<L>(cst, C.conv + (size_t)(2 * j) * H, ln.g);
+        montmul_q<G, L>(u, K.row_a, cst, K.row_m, K.n, K.n0inv, ln);
+        wave::lds_fence();
+        load_row<L>(cst, C.conv + (size_t)(2 * j + 1) * H, ln.g);
+        montmac2<G, L>(t, K.row_a, cst, K.row_m, K.gam, K.n, K.n0inv, ln);
+        if (j == 0) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                X0[k] = u[k];
+                X1[k] = t[k];
+            }
+        } else {
+            add_normalize<G, L>(X0, u, ln);
+            add_normalize<G, L>(X1, t, ln);
+        }
+    }
+    if (chunks > 1) {  // the sums exceed the lazy bounds: one product with the pair of 1 restores them
+        load_row<L>(cst, C.e, ln.g);
+        load_row<L>(tmp, C.e + H, ln.g);
+        split_mul<G, L>(X0, X1, cst, tmp, K, ln);
+    }
+}
+
+// canonical 2H-limb number (lo, hi) <- (lo, hi) - (mlo, mhi) if that is not negative
+template <int G, int L>
+PHE_DEV void cond_sub_pair(uint32_t (&lo)[L], uint32_t (&hi)[L], const uint32_t (&mlo)[L], const uint32_t (&mhi)[L],
+                           const Lanes<G>& ln) {
+    uint32_t dl[L], dh[L];
+    uint32_t br = 0, nz = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        const uint32_t v = lo[k] - mlo[k] - br;
+        br = v >> 31;
+        dl[k] = v & kLimbMask;
+        nz |= dl[k];
+    }
+    uint64_t out_lo, out_hi;
+    const uint64_t bin_lo = group_carry_in<G>(wave::ballot(br != 0), wave::ballot(nz == 0), out_lo);
+    uint32_t bi = lane_bit(bin_lo, ln.lane);
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        const uint32_t v = dl[k] - bi;
+        bi = v >> 31;
+        dl[k] = v & kLimbMask;
+    }
+    // the low half's borrow enters lane 0 of the high half
+    br = (ln.g == 0u) ? group_top_bit<G>(out_lo, ln.lane) : 0u;
+    nz = 0;
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        const uint32_t v = hi[k] - mhi[k] - br;
+        br = v >> 31;
+        dh[k] = v & kLimbMask;
+        nz |= dh[k];
+    }
+    const uint64_t bin_hi = group_carry_in<G>(wave::ballot(br != 0), wave::ballot(nz == 0), out_hi);
+    const uint64_t take = ~out_hi & GroupMasks<G>::top;  // no final borrow: value >= modulus
+    const uint32_t sel = group_top_bit<G>(take, ln.lane);
+    bi = lane_bit(bin_hi, ln.lane);
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        const uint32_t v = dh[k] - bi;
+        bi = v >> 31;
+        hi[k] = sel ? (v & kLimbMask) : hi[k];
+        lo[k] = sel ? dl[k] : lo[k];
+    }
+}
+
+// canonical limbs (lo, hi) -> little-endian 32-bit words at p, repacked through the group's 2H-word LDS row
+template <int G, int L>
+PHE_DEV void store_pair_as_u32(uint32_t* p, int limbs32, const uint32_t (&lo)[L], const uint32_t (&hi)[L],
+                               uint32_t* row, uint32_t g, bool live) {
+    constexpr int H = G * L, S2 = 2 * H;
+    wave::lds_fence();
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        row[g * L + k] = lo[k];
+        row[H + g * L + k] = hi[k];
+    }
+    wave::lds_fence();
+    if (live) {
+        for (int j = (int)g; j < limbs32; j += G) {
+            const int bit = 32 * j;
+            const int q = bit / kRadixBits, o = bit - q * kRadixBits;
+            uint64_t v = (q < S2) ? row[q] : 0u;
+            if (q + 1 < S2) v |= (uint64_t)row[q + 1] << kRadixBits;
+            if (q + 2 < S2) v |= (uint64_t)row[q + 2] << (2 * kRadixBits);
+            p[j] = (uint32_t)(v >> o);
+        }
+    }
+    wave::lds_fence();
+}
+
+// pair -> canonical residue of x * (1 + n*mp) mod n^2 (mp == nullptr: of x), written as 32-bit words
+template <int G, int L>
+PHE_DEV void split_exit(uint32_t* out, int out_limbs, uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t* mp,
+                        int mp_limbs, const SplitConsts& C, const SplitLane<G, L>& K, const Lanes<G>& ln, bool live) {
+    constexpr int H = G * L;
+    const uint32_t g = ln.g;
+    uint32_t u[L], t[L], cst[L];
+    // X0*beta = u - m*beta*n
+    lds_put<L>(K.row_a, X0, g);
+#pragma unroll
+    for (int k = 0; k < L; ++k) cst[k] = (g == 0u && k == 0) ? 1u : 0u;
+    montmul_q<G, L>(u, K.row_a, cst, K.row_m, K.n, K.n0inv, ln);
+    wave::lds_fence();
+    // t = X1 - m*R^-1 = X1 + MONT(m, n-1)
+#pragma unroll
+    for (int k = 0; k < L; ++k) cst[k] = K.n[k] - ((g == 0u && k == 0) ? 1u : 0u);  // n is odd: no borrow
+    montmul<G, L>(t, K.row_m, cst, K.n, K.n0inv, ln);
+    add_normalize<G, L>(t, X1, ln);
+    if (mp != nullptr) {  // + mp*u: the plaintext term of (1 + n*mp), phe/paillier.py:134
+        uint32_t w[L];
+        load_u32_as_r29<L>(w, mp, mp_limbs, 0, g);
+        lds_put<L>(K.row_a, w, g);
+        load_row<L>(cst, C.r2, g);
+        montmul<G, L>(w, K.row_a, cst, K.n, K.n0inv, ln);  // mp*R
+        lds_put<L>(K.row_a, w, g);
+        montmul<G, L>(w, K.row_a, u, K.n, K.n0inv, ln);  // mp*u
+        add_normalize<G, L>(t, w, ln);
+    }
+    // t mod n, canonical
+    lds_put<L>(K.row_a, t, g);
+    load_row<L>(cst, C.r1, g);
+    montmul<G, L>(t, K.row_a, cst, K.n, K.n0inv, ln);
+    canonicalize<G, L>(t, K.n, ln);
+    // v = u + n*t  (< n^2 + n), then the canonical residue
+    lds_put<L>(K.row_a, t, g);
+    uint32_t hi[L], lo[L];
+    mul_wide<G, L>(hi, K.row_a, K.n, u, K.row_m, ln);
+    wave::lds_fence();
+    load_row<L>(lo, K.row_m, g);
+    normalize_full<G, L>(hi, ln);
+    load_row<L>(cst, C.nsq, g);
+    load_row<L>(t, C.nsq + H, g);
+    cond_sub_pair<G, L>(lo, hi, cst, t, ln);
+    store_pair_as_u32<G, L>(out, out_limbs, lo, hi, K.row_a, g, live);
+}
+
+// ---- the batched exponentiation -------------------------------------------------------------------------------
+template <int G, int L, int MODE>
+PHE_DEV void modexp_split_body(const SplitArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots,
+                               uint32_t lane) {
+    constexpr int H = G * L, S2 = 2 * H;
+    const Lanes<G> ln(lane);
+    const uint32_t g = ln.g;
+    SplitLane<G, L> K;
+    load_row<L>(K.n, A.mod.n, g);
+    load_row<L>(K.gam, A.mod.gam, g);
+    K.n0inv = A.mod.n0inv;
+    K.row_a = lds_row;
+    K.row_m = lds_row + H;
+    uint32_t* tbl = A.table + (size_t)slot * (size_t)A.tbl_entries * S2;
+    const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
+    for (uint64_t it = 0; it < n_iter; ++it) {
+        uint64_t item = slot + it * (uint64_t)total_slots;
+        const bool live = item < A.batch;
+        if (!live) item = A.batch - 1;
+        uint32_t X0[L], X1[L], Y0[L], Y1[L];
+        split_conv<G, L>(X0, X1, A.base + item * (uint64_t)A.base_limbs, A.base_limbs, A.base_chunks, A.mod, K, ln);
+        // ---- odd powers base^1, base^3, ... ---------------------------------------------------------------
+        store_row<L>(tbl, X0, g);
+        store_row<L>(tbl + H, X1, g);
+        if (A.tbl_entries > 1) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                Y0[k] = X0[k];
+                Y1[k] = X1[k];
+            }
+            split_square<G, L>(Y0, Y1, K, ln);  // base^2
+            for (int j = 1; j < A.tbl_entries; ++j) {
+                split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
+                store_row<L>(tbl + (size_t)j * S2, X0, g);
+                store_row<L>(tbl + (size_t)j * S2 + H, X1, g);
+            }
+        }
+        // ---- left-to-right sliding window ------------------------------------------------------------------
+        load_row<L>(X0, tbl + (size_t)A.first_idx * S2, g);
+        load_row<L>(X1, tbl + (size_t)A.first_idx * S2 + H, g);
+        for (int op = 0; op < A.n_ops; ++op) {
+            const uint32_t w = A.sched[op];
+            const int nsq = (int)(w >> 8);
+            const int sel = (int)(w & 0xffu);
+            for (int s = 0; s < nsq; ++s) split_square<G, L>(X0, X1, K, ln);
+            if (sel) {
+                load_row<L>(Y0, tbl + (size_t)(sel - 1) * S2, g);
+                load_row<L>(Y1, tbl + (size_t)(sel - 1) * S2 + H, g);
+                split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
+            }
+        }
+        // ---- the op's final factor and the way out of the pair representation --------------------------------
+        const uint32_t* mp = nullptr;
+        if (MODE == kModeEncrypt) {
+            mp = A.post + item * (uint64_t)A.post_limbs;  // nude ciphertext 1 + n*m folded into split_exit
+        } else if (MODE == kModeObfuscate) {
+            split_conv<G, L>(Y0, Y1, A.post + item * (uint64_t)A.post_limbs, A.post_limbs, A.post_chunks, A.mod, K, ln);
+            split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
+        }
+        split_exit<G, L>(A.out + item * (uint64_t)A.out_limbs, A.out_limbs, X0, X1, mp, A.post_limbs, A.mod, K, ln, live);
+    }
+}
+
+}  // namespace phe

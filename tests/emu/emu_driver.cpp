@@ -7,6 +7,7 @@
 #include "wave_emu.h"
 // clang-format off
 #include "../../python-paillier_amd/csrc/mont_core.h"
+#include "../../python-paillier_amd/csrc/split_core.h"
 #include "../../python-paillier_amd/csrc/decrypt_tail.h"
 #include "../../python-paillier_amd/csrc/key_setup.h"
 // clang-format on
@@ -104,9 +105,59 @@ static void run_mul(MulArgs A) {
     }
 }
 
+// geometries of the split-modulus kernels (key_setup.h: kS2 / kS4 / kS8 / kS16)
+#define DISPATCH_SPLIT(G_, L_, CALL)                                                  \
+    switch ((G_) * 100 + (L_)) {                                                      \
+        case 1601: { constexpr int GG = 16, LL = 1; CALL; break; }                    \
+        case 1602: { constexpr int GG = 16, LL = 2; CALL; break; }                    \
+        case 1603: { constexpr int GG = 16, LL = 3; CALL; break; }                    \
+        case 1605: { constexpr int GG = 16, LL = 5; CALL; break; }                    \
+        case 1607: { constexpr int GG = 16, LL = 7; CALL; break; }                    \
+        case 1609: { constexpr int GG = 16, LL = 9; CALL; break; }                    \
+        case 1614: { constexpr int GG = 16, LL = 14; CALL; break; }                   \
+        case 1618: { constexpr int GG = 16, LL = 18; CALL; break; }                   \
+        case 209: { constexpr int GG = 2, LL = 9; CALL; break; }                      \
+        case 218: { constexpr int GG = 2, LL = 18; CALL; break; }                     \
+        case 409: { constexpr int GG = 4, LL = 9; CALL; break; }                      \
+        case 414: { constexpr int GG = 4, LL = 14; CALL; break; }                     \
+        case 418: { constexpr int GG = 4, LL = 18; CALL; break; }                     \
+        case 807: { constexpr int GG = 8, LL = 7; CALL; break; }                      \
+        case 809: { constexpr int GG = 8, LL = 9; CALL; break; }                      \
+        case 814: { constexpr int GG = 8, LL = 14; CALL; break; }                     \
+        case 818: { constexpr int GG = 8, LL = 18; CALL; break; }                     \
+        default: throw std::invalid_argument("unsupported split geometry");           \
+    }
+
+static SplitConsts split_consts_of(const host::SplitPack& m) {
+    SplitConsts c;
+    c.n = m.n.data(); c.gam = m.gam.data(); c.r1 = m.r1.data(); c.r2 = m.r2.data();
+    c.e = m.e.data(); c.conv = m.conv.data(); c.nsq = m.nsq.data(); c.n0inv = m.n0inv;
+    return c;
+}
+static int chunks_for(int limbs32, int H) { return std::max(1, (32 * limbs32 + 29 * H - 1) / (29 * H)); }
+
+template <int G, int L, int MODE>
+static void run_split(SplitArgs A) {
+    constexpr int S2 = 2 * G * L, kPer = 64 / G;
+    const int n_waves = waves_for(A.batch, G);
+    const uint32_t total = (uint32_t)(kPer * n_waves);
+    std::vector<uint32_t> table((size_t)total * (size_t)A.tbl_entries * S2);
+    A.table = table.data();
+    for (int w = 0; w < n_waves; ++w) {
+        std::vector<uint32_t> lds(kPer * (S2 + kLdsPad));
+        wave::run_wave([&](uint32_t lane) {
+            const uint32_t grp = lane / G;
+            modexp_split_body<G, L, MODE>(A, lds.data() + grp * (S2 + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
+        });
+    }
+}
+
 static int g_prefer_group = 0;
+static int g_engine = 1;  // 1: split-modulus kernels where a geometry exists (the product default), 0: full-width only
 
 extern "C" {
+
+void emu_set_engine(int e) { g_engine = e ? 1 : 0; }
 
 const char* emu_last_error() { return g_err.c_str(); }
 
@@ -142,6 +193,20 @@ int emu_encrypt(const uint32_t* n, int n_limbs, const uint32_t* m, const uint32_
     try {
         if (B == 0) return 0;
         host::PublicPlan P = host::build_public(n, n_limbs, g_prefer_group);
+        if (g_engine && P.nsplit.G) {
+            const host::SplitPack& M = P.nsplit;
+            SplitArgs A;
+            memset(&A, 0, sizeof A);
+            A.mod = split_consts_of(M);
+            A.sched = P.exp_n.ops.data(); A.n_ops = (int)P.exp_n.ops.size();
+            A.first_idx = P.exp_n.first_idx; A.tbl_entries = P.exp_n.tbl_entries;
+            A.base = r; A.base_limbs = P.s1; A.base_chunks = chunks_for(P.s1, M.H);
+            A.post = c_in ? c_in : m; A.post_limbs = c_in ? P.s2 : P.s1; A.post_chunks = chunks_for(A.post_limbs, M.H);
+            A.out = c_out; A.out_limbs = P.s2; A.batch = B;
+            if (c_in) { DISPATCH_SPLIT(M.G, M.L, (run_split<GG, LL, kModeObfuscate>(A))); }
+            else { DISPATCH_SPLIT(M.G, M.L, (run_split<GG, LL, kModeEncrypt>(A))); }
+            return 0;
+        }
         UniformArgs A;
         memset(&A, 0, sizeof A);
         A.mod = consts_of(P.nsq);
@@ -167,6 +232,18 @@ int emu_decrypt(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const 
         for (int half = 0; half < 2; ++half) {
             const host::ModulusPack& M = half ? P.qsq : P.psq;
             const host::Schedule& E = half ? P.exp_q : P.exp_p;
+            const host::SplitPack& SP = half ? P.qsplit : P.psplit;
+            if (g_engine && SP.G) {
+                SplitArgs A;
+                memset(&A, 0, sizeof A);
+                A.mod = split_consts_of(SP);
+                A.sched = E.ops.data(); A.n_ops = (int)E.ops.size();
+                A.first_idx = E.first_idx; A.tbl_entries = E.tbl_entries;
+                A.base = c; A.base_limbs = P.s2; A.base_chunks = chunks_for(P.s2, SP.H);
+                A.out = half ? xq.data() : xp.data(); A.out_limbs = S; A.batch = B;
+                DISPATCH_SPLIT(SP.G, SP.L, (run_split<GG, LL, kModeHalfDecrypt>(A)));
+                continue;
+            }
             UniformArgs A;
             memset(&A, 0, sizeof A);
             A.mod = consts_of(M);
@@ -238,6 +315,15 @@ int emu_powmod_var(const uint32_t* N, int limbs, const uint32_t* base, const uin
         A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
         A.out = out; A.out_limbs = limbs; A.batch = B;
         DISPATCH_GL(M.G, M.L, (run_var<GG, LL>(A)));
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// geometry of the split-modulus kernels for modulus n (given as `limbs` words): GL_out = {G, L}; G = 0 if none
+int emu_split_geometry(const uint32_t* n, int limbs, int* GL_out) {
+    try {
+        const host::Geometry geo = host::pick_geometry_split(host::big_bits(host::big_from(n, limbs, limbs)), g_prefer_group);
+        GL_out[0] = geo.G; GL_out[1] = geo.L;
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }

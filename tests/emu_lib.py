@@ -28,6 +28,15 @@ class Emu:
     def set_group(self, g):
         self.L.emu_set_group(int(g))
 
+    def set_engine(self, split):
+        """True: split-modulus kernels where a geometry exists (the product default); False: full-width only"""
+        self.L.emu_set_engine(1 if split else 0)
+
+    def split_geometry(self, n):
+        gl = (ctypes.c_int * 2)()
+        self._ck(self.L.emu_split_geometry(P(n), len(n), gl))
+        return gl[0], gl[1]
+
     def montmul(self, G, L, a, b, n, n0inv):
         """a, b: (64/G, G*L) arrays of 29-bit limbs; n: (G*L,) limbs."""
         out = np.zeros((64 // G, G * L), np.uint32)
