@@ -149,19 +149,6 @@ inline void big_divmod(const Big& a, const Big& n, Big& q, Big& r) {
     rem.resize(w);
     r = rem;
 }
-// a >> k
-inline Big big_shr(const Big& a, int k) {
-    Big r(a.size(), 0u);
-    const size_t ws = (size_t)(k >> 5);
-    const int bs = k & 31;
-    for (size_t i = 0; i + ws < a.size(); ++i) {
-        uint64_t v = a[i + ws];
-        if (i + ws + 1 < a.size()) v |= (uint64_t)a[i + ws + 1] << 32;
-        r[i] = (uint32_t)(v >> bs);
-    }
-    return r;
-}
-
 // ---- radix-2^29 geometry -----------------------------------------------------------------------
 constexpr int kRadixBits = 29;
 
@@ -292,9 +279,9 @@ inline ModulusPack build_modulus(const Big& N_any, const Big* aux_src, int min_b
 }
 
 // ---- split-modulus ("n-adic") arithmetic: constants of csrc/split_core.h -----------------------------------
-// Work modulo n^2 is done on pairs (X0, X1), x = X0*beta + X1*n (mod n^2), beta = R^-1 mod n^2, with half-width
-// Montgomery passes modulo n only: R = 2^(29 H) >= 16 n, H = G*L limbs.  The widest pass adds three products per
-// digit to a column accumulator, so 3L * 2^58 < 2^64 bounds L by 21.
+// Work modulo n^2 is done on pairs (X0, X1), x*R = X0 - n*X1 (mod n^2), with half-width Montgomery passes modulo n
+// only: R = 2^(29 H) >= 16 n, H = G*L limbs.  The widest pass adds three products per digit to a column
+// accumulator, so 3L * 2^58 < 2^64 bounds L by 21.
 static const int kS16[] = {1, 2, 3, 5, 7, 9, 14, 18};
 static const int kS8[] = {7, 9, 14, 18};
 static const int kS4[] = {9, 14, 18};
@@ -330,11 +317,11 @@ struct SplitPack {
     int G = 0, L = 0, H = 0;  // H = G*L limbs of 29 bits cover n (+4 bits)
     int bits = 0;             // bits of n
     int chunks = 0;           // conv rows available: inputs of up to chunks*29*H bits
-    std::vector<uint32_t> n, gam, r1, r2;  // H limbs each: n, -R^-1 mod n, R mod n, R^2 mod n
-    std::vector<uint32_t> e;               // rep_1(1) = E0 | E1                       (2H)
-    std::vector<uint32_t> conv;            // chunk j: D0_j | D1'_j = rep_2(R^j)        (chunks * 2H)
-    std::vector<uint32_t> nsq;             // n^2, 2H limbs
-    uint32_t n0inv = 0;                    // -n^-1 mod 2^29
+    std::vector<uint32_t> n, r1;  // H limbs each: n, R mod n
+    std::vector<uint32_t> e;      // pair of 1:       R mod n^2       = E0 - n*E1      (E0 | E1, 2H)
+    std::vector<uint32_t> conv;   // chunk j:         R^(j+2) mod n^2 = D0 - n*D1      (chunks * 2H)
+    std::vector<uint32_t> nsq;    // n^2, 2H limbs
+    uint32_t n0inv = 0;           // -n^-1 mod 2^29
 };
 
 // max_input_bits: widest number that will be converted into the pair representation (a ciphertext).
@@ -351,40 +338,21 @@ inline SplitPack build_split(const Big& n_any, int max_input_bits, int prefer_gr
     if ((n[0] & 1u) == 0u) throw std::invalid_argument("modulus must be odd");
     const int rbits = kRadixBits * P.H;
     P.chunks = std::max(1, (max_input_bits + rbits - 1) / rbits);
-    Big nsq = big_resize(big_mul(n, n), 2 * w);
-    // rho = R^-1 mod n = (1 + n * (-n^-1 mod R)) / R
-    const int rw = (rbits + 31) / 32;
-    Big ninv = inv_mod_pow2(big_resize(n, std::max(rw, w)), std::max(rw, w));  // n^-1 mod 2^(32 rw')
-    Big nprime(ninv.size(), 0u);
-    big_sub_inplace(nprime, ninv);  // -n^-1
-    for (size_t i = 0; i < nprime.size(); ++i) {  // mod 2^rbits
-        const int lo = 32 * (int)i;
-        if (lo >= rbits) nprime[i] = 0u;
-        else if (lo + 32 > rbits) nprime[i] &= (1u << (rbits - lo)) - 1u;
-    }
-    Big prod = big_mul(n, nprime);
-    Big one_p(prod.size(), 0u);
-    one_p[0] = 1;
-    big_add_inplace(prod, one_p);
-    Big rho = big_resize(big_shr(prod, rbits), w);
-    Big gam = n;
-    big_sub_inplace(gam, rho);
+    const Big nsq = big_resize(big_mul(n, n), 2 * w);
     Big one((size_t)w, 0u);
     one[0] = 1;
-    const Big r1 = big_shift_mod(one, rbits, n);
-    const Big r2 = big_shift_mod(r1, rbits, n);
     P.n = to_r29(n, P.H);
-    P.gam = to_r29(gam, P.H);
-    P.r1 = to_r29(r1, P.H);
-    P.r2 = to_r29(r2, P.H);
+    P.r1 = to_r29(big_shift_mod(one, rbits, n), P.H);
     P.nsq = to_r29(nsq, 2 * P.H);
     P.n0inv = neg_inv32(n[0]) & ((1u << kRadixBits) - 1u);
-    // K*R^j = z0 + z1*n (mod n^2)  ->  (z0, z1*rho mod n); Z is handed in as R^j*K mod n^2
+    // Z = z0 + z1*n (Z < n^2)  ->  the pair (z0, -z1 mod n)
     auto pair_of = [&](const Big& Z, std::vector<uint32_t>& out) {
         Big q, r;
         big_divmod(Z, n, q, r);
-        Big z1rho = big_mod(big_mul(big_resize(q, w), rho), n);
-        const std::vector<uint32_t> a = to_r29(r, P.H), b = to_r29(z1rho, P.H);
+        Big z1 = big_resize(q, w), neg = n;
+        big_sub_inplace(neg, z1);
+        if (big_is_zero(z1)) neg = z1;
+        const std::vector<uint32_t> a = to_r29(r, P.H), b = to_r29(neg, P.H);
         out.insert(out.end(), a.begin(), a.end());
         out.insert(out.end(), b.begin(), b.end());
     };

@@ -197,7 +197,7 @@ struct DevModulus {  // device copies of a host::ModulusPack
 };
 struct DevSplit {  // device copies of a host::SplitPack
     int G = 0, L = 0, H = 0;  // G == 0: no split kernel for this modulus
-    uint32_t* blob = nullptr;  // n | gam | r1 | r2 | e | nsq | conv
+    uint32_t* blob = nullptr;  // n | r1 | e | nsq | conv
     SplitConsts c{};
 };
 struct DevSchedule {
@@ -261,24 +261,20 @@ static int upload_split(const host::SplitPack& m, DevSplit& d) {
     d.L = m.L;
     d.H = m.H;
     if (m.G == 0) return PHE_HIP_OK;
-    const size_t H = (size_t)m.H;
     std::vector<uint32_t> h;
-    const std::vector<uint32_t>* parts[7] = {&m.n, &m.gam, &m.r1, &m.r2, &m.e, &m.nsq, &m.conv};
-    size_t off[7];
-    for (int i = 0; i < 7; ++i) {
+    const std::vector<uint32_t>* parts[5] = {&m.n, &m.r1, &m.e, &m.nsq, &m.conv};
+    size_t off[5];
+    for (int i = 0; i < 5; ++i) {
         off[i] = h.size();
         h.insert(h.end(), parts[i]->begin(), parts[i]->end());
     }
     HIP_TRY(hipMalloc((void**)&d.blob, h.size() * 4));
     HIP_TRY(hipMemcpy(d.blob, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-    (void)H;
     d.c.n = d.blob + off[0];
-    d.c.gam = d.blob + off[1];
-    d.c.r1 = d.blob + off[2];
-    d.c.r2 = d.blob + off[3];
-    d.c.e = d.blob + off[4];
-    d.c.nsq = d.blob + off[5];
-    d.c.conv = d.blob + off[6];
+    d.c.r1 = d.blob + off[1];
+    d.c.e = d.blob + off[2];
+    d.c.nsq = d.blob + off[3];
+    d.c.conv = d.blob + off[4];
     d.c.n0inv = m.n0inv;
     return PHE_HIP_OK;
 }

@@ -2,30 +2,32 @@
 //
 // The moduli of Paillier are squares: n^2 for encrypt/obfuscate (phe/paillier.py:137, :622 powmod(r, n, nsquare)),
 // p^2 and q^2 for the CRT halves of decrypt (:347, :351).  mont_core.h treats them as opaque 2k-bit moduli; here
-// an element x of Z/n^2 is kept as a pair (X0, X1) of numbers modulo n with
+// an element x of Z/n^2 is kept in HALF-width Montgomery form, x~ = x*R mod n^2 with R = 2^(29 H) >= 16 n, written
+// in n-adic digits with a minus sign:
 //
-//        x = X0 * beta + X1 * n   (mod n^2),      beta = R^-1 mod n^2,  R = 2^(29 H) >= 16 n,
+//        x~ = X0 - n * X1   (mod n^2),      X0, X1 numbers modulo n (H limbs each).
 //
-// and every product needs half-width Montgomery passes modulo n only.  With MQ a Montgomery product that also
-// keeps its quotient m (X0*Y0 + m*n = u*R exactly) and gamma = -R^-1 mod n:
+// With MQ a Montgomery product modulo n that keeps its quotient m (X0*Y0 + m*n = u*R exactly),
+// x~ y~ = X0 Y0 - n (X0 Y1 + X1 Y0) = u R - n (m + X0 Y1 + X1 Y0)  (mod n^2), so
 //
-//     x*y :  (u, m) = MQ(X0, Y0)                       X0' = u
-//            X1' = MAC2(X0, Y1; m, gamma) + MONT(X1, Y0)          MAC2(a,b;m,g) = (a*b + m*g) * R^-1 mod n
-//     x^2 :  (u, m) = MQ(X0, X0),   X1' = MAC2(X0, 2*X1; m, gamma)
+//     x*y :  Z0 = u,   Z1 = (m + X0*Y1 + X1*Y0) * R^-1 mod n
+//     x^2 :  Z0 = u,   Z1 = (m + X0*(2 X1))     * R^-1 mod n
 //
-// (X0*Y0*beta^2 = u*beta - m*beta^2*n because R*beta = 1, and (X0*Y1 + X1*Y0)*beta - m*beta^2 is exactly the
-// Montgomery reduction of X0*Y1 + X1*Y0 + m*gamma.)  In units of one half-width pass (H digits x L multiply-adds
-// per lane) a squaring costs 2 + 3 = 5 and a product 2 + 3 + 2 = 7, against 8 for either on the full-width modulus:
-// the exponentiations of encrypt and decrypt are ~85 % squarings, so ~1/3 of the multiply-adds disappear.
+// Both words come out of ONE sweep over the H digits of X0 (pair_pass2 / pair_pass3): two column-accumulator sets
+// advance together, and the quotient digit m_i of the first enters the second at the column it belongs to, so the
+// quotient never exists as a number.  In multiply-adds per lane a squaring costs 4*L*H and a product 5*L*H, against
+// 8*L*H for either on the full-width modulus (2L limbs per lane, 2H digits): the exponentiations of encrypt and
+// decrypt are ~85 % squarings, so about half of the multiply-adds disappear.
 // tools/exp/split_model.py checks the algebra and the lazy-reduction bounds below with plain integers.
 //
-// Lazy bounds (R >= 16 n): X0 < 2n, X1 < 5n are closed under both operations; sums made while converting inputs
-// stay below R.  Limbs are almost-normalised (< 2^29 + 2^8) exactly as in mont_core.h, and a column accumulator
-// takes at most three products per digit for L digits: L <= 21 keeps it below 2^64 for any operands.
+// Lazy bounds (R >= 16 n): X0 < 2n, X1 < 2n are closed under both operations (inputs up to 3n are fine); sums made
+// while converting inputs stay below R.  Limbs are almost-normalised (< 2^29 + 2^8) exactly as in mont_core.h, and
+// a column accumulator takes at most three products per digit for L digits: L <= 21 keeps it below 2^64 for any
+// operands.
 //
-// Conversions happen once per element: in  — x = sum_j x_j R^j with x_j < R is sum_j (x_j (*) rep_2(R^j)), where
-// x (*) (D0, D1') = (u, MAC2(x, D1'; m, gamma)) with (u, m) = MQ(x, D0);  out — X0*beta = u - m*beta*n with
-// (u, m) = MQ(X0, 1), so  x*(1 + n*mp) = u + n*t,  t = X1 + MONT(m, n-1) + mp*u  (mod n), made canonical.
+// Conversions happen once per element: in  — x = sum_j x_j R^j (x_j < R) is the sum of the pair products
+// (x_j, 0) * pair(R^(j+2));  out — with (u, m) = MQ(X0, 1):  x*(1 + n*mp) = u + n*t,
+// t = (mp*X0 - X1 - m) * R^-1 mod n = MONT(mp, X0) + MAC2(X1, n-1; m, n-1), made canonical.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -37,11 +39,9 @@ namespace phe {
 // per-modulus constants (device pointers; H = G*L words of 29-bit limbs per row)
 struct SplitConsts {
     const uint32_t* n;     // n
-    const uint32_t* gam;   // -R^-1 mod n
     const uint32_t* r1;    // R mod n
-    const uint32_t* r2;    // R^2 mod n
-    const uint32_t* e;     // rep_1(1): E0 | E1
-    const uint32_t* conv;  // chunk j: D0_j | D1'_j
+    const uint32_t* e;     // pair of 1: E0 | E1              (R mod n^2 = E0 - n*E1)
+    const uint32_t* conv;  // chunk j: D0_j | D1_j             (R^(j+2) mod n^2 = D0 - n*D1)
     const uint32_t* nsq;   // n^2, 2H limbs
     uint32_t n0inv;        // -n^-1 mod 2^29
 };
@@ -62,11 +62,11 @@ struct SplitArgs {
     int post_chunks;
     uint32_t* out;  // (batch, out_limbs)
     int out_limbs;
-    uint32_t* table;  // scratch: total_groups * tbl_entries * 2H words
+    uint32_t* table;  // scratch: total_groups * tbl_entries * 2H words (entry = X0 row | X1 row)
     uint64_t batch;
 };
 
-// ---- the three passes ------------------------------------------------------------------------------------
+// ---- single-word passes (used by the conversions out of the pair form) -----------------------------------------
 // out = (a*b + m*n) / R with the quotient digits m_i stored to m_row (LDS, H words); a: H digits in LDS.
 template <int G, int L>
 PHE_DEV void montmul_q(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[L], uint32_t* m_row,
@@ -174,42 +174,123 @@ PHE_DEV void mul_wide(uint32_t (&hi)[L], const uint32_t* a, const uint32_t (&b)[
     normalize_partial<G, L>(hi, acc, ln);
 }
 
-// ---- pair operations ------------------------------------------------------------------------------------------
+// ---- pair products: both words in one sweep -------------------------------------------------------------------
+// shift of one column-accumulator set by one digit (the tail of every row of a Montgomery sweep)
+template <int G, int L>
+PHE_DEV void shift_row(uint64_t (&acc)[L], int j, const Lanes<G>& ln) {
+    const uint64_t low = acc[j];
+    const uint32_t recv = wave::grp_down1<G>((uint32_t)low & kLimbMask, ln);
+    if constexpr (L > 1) {
+        acc[(j + 1) % L] += low >> kRadixBits;
+        acc[j] = recv;
+    } else {
+        acc[0] = (low >> kRadixBits) + recv;
+    }
+}
+
+// z0 = (a*b0 + m*n) / R,   z1 = (m + a*b1 + m2*n) / R.     a: H digits in LDS.
+// Squaring: b0 = X0, b1 = 2*X1.  Conversion of a plain chunk a: (b0, b1) = pair(R^(j+2)).
+template <int G, int L>
+PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a, const uint32_t (&b0)[L],
+                        const uint32_t (&b1)[L], const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln) {
+    constexpr int H = G * L;
+    const uint32_t lane0 = ~ln.not_low;  // all-ones in lane 0 of the group
+    uint64_t p[L], q[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) p[k] = q[k] = 0;
+#pragma unroll 1
+    for (int i = 0; i < H; i += L) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const uint32_t ai = a[i + j];
+#pragma unroll
+            for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(ai, b0[k], p[(k + j) % L]);
+#pragma unroll
+            for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(ai, b1[k], q[(k + j) % L]);
+            const uint32_t mloc = ((uint32_t)p[j] * n0inv) & kLimbMask;
+            const uint32_t m = wave::grp_bcast0<G>(mloc, ln);
+            q[j] += (uint64_t)(mloc & lane0);  // quotient digit i of the first sum = digit i of the addend m
+#pragma unroll
+            for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(m, n[k], p[(k + j) % L]);
+            const uint32_t m2 = wave::grp_bcast0<G>(((uint32_t)q[j] * n0inv) & kLimbMask, ln);
+#pragma unroll
+            for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(m2, n[k], q[(k + j) % L]);
+            shift_row<G, L>(p, j, ln);
+            shift_row<G, L>(q, j, ln);
+        }
+    }
+    normalize_partial<G, L>(z0, p, ln);
+    normalize_partial<G, L>(z1, q, ln);
+}
+
+// z0 = (a*b0 + m*n) / R,   z1 = (m + a*b1 + c*b0 + m2*n) / R.     a, c: H digits each in LDS.
+// Product (X0, X1) * (Y0, Y1): a = X0, c = X1, b = (Y0, Y1).
+template <int G, int L>
+PHE_DEV void pair_pass3(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a, const uint32_t* c,
+                        const uint32_t (&b0)[L], const uint32_t (&b1)[L], const uint32_t (&n)[L], uint32_t n0inv,
+                        const Lanes<G>& ln) {
+    constexpr int H = G * L;
+    const uint32_t lane0 = ~ln.not_low;
+    uint64_t p[L], q[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) p[k] = q[k] = 0;
+#pragma unroll 1
+    for (int i = 0; i < H; i += L) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const uint32_t ai = a[i + j];
+            const uint32_t ci = c[i + j];
+#pragma unroll
+            for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(ai, b0[k], p[(k + j) % L]);
+#pragma unroll
+            for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(ai, b1[k], q[(k + j) % L]);
+#pragma unroll
+            for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(ci, b0[k], q[(k + j) % L]);
+            const uint32_t mloc = ((uint32_t)p[j] * n0inv) & kLimbMask;
+            const uint32_t m = wave::grp_bcast0<G>(mloc, ln);
+            q[j] += (uint64_t)(mloc & lane0);
+#pragma unroll
+            for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(m, n[k], p[(k + j) % L]);
+            const uint32_t m2 = wave::grp_bcast0<G>(((uint32_t)q[j] * n0inv) & kLimbMask, ln);
+#pragma unroll
+            for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(m2, n[k], q[(k + j) % L]);
+            shift_row<G, L>(p, j, ln);
+            shift_row<G, L>(q, j, ln);
+        }
+    }
+    normalize_partial<G, L>(z0, p, ln);
+    normalize_partial<G, L>(z1, q, ln);
+}
+
 template <int G, int L>
 struct SplitLane {  // what every pass needs, loaded once per kernel
-    uint32_t n[L], gam[L];
+    uint32_t n[L];
     uint32_t n0inv;
-    uint32_t* row_a;  // H words: multiplier digits
-    uint32_t* row_m;  // H words: quotient digits
+    uint32_t* row_a;  // H words: digits of X0 (or of a plain multiplier)
+    uint32_t* row_c;  // H words: digits of X1 (quotient digits in split_exit)
 };
 
 template <int G, int L>
 PHE_DEV void split_square(uint32_t (&X0)[L], uint32_t (&X1)[L], const SplitLane<G, L>& K, const Lanes<G>& ln) {
-    uint32_t u[L], d[L];
+    uint32_t d[L];
     lds_put<L>(K.row_a, X0, ln.g);
-    montmul_q<G, L>(u, K.row_a, X0, K.row_m, K.n, K.n0inv, ln);
 #pragma unroll
     for (int k = 0; k < L; ++k) d[k] = X1[k];
     add_normalize<G, L>(d, X1, ln);  // 2*X1
-    wave::lds_fence();
-    montmac2<G, L>(X1, K.row_a, d, K.row_m, K.gam, K.n, K.n0inv, ln);
-#pragma unroll
-    for (int k = 0; k < L; ++k) X0[k] = u[k];
+    pair_pass2<G, L>(X0, X1, K.row_a, X0, d, K.n, K.n0inv, ln);
 }
 
 template <int G, int L>
 PHE_DEV void split_mul(uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t (&Y0)[L], const uint32_t (&Y1)[L],
                        const SplitLane<G, L>& K, const Lanes<G>& ln) {
-    uint32_t u[L], t[L];
-    lds_put<L>(K.row_a, X0, ln.g);
-    montmul_q<G, L>(u, K.row_a, Y0, K.row_m, K.n, K.n0inv, ln);
     wave::lds_fence();
-    montmac2<G, L>(t, K.row_a, Y1, K.row_m, K.gam, K.n, K.n0inv, ln);
-    lds_put<L>(K.row_a, X1, ln.g);
-    montmul<G, L>(X1, K.row_a, Y0, K.n, K.n0inv, ln);
-    add_normalize<G, L>(X1, t, ln);
 #pragma unroll
-    for (int k = 0; k < L; ++k) X0[k] = u[k];
+    for (int k = 0; k < L; ++k) {
+        K.row_a[ln.g * L + k] = X0[k];
+        K.row_c[ln.g * L + k] = X1[k];
+    }
+    wave::lds_fence();
+    pair_pass3<G, L>(X0, X1, K.row_a, K.row_c, Y0, Y1, K.n, K.n0inv, ln);
 }
 
 // the number in the 32-bit-word row src -> pair representation
@@ -217,30 +298,24 @@ template <int G, int L>
 PHE_DEV void split_conv(uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t* src, int limbs32, int chunks,
                         const SplitConsts& C, const SplitLane<G, L>& K, const Lanes<G>& ln) {
     constexpr int H = G * L;
-    uint32_t tmp[L], cst[L], u[L], t[L];
+    uint32_t tmp[L], d0[L], d1[L], u[L], t[L];
     for (int j = 0; j < chunks; ++j) {
         load_u32_as_r29<L>(tmp, src, limbs32, j * H, ln.g);
         lds_put<L>(K.row_a, tmp, ln.g);
-        load_row<L>(cst, C.conv + (size_t)(2 * j) * H, ln.g);
-        montmul_q<G, L>(u, K.row_a, cst, K.row_m, K.n, K.n0inv, ln);
-        wave::lds_fence();
-        load_row<L>(cst, C.conv + (size_t)(2 * j + 1) * H, ln.g);
-        montmac2<G, L>(t, K.row_a, cst, K.row_m, K.gam, K.n, K.n0inv, ln);
+        load_row<L>(d0, C.conv + (size_t)(2 * j) * H, ln.g);
+        load_row<L>(d1, C.conv + (size_t)(2 * j + 1) * H, ln.g);
         if (j == 0) {
-#pragma unroll
-            for (int k = 0; k < L; ++k) {
-                X0[k] = u[k];
-                X1[k] = t[k];
-            }
+            pair_pass2<G, L>(X0, X1, K.row_a, d0, d1, K.n, K.n0inv, ln);
         } else {
+            pair_pass2<G, L>(u, t, K.row_a, d0, d1, K.n, K.n0inv, ln);
             add_normalize<G, L>(X0, u, ln);
             add_normalize<G, L>(X1, t, ln);
         }
     }
     if (chunks > 1) {  // the sums exceed the lazy bounds: one product with the pair of 1 restores them
-        load_row<L>(cst, C.e, ln.g);
-        load_row<L>(tmp, C.e + H, ln.g);
-        split_mul<G, L>(X0, X1, cst, tmp, K, ln);
+        load_row<L>(d0, C.e, ln.g);
+        load_row<L>(d1, C.e + H, ln.g);
+        split_mul<G, L>(X0, X1, d0, d1, K, ln);
     }
 }
 
@@ -321,25 +396,21 @@ PHE_DEV void split_exit(uint32_t* out, int out_limbs, uint32_t (&X0)[L], uint32_
     constexpr int H = G * L;
     const uint32_t g = ln.g;
     uint32_t u[L], t[L], cst[L];
-    // X0*beta = u - m*beta*n
+    // X0 / R = u - n * m / R
     lds_put<L>(K.row_a, X0, g);
 #pragma unroll
     for (int k = 0; k < L; ++k) cst[k] = (g == 0u && k == 0) ? 1u : 0u;
-    montmul_q<G, L>(u, K.row_a, cst, K.row_m, K.n, K.n0inv, ln);
-    wave::lds_fence();
-    // t = X1 - m*R^-1 = X1 + MONT(m, n-1)
+    montmul_q<G, L>(u, K.row_a, cst, K.row_c, K.n, K.n0inv, ln);
+    // t = -(X1 + m) / R = (X1 + m) * (n - 1) / R   (mod n)
+    lds_put<L>(K.row_a, X1, g);  // (its fences also order the quotient digits in row_c)
 #pragma unroll
     for (int k = 0; k < L; ++k) cst[k] = K.n[k] - ((g == 0u && k == 0) ? 1u : 0u);  // n is odd: no borrow
-    montmul<G, L>(t, K.row_m, cst, K.n, K.n0inv, ln);
-    add_normalize<G, L>(t, X1, ln);
-    if (mp != nullptr) {  // + mp*u: the plaintext term of (1 + n*mp), phe/paillier.py:134
+    montmac2<G, L>(t, K.row_a, cst, K.row_c, cst, K.n, K.n0inv, ln);
+    if (mp != nullptr) {  // + mp * X0 / R: the plaintext term of (1 + n*mp), phe/paillier.py:134
         uint32_t w[L];
         load_u32_as_r29<L>(w, mp, mp_limbs, 0, g);
         lds_put<L>(K.row_a, w, g);
-        load_row<L>(cst, C.r2, g);
-        montmul<G, L>(w, K.row_a, cst, K.n, K.n0inv, ln);  // mp*R
-        lds_put<L>(K.row_a, w, g);
-        montmul<G, L>(w, K.row_a, u, K.n, K.n0inv, ln);  // mp*u
+        montmul<G, L>(w, K.row_a, X0, K.n, K.n0inv, ln);
         add_normalize<G, L>(t, w, ln);
     }
     // t mod n, canonical
@@ -347,12 +418,12 @@ PHE_DEV void split_exit(uint32_t* out, int out_limbs, uint32_t (&X0)[L], uint32_
     load_row<L>(cst, C.r1, g);
     montmul<G, L>(t, K.row_a, cst, K.n, K.n0inv, ln);
     canonicalize<G, L>(t, K.n, ln);
-    // v = u + n*t  (< n^2 + n), then the canonical residue
+    // v = u + n*t  (< n^2 + 2n), then the canonical residue
     lds_put<L>(K.row_a, t, g);
     uint32_t hi[L], lo[L];
-    mul_wide<G, L>(hi, K.row_a, K.n, u, K.row_m, ln);
+    mul_wide<G, L>(hi, K.row_a, K.n, u, K.row_c, ln);
     wave::lds_fence();
-    load_row<L>(lo, K.row_m, g);
+    load_row<L>(lo, K.row_c, g);
     normalize_full<G, L>(hi, ln);
     load_row<L>(cst, C.nsq, g);
     load_row<L>(t, C.nsq + H, g);
@@ -369,10 +440,9 @@ PHE_DEV void modexp_split_body(const SplitArgs& A, uint32_t* lds_row, uint32_t s
     const uint32_t g = ln.g;
     SplitLane<G, L> K;
     load_row<L>(K.n, A.mod.n, g);
-    load_row<L>(K.gam, A.mod.gam, g);
     K.n0inv = A.mod.n0inv;
     K.row_a = lds_row;
-    K.row_m = lds_row + H;
+    K.row_c = lds_row + H;
     uint32_t* tbl = A.table + (size_t)slot * (size_t)A.tbl_entries * S2;
     const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
     for (uint64_t it = 0; it < n_iter; ++it) {

@@ -130,7 +130,7 @@ static void run_mul(MulArgs A) {
 
 static SplitConsts split_consts_of(const host::SplitPack& m) {
     SplitConsts c;
-    c.n = m.n.data(); c.gam = m.gam.data(); c.r1 = m.r1.data(); c.r2 = m.r2.data();
+    c.n = m.n.data(); c.r1 = m.r1.data();
     c.e = m.e.data(); c.conv = m.conv.data(); c.nsq = m.nsq.data(); c.n0inv = m.n0inv;
     return c;
 }

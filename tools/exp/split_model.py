@@ -1,18 +1,17 @@
-"""Integer model of the split-modulus ("n-adic") arithmetic used by csrc/split_core.h.
+"""Integer model of the split-modulus arithmetic of csrc/split_core.h (checks the algebra and the lazy bounds).
 
-Elements of Z/n^2 are kept as pairs (X0, X1) with  x = X0*beta + X1*n (mod n^2),  beta = R^-1 mod n^2,
-R = 2^(29h) >= 16 n.  Every product then costs half-width (mod n) Montgomery passes only:
+An element x of Z/n^2 is kept in half-width Montgomery form, x~ = x*R mod n^2 with R = 2^(29h) >= 16 n, written in
+"n-adic digits with a minus sign":   x~ = X0 - n*X1  (mod n^2),   X0 < 2n, X1 < 2n (lazily reduced).
 
-    square:   (u, m) = MQ(X0, X0);  X1' = MAC2(X0, 2*X1, m, gamma)
-    multiply: (u, m) = MQ(X0, Y0);  X1' = MAC2(X0, Y1, m, gamma) + MONT(X1, Y0)
+With MQ a Montgomery product modulo n that also returns its quotient m (X0*Y0 + m*n = u*R exactly):
 
-MQ is a Montgomery product that also returns its quotient m (X0*Y0 + m*n = u*R exactly), gamma = -R^-1 mod n.
-This file checks the algebra and the lazy-reduction bounds with Python integers (no limbs)."""
+    x*y :  (u, m) = MQ(X0, Y0);   Z0 = u;   Z1 = (m + X0*Y1 + X1*Y0) * R^-1 mod n
+    x^2 :  (u, m) = MQ(X0, X0);   Z0 = u;   Z1 = (m + X0*(2*X1))     * R^-1 mod n
+
+because x~ y~ = X0 Y0 - n (X0 Y1 + X1 Y0) = u R - n (m + X0 Y1 + X1 Y0) (mod n^2).  A squaring is two half-width
+Montgomery passes (one quarter of the multiply-adds of a full-width pass each), a product is one pass plus one
+pass with two products per digit."""
 import random
-
-
-def egcd_inv(a, n):
-    return pow(a, -1, n)
 
 
 class Split:
@@ -21,23 +20,17 @@ class Split:
         self.n2 = n * n
         self.R = 1 << (29 * h)
         assert self.R >= 16 * n
-        self.nprime = (-egcd_inv(n, self.R)) % self.R
-        self.rho = egcd_inv(self.R, n)
-        self.gamma = (n - self.rho) % n
-        self.beta = egcd_inv(self.R, self.n2)
+        self.nprime = (-pow(n, -1, self.R)) % self.R
         self.r1 = self.R % n
-        self.r2 = self.R * self.R % n
-        self.E = self.rep(1, 1)
+        self.E = self.pair_of(self.R % self.n2)  # the pair of 1
 
-    # constants.  K*R^j = z0 + z1*n (mod n^2) gives the pair (z0, z1*rho):
-    #   j = 1: rep_1(K) = (X0, X1)            (X1*R = z1 mod n)
-    #   j = 2: (D0, D1') with D1' = D1*R      (D1*R^2 = z1 mod n), the multiplier-side constant of conv()
-    def rep(self, K, j):
-        Z = K * pow(self.R, j, self.n2) % self.n2
-        return Z % self.n, (Z // self.n) * self.rho % self.n
+    def pair_of(self, xt):
+        """constant pair for Montgomery form xt = z0 + z1*n: (z0, -z1 mod n)"""
+        z0, z1 = xt % self.n, xt // self.n
+        return z0, (self.n - z1) % self.n
 
     def value(self, X):
-        return (X[0] * self.beta + X[1] * self.n) % self.n2
+        return (X[0] - self.n * X[1]) * pow(self.R, -1, self.n2) % self.n2
 
     def MQ(self, a, b):
         t = a * b
@@ -46,44 +39,39 @@ class Split:
         assert rem == 0
         return u, m
 
-    def MAC2(self, a, b, m, g):
-        v = a * b + m * g
+    def RED(self, v):
         m2 = v * self.nprime % self.R
         return (v + m2 * self.n) // self.R
 
-    def MONT(self, a, b):
-        return self.MAC2(a, b, 0, 0)
-
     def square(self, X):
         u, m = self.MQ(X[0], X[0])
-        return u, self.MAC2(X[0], 2 * X[1], m, self.gamma)
+        return u, self.RED(m + X[0] * (2 * X[1]))
 
     def mul(self, X, Y):
         u, m = self.MQ(X[0], Y[0])
-        return u, self.MAC2(X[0], Y[1], m, self.gamma) + self.MONT(X[1], Y[0])
+        return u, self.RED(m + X[0] * Y[1] + X[1] * Y[0])
 
     def conv(self, chunks):
-        """integer sum(chunks[j] * R^j) -> rep_1"""
+        """integer sum(chunks[j] * R^j), chunks < R  ->  pair"""
         X0 = X1 = 0
         for j, x in enumerate(chunks):
-            D0, D1 = self.rep(pow(self.R, j, self.n2), 2)
-            u, m = self.MQ(x, D0)
+            D = self.pair_of(pow(self.R, j + 2, self.n2))
+            u, m = self.MQ(x, D[0])
             X0 += u
-            X1 += self.MAC2(x, D1, m, self.gamma)
+            X1 += self.RED(m + x * D[1])
         X = (X0, X1)
         if len(chunks) > 1:
             X = self.mul(X, self.E)
         return X
 
     def exit(self, X, mp=0):
-        """plain canonical value of x * (1 + n*mp) mod n^2"""
+        """canonical value of x * (1 + n*mp) mod n^2"""
         n = self.n
         u, m = self.MQ(X[0], 1)
-        t = X[1] + self.MONT(m, n - 1)
+        t = self.RED(X[1] * (n - 1) + m * (n - 1))
         if mp:
-            t += self.MONT(self.MONT(mp, self.r2), u)
-        t = self.MONT(t, self.r1)
-        t %= n  # canonicalize
+            t += self.RED(mp * X[0])
+        t = self.RED(t * self.r1) % n
         v = u + n * t
         assert v < 2 * self.n2
         return v - self.n2 if v >= self.n2 else v
@@ -91,34 +79,34 @@ class Split:
 
 def check(bits, h, seed):
     rnd = random.Random(seed)
-    while True:
-        n = rnd.getrandbits(bits) | (1 << (bits - 1)) | 1
-        if n % 3 and n % 5:
-            break
+    n = rnd.getrandbits(bits) | (1 << (bits - 1)) | 1
     S = Split(n, h)
     n2 = n * n
-    # rep / value round trip
     for _ in range(5):
         x = rnd.randrange(n2)
-        X = S.conv([x % S.R, x // S.R])
-        assert S.value(X) == x, "conv"
-        assert X[0] < 2 * n and X[1] < 5 * n
-        assert S.exit(X) == x, "exit"
-    # products with worst-case lazy operands
+        chunks = []
+        while x or not chunks:
+            chunks.append(x % S.R)
+            x //= S.R
+        x = sum(c * S.R ** j for j, c in enumerate(chunks))
+        for pad in (0, 2):
+            X = S.conv(chunks + [0] * pad)
+            assert S.value(X) == x, "conv"
+            assert X[0] < 2 * n and X[1] < 3 * n
+            assert S.exit(X) == x, "exit"
     for _ in range(200):
-        X = (rnd.randrange(2 * n), rnd.randrange(5 * n))
-        Y = (rnd.randrange(2 * n), rnd.randrange(5 * n))
+        X = (rnd.randrange(2 * n), rnd.randrange(3 * n))
+        Y = (rnd.randrange(2 * n), rnd.randrange(3 * n))
         if rnd.random() < 0.2:
-            X = (2 * n - 1, 5 * n - 1)
+            X = (2 * n - 1, 3 * n - 1)
         if rnd.random() < 0.2:
-            Y = (2 * n - 1, 5 * n - 1)
+            Y = (2 * n - 1, 3 * n - 1)
         Z = S.mul(X, Y)
         assert S.value(Z) == S.value(X) * S.value(Y) % n2
-        assert Z[0] < 2 * n and Z[1] < 5 * n, (Z[0] / n, Z[1] / n)
+        assert Z[0] < 2 * n and Z[1] < 2 * n, (Z[0] / n, Z[1] / n)
         Q = S.square(X)
         assert S.value(Q) == pow(S.value(X), 2, n2)
-        assert Q[0] < 2 * n and Q[1] < 5 * n
-    # a whole encryption
+        assert Q[0] < 2 * n and Q[1] < 2 * n
     r = rnd.randrange(1, n)
     mp = rnd.randrange(n)
     X = S.conv([r])
