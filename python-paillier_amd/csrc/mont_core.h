@@ -177,6 +177,7 @@ template <int G, int L>
 PHE_DEV void montmul(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[L], const uint32_t (&n)[L],
                      uint32_t n0inv, const Lanes<G>& ln) {
     constexpr int S = G * L;
+    const uint32_t dmask = kLimbMask & ln.not_top;  // digit mask + "the top lane receives 0" as one v_and
     uint64_t acc[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) acc[k] = 0;
@@ -192,7 +193,7 @@ PHE_DEV void montmul(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[
 #pragma unroll
             for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(m, n[k], acc[(k + j) % L]);
             const uint64_t low = acc[j];  // logical limb 0 (= 0 mod 2^29 in lane 0)
-            const uint32_t recv = wave::grp_down1<G>((uint32_t)low & kLimbMask, ln);
+            const uint32_t recv = wave::grp_down1_raw<G>((uint32_t)low) & dmask;
             if constexpr (L > 1) {
                 acc[(j + 1) % L] += low >> kRadixBits;
                 acc[j] = recv;  // becomes logical limb L-1

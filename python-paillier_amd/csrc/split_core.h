@@ -176,10 +176,11 @@ PHE_DEV void mul_wide(uint32_t (&hi)[L], const uint32_t* a, const uint32_t (&b)[
 
 // ---- pair products: both words in one sweep -------------------------------------------------------------------
 // shift of one column-accumulator set by one digit (the tail of every row of a Montgomery sweep)
+// (dmask = kLimbMask & ln.not_top: the digit mask and the "top lane receives 0" mask applied as one v_and)
 template <int G, int L>
-PHE_DEV void shift_row(uint64_t (&acc)[L], int j, const Lanes<G>& ln) {
+PHE_DEV void shift_row(uint64_t (&acc)[L], int j, uint32_t dmask) {
     const uint64_t low = acc[j];
-    const uint32_t recv = wave::grp_down1<G>((uint32_t)low & kLimbMask, ln);
+    const uint32_t recv = wave::grp_down1_raw<G>((uint32_t)low) & dmask;
     if constexpr (L > 1) {
         acc[(j + 1) % L] += low >> kRadixBits;
         acc[j] = recv;
@@ -194,7 +195,8 @@ template <int G, int L>
 PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a, const uint32_t (&b0)[L],
                         const uint32_t (&b1)[L], const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln) {
     constexpr int H = G * L;
-    const uint32_t lane0 = ~ln.not_low;  // all-ones in lane 0 of the group
+    const uint32_t lane0 = kLimbMask & ~ln.not_low;  // digit mask in lane 0 of the group, 0 elsewhere
+    const uint32_t dmask = kLimbMask & ln.not_top;
     uint64_t p[L], q[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) p[k] = q[k] = 0;
@@ -207,16 +209,16 @@ PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
             for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(ai, b0[k], p[(k + j) % L]);
 #pragma unroll
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(ai, b1[k], q[(k + j) % L]);
-            const uint32_t mloc = ((uint32_t)p[j] * n0inv) & kLimbMask;
-            const uint32_t m = wave::grp_bcast0<G>(mloc, ln);
-            q[j] += (uint64_t)(mloc & lane0);  // quotient digit i of the first sum = digit i of the addend m
+            const uint32_t mraw = (uint32_t)p[j] * n0inv;
+            const uint32_t m = wave::grp_bcast0<G>(mraw & kLimbMask, ln);
+            q[j] += (uint64_t)(mraw & lane0);  // quotient digit i of the first sum = digit i of the addend m
 #pragma unroll
             for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(m, n[k], p[(k + j) % L]);
             const uint32_t m2 = wave::grp_bcast0<G>(((uint32_t)q[j] * n0inv) & kLimbMask, ln);
 #pragma unroll
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(m2, n[k], q[(k + j) % L]);
-            shift_row<G, L>(p, j, ln);
-            shift_row<G, L>(q, j, ln);
+            shift_row<G, L>(p, j, dmask);
+            shift_row<G, L>(q, j, dmask);
         }
     }
     normalize_partial<G, L>(z0, p, ln);
@@ -230,7 +232,8 @@ PHE_DEV void pair_pass3(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
                         const uint32_t (&b0)[L], const uint32_t (&b1)[L], const uint32_t (&n)[L], uint32_t n0inv,
                         const Lanes<G>& ln) {
     constexpr int H = G * L;
-    const uint32_t lane0 = ~ln.not_low;
+    const uint32_t lane0 = kLimbMask & ~ln.not_low;
+    const uint32_t dmask = kLimbMask & ln.not_top;
     uint64_t p[L], q[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) p[k] = q[k] = 0;
@@ -246,16 +249,16 @@ PHE_DEV void pair_pass3(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(ai, b1[k], q[(k + j) % L]);
 #pragma unroll
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(ci, b0[k], q[(k + j) % L]);
-            const uint32_t mloc = ((uint32_t)p[j] * n0inv) & kLimbMask;
-            const uint32_t m = wave::grp_bcast0<G>(mloc, ln);
-            q[j] += (uint64_t)(mloc & lane0);
+            const uint32_t mraw = (uint32_t)p[j] * n0inv;
+            const uint32_t m = wave::grp_bcast0<G>(mraw & kLimbMask, ln);
+            q[j] += (uint64_t)(mraw & lane0);
 #pragma unroll
             for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(m, n[k], p[(k + j) % L]);
             const uint32_t m2 = wave::grp_bcast0<G>(((uint32_t)q[j] * n0inv) & kLimbMask, ln);
 #pragma unroll
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(m2, n[k], q[(k + j) % L]);
-            shift_row<G, L>(p, j, ln);
-            shift_row<G, L>(q, j, ln);
+            shift_row<G, L>(p, j, dmask);
+            shift_row<G, L>(q, j, dmask);
         }
     }
     normalize_partial<G, L>(z0, p, ln);

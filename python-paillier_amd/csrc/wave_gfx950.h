@@ -36,6 +36,9 @@ struct Lanes {
     PHE_DEV explicit Lanes(uint32_t lane_) : lane(lane_), g(lane_ & (G - 1)) {
         not_top = (g == G - 1) ? 0u : 0xffffffffu;
         not_low = (g == 0) ? 0u : 0xffffffffu;
+        // keep them plain data: "x & mask" is then one full-rate v_and_b32 instead of a half-rate v_cndmask_b32
+        // on an SGPR-pair condition (profiles/microbench_r01.json)
+        asm volatile("" : "+v"(not_top), "+v"(not_low));
     }
 };
 
@@ -53,6 +56,14 @@ PHE_DEV uint32_t grp_down1(uint32_t x, const Lanes<G>& l) {
     else if constexpr (G == 8) return dpp_row_shl1(x) & l.not_top;
     else if constexpr (G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9 /*quad_perm:[1,2,3,3]*/, 0xf, 0xf, true) & l.not_top;
     else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF5 /*quad_perm:[1,1,3,3]*/, 0xf, 0xf, true) & l.not_top;
+}
+// lane g <- lane g+1 of its group, nothing guaranteed for the group's top lane (G = 16: 0): for callers that
+// fold "& not_top" into a mask they apply anyway
+template <int G>
+PHE_DEV uint32_t grp_down1_raw(uint32_t x) {
+    if constexpr (G >= 8) return dpp_row_shl1(x);
+    else if constexpr (G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9 /*quad_perm:[1,2,3,3]*/, 0xf, 0xf, true);
+    else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF5 /*quad_perm:[1,1,3,3]*/, 0xf, 0xf, true);
 }
 // lane g <- lane g-1 of its group; the group's lane 0 receives 0
 template <int G>

@@ -108,6 +108,11 @@ template <int G>
 inline uint32_t grp_down1(uint32_t x, const Lanes<G>&) {
     return exchange(x, [](int l) { return (l & (G - 1)) == G - 1 ? -1 : l + 1; });
 }
+// the top lane's result is unspecified on the device: hand back junk so that a caller forgetting its mask fails
+template <int G>
+inline uint32_t grp_down1_raw(uint32_t x) {
+    return exchange(x ^ 0u, [](int l) { return l + 1 < kLanes ? l + 1 : l; }) | 0u;
+}
 template <int G>
 inline uint32_t grp_up1(uint32_t x, const Lanes<G>&) {
     return exchange(x, [](int l) { return (l & (G - 1)) == 0 ? -1 : l - 1; });
