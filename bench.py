@@ -11,9 +11,12 @@ timed region starts.  One process per GPU; N>1 is launched by torch.distributed.
 at the barriers (the batch is embarrassingly sharded: no data-path collective).
 
 Also printed in the same JSON line:
-  roofline     — dominant kernel (k_modexp_uniform<8, encrypt>): algorithmic MAC32 per launch
-                 / average launch duration measured with HIP events on the launch stream, against the
-                 integer-VALU peak calibrated by csrc/microbench.hip (profiles/microbench_*.json).
+  roofline     — dominant kernel (k_modexp_split<4,18,encrypt> at 2048 bits): algorithmic MAC32 (SURVEY.md 8(d):
+                 the canonical full-width Montgomery count) per launch / average launch duration measured with
+                 HIP events on the launch stream, against the integer-VALU peak calibrated by csrc/microbench.hip
+                 (profiles/microbench_*.json).  The split-modulus kernels execute fewer multiply-adds than that
+                 canonical count (csrc/split_core.h), so `frac` can exceed 1; `executed` gives the multiply-adds
+                 the kernel really issues and their fraction of the same peak.
   cpu_baseline — the libgmp oracle (what gmpy2 executes) on all host cores over a bounded sample of the same
                  workload, rank 0 at N=1 only.
 """
@@ -40,6 +43,27 @@ def mac32_counts(key_bits):
     E = lambda t: t + -(-t // 6) + 16
     enc = s1 * s1 + (E(key_bits) + 3) * mont(s2)
     dec = 2 * mont(s1) + 2 * (E(key_bits // 2) + 2) * mont(s1) + 3 * sh * sh + 4 * mont(sh)
+    return enc, dec
+
+
+def executed_mads(key_bits, info):
+    """v_mad_u64_u32 lane-operations one encrypt / one decrypt really executes (29-bit limbs; schedule counted like
+    SURVEY's E(t): t squarings, ceil(t/6) + 16 products).  Split engine: a squaring is 4 H^2, a product 5 H^2, entry
+    4 H^2 per input chunk (+5 H^2 when more than one), exit ~10 H^2 (csrc/split_core.h); full-width engine: 2 S^2 per
+    Montgomery product."""
+    E_sq = lambda t: t
+    E_mul = lambda t: -(-t // 6) + 16
+
+    def modexp(t, lane_limbs, split, in_bits, extra):
+        G, L = divmod(lane_limbs, 100)
+        H = G * L
+        if split:
+            chunks = max(1, -(-in_bits // (29 * H)))
+            return (4 * E_sq(t) + 5 * E_mul(t) + 4 * chunks + (5 if chunks > 1 else 0) + 10 + extra) * H * H
+        return (E_sq(t) + E_mul(t) + 3) * 2 * H * H
+
+    enc = modexp(key_bits, info["lane_limbs_pub"], info["engine_pub"] == "split", key_bits, 2)
+    dec = 2 * modexp(key_bits // 2, info["lane_limbs_priv"], info["engine_priv"] == "split", 2 * key_bits, 0)
     return enc, dec
 
 
@@ -220,8 +244,12 @@ def main():
     if rank == 0:
         enc_mac, dec_mac = mac32_counts(args.key_bits)
         peak, sustained, peak_src = valu_peak_mac32()
-        traffic_unit, traffic_src = measured_traffic_per_unit("k_modexp_uniform<4,36,encrypt>") if (
-            args.key_bits == 2048 and ctx.info()["lane_limbs_pub"] == 436) else (None, None)
+        info = ctx.info()
+        kname = lambda limbs, eng, mode: "k_modexp_%s<%d,%d,%s>" % (("split" if eng == "split" else "uniform",) + divmod(limbs, 100) + (mode,))
+        enc_kernel = kname(info["lane_limbs_pub"], info["engine_pub"], "encrypt")
+        dec_kernel = kname(info["lane_limbs_priv"], info["engine_priv"], "half_decrypt")
+        traffic_unit, traffic_src = measured_traffic_per_unit(enc_kernel) if args.key_bits == 2048 else (None, None)
+        enc_exec, dec_exec = executed_mads(args.key_bits, info)
         enc_kernel_s = sum(enc_launch_ms) / len(enc_launch_ms) * 1e-3
         dec_kernel_s = sum(dec_launch_ms) / len(dec_launch_ms) * 1e-3
         achieved = enc_mac * B / enc_kernel_s
@@ -234,13 +262,17 @@ def main():
             "config": {"workload": "configs[1]: %d-bit key, %d-plaintext batch per GPU, raw_encrypt then raw_decrypt, "
                                    "operands resident in HBM" % (args.key_bits, B),
                        "key_bits": args.key_bits, "batch_per_gpu": B, "parallelism": "batch-sharded x%d" % world,
-                       "geometry": ctx.info()},
+                       "geometry": info},
             "decrypt": {"value": world * B * args.steps / dec_dt, "unit": "decrypts/s",
                         "ms_per_step": dec_dt / args.steps * 1e3},
             "bit_exact": {"roundtrip_full_batch": roundtrip_ok, "strided_sample_vs_gmp_oracle": sample_ok},
             "roofline": {
-                "bound": "valu_int32", "kernel": "k_modexp_uniform<G=%d, L=%d, encrypt> (radix 2^29)" % divmod(ctx.info()["lane_limbs_pub"], 100),
+                "bound": "valu_int32", "kernel": enc_kernel + " (radix 2^29)",
                 "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": achieved / peak,
+                "achieved_note": "SURVEY.md 8(d) canonical MAC32 per encrypt (full-width Montgomery) x batch / launch time",
+                "executed": {"mad_per_encrypt": enc_exec, "rate_Tmad_per_s": enc_exec * B / enc_kernel_s / 1e12,
+                             "frac_of_peak": enc_exec * B / enc_kernel_s / peak,
+                             "note": "v_mad_u64_u32 lane-operations the kernel really issues (29-bit limbs)"},
                 "traffic": (traffic_unit * B) if traffic_unit else None,
                 "traffic_note": ("HBM+MALL bytes per launch = %.0f B/encrypt (PMC FETCH_SIZE x2 + WRITE_SIZE, %s) x batch; "
                                  "algorithmic bytes are %d B/encrypt" % (traffic_unit, traffic_src, (2 * s1 + s2) * 4))
@@ -249,10 +281,11 @@ def main():
                 "peak_source": "256 CUs x 4 SIMD x 64 lanes x 2.4 GHz / 4 cycles per v_mad_u64_u32 (half-rate, calibrated)",
                 "peak_sustained_microbench": (sustained / 1e12) if sustained else None, "microbench": peak_src,
                 "hbm_algorithmic_GBps": (2 * s1 + s2) * 4 * B / enc_kernel_s / 1e9, "hbm_peak_GBps": 8000.0,
-                "decrypt": {"kernel": "2 x k_modexp_uniform<G=%d, L=%d, half_decrypt> + k_decrypt_tail" % divmod(
-                                ctx.info()["lane_limbs_priv"], 100),
+                "decrypt": {"kernel": "2 x %s + k_decrypt_tail" % dec_kernel,
                             "achieved": dec_mac * B / dec_kernel_s / 1e12, "frac": dec_mac * B / dec_kernel_s / peak,
-                            "mac32_per_decrypt": dec_mac, "launch_ms_avg": dec_kernel_s * 1e3},
+                            "mac32_per_decrypt": dec_mac, "launch_ms_avg": dec_kernel_s * 1e3,
+                            "executed": {"mad_per_decrypt": dec_exec, "rate_Tmad_per_s": dec_exec * B / dec_kernel_s / 1e12,
+                                         "frac_of_peak": dec_exec * B / dec_kernel_s / peak}},
             },
             "cpu_baseline": cpu,
         }

@@ -67,6 +67,13 @@ void phe_hip_ctx_destroy(phe_hip_ctx* ctx);
 int phe_hip_ctx_info(const phe_hip_ctx* ctx, int* n_limbs, int* ct_limbs, int* lanes_limbs_pub,
                      int* lane_limbs_priv, int* rows_in_flight, int* has_private);
 
+/* Which kernels run the batch-uniform exponentiations of this context: *split_pub / *split_priv = 1 when the
+ * split-modulus kernels (k_modexp_split, half-width pair arithmetic modulo n / p / q, csrc/split_core.h) are in
+ * use for encrypt+obfuscate / decrypt, 0 for the full-width kernels (k_modexp_uniform; PHE_HIP_ENGINE=full or a
+ * key width no split kernel is compiled for).  lane_limbs_* of phe_hip_ctx_info describe the kernels in use.
+ * Results are identical either way.  Any pointer may be NULL. */
+int phe_hip_ctx_engine(const phe_hip_ctx* ctx, int* split_pub, int* split_priv);
+
 /* Tuning: workgroups (256 threads) resident per CU for the modexp kernels; 0 = ask the HIP occupancy API
  * per kernel (the default). */
 int phe_hip_ctx_set_blocks_per_cu(phe_hip_ctx* ctx, int blocks_per_cu);

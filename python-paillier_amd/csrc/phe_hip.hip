@@ -6,7 +6,8 @@
 //   k_modexp_split<G, L, MODE>    the same three jobs on the split-modulus pair representation (split_core.h):
 //                                 half-width passes modulo n / p / q, ~1/3 fewer multiply-adds; the default engine
 //                                 (PHE_HIP_ENGINE=full selects k_modexp_uniform instead)
-//   k_modexp_var<G, L>            per-element exponent (powmod of _raw_mul)
+//   k_modexp_var_split<G, L>      per-element exponent (powmod of _raw_mul) on the pair representation
+//   k_modexp_var<G, L>            the same on the full-width modulus (PHE_HIP_ENGINE=full)
 //   k_mulmod<G, L>                a*b mod n^2 (_raw_add, add-plaintext, the product tree of batched inversion)
 //     (these three live in group_kernels.inc, instantiated by kernels_g*.hip, one TU per group width)
 //   k_decrypt_tail                L-function, *hp, CRT recombination, one ciphertext per thread
@@ -65,6 +66,8 @@ PHE_DECLARE_PART(g16b)
     namespace P {                                                                                 \
     int occ_split(int L, int mode);                                                               \
     int launch_split(int L, int mode, int blocks, hipStream_t st, const SplitArgs& A);            \
+    int occ_var_split(int L);                                                                     \
+    int launch_var_split(int L, int blocks, hipStream_t st, const SplitVarArgs& A);               \
     }
 PHE_DECLARE_SPLIT_PART(s2a)
 PHE_DECLARE_SPLIT_PART(s2b)
@@ -104,13 +107,20 @@ struct SplitPart {
     int G;
     int (*occ_split)(int, int);
     int (*launch_split)(int, int, int, hipStream_t, const SplitArgs&);
+    int (*occ_var_split)(int);
+    int (*launch_var_split)(int, int, hipStream_t, const SplitVarArgs&);
 };
 static const SplitPart kSplitParts[] = {
-    {2, phe::s2a::occ_split, phe::s2a::launch_split},    {2, phe::s2b::occ_split, phe::s2b::launch_split},
-    {4, phe::s4a::occ_split, phe::s4a::launch_split},    {4, phe::s4b::occ_split, phe::s4b::launch_split},
-    {8, phe::s8a::occ_split, phe::s8a::launch_split},    {8, phe::s8b::occ_split, phe::s8b::launch_split},
-    {8, phe::s8c::occ_split, phe::s8c::launch_split},    {16, phe::s16a::occ_split, phe::s16a::launch_split},
-    {16, phe::s16b::occ_split, phe::s16b::launch_split}, {16, phe::s16c::occ_split, phe::s16c::launch_split},
+    {2, phe::s2a::occ_split, phe::s2a::launch_split, phe::s2a::occ_var_split, phe::s2a::launch_var_split},
+    {2, phe::s2b::occ_split, phe::s2b::launch_split, phe::s2b::occ_var_split, phe::s2b::launch_var_split},
+    {4, phe::s4a::occ_split, phe::s4a::launch_split, phe::s4a::occ_var_split, phe::s4a::launch_var_split},
+    {4, phe::s4b::occ_split, phe::s4b::launch_split, phe::s4b::occ_var_split, phe::s4b::launch_var_split},
+    {8, phe::s8a::occ_split, phe::s8a::launch_split, phe::s8a::occ_var_split, phe::s8a::launch_var_split},
+    {8, phe::s8b::occ_split, phe::s8b::launch_split, phe::s8b::occ_var_split, phe::s8b::launch_var_split},
+    {8, phe::s8c::occ_split, phe::s8c::launch_split, phe::s8c::occ_var_split, phe::s8c::launch_var_split},
+    {16, phe::s16a::occ_split, phe::s16a::launch_split, phe::s16a::occ_var_split, phe::s16a::launch_var_split},
+    {16, phe::s16b::occ_split, phe::s16b::launch_split, phe::s16b::occ_var_split, phe::s16b::launch_var_split},
+    {16, phe::s16c::occ_split, phe::s16c::launch_split, phe::s16c::occ_var_split, phe::s16c::launch_var_split},
 };
 #define PHE_SPLIT_BY_GROUP(G_, CALL2)                 \
     [&]() -> int {                                    \
@@ -410,6 +420,35 @@ static int launch_split(phe_hip_ctx* ctx, const DevSplit& M, const DevSchedule& 
     return PHE_HIP_OK;
 }
 
+static int launch_var_split(phe_hip_ctx* ctx, const DevSplit& M, const uint32_t* base, int base_limbs,
+                            const uint32_t* e, int exp_limbs, int max_bits, uint32_t* out, int out_limbs, size_t batch,
+                            hipStream_t stream) {
+    SplitVarArgs A;
+    A.mod = M.c;
+    A.base = base;
+    A.base_limbs = base_limbs;
+    A.base_chunks = chunks_for(base_limbs, M.H);
+    A.exps = e;
+    A.exp_limbs = exp_limbs;
+    A.window = host::pick_window(max_bits);
+    A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
+    A.out = out;
+    A.out_limbs = out_limbs;
+    A.batch = batch;
+    int per_cu = ctx->blocks_per_cu;
+    if (per_cu == 0) per_cu = PHE_SPLIT_BY_GROUP(M.G, occ_var_split(M.L));
+    if (per_cu < 0) return fail(PHE_HIP_EINVAL, "unsupported split geometry");
+    const int blocks = grid_blocks(ctx, batch, M.G, per_cu);
+    const size_t rows = (size_t)blocks * (size_t)(kBlock / M.G);
+    int rc = ensure_words(&ctx->table, &ctx->table_words, rows * ((size_t)1 << A.window) * 2 * M.H);
+    if (rc) return rc;
+    A.table = ctx->table;
+    if (PHE_SPLIT_BY_GROUP(M.G, launch_var_split(M.L, blocks, stream, A)) < 0)
+        return fail(PHE_HIP_EINVAL, "unsupported split geometry");
+    HIP_TRY(hipGetLastError());
+    return PHE_HIP_OK;
+}
+
 static int launch_var(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* base, int base_limbs,
                       const uint32_t* e, int exp_limbs, int max_bits, uint32_t* out, int out_limbs, size_t batch,
                       hipStream_t stream) {
@@ -626,6 +665,13 @@ int phe_hip_ctx_info(const phe_hip_ctx* ctx, int* n_limbs, int* ct_limbs, int* l
     return PHE_HIP_OK;
 }
 
+int phe_hip_ctx_engine(const phe_hip_ctx* ctx, int* split_pub, int* split_priv) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (split_pub) *split_pub = (ctx->use_split && ctx->pub.nsplit.G) ? 1 : 0;
+    if (split_priv) *split_priv = (ctx->has_private && ctx->use_split && ctx->priv.psplit.G && ctx->priv.qsplit.G) ? 1 : 0;
+    return PHE_HIP_OK;
+}
+
 int phe_hip_ctx_set_blocks_per_cu(phe_hip_ctx* ctx, int blocks_per_cu) {
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
     if (blocks_per_cu < 0 || blocks_per_cu > 8) return fail(PHE_HIP_EINVAL, "blocks_per_cu must be in 0..8 (0 = automatic)");
@@ -727,6 +773,9 @@ int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e
     if (!base || !e || !out || exp_limbs < 1) return fail(PHE_HIP_EINVAL, "null buffer / exp_limbs");
     if (max_exp_bits <= 0 || max_exp_bits > 32 * exp_limbs) max_exp_bits = 32 * exp_limbs;
     if (int rc = bind_device(ctx)) return rc;
+    if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G)
+        return launch_var_split(ctx, sp, base, ctx->pub.s2, e, exp_limbs, max_exp_bits, out, ctx->pub.s2, batch,
+                                (hipStream_t)stream);
     return launch_var(ctx, pick_nsq(ctx, batch), base, ctx->pub.s2, e, exp_limbs, max_exp_bits, out, ctx->pub.s2, batch,
                       (hipStream_t)stream);
 }

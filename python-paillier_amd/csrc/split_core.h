@@ -496,4 +496,75 @@ PHE_DEV void modexp_split_body(const SplitArgs& A, uint32_t* lds_row, uint32_t s
     }
 }
 
+// Per-element exponents (phe/paillier.py:751 powmod(c, scalar, n^2); :749 with the inverted base) on the pair
+// representation: fixed 2^w-ary windows over the batch-wide maximum bit length, as modexp_var_body (mont_core.h).
+struct SplitVarArgs {
+    SplitConsts mod;
+    const uint32_t* base;  // (batch, base_limbs), any value below 2^(32*base_limbs)
+    int base_limbs;
+    int base_chunks;
+    const uint32_t* exps;  // (batch, exp_limbs)
+    int exp_limbs;
+    int window;      // w in 1..5
+    int n_windows;   // ceil(max_bits / w), >= 1
+    uint32_t* out;
+    int out_limbs;
+    uint32_t* table;  // scratch: total_groups * 2^w * 2H words
+    uint64_t batch;
+};
+
+template <int G, int L>
+PHE_DEV void modexp_var_split_body(const SplitVarArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots,
+                                   uint32_t lane) {
+    constexpr int H = G * L, S2 = 2 * H;
+    const Lanes<G> ln(lane);
+    const uint32_t g = ln.g;
+    SplitLane<G, L> K;
+    load_row<L>(K.n, A.mod.n, g);
+    K.n0inv = A.mod.n0inv;
+    K.row_a = lds_row;
+    K.row_c = lds_row + H;
+    const int tbl_entries = 1 << A.window;
+    uint32_t* tbl = A.table + (size_t)slot * (size_t)tbl_entries * S2;
+    const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
+    for (uint64_t it = 0; it < n_iter; ++it) {
+        uint64_t item = slot + it * (uint64_t)total_slots;
+        const bool live = item < A.batch;
+        if (!live) item = A.batch - 1;
+        uint32_t X0[L], X1[L], Y0[L], Y1[L];
+        split_conv<G, L>(Y0, Y1, A.base + item * (uint64_t)A.base_limbs, A.base_limbs, A.base_chunks, A.mod, K, ln);
+        // table: base^0 (the pair of 1) .. base^(2^w - 1)
+        load_row<L>(X0, A.mod.e, g);
+        load_row<L>(X1, A.mod.e + H, g);
+        store_row<L>(tbl, X0, g);
+        store_row<L>(tbl + H, X1, g);
+        store_row<L>(tbl + S2, Y0, g);
+        store_row<L>(tbl + S2 + H, Y1, g);
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            X0[k] = Y0[k];
+            X1[k] = Y1[k];
+        }
+        for (int j = 2; j < tbl_entries; ++j) {
+            split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
+            store_row<L>(tbl + (size_t)j * S2, X0, g);
+            store_row<L>(tbl + (size_t)j * S2 + H, X1, g);
+        }
+        const uint32_t* e = A.exps + item * (uint64_t)A.exp_limbs;
+        uint32_t d = exp_digit(e, A.exp_limbs, (A.n_windows - 1) * A.window, A.window);
+        load_row<L>(X0, tbl + (size_t)d * S2, g);
+        load_row<L>(X1, tbl + (size_t)d * S2 + H, g);
+        for (int wi = A.n_windows - 2; wi >= 0; --wi) {
+            for (int s = 0; s < A.window; ++s) split_square<G, L>(X0, X1, K, ln);
+            d = exp_digit(e, A.exp_limbs, wi * A.window, A.window);
+            if (wave::ballot(d != 0) != 0) {  // wave-uniform: skip when every group has a zero digit
+                load_row<L>(Y0, tbl + (size_t)d * S2, g);
+                load_row<L>(Y1, tbl + (size_t)d * S2 + H, g);
+                split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
+            }
+        }
+        split_exit<G, L>(A.out + item * (uint64_t)A.out_limbs, A.out_limbs, X0, X1, nullptr, 0, A.mod, K, ln, live);
+    }
+}
+
 }  // namespace phe

@@ -39,6 +39,7 @@ def lib():
         L.phe_hip_ctx_destroy.argtypes = [vp]
         L.phe_hip_ctx_destroy.restype = None
         L.phe_hip_ctx_info.argtypes = [vp] + [ctypes.POINTER(ci)] * 6
+        L.phe_hip_ctx_engine.argtypes = [vp] + [ctypes.POINTER(ci)] * 2
         L.phe_hip_ctx_set_blocks_per_cu.argtypes = [vp, ci]
         L.phe_hip_encrypt.argtypes = [vp, vp, vp, vp, sz]
         L.phe_hip_obfuscate.argtypes = [vp, vp, vp, vp, sz]
@@ -73,7 +74,7 @@ EXPORTED_SYMBOLS = [
     "phe_hip_encrypt_dev", "phe_hip_obfuscate_dev", "phe_hip_decrypt_dev", "phe_hip_mulmod_dev",
     "phe_hip_powmod_dev", "phe_hip_malloc", "phe_hip_free", "phe_hip_memcpy_h2d", "phe_hip_memcpy_d2h",
     "phe_hip_stream_sync", "phe_hip_selftest_prims", "phe_hip_memcpy_d2d", "phe_hip_invert_dev",
-    "phe_hip_select_rows_dev", "phe_hip_add_plain", "phe_hip_add_plain_dev",
+    "phe_hip_select_rows_dev", "phe_hip_add_plain", "phe_hip_add_plain_dev", "phe_hip_ctx_engine",
 ]
 
 
@@ -171,7 +172,12 @@ class Context:
         vals = [ctypes.c_int(0) for _ in range(6)]
         _check(lib().phe_hip_ctx_info(self._h, *[ctypes.byref(v) for v in vals]))
         keys = ["n_limbs", "ct_limbs", "lane_limbs_pub", "lane_limbs_priv", "rows_in_flight", "has_private"]
-        return dict(zip(keys, [v.value for v in vals]))
+        out = dict(zip(keys, [v.value for v in vals]))
+        eng = [ctypes.c_int(0), ctypes.c_int(0)]
+        _check(lib().phe_hip_ctx_engine(self._h, ctypes.byref(eng[0]), ctypes.byref(eng[1])))
+        out["engine_pub"] = "split" if eng[0].value else "full"
+        out["engine_priv"] = ("split" if eng[1].value else "full") if out["has_private"] else None
+        return out
 
     def set_blocks_per_cu(self, k):
         _check(lib().phe_hip_ctx_set_blocks_per_cu(self._h, int(k)))

@@ -152,6 +152,22 @@ static void run_split(SplitArgs A) {
     }
 }
 
+template <int G, int L>
+static void run_var_split(SplitVarArgs A) {
+    constexpr int S2 = 2 * G * L, kPer = 64 / G;
+    const int n_waves = waves_for(A.batch, G);
+    const uint32_t total = (uint32_t)(kPer * n_waves);
+    std::vector<uint32_t> table((size_t)total * ((size_t)1 << A.window) * S2);
+    A.table = table.data();
+    for (int w = 0; w < n_waves; ++w) {
+        std::vector<uint32_t> lds(kPer * (S2 + kLdsPad));
+        wave::run_wave([&](uint32_t lane) {
+            const uint32_t grp = lane / G;
+            modexp_var_split_body<G, L>(A, lds.data() + grp * (S2 + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
+        });
+    }
+}
+
 static int g_prefer_group = 0;
 static int g_engine = 1;  // 1: split-modulus kernels where a geometry exists (the product default), 0: full-width only
 
@@ -315,6 +331,40 @@ int emu_powmod_var(const uint32_t* N, int limbs, const uint32_t* base, const uin
         A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
         A.out = out; A.out_limbs = limbs; A.batch = B;
         DISPATCH_GL(M.G, M.L, (run_var<GG, LL>(A)));
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// out = base^exp mod n^2 with per-row exponents, the way phe_hip_powmod runs it (split-modulus kernel when the
+// engine is on and a geometry exists, else the full-width kernel on n^2)
+int emu_powmod_n2(const uint32_t* n, int n_limbs, const uint32_t* base, const uint32_t* exps, int exp_limbs,
+                  uint32_t* out, uint64_t B) {
+    try {
+        if (B == 0) return 0;
+        host::PublicPlan P = host::build_public(n, n_limbs, g_prefer_group);
+        int max_bits = 0;
+        for (uint64_t i = 0; i < B; ++i)
+            max_bits = std::max(max_bits, host::big_bits(host::big_from(exps + i * exp_limbs, exp_limbs, exp_limbs)));
+        if (g_engine && P.nsplit.G) {
+            const host::SplitPack& M = P.nsplit;
+            SplitVarArgs A;
+            memset(&A, 0, sizeof A);
+            A.mod = split_consts_of(M);
+            A.base = base; A.base_limbs = P.s2; A.base_chunks = chunks_for(P.s2, M.H);
+            A.exps = exps; A.exp_limbs = exp_limbs;
+            A.window = host::pick_window(max_bits);
+            A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
+            A.out = out; A.out_limbs = P.s2; A.batch = B;
+            DISPATCH_SPLIT(M.G, M.L, (run_var_split<GG, LL>(A)));
+            return 0;
+        }
+        VarArgs A;
+        memset(&A, 0, sizeof A);
+        A.mod = consts_of(P.nsq); A.base = base; A.base_limbs = P.s2; A.exps = exps; A.exp_limbs = exp_limbs;
+        A.window = host::pick_window(max_bits);
+        A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
+        A.out = out; A.out_limbs = P.s2; A.batch = B;
+        DISPATCH_GL(P.nsq.G, P.nsq.L, (run_var<GG, LL>(A)));
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }

@@ -72,7 +72,7 @@ class EmuContext:
     def powmod(self, base, exps):
         if base.shape[0] == 0:
             return base.copy()
-        return emu().powmod_var(self._nsq_arr, np.ascontiguousarray(base), np.ascontiguousarray(exps))
+        return emu().powmod_n2(self._n_arr, np.ascontiguousarray(base), np.ascontiguousarray(exps))
 
     def invert(self, a):
         # the product runs a mulmod product tree on the GPU plus one scalar inversion; the emulator

@@ -77,6 +77,13 @@ class Emu:
                                        ctypes.c_uint64(base.shape[0])))
         return out
 
+    def powmod_n2(self, n, base, exps):
+        """base^exp mod n^2 the way phe_hip_powmod runs it (split-modulus kernel when the engine is on)"""
+        out = np.zeros_like(base)
+        self._ck(self.L.emu_powmod_n2(P(n), n.shape[0], P(base), P(exps), exps.shape[1], P(out),
+                                      ctypes.c_uint64(base.shape[0])))
+        return out
+
     def modulus_geometry(self, N):
         GL = (ctypes.c_int * 2)()
         self._ck(self.L.emu_modulus_geometry(P(N), N.shape[0], GL))

@@ -115,9 +115,13 @@ def test_reference_kat(emu):
     assert limbs_to_ints(m) == [k["m"], 1]
 
 
-@pytest.mark.parametrize("key_bits,count,group", [(256, None, 16), (256, None, 8), (1024, 5, 0), (1024, 3, 16),
-                                                  (1024, 3, 4), (1024, 3, 2), (2048, 2, 0)])
-def test_golden_through_emulator(emu, key_bits, count, group):
+# engine "split": the split-modulus kernels (csrc/split_core.h, the product default); "full": mont_core.h on n^2, p^2, q^2
+@pytest.mark.parametrize("engine,key_bits,count,group", [
+    ("split", 256, None, 16), ("split", 256, None, 8), ("split", 1024, 5, 0), ("split", 1024, 3, 16),
+    ("split", 1024, 3, 4), ("split", 1024, 2, 8), ("split", 2048, 1, 0),
+    ("full", 256, None, 16), ("full", 1024, 2, 0), ("full", 1024, 2, 4)])
+def test_golden_through_emulator(emu, engine, key_bits, count, group):
+    emu.set_engine(engine == "split")
     emu.set_group(group)
     g = load_golden(key_bits)
     s1, s2, h = key_bits // 32, key_bits // 16, key_bits // 64
@@ -134,9 +138,13 @@ def test_golden_through_emulator(emu, key_bits, count, group):
     key = [int_to_limbs(H(g[k]), h) for k in ("p", "q", "hp", "hq", "p_inverse")]
     m = emu.decrypt(*key, s1, ints_to_limbs([H(e["c"]) for e in dec], s2))
     assert limbs_to_ints(m) == [H(e["m"]) for e in dec]
+    emu.set_engine(True)
+    emu.set_group(0)
 
 
-def test_homomorphic_ops_through_emulator(emu):
+@pytest.mark.parametrize("engine", ["split", "full"])
+def test_homomorphic_ops_through_emulator(emu, engine):
+    emu.set_engine(engine == "split")
     g = load_golden(256)
     s1, s2 = 8, 16
     n_int = H(g["n"])
@@ -153,13 +161,35 @@ def test_homomorphic_ops_through_emulator(emu):
     # positive-branch scalar multiplications are plain powmods (phe/paillier.py:751)
     max_int = H(g["max_int"])
     mul = [e for e in g["raw_mul"] if H(e["s"]) < n_int - max_int]
-    got = emu.powmod_var(N, ints_to_limbs([H(e["c"]) for e in mul], s2), ints_to_limbs([H(e["s"]) for e in mul], s1))
+    n_arr = int_to_limbs(n_int, s1)
+    got = emu.powmod_n2(n_arr, ints_to_limbs([H(e["c"]) for e in mul], s2), ints_to_limbs([H(e["s"]) for e in mul], s1))
     assert limbs_to_ints(got) == [H(e["out"]) for e in mul]
     # negative branch: powmod(invert(c), n - s) (phe/paillier.py:745-749); the inverse comes from Python here
     neg = [e for e in g["raw_mul"] if H(e["s"]) >= n_int - max_int]
     bases = [pow(H(e["c"]), -1, n_int * n_int) for e in neg]
-    got = emu.powmod_var(N, ints_to_limbs(bases, s2), ints_to_limbs([n_int - H(e["s"]) for e in neg], s1))
+    got = emu.powmod_n2(n_arr, ints_to_limbs(bases, s2), ints_to_limbs([n_int - H(e["s"]) for e in neg], s1))
     assert limbs_to_ints(got) == [H(e["out"]) for e in neg]
+    emu.set_engine(True)
+
+
+@pytest.mark.parametrize("key_bits,group", [(1024, 0), (1024, 8), (2048, 0)])
+def test_powmod_n2_split_engine(emu, key_bits, group):
+    """per-element exponents through k_modexp_var_split's body: 0, 1, short, long and full-width exponents; bases
+    0, 1, n^2 - 1, multiples of n and random residues"""
+    emu.set_engine(True)
+    emu.set_group(group)
+    g = load_golden(key_bits)
+    n_int = H(g["n"])
+    nsq = n_int * n_int
+    s1, s2 = key_bits // 32, key_bits // 16
+    rng = random.Random(key_bits + group)
+    bases = [0, 1, nsq - 1, n_int, n_int * (n_int - 1), rng.randrange(nsq), rng.randrange(nsq), rng.randrange(nsq)]
+    exps = [5, 0, 3, 2, 1, rng.getrandbits(56), 16 ** 9, rng.getrandbits(32 * s1)]
+    if key_bits > 1024:
+        bases, exps = bases[:6], exps[:6]
+    got = emu.powmod_n2(int_to_limbs(n_int, s1), ints_to_limbs(bases, s2), ints_to_limbs(exps, s1))
+    assert limbs_to_ints(got) == [pow(b, e, nsq) for b, e in zip(bases, exps)]
+    emu.set_group(0)
 
 
 def test_powmod_var_mixed_lengths(emu):

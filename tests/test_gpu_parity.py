@@ -74,6 +74,20 @@ def group(request, monkeypatch):
 
 @pytest.mark.parametrize("key_bits", [256, 1024, 2048, 3072])
 def test_golden_vectors(native, key_bits, group):
+    """Every golden vector through the default engine: the split-modulus kernels (k_modexp_split /
+    k_modexp_var_split) for encrypt, obfuscate, decrypt and powmod, the full-width kernels for mulmod / invert."""
+    check_golden(native, key_bits)
+
+
+@pytest.mark.parametrize("key_bits", [256, 1024, 2048, 3072])
+def test_golden_vectors_full_width_engine(native, key_bits, monkeypatch):
+    """PHE_HIP_ENGINE=full: the same vectors through k_modexp_uniform / k_modexp_var on n^2, p^2, q^2."""
+    monkeypatch.setenv("PHE_HIP_ENGINE", "full")
+    ctx = check_golden(native, key_bits)
+    assert ctx.info()["engine_pub"] == "full" and ctx.info()["engine_priv"] == "full"
+
+
+def check_golden(native, key_bits):
     g = load_golden(key_bits)
     s1, s2 = key_bits // 32, key_bits // 16
     n_int = H(g["n"])
@@ -102,6 +116,7 @@ def test_golden_vectors(native, key_bits, group):
     assert native.limbs_to_ints(inv) == [pow(H(e["c"]), -1, nsq) for e in neg]
     out = ctx.powmod(inv, L([n_int - H(e["s"]) for e in neg], s1))
     assert native.limbs_to_ints(out) == [H(e["out"]) for e in neg]
+    return ctx
 
 
 @pytest.mark.parametrize("key_bits,batch", [(1024, 300), (2048, 150), (3072, 40)])

@@ -23,8 +23,8 @@ def main():
             print("== %s" % os.path.relpath(db))
             rows = con.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
             if rows:
-                print("-- kernel trace stats (durations in ns)")
-                print("%-92s %6s %16s %16s %8s" % ("kernel", "calls", "total_ns", "avg_ns", "pct"))
+                print("-- kernel trace stats (durations in us, as the rocpd top_kernels view reports them)")
+                print("%-92s %6s %16s %16s %8s" % ("kernel", "calls", "total_us", "avg_us", "pct"))
                 for r in rows:
                     if r[4] < 0.0005:
                         continue
