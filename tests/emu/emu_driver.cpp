@@ -335,6 +335,49 @@ int emu_powmod_var(const uint32_t* N, int limbs, const uint32_t* base, const uin
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
+// Unit access to the pair arithmetic of split_core.h for 64/G independent groups: X, Y are pairs given as 2H 29-bit
+// limbs (word 0 | word 1, any lazily reduced values below R); op 0: Z = X*Y, op 1: Z = X^2 (Z written as 2H limbs),
+// op 2: the canonical residue of value(X) as `out_limbs` 32-bit words per group.
+int emu_split_pair_op(int G, int L, const uint32_t* n, int n_limbs, int op, const uint32_t* X, const uint32_t* Y,
+                      uint32_t* out, int out_limbs) {
+    try {
+        host::SplitPack M = host::build_split(host::big_from(n, n_limbs, n_limbs), 64 * n_limbs, 0);
+        // constants are rows of H limbs in global limb order: any (G, L) with the same H can use them
+        if (G * L != M.H) throw std::invalid_argument("G*L must equal the H key_setup picks for this modulus");
+        const SplitConsts C = split_consts_of(M);
+        DISPATCH_SPLIT(G, L, ({
+            constexpr int H = GG * LL, S2 = 2 * H, kPer = 64 / GG;
+            std::vector<uint32_t> lds(kPer * (S2 + kLdsPad));
+            wave::run_wave([&](uint32_t lane) {
+                const Lanes<GG> ln(lane);
+                const uint32_t grp = lane / GG, g = ln.g;
+                SplitLane<GG, LL> K;
+                load_row<LL>(K.n, C.n, g);
+                K.n0inv = C.n0inv;
+                K.row_a = lds.data() + grp * (S2 + kLdsPad);
+                K.row_c = K.row_a + H;
+                uint32_t x0[LL], x1[LL], y0[LL], y1[LL];
+                load_row<LL>(x0, X + grp * S2, g);
+                load_row<LL>(x1, X + grp * S2 + H, g);
+                if (op == 0) {
+                    load_row<LL>(y0, Y + grp * S2, g);
+                    load_row<LL>(y1, Y + grp * S2 + H, g);
+                    split_mul<GG, LL>(x0, x1, y0, y1, K, ln);
+                } else if (op == 1) {
+                    split_square<GG, LL>(x0, x1, K, ln);
+                }
+                if (op == 2) {
+                    split_exit<GG, LL>(out + grp * out_limbs, out_limbs, x0, x1, nullptr, 0, C, K, ln, true);
+                } else {
+                    store_row<LL>(out + grp * S2, x0, g);
+                    store_row<LL>(out + grp * S2 + H, x1, g);
+                }
+            });
+        }));
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
 // out = base^exp mod n^2 with per-row exponents, the way phe_hip_powmod runs it (split-modulus kernel when the
 // engine is on and a geometry exists, else the full-width kernel on n^2)
 int emu_powmod_n2(const uint32_t* n, int n_limbs, const uint32_t* base, const uint32_t* exps, int exp_limbs,

@@ -77,6 +77,14 @@ class Emu:
                                        ctypes.c_uint64(base.shape[0])))
         return out
 
+    def split_pair_op(self, G, L, n, op, X, Y=None, out_limbs=0):
+        """op 0: X*Y, 1: X^2 (pairs as (64/G, 2*G*L) arrays of 29-bit limbs); 2: canonical value(X) as 32-bit words"""
+        groups = 64 // G
+        out = np.zeros((groups, out_limbs if op == 2 else 2 * G * L), dtype=np.uint32)
+        Yp = P(Y) if Y is not None else None
+        self._ck(self.L.emu_split_pair_op(G, L, P(n), len(n), op, P(X), Yp, P(out), out_limbs))
+        return out
+
     def powmod_n2(self, n, base, exps):
         """base^exp mod n^2 the way phe_hip_powmod runs it (split-modulus kernel when the engine is on)"""
         out = np.zeros_like(base)

@@ -1,0 +1,92 @@
+"""The pair arithmetic of csrc/split_core.h at the limb level (CPU wave emulator): products, squarings and the way
+out of the pair form for lazily reduced, almost-normalised operands, worst-case bounds and dense moduli, against
+Python integers; plus the integer model that documents the algebra (tools/exp/split_model.py)."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "..", "tools", "exp"))
+
+from emu_lib import Emu, from_r29, to_r29  # noqa: E402
+
+MASK = (1 << 29) - 1
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return Emu()
+
+
+def sloppy(limbs, rng):
+    """same value, some limbs pushed to the almost-normalised range (< 2^29 + 2^8) by borrowing from the limb above"""
+    limbs = list(limbs)
+    for k in range(len(limbs) - 1):
+        if limbs[k] < 256 and limbs[k + 1] >= 1 and rng.random() < 0.7:
+            limbs[k] += 1 << 29
+            limbs[k + 1] -= 1
+    return limbs
+
+
+def pair_rows(pairs, H, rng):
+    rows = []
+    for x0, x1 in pairs:
+        rows.append(sloppy(to_r29(x0, H), rng) + sloppy(to_r29(x1, H), rng))
+    return np.array(rows, dtype=np.uint32)
+
+
+def read_pairs(arr, H):
+    out = []
+    for row in arr:
+        assert int(row.max()) < (1 << 29) + 256, "limbs must stay almost-normalised"
+        out.append((from_r29(row[:H]), from_r29(row[H:])))
+    return out
+
+
+@pytest.mark.parametrize("G,L,dense", [(16, 1, False), (16, 3, True), (8, 7, False), (8, 9, True), (4, 9, False),
+                                       (4, 18, True), (4, 18, False), (2, 18, False), (2, 9, True), (8, 14, False)])
+def test_pair_products_worst_case_operands(emu, G, L, dense):
+    H = G * L
+    bits = 29 * H - 4                      # the widest modulus this geometry takes: R = 16 * 2^bits
+    rng = random.Random(1000 * G + L)
+    if dense:
+        n = (1 << bits) - 1                # every limb 2^29 - 1: the largest column sums
+    else:
+        n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+    limbs32 = (bits + 31) // 32
+    n_arr = np.frombuffer(n.to_bytes(4 * limbs32, "little"), dtype=np.uint32).copy()
+    assert emu.split_geometry(n_arr)[0] * emu.split_geometry(n_arr)[1] == H
+    n2, R = n * n, 1 << (29 * H)
+    Rinv = pow(R, -1, n2)
+    value = lambda X: (X[0] - n * X[1]) * Rinv % n2
+    groups = 64 // G
+    worst = (2 * n - 1, 3 * n - 1)
+    xs = [worst, (n, n), (0, 0), (1, 0), (2 * n - 1, 0), (0, 3 * n - 1)]
+    ys = [worst, (n, 2 * n), worst, (0, 1), (2 * n - 1, 3 * n - 1), (2 * n - 1, 1)]
+    while len(xs) < groups:
+        xs.append((rng.randrange(2 * n), rng.randrange(3 * n)))
+        ys.append((rng.randrange(2 * n), rng.randrange(3 * n)))
+    xs, ys = xs[:groups], ys[:groups]
+    X, Y = pair_rows(xs, H, rng), pair_rows(ys, H, rng)
+
+    for Z, x, y in zip(read_pairs(emu.split_pair_op(G, L, n_arr, 0, X, Y), H), xs, ys):
+        assert Z[0] < 2 * n and Z[1] < 2 * n
+        assert value(Z) == value(x) * value(y) % n2
+    for Z, x in zip(read_pairs(emu.split_pair_op(G, L, n_arr, 1, X), H), xs):
+        assert Z[0] < 2 * n and Z[1] < 2 * n
+        assert value(Z) == value(x) * value(x) % n2
+    # the way out: canonical residues, including X0 = n (u = n, the one case where u + n*t can reach n^2)
+    out_limbs = (2 * bits + 31) // 32
+    got = emu.split_pair_op(G, L, n_arr, 2, X, out_limbs=out_limbs)
+    for row, x in zip(got, xs):
+        assert int.from_bytes(row.tobytes(), "little") == value(x)
+
+
+def test_integer_model_of_the_algebra():
+    import split_model
+    for bits, h in ((64, 3), (200, 8), (521, 19)):
+        assert split_model.check(bits, h, seed=bits)
