@@ -83,6 +83,44 @@ DEF_U64_TEST(k_fma_f64, "v_fma_f64 %0, %0, %0, %0")
 DEF_U64_TEST(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 1, %0")
 DEF_U64_TEST(k_lshrrev_b64, "v_lshrrev_b64 %0, 1, %0")
 
+// --- v_mad_u64_u32 with hand-placed registers: does the VGPR bank (index mod 4) of the operands matter? ---------
+// 8 chains, accumulators ACC0..ACC7 (even-aligned pairs), multiplicands in SRC0 / SRC1; the whole loop is one asm block
+// so the register numbers are exactly the ones written here.
+#define DEF_MAD_PLACED(NAME, S0, S1, A0, A1, A2, A3, A4, A5, A6, A7)                                           \
+    KERNEL_BEGIN(NAME)                                                                                          \
+        uint32_t r;                                                                                             \
+        asm volatile(                                                                                           \
+            "v_mov_b32 v" #S0 ", %1\n\tv_mov_b32 v" #S1 ", %2\n\t"                                              \
+            "v_mov_b32 v" #A0 ", %1\n\tv_mov_b32 v" #A1 ", %2\n\tv_mov_b32 v" #A2 ", %1\n\tv_mov_b32 v" #A3 ", %2\n\t" \
+            "v_mov_b32 v" #A4 ", %1\n\tv_mov_b32 v" #A5 ", %2\n\tv_mov_b32 v" #A6 ", %1\n\tv_mov_b32 v" #A7 ", %2\n\t" \
+            "s_movk_i32 s20, 0x4000\n"                                                                          \
+            "1:\n\t"                                                                                            \
+            "v_mad_u64_u32 v[" #A0 ":" #A0 "+1], vcc, v" #S0 ", v" #S1 ", v[" #A0 ":" #A0 "+1]\n\t"               \
+            "v_mad_u64_u32 v[" #A1 ":" #A1 "+1], vcc, v" #S0 ", v" #S1 ", v[" #A1 ":" #A1 "+1]\n\t"               \
+            "v_mad_u64_u32 v[" #A2 ":" #A2 "+1], vcc, v" #S0 ", v" #S1 ", v[" #A2 ":" #A2 "+1]\n\t"               \
+            "v_mad_u64_u32 v[" #A3 ":" #A3 "+1], vcc, v" #S0 ", v" #S1 ", v[" #A3 ":" #A3 "+1]\n\t"               \
+            "v_mad_u64_u32 v[" #A4 ":" #A4 "+1], vcc, v" #S0 ", v" #S1 ", v[" #A4 ":" #A4 "+1]\n\t"               \
+            "v_mad_u64_u32 v[" #A5 ":" #A5 "+1], vcc, v" #S0 ", v" #S1 ", v[" #A5 ":" #A5 "+1]\n\t"               \
+            "v_mad_u64_u32 v[" #A6 ":" #A6 "+1], vcc, v" #S0 ", v" #S1 ", v[" #A6 ":" #A6 "+1]\n\t"               \
+            "v_mad_u64_u32 v[" #A7 ":" #A7 "+1], vcc, v" #S0 ", v" #S1 ", v[" #A7 ":" #A7 "+1]\n\t"               \
+            "s_sub_u32 s20, s20, 1\n\ts_cmp_lg_u32 s20, 0\n\ts_cbranch_scc1 1b\n\t"                             \
+            "v_xor_b32 %0, v" #A0 ", v" #A1 "\n\tv_xor_b32 %0, %0, v" #A2 "\n\tv_xor_b32 %0, %0, v" #A3 "\n\t"    \
+            "v_xor_b32 %0, %0, v" #A4 "\n\tv_xor_b32 %0, %0, v" #A5 "\n\tv_xor_b32 %0, %0, v" #A6 "\n\tv_xor_b32 %0, %0, v" #A7 \
+            : "=&v"(r) : "v"(a), "v"(b)                                                                         \
+            : "vcc", "scc", "s20", "v" #S0, "v" #S1, "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49",  \
+              "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64",   \
+              "v65", "v66", "v67", "v68", "v69", "v70", "v71");                                               \
+    KERNEL_END(r)
+
+// accumulators on banks (0,1), multiplicands on banks 2 and 3: no operand shares a bank
+DEF_MAD_PLACED(k_mad_banks_apart, 34, 35, 40, 44, 48, 52, 56, 60, 64, 68)
+// accumulators on banks (0,1), multiplicands on banks 0 and 1: both collide with the addend
+DEF_MAD_PLACED(k_mad_banks_clash, 32, 33, 40, 44, 48, 52, 56, 60, 64, 68)
+// multiplicands on the same bank as each other, accumulators elsewhere
+DEF_MAD_PLACED(k_mad_srcs_same_bank, 34, 38, 40, 44, 48, 52, 56, 60, 64, 68)
+// accumulators alternating (0,1) / (2,3), multiplicands on banks 2 and 3: what a compiler-chosen layout looks like
+DEF_MAD_PLACED(k_mad_banks_mixed, 34, 35, 40, 42, 44, 46, 48, 50, 52, 54)
+
 // --- the inner-loop mix of mont_core.h: mad + addc (+ mov), to see what co-issues ---------------
 KERNEL_BEGIN(k_mix_mad_addc)
     uint64_t x[kChains];
@@ -167,6 +205,10 @@ int main() {
         {"v_and_b32", k_and_b32, kChains},
         {"v_alignbit_b32", k_alignbit, kChains},
         {"v_mad_u64_u32", k_mad_u64_u32, kChains},
+        {"v_mad_u64_u32_banks_apart", k_mad_banks_apart, kChains},
+        {"v_mad_u64_u32_banks_clash", k_mad_banks_clash, kChains},
+        {"v_mad_u64_u32_srcs_same_bank", k_mad_srcs_same_bank, kChains},
+        {"v_mad_u64_u32_banks_mixed", k_mad_banks_mixed, kChains},
         {"v_mul_lo_u32", k_mul_lo_u32, kChains},
         {"v_mul_hi_u32", k_mul_hi_u32, kChains},
         {"v_mad_u32_u24", k_mad_u32_u24, kChains},

@@ -1,6 +1,6 @@
 // tests/emu/wave_emu.h — TEST INFRASTRUCTURE: a host stand-in for csrc/wave_gfx950.h.
 //
-// Runs the 64 lanes of one wavefront as 64 ucontext fibers so that mont_core.h (the code the
+// Runs the 64 lanes of one wavefront as 64 fibers so that mont_core.h / split_core.h (the code the
 // GPU executes) can be exercised on a CPU-only box.  Cross-lane primitives exchange values
 // through a double-buffered mailbox and yield to the scheduler; all lanes must execute the same
 // sequence of cross-lane primitives (true for these kernels: control flow is wave-uniform).
@@ -20,9 +20,46 @@ namespace wave {
 constexpr int kRow = 16;
 constexpr int kLanes = 64;
 
+// Fiber switch.  glibc's swapcontext makes a sigprocmask system call per switch, and a 2048-bit product switches
+// ~10^5 times; on x86-64 the switch is therefore a dozen instructions of our own (callee-saved registers + stack
+// pointer), with ucontext kept as the portable fallback.
+#if defined(__x86_64__)
+#define PHE_EMU_ASM_SWITCH 1
+extern "C" void phe_emu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .globl phe_emu_switch
+    .type phe_emu_switch,@function
+phe_emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size phe_emu_switch,.-phe_emu_switch
+)");
+#else
+#define PHE_EMU_ASM_SWITCH 0
+#endif
+
 struct Emu {
+#if PHE_EMU_ASM_SWITCH
+    void* sched_sp = nullptr;
+    void* fib_sp[kLanes];
+#else
     ucontext_t sched;
     ucontext_t fib[kLanes];
+#endif
     char* stacks[kLanes];
     bool done[kLanes];
     int cur = 0;
@@ -39,7 +76,11 @@ inline Emu*& emu() {
 
 inline void yield_all() {
     Emu* e = emu();
+#if PHE_EMU_ASM_SWITCH
+    phe_emu_switch(&e->fib_sp[e->cur], e->sched_sp);
+#else
     swapcontext(&e->fib[e->cur], &e->sched);
+#endif
 }
 
 inline void fiber_entry() {
@@ -47,7 +88,8 @@ inline void fiber_entry() {
     const int l = e->cur;
     e->body((uint32_t)l);
     e->done[l] = true;
-    swapcontext(&e->fib[l], &e->sched);
+    yield_all();
+    abort();  // a finished fiber is never resumed
 }
 
 // run `body(lane)` for the 64 lanes of one wave
@@ -61,11 +103,22 @@ inline void run_wave(const std::function<void(uint32_t)>& body) {
         e->done[l] = false;
         e->lane_phase[l] = 0;
         e->stacks[l] = (char*)malloc(kStack);
+#if PHE_EMU_ASM_SWITCH
+        // initial frame: six zeroed callee-saved registers, then the entry point as the return address (its slot is
+        // 16-byte aligned so that the entry function sees the stack alignment of a normal call)
+        uintptr_t top = ((uintptr_t)e->stacks[l] + kStack) & ~(uintptr_t)15;
+        void** frame = (void**)(top - 16) - 6;
+        for (int i = 0; i < 6; ++i) frame[i] = nullptr;
+        frame[6] = (void*)&fiber_entry;
+        frame[7] = nullptr;
+        e->fib_sp[l] = (void*)frame;
+#else
         getcontext(&e->fib[l]);
         e->fib[l].uc_stack.ss_sp = e->stacks[l];
         e->fib[l].uc_stack.ss_size = kStack;
         e->fib[l].uc_link = &e->sched;
         makecontext(&e->fib[l], (void (*)())fiber_entry, 0);
+#endif
     }
     for (;;) {
         bool any = false;
@@ -73,7 +126,11 @@ inline void run_wave(const std::function<void(uint32_t)>& body) {
             if (e->done[l]) continue;
             any = true;
             e->cur = l;
+#if PHE_EMU_ASM_SWITCH
+            phe_emu_switch(&e->sched_sp, e->fib_sp[l]);
+#else
             swapcontext(&e->sched, &e->fib[l]);
+#endif
         }
         if (!any) break;
     }

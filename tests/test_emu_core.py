@@ -118,8 +118,10 @@ def test_reference_kat(emu):
 # engine "split": the split-modulus kernels (csrc/split_core.h, the product default); "full": mont_core.h on n^2, p^2, q^2
 @pytest.mark.parametrize("engine,key_bits,count,group", [
     ("split", 256, None, 16), ("split", 256, None, 8), ("split", 1024, 5, 0), ("split", 1024, 3, 16),
-    ("split", 1024, 3, 4), ("split", 1024, 2, 8), ("split", 2048, 1, 0),
-    ("full", 256, None, 16), ("full", 1024, 2, 0), ("full", 1024, 2, 4)])
+    ("split", 1024, 3, 4), ("split", 1024, 3, 8), ("split", 2048, 3, 0), ("split", 2048, 2, 8), ("split", 2048, 2, 16),
+    ("split", 3072, 2, 0), ("split", 3072, 1, 8),
+    ("full", 256, None, 16), ("full", 256, None, 8), ("full", 1024, 3, 0), ("full", 1024, 2, 4), ("full", 2048, 2, 0),
+    ("full", 3072, 1, 0)])
 def test_golden_through_emulator(emu, engine, key_bits, count, group):
     emu.set_engine(engine == "split")
     emu.set_group(group)
@@ -128,7 +130,7 @@ def test_golden_through_emulator(emu, engine, key_bits, count, group):
     n = int_to_limbs(H(g["n"]), s1)
     enc = g["raw_encrypt"]
     if count:  # edge cases first (m = 0, 1, ..., n-1, n, n+1), then a few random
-        enc = enc[8:8 + count] if key_bits > 1024 else enc[7:7 + count]
+        enc = enc[7:7 + count]
     c = emu.encrypt(n, ints_to_limbs([H(e["m"]) for e in enc], s1), ints_to_limbs([H(e["r"]) for e in enc], s1))
     assert limbs_to_ints(c) == [H(e["c"]) for e in enc]
 
