@@ -150,6 +150,42 @@ KERNEL_BEGIN(k_mix_mad_addc_mov)
     for (int i = 0; i < kChains; ++i) r ^= x[i] ^ y[i] ^ z[i];
 KERNEL_END((uint32_t)(r ^ (r >> 32)))
 
+// --- the matrix pipe beside the integer VALU: int8 MFMA alone, and one MFMA per 16 v_mad_u64_u32 ---------------
+// (groundwork for moving the batch-constant half of the reductions, m*n, onto the otherwise idle matrix cores)
+typedef int v4i __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_mfma_i8(uint32_t* out, uint32_t seed) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    v4i a = {(int)(seed + tid), (int)(seed ^ tid), (int)tid, (int)seed}, b = {(int)tid, 3, (int)seed, 7};
+    v4i c[4] = {{0, 0, 0, 0}, {1, 1, 1, 1}, {2, 2, 2, 2}, {3, 3, 3, 3}};
+    for (int it = 0; it < kIters / 4; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c[i], 0, 0, 0);
+    }
+    const v4i r = c[0] + c[1] + c[2] + c[3];
+    if ((uint32_t)(r.x ^ r.y ^ r.z ^ r.w) == 0x12345678u) out[tid] = (uint32_t)r.x;
+}
+__global__ void __launch_bounds__(256) k_mix_mfma_mad(uint32_t* out, uint32_t seed) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t aa = seed * 2654435761u + tid, bb = (seed ^ tid) | 1u;
+    v4i a = {(int)(seed + tid), (int)(seed ^ tid), (int)tid, (int)seed}, b = {(int)tid, 3, (int)seed, 7};
+    v4i c[2] = {{0, 0, 0, 0}, {1, 1, 1, 1}};
+    uint64_t x[kChains];
+    for (int i = 0; i < kChains; ++i) x[i] = ((uint64_t)bb << 32) | (aa + i);
+    for (int it = 0; it < kIters / 2; ++it) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            c[h] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c[h], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < kChains; ++i)
+                asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(x[i]) : "v"(aa), "v"(bb) : "vcc");
+        }
+    }
+    uint64_t r = 0;
+    for (int i = 0; i < kChains; ++i) r ^= x[i];
+    const v4i s = c[0] + c[1];
+    if ((uint32_t)(r ^ (r >> 32)) + (uint32_t)(s.x ^ s.y ^ s.z ^ s.w) == 0x12345678u) out[tid] = (uint32_t)r;
+}
+
 // --- LDS: the broadcast read used for the multiplier limbs, and ds_bpermute ---------------------
 __global__ void __launch_bounds__(256) k_lds_bcast_b128(uint32_t* out, uint32_t seed) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[16 * 132];
@@ -221,6 +257,10 @@ int main() {
         {"v_mov_b32_dpp_row_newbcast", k_dpp_newbcast, kChains},
         {"ds_bpermute_b32", k_ds_bpermute, kChains},
         {"ds_read_b128_row_broadcast", k_lds_bcast_b128, 32.0 / 4.0},
+        // ops counted: MFMAs per lane-iteration (x kIters); 16x16x64 = 16384 int8 MACs per wave instruction
+        {"mfma_i32_16x16x64_i8", k_mfma_i8, 1.0},
+        // per trip: 8 v_mad_u64_u32 + 1 MFMA, counted as the 8 mads: compare with the v_mad_u64_u32 row
+        {"mix_8mad+1mfma_i8(mads)", k_mix_mfma_mad, (double)kChains},
         {"mix_mad+addc", k_mix_mad_addc, 2.0 * kChains},
         {"mix_mad+addc+mov", k_mix_mad_addc_mov, 3.0 * kChains},
     };
