@@ -13,7 +13,6 @@ hot functions of the reference on *batches* of Python ints or uint32 limb arrays
 There is no CPU implementation behind these: if lib/libphe_hip.so or a GPU is missing, they raise.
 """
 import os
-import secrets
 
 import numpy as np
 
@@ -36,35 +35,67 @@ def random_lt_n(n, count):
     return _native.limbs_to_ints(random_lt_n_limbs(n, count, limbs)) if count else []
 
 
-def random_lt_n_limbs(n, count, limbs):
+_urandom = None
+
+
+def _urandom_into(view):
+    """Fill a writable buffer from the kernel CSPRNG (/dev/urandom, what os.urandom and random.SystemRandom read)
+    without an intermediate bytes object."""
+    global _urandom
+    if _urandom is None:
+        _urandom = open("/dev/urandom", "rb", buffering=0)
+    mv = memoryview(view).cast("B")
+    got = 0
+    while got < len(mv):
+        k = _urandom.readinto(mv[got:])
+        if not k:
+            raise OSError("/dev/urandom returned no data")
+        got += k
+
+
+def random_lt_n_limbs(n, count, limbs, out=None):
     """`count` cryptographically random integers in [1, n) as a (count, limbs) uint32 array — the bulk form of
     PaillierPublicKey.get_random_lt_n (phe/paillier.py:141-143, random.SystemRandom().randrange(1, n)): same
-    source (os.urandom), same distribution (rejection sampling on bit_length(n-1) bits), vectorised with numpy."""
+    source (the kernel CSPRNG), same distribution (rejection sampling on bit_length(n-1) bits), vectorised with
+    numpy.  `out`: optional (count, limbs) uint32 array to fill (saves the first-touch cost of a fresh buffer)."""
     k = (n - 1).bit_length()
     top_limb, top_bits = (k - 1) // 32, k - 32 * ((k - 1) // 32)
     top_mask = np.uint32((1 << top_bits) - 1) if top_bits < 32 else np.uint32(0xffffffff)
     n_arr = _native.int_to_limbs(n, limbs)
-    out = np.frombuffer(bytearray(secrets.token_bytes(count * limbs * 4)), dtype=np.uint32).reshape(count, limbs)
-    rows = np.arange(count)
-    while len(rows):
-        out[rows, top_limb] &= top_mask
+    if out is None:
+        out = np.empty((count, limbs), dtype=np.uint32)
+    if count == 0:
+        return out
+    _urandom_into(out)
+    rows = None                                  # None = every row (column views, no gather)
+    while True:
+        sub = out if rows is None else out[rows]
+        if top_bits < 32:
+            sub[:, top_limb] &= top_mask
         if top_limb + 1 < limbs:
-            out[rows, top_limb + 1:] = 0
+            sub[:, top_limb + 1:] = 0
         # rows that are >= n (lexicographic compare from the most significant limb down) or zero are redrawn
-        lt = np.zeros(len(rows), dtype=bool)
-        undecided = np.ones(len(rows), dtype=bool)
+        lt = np.zeros(len(sub), dtype=bool)
+        undecided = np.ones(len(sub), dtype=bool)
         for j in range(top_limb, -1, -1):
-            col = out[rows, j]
+            col = sub[:, j]
             lt |= undecided & (col < n_arr[j])
             undecided &= (col == n_arr[j])
             if not undecided.any():
                 break
-        bad = ~lt
-        bad[lt] = ~out[rows[lt]].any(axis=1) if len(rows) < count else ~out.any(axis=1)[lt]
-        rows = rows[bad]
-        if len(rows):
-            out[rows] = np.frombuffer(secrets.token_bytes(len(rows) * limbs * 4), dtype=np.uint32).reshape(len(rows), limbs)
-    return out
+        maybe_zero = lt & (sub[:, top_limb] == 0)
+        if maybe_zero.any():
+            idx = np.nonzero(maybe_zero)[0]
+            lt[idx] = sub[idx].any(axis=1)
+        if rows is not None:
+            out[rows] = sub
+        bad = np.nonzero(~lt)[0]
+        if len(bad) == 0:
+            return out
+        rows = bad if rows is None else rows[bad]
+        fresh = np.empty((len(rows), limbs), dtype=np.uint32)
+        _urandom_into(fresh)
+        out[rows] = fresh
 
 
 class Engine:
@@ -76,6 +107,19 @@ class Engine:
         self.ctx = _native.Context(n, p, q, hp, hq, p_inverse, device=self.device)
         self.n_limbs = self.ctx.n_limbs
         self.ct_limbs = self.ctx.ct_limbs
+
+    # ---- reusable host staging (a fresh 32 MB numpy buffer costs more in page faults than the kernel it feeds) ---
+    def scratch(self, name, rows, cols):
+        """A (rows, cols) uint32 view of a grow-only buffer owned by this engine; contents are transient: valid
+        until the next scratch(name, ...) call."""
+        if not hasattr(self, "_scratch"):
+            self._scratch = {}
+        need = rows * cols
+        buf = self._scratch.get(name)
+        if buf is None or buf.size < need:
+            buf = np.empty(max(need, 1), dtype=np.uint32)
+            self._scratch[name] = buf
+        return buf[:need].reshape(rows, cols)
 
     # ---- limb helpers -------------------------------------------------------------------------
     def plain_limbs(self, ints):
@@ -134,6 +178,40 @@ class Engine:
             base[idx] = self.ctx.invert(np.ascontiguousarray(c[idx]))
         width = max(1, (max(e.bit_length() for e in exps) + 31) // 32) if exps else 1
         return self.ctx.powmod(base, _native.ints_to_limbs(exps, width))
+
+    @staticmethod
+    def _mag_limbs(mag):
+        mag = np.ascontiguousarray(mag, dtype=np.uint64)
+        bits = int(mag.max()).bit_length() if len(mag) else 1
+        return mag.view(np.uint32).reshape(len(mag), 2)[:, :1 if bits <= 32 else 2].copy(), max(bits, 1)
+
+    def raw_mul_signed(self, c, mag, neg):
+        """raw_mul for scalars given as sign + 64-bit magnitude (the array form of the codec): a negative scalar -v
+        is the residue n - v >= n - max_int, so it takes the inverse branch with exponent v (phe/paillier.py:745-749)."""
+        c = self._as_cipher(c)
+        exps, _ = self._mag_limbs(mag)
+        base = c
+        if neg.any():
+            idx = np.nonzero(neg)[0]
+            base = c.copy()
+            base[idx] = self.ctx.invert(np.ascontiguousarray(c[idx]))
+        return self.ctx.powmod(base, exps)
+
+    def raw_mul_signed_dev(self, c, mag, neg):
+        exps, bits = self._mag_limbs(mag)
+        base = c
+        if neg.any():
+            inv = DeviceArray(self.ctx, c.rows, self.ct_limbs)
+            self.ctx.invert_dev(c.ptr, inv.ptr, c.rows)
+            mask = DeviceArray.from_host(self.ctx, neg.astype(np.uint8), dtype=np.uint8)
+            base = DeviceArray(self.ctx, c.rows, self.ct_limbs)
+            self.ctx.select_rows_dev(c.ptr, inv.ptr, mask.ptr, base.ptr, self.ct_limbs, c.rows)
+            self.ctx.sync()
+        e = DeviceArray.from_host(self.ctx, exps)
+        out = DeviceArray(self.ctx, base.rows, self.ct_limbs)
+        self.ctx.powmod_dev(base.ptr, e.ptr, exps.shape[1], bits, out.ptr, base.rows)
+        self.ctx.sync()
+        return out
 
     def powmod_n2(self, base, exps):
         exps = list(exps)

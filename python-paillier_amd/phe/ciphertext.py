@@ -131,12 +131,28 @@ class EncryptedVector(object):
         self.public_key = public_key
         self.on_device = isinstance(limbs, DeviceArray)
         self._limbs = limbs if self.on_device else np.ascontiguousarray(limbs, dtype=np.uint32)
-        self.exponents = list(exponents)
+        self._exps = np.array(exponents if isinstance(exponents, np.ndarray) else list(exponents), dtype=np.int64).reshape(-1)
         shape = self._limbs.shape
-        if len(shape) != 2 or shape[0] != len(self.exponents):
+        if len(shape) != 2 or shape[0] != len(self._exps):
             raise ValueError("limbs must be (batch, ct_limbs) with one exponent per row")
-        flags = obfuscated if isinstance(obfuscated, np.ndarray) else np.full(len(self.exponents), bool(obfuscated))
+        flags = obfuscated if isinstance(obfuscated, np.ndarray) else np.full(len(self._exps), bool(obfuscated))
         self._obfuscated = flags.astype(bool)
+
+    @property
+    def exponents(self):
+        """per-row exponents as a list of ints (like EncryptedNumber.exponent); `exponent_array` is the numpy form"""
+        return self._exps.tolist()
+
+    @exponents.setter
+    def exponents(self, value):
+        value = np.array(list(value), dtype=np.int64).reshape(-1)
+        if len(value) != len(self._exps):
+            raise ValueError("one exponent per row")
+        self._exps = value
+
+    @property
+    def exponent_array(self):
+        return self._exps
 
     # ---- construction / movement -------------------------------------------------------------------------
     @classmethod
@@ -164,30 +180,30 @@ class EncryptedVector(object):
         if self.on_device:
             return self
         eng = self.public_key._get_engine()
-        return EncryptedVector(self.public_key, eng.upload_cipher(self._limbs), self.exponents, self._obfuscated.copy())
+        return EncryptedVector(self.public_key, eng.upload_cipher(self._limbs), self._exps, self._obfuscated.copy())
 
     def to_host(self):
         if not self.on_device:
             return self
-        return EncryptedVector(self.public_key, self._limbs.to_host(), self.exponents, self._obfuscated.copy())
+        return EncryptedVector(self.public_key, self._limbs.to_host(), self._exps, self._obfuscated.copy())
 
     def _like(self, limbs, exponents, obfuscated=False):
         return EncryptedVector(self.public_key, limbs, exponents, obfuscated)
 
     def __len__(self):
-        return len(self.exponents)
+        return len(self._exps)
 
     def __getitem__(self, i):
         if isinstance(i, slice):
             lo, hi, step = i.indices(len(self))
             if self.on_device and step == 1:
-                return self._like(self._limbs.rows_view(lo, hi), self.exponents[i], self._obfuscated[i])
+                return self._like(self._limbs.rows_view(lo, hi), self._exps[i], self._obfuscated[i])
             host = self._limbs.to_host() if self.on_device else self._limbs
-            return self._like(host[i], self.exponents[i], self._obfuscated[i])
+            return self._like(host[i], self._exps[i], self._obfuscated[i])
         i = range(len(self))[i]
         row = self._limbs.rows_view(i, i + 1).to_host() if self.on_device else self._limbs[i:i + 1]
         eng = self.public_key._get_engine()
-        x = EncryptedNumber(self.public_key, eng.to_ints(row)[0], self.exponents[i])
+        x = EncryptedNumber(self.public_key, eng.to_ints(row)[0], int(self._exps[i]))
         x._EncryptedNumber__is_obfuscated = bool(self._obfuscated[i])
         return x
 
@@ -227,39 +243,39 @@ class EncryptedVector(object):
     def decrease_exponent_to(self, new_exps):
         """Per-element EncryptedNumber.decrease_exponent_to: rows whose exponent is above the target are
         multiplied by BASE**delta (one variable-exponent modexp launch)."""
-        if isinstance(new_exps, int):
-            new_exps = [new_exps] * len(self)
-        new_exps = list(new_exps)
-        rows, scal = [], []
-        for i, (old, new) in enumerate(zip(self.exponents, new_exps)):
-            if new > old:
-                raise ValueError('New exponent %i should be more negative than old exponent %i' % (new, old))
-            if new < old:
-                rows.append(i)
-                scal.append(pow(EncodedNumber.BASE, old - new))
+        old = self._exps
+        new = np.broadcast_to(np.asarray(new_exps if isinstance(new_exps, (int, np.ndarray)) else list(new_exps),
+                                         dtype=np.int64), old.shape).copy()
+        up = np.nonzero(new > old)[0]
+        if len(up):
+            i = int(up[0])
+            raise ValueError('New exponent %i should be more negative than old exponent %i' % (new[i], old[i]))
+        rows = np.nonzero(new < old)[0]
         flags = self._obfuscated.copy()
-        if not rows:
+        if len(rows) == 0:
             limbs = self._limbs if self.on_device else self._limbs.copy()
-            return self._like(limbs, new_exps, flags)
+            return self._like(limbs, new, flags)
         pk = self.public_key
-        if max(scal) >= pk.n:
-            raise ValueError('Scalar out of bounds: %i' % max(scal))
-        idx = np.asarray(rows)
-        flags[idx] = False
+        delta = (old - new)[rows]
+        powers = {int(d): pow(EncodedNumber.BASE, int(d)) for d in np.unique(delta).tolist()}
+        if max(powers.values()) >= pk.n:
+            raise ValueError('Scalar out of bounds: %i' % max(powers.values()))
+        scal = [powers[d] for d in delta.tolist()]
+        flags[rows] = False
         eng = pk._get_engine()
         if self.on_device:
             # whole-vector launch: untouched rows are raised to the power 1 (c^1 = c, still canonical)
             exps = [1] * len(self)
-            for i, sc in zip(rows, scal):
+            for i, sc in zip(rows.tolist(), scal):
                 exps[i] = sc
-            return self._like(eng.powmod_dev(self._limbs, exps), new_exps, flags)
+            return self._like(eng.powmod_dev(self._limbs, exps), new, flags)
         limbs = self._limbs.copy()
-        limbs[idx] = eng.raw_mul(np.ascontiguousarray(limbs[idx]), scal)
-        return self._like(limbs, new_exps, flags)
+        limbs[rows] = eng.raw_mul(np.ascontiguousarray(limbs[rows]), scal)
+        return self._like(limbs, new, flags)
 
     # ---- arithmetic --------------------------------------------------------------------------------------
     def _aligned(self, other_exps):
-        target = [min(a, b) for a, b in zip(self.exponents, other_exps)]
+        target = np.minimum(self._exps, np.asarray(other_exps, dtype=np.int64))
         return self.decrease_exponent_to(target), target
 
     def _raw_add(self, a_limbs, b):
@@ -278,13 +294,29 @@ class EncryptedVector(object):
                 raise ValueError("vector lengths differ")
             if other.on_device != self.on_device:
                 other = other.to_device() if self.on_device else other.to_host()
-            a, target = self._aligned(other.exponents)
+            a, target = self._aligned(other._exps)
             b = other.decrease_exponent_to(target)
             return self._like(self._raw_add(a._limbs, b._limbs), target)
         # plain operand(s): scalar broadcast or sequence; encode with max_exponent = own exponent per row
         values = other if isinstance(other, (list, tuple, np.ndarray)) else [other] * len(self)
         if len(values) != len(self):
             raise ValueError("vector lengths differ")
+        eng = pk._get_engine()
+        signed = EncodedNumber.encode_signed(values) if eng.n_limbs >= 4 else None
+        if signed is not None:
+            # array form of the loop below: encode(v, max_exponent=e) = the natural encoding with its mantissa
+            # shifted down to min(natural exponent, e) — exact while the shifted magnitude still fits 64 bits
+            mag, neg, nat = signed
+            target = np.minimum(nat, self._exps)
+            shift = (nat - target) * int(round(EncodedNumber.LOG2_BASE))
+            bits = np.zeros(len(mag), dtype=np.int64)
+            nz = mag != 0
+            bits[nz] = np.floor(np.log2(mag[nz].astype(np.float64))).astype(np.int64) + 2   # upper bound on the bit length
+            if np.all(bits + shift <= 63):
+                a = self.decrease_exponent_to(target)
+                plain = EncodedNumber.signed_to_limbs(pk, mag << shift.astype(np.uint64), neg, eng.n_limbs)
+                limbs = eng.add_plain_dev(a._limbs, plain) if self.on_device else eng.add_plain(a._limbs, plain)
+                return self._like(limbs, target)
         values = values.tolist() if isinstance(values, np.ndarray) else values
         encs, exps = [], []
         for v, e in zip(values, self.exponents):
@@ -294,8 +326,7 @@ class EncryptedVector(object):
             encs.append(enc)
             exps.append(enc.exponent)
         a, target = self._aligned(exps)
-        plain = [enc.decrease_exponent_to(t).encoding for enc, t in zip(encs, target)]
-        eng = pk._get_engine()
+        plain = [enc.decrease_exponent_to(t).encoding for enc, t in zip(encs, target.tolist())]
         limbs = eng.add_plain_dev(a._limbs, plain) if self.on_device else eng.add_plain(a._limbs, plain)
         return self._like(limbs, target)
 
@@ -308,14 +339,19 @@ class EncryptedVector(object):
         values = other if isinstance(other, (list, tuple, np.ndarray)) else [other] * len(self)
         if len(values) != len(self):
             raise ValueError("vector lengths differ")
+        eng = pk._get_engine()
+        signed = EncodedNumber.encode_signed(values) if eng.n_limbs >= 4 else None
+        if signed is not None:
+            mag, neg, exps = signed
+            limbs = eng.raw_mul_signed_dev(self._limbs, mag, neg) if self.on_device else eng.raw_mul_signed(self._limbs, mag, neg)
+            return self._like(limbs, self._exps + exps)
         if isinstance(values, np.ndarray) or not any(isinstance(v, EncodedNumber) for v in values):
             encs, exps = EncodedNumber.encode_many(pk, values)
         else:
             pairs = [v if isinstance(v, EncodedNumber) else EncodedNumber.encode(pk, v) for v in values]
             encs, exps = [e.encoding for e in pairs], [e.exponent for e in pairs]
-        eng = pk._get_engine()
         limbs = eng.raw_mul_dev(self._limbs, encs) if self.on_device else eng.raw_mul(self._limbs, encs)
-        return self._like(limbs, [a + b for a, b in zip(self.exponents, exps)])
+        return self._like(limbs, self._exps + np.asarray(exps, dtype=np.int64))
 
     __rmul__ = __mul__
 
@@ -339,8 +375,8 @@ class EncryptedVector(object):
             raise ValueError("empty vector")
         pk = self.public_key
         eng = pk._get_engine()
-        cur = self.decrease_exponent_to(min(self.exponents))
-        limbs, exp = cur._limbs, cur.exponents[0]
+        cur = self.decrease_exponent_to(int(self._exps.min()))
+        limbs, exp = cur._limbs, int(cur._exps[0])
         if self.on_device:
             while limbs.rows > 1:
                 half = limbs.rows // 2

@@ -122,6 +122,104 @@ class EncodedNumber(object):
             exps.append(e.exponent)
         return encs, exps
 
+    # ---- limb-array forms: no Python integer per element ----------------------------------
+    @classmethod
+    def encode_signed(cls, values, precision=None, max_exponent=None):
+        """float64 / integer numpy array -> (magnitude uint64, negative bool, exponents int64) with
+        value = (-1)^negative * magnitude * BASE^exponent, element-wise the int_rep / exponent `encode` picks
+        (phe/encoding.py:160-199).  None when the array form does not apply (other dtypes, precision / max_exponent
+        given, BASE not a power of two): the caller then encodes element by element."""
+        if not isinstance(values, np.ndarray) or precision is not None or max_exponent is not None:
+            return None
+        log2b = int(round(cls.LOG2_BASE))
+        if (1 << log2b) != cls.BASE or log2b + cls.FLOAT_MANTISSA_BITS > 62:
+            return None
+        arr = values.reshape(-1)
+        if arr.dtype == np.float64:
+            if not np.all(np.isfinite(arr)):
+                raise ValueError("cannot encode inf / nan")
+            mant, e2 = np.frexp(arr)
+            lsb = e2.astype(np.int64) - cls.FLOAT_MANTISSA_BITS
+            exps = np.floor_divide(lsb, log2b)
+            shift = lsb - exps * log2b                                           # 0 .. log2b-1
+            rep = np.ldexp(mant, cls.FLOAT_MANTISSA_BITS).astype(np.int64) << shift   # exact: |mant| < 1, 53 bits
+            neg = rep < 0
+            return np.abs(rep).astype(np.uint64), neg, exps
+        if arr.dtype.kind == "u":
+            return arr.astype(np.uint64), np.zeros(arr.shape, dtype=bool), np.zeros(arr.shape, dtype=np.int64)
+        if arr.dtype.kind == "i":
+            rep = arr.astype(np.int64)
+            neg = rep < 0
+            mag = rep.astype(np.uint64)
+            mag[neg] = (~mag[neg]) + np.uint64(1)                                 # two's complement: safe for -2^63
+            return mag, neg, np.zeros(arr.shape, dtype=np.int64)
+        return None
+
+    @staticmethod
+    def signed_to_limbs(public_key, mag, neg, n_limbs):
+        """(-1)^neg * mag mod n as (len, n_limbs) little-endian uint32 rows, magnitudes below 2^64 (n_limbs >= 3).
+        Raises the reference's range error if a magnitude exceeds max_int (only possible for toy keys)."""
+        mag = np.ascontiguousarray(mag, dtype=np.uint64)
+        n = public_key.n
+        if len(mag) and public_key.max_int < (1 << 64):
+            worst = int(mag.max())
+            if worst > public_key.max_int:
+                raise ValueError('Integer needs to be within +/- %d but got %d' % (public_key.max_int, worst))
+        neg = np.asarray(neg, dtype=bool) & (mag != 0)
+        n_arr = np.frombuffer(n.to_bytes(4 * n_limbs, "little"), dtype=np.uint32)
+        n_lo = np.uint64(n & 0xffffffffffffffff)
+        out = np.empty((len(mag), n_limbs), dtype=np.uint32)
+        # limbs 2..: n's own where the value is negative (n - mag with mag < 2^64), zero elsewhere — written in place
+        np.multiply(neg.astype(np.uint32)[:, None], n_arr[None, 2:], out=out[:, 2:])
+        lo = np.where(neg, n_lo - mag, mag)                    # uint64, wraps when the subtraction borrows
+        out[:, 0] = (lo & np.uint64(0xffffffff)).astype(np.uint32)
+        out[:, 1] = (lo >> np.uint64(32)).astype(np.uint32)
+        for i in np.nonzero(neg & (mag > n_lo))[0].tolist():   # a borrow out of the low 64 bits: rare, exact by hand
+            out[i] = np.frombuffer((n - int(mag[i])).to_bytes(4 * n_limbs, "little"), dtype=np.uint32)
+        return out
+
+    @classmethod
+    def decode_limbs(cls, public_key, limbs, exponents):
+        """Plaintext rows (len, n_limbs) + exponents -> list of numbers, element-wise identical to
+        cls(public_key, value, exponent).decode().  Rows whose magnitude fits 64 bits and whose exponent is in
+        -64..0 are decoded with numpy; everything else (and every error) goes through `decode`."""
+        limbs = np.ascontiguousarray(limbs, dtype=np.uint32)
+        exps = np.asarray(exponents, dtype=np.int64).reshape(-1)
+        count, n_limbs = limbs.shape
+        n = public_key.n
+        out = [None] * count
+        fast = np.zeros(count, dtype=bool)
+        if n_limbs >= 4 and n.bit_length() > 32 * (n_limbs - 1) and count:
+            lo = limbs[:, 0].astype(np.uint64) | (limbs[:, 1].astype(np.uint64) << np.uint64(32))
+            pos = ~limbs[:, 2:].any(axis=1)                    # value < 2^64 <= max_int
+            # negative with |value| < 2^64 and no borrow out of the low 64 bits: high limbs are n's, low part below n's
+            n_arr = np.frombuffer(n.to_bytes(4 * n_limbs, "little"), dtype=np.uint32)
+            n_lo = np.uint64(n & 0xffffffffffffffff)
+            neg = (limbs[:, 2:] == n_arr[None, 2:]).all(axis=1) & (lo < n_lo)
+            in_range = (exps <= 0) & (exps >= -64)
+            fast = (pos | neg) & in_range
+            mag = np.where(neg, n_lo - lo, lo)
+            # floats: correctly rounded uint64 -> float64, then an exact power-of-two scaling = the reference's true division
+            fl = np.nonzero(fast & (exps < 0))[0]
+            if len(fl):
+                vals = np.ldexp(mag[fl].astype(np.float64), (exps[fl] * int(round(cls.LOG2_BASE))).astype(np.int64))
+                vals = np.where(neg[fl], -vals, vals).tolist()
+                if len(fl) == count:
+                    out = vals
+                else:
+                    for i, v in zip(fl.tolist(), vals):
+                        out[i] = v
+            it = np.nonzero(fast & (exps == 0))[0]
+            if len(it):
+                for i, m, sgn in zip(it.tolist(), mag[it].tolist(), neg[it].tolist()):
+                    out[i] = -m if sgn else m
+        slow = np.nonzero(~fast)[0]
+        if len(slow):
+            from . import _native
+            for i, v in zip(slow.tolist(), _native.limbs_to_ints(limbs[slow])):
+                out[i] = cls(public_key, v, int(exps[i])).decode()
+        return out
+
     @classmethod
     def decode_many(cls, public_key, encodings, exponents):
         """Inverse of encode_many: list of ints/floats, element-wise identical to

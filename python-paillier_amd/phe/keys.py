@@ -109,13 +109,23 @@ class PaillierPublicKey(object):
 
     def encrypt_batch(self, values, precision=None, r_values=None, device=False):
         """Encode + encrypt a whole sequence / numpy array -> EncryptedVector (one kernel launch).
-        device=True keeps the ciphertexts resident in HBM for later homomorphic operations."""
+        device=True keeps the ciphertexts resident in HBM for later homomorphic operations.
+        float64 / integer numpy arrays are encoded and drawn without a Python integer per element."""
         from .ciphertext import EncryptedVector
-        encs, exps = EncodedNumber.encode_many(self, values, precision)
         eng = self._get_engine()
         fresh = r_values is None
-        r = random_lt_n_limbs(self.n, len(encs), eng.n_limbs) if fresh else list(r_values)
-        limbs = eng.raw_encrypt_dev(encs, r) if device else eng.raw_encrypt(encs, r)
+        signed = EncodedNumber.encode_signed(values, precision) if eng.n_limbs >= 4 else None
+        if signed is not None:
+            mag, neg, exps = signed
+            m = EncodedNumber.signed_to_limbs(self, mag, neg, eng.n_limbs)
+        else:
+            m, exps = EncodedNumber.encode_many(self, values, precision)
+        count = len(exps)
+        if fresh:
+            r = random_lt_n_limbs(self.n, count, eng.n_limbs, out=eng.scratch("r", count, eng.n_limbs))
+        else:
+            r = list(r_values)
+        limbs = eng.raw_encrypt_dev(m, r) if device else eng.raw_encrypt(m, r)
         return EncryptedVector(self, limbs, exps, obfuscated=fresh)
 
 
@@ -216,10 +226,12 @@ class PaillierPrivateKey(object):
             raise ValueError('encrypted_number was encrypted against a different key!')
         eng = self._get_engine()
         if vector.on_device:     # device pointers are valid across contexts of the same GPU
-            plain = eng.to_ints(eng.raw_decrypt_dev(vector.limbs(be_secure=False)))
+            plain = eng.raw_decrypt_dev(vector.limbs(be_secure=False))
         else:
-            plain = eng.to_ints(eng.raw_decrypt(vector.limbs(be_secure=False)))
-        return (Encoding or EncodedNumber).decode_many(self.public_key, plain, vector.exponents)
+            plain = eng.raw_decrypt(vector.limbs(be_secure=False))
+        if Encoding is None or Encoding is EncodedNumber:
+            return EncodedNumber.decode_limbs(self.public_key, plain, vector.exponent_array)
+        return Encoding.decode_many(self.public_key, eng.to_ints(plain), vector.exponents)
 
 
 class PaillierPrivateKeyring(Mapping):

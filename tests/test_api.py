@@ -294,6 +294,33 @@ def test_encrypted_vector(keys):
     assert [priv.decrypt(x) for x in singles_rec] == vals.tolist()
 
 
+def test_array_operands_take_the_same_path_as_lists(keys):
+    """numpy operands are encoded without a Python integer per element (codec array forms); the ciphertext bits must
+    be the ones the element-by-element path produces."""
+    g, pub, priv = keys
+    rng = np.random.Generator(np.random.PCG64(3))
+    vals = rng.standard_normal(9) * 10.0 ** rng.integers(-4, 5, 9)
+    rs = [H(e["r"]) for e in g["raw_encrypt"][3:12]]
+    vec = pub.encrypt_batch(vals, r_values=rs)
+    assert vec.ciphertexts(False) == pub.encrypt_batch(vals.tolist(), r_values=rs).ciphertexts(False)
+    w = rng.standard_normal(9)
+    w[0], w[1], w[2] = 0.0, 1.0, -1.0
+    assert (vec * w).ciphertexts(False) == (vec * w.tolist()).ciphertexts(False)
+    assert (vec * w).exponents == (vec * w.tolist()).exponents
+    k = rng.integers(-1000, 1000, 9)
+    assert (vec * k).ciphertexts(False) == (vec * [int(x) for x in k]).ciphertexts(False)
+    b = rng.standard_normal(9) * 10.0 ** rng.integers(-6, 3, 9)       # exponents above and below the vector's
+    assert (vec + b).ciphertexts(False) == (vec + b.tolist()).ciphertexts(False)
+    assert (vec + b).exponents == (vec + b.tolist()).exponents
+    assert (vec - b).ciphertexts(False) == (vec - b.tolist()).ciphertexts(False)
+    assert (vec + k).ciphertexts(False) == (vec + [int(x) for x in k]).ciphertexts(False)
+    got = priv.decrypt_batch(vec * w + b)
+    assert all(math.isclose(a, v * x + y, rel_tol=1e-9, abs_tol=1e-12) for a, v, x, y in zip(got, vals, w, b))
+    ints = pub.encrypt_batch(np.array([5, -6, 7], dtype=np.int64), r_values=rs[:3])
+    assert priv.decrypt_batch(ints) == [5, -6, 7] and ints.exponents == [0, 0, 0]
+    assert priv.decrypt_batch(ints * np.array([2, -3, 0])) == [10, 18, 0]
+
+
 @pytest.mark.gpu
 def test_device_resident_vector_matches_host_vector():
     """EncryptedVector(device=True): every op stays in HBM and gives the same ciphertext bits as the host-array path
