@@ -13,7 +13,8 @@ class DeviceArray:
         self.rows, self.cols = int(rows), int(cols)
         self._owner = _owner                      # keeps the allocation alive for row views
         if _ptr is None:
-            self.ptr = ctx.malloc(max(4, self.nbytes))
+            self._alloc = max(4, self.nbytes)
+            self.ptr = ctx.malloc(self._alloc)
             self._owns = True
         else:
             self.ptr = _ptr
@@ -69,7 +70,7 @@ class DeviceArray:
     def __del__(self):
         try:
             if getattr(self, "_owns", False) and self.ptr:
-                self.ctx.free(self.ptr)
+                self.ctx.free(self.ptr, self._alloc)
                 self.ptr = None
         except Exception:
             pass

@@ -236,6 +236,24 @@ class Engine:
         self.ctx.sync()
         return out
 
+    def raw_encrypt_fresh(self, m, device):
+        """raw_encrypt with freshly drawn obfuscators, in chunks: the draw of chunk k+1 (the kernel CSPRNG, host side)
+        overlaps the kernel of chunk k — launches are asynchronous, the only host/device rendezvous inside the loop is
+        the upload of the next operands.  m: (count, n_limbs) plaintext limbs.  Returns a DeviceArray or a host array."""
+        count = m.shape[0]
+        chunk = 1 << 16
+        out = DeviceArray(self.ctx, count, self.ct_limbs)
+        keep = []                                         # operand buffers stay alive until the final sync
+        for lo in range(0, count, chunk):
+            hi = min(count, lo + chunk)
+            r = random_lt_n_limbs(self.n, hi - lo, self.n_limbs, out=self.scratch("r", hi - lo, self.n_limbs))
+            m_d = DeviceArray.from_host(self.ctx, m[lo:hi])
+            r_d = DeviceArray.from_host(self.ctx, r)      # synchronous copy: the scratch buffer is free again
+            keep += [m_d, r_d]
+            self.ctx.encrypt_dev(m_d.ptr, r_d.ptr, out.rows_view(lo, hi).ptr, hi - lo)
+        self.ctx.sync()
+        return out if device else out.to_host()
+
     def obfuscate_dev(self, c, r):
         r = self.upload_plain(r)
         out = DeviceArray(self.ctx, c.rows, self.ct_limbs)

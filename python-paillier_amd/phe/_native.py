@@ -159,6 +159,7 @@ class Context:
 
     def close(self):
         if self._h and self._h.value:
+            self.trim_pool()
             lib().phe_hip_ctx_destroy(self._h)
             self._h = ctypes.c_void_p(None)
 
@@ -275,14 +276,37 @@ class Context:
         _check(lib().phe_hip_stream_sync(self._h, stream))
 
     # ---- raw device memory (for hosts without a tensor library) ----
+    # Freed blocks are kept for reuse by size (a hipMalloc/hipFree pair of a ciphertext vector costs more than the
+    # homomorphic add that fills it).  Safe because every Python-level operation synchronises before it returns, so a
+    # block is idle by the time its owner is garbage-collected.
+    POOL_LIMIT = 4 << 30
+
     def malloc(self, nbytes):
+        pool = self.__dict__.setdefault("_pool", {})
+        blocks = pool.get(nbytes)
+        if blocks:
+            self._pooled -= nbytes
+            return blocks.pop()
         p = ctypes.c_void_p(None)
         _check(lib().phe_hip_malloc(self._h, nbytes, ctypes.byref(p)))
         return p.value
 
-    def free(self, ptr):
-        if self._h and self._h.value:
-            _check(lib().phe_hip_free(self._h, ptr))
+    def free(self, ptr, nbytes=None):
+        if not (self._h and self._h.value):
+            return
+        pool = self.__dict__.setdefault("_pool", {})
+        pooled = self.__dict__.setdefault("_pooled", 0)
+        if nbytes is not None and pooled + nbytes <= self.POOL_LIMIT:
+            pool.setdefault(nbytes, []).append(ptr)
+            self._pooled = pooled + nbytes
+            return
+        _check(lib().phe_hip_free(self._h, ptr))
+
+    def trim_pool(self):
+        for blocks in self.__dict__.get("_pool", {}).values():
+            for ptr in blocks:
+                lib().phe_hip_free(self._h, ptr)
+        self._pool, self._pooled = {}, 0
 
     def h2d(self, dst_ptr, arr):
         arr = np.ascontiguousarray(arr)

@@ -121,11 +121,11 @@ class PaillierPublicKey(object):
         else:
             m, exps = EncodedNumber.encode_many(self, values, precision)
         count = len(exps)
-        if fresh:
-            r = random_lt_n_limbs(self.n, count, eng.n_limbs, out=eng.scratch("r", count, eng.n_limbs))
+        if fresh and isinstance(m, np.ndarray) and hasattr(eng.ctx, "encrypt_dev"):
+            limbs = eng.raw_encrypt_fresh(m, device)
         else:
-            r = list(r_values)
-        limbs = eng.raw_encrypt_dev(m, r) if device else eng.raw_encrypt(m, r)
+            r = random_lt_n_limbs(self.n, count, eng.n_limbs) if fresh else list(r_values)
+            limbs = eng.raw_encrypt_dev(m, r) if device else eng.raw_encrypt(m, r)
         return EncryptedVector(self, limbs, exps, obfuscated=fresh)
 
 
