@@ -178,6 +178,8 @@ PHE_DEV void montmul(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[
                      uint32_t n0inv, const Lanes<G>& ln) {
     constexpr int S = G * L;
     const uint32_t dmask = kLimbMask & ln.not_top;  // digit mask + "the top lane receives 0" as one v_and
+    // kLimbMask as plain VGPR data (no lane of a group is both top and low): lets "dpp(x) & mask" be one v_and_b32_dpp
+    const uint32_t vmask = kLimbMask & (ln.not_top | ln.not_low);
     uint64_t acc[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) acc[k] = 0;
@@ -189,7 +191,7 @@ PHE_DEV void montmul(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[
             const uint32_t ai = a[i + j];
 #pragma unroll
             for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(ai, b[k], acc[(k + j) % L]);
-            const uint32_t m = wave::grp_bcast0<G>(((uint32_t)acc[j] * n0inv) & kLimbMask, ln);
+            const uint32_t m = wave::grp_bcast0<G>((uint32_t)acc[j] * n0inv, ln) & vmask;
 #pragma unroll
             for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(m, n[k], acc[(k + j) % L]);
             const uint64_t low = acc[j];  // logical limb 0 (= 0 mod 2^29 in lane 0)

@@ -197,6 +197,9 @@ PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
     constexpr int H = G * L;
     const uint32_t lane0 = kLimbMask & ~ln.not_low;  // digit mask in lane 0 of the group, 0 elsewhere
     const uint32_t dmask = kLimbMask & ln.not_top;
+    // = kLimbMask in every lane (no lane of a group of >= 2 is both top and low), but plain VGPR data to the compiler,
+    // so that "dpp(x) & mask" becomes one v_and_b32_dpp instead of v_and (literal) + v_mov_b32_dpp
+    const uint32_t vmask = kLimbMask & (ln.not_top | ln.not_low);
     uint64_t p[L], q[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) p[k] = q[k] = 0;
@@ -210,11 +213,11 @@ PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
 #pragma unroll
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(ai, b1[k], q[(k + j) % L]);
             const uint32_t mraw = (uint32_t)p[j] * n0inv;
-            const uint32_t m = wave::grp_bcast0<G>(mraw & kLimbMask, ln);
+            const uint32_t m = wave::grp_bcast0<G>(mraw, ln) & vmask;
             q[j] += (uint64_t)(mraw & lane0);  // quotient digit i of the first sum = digit i of the addend m
 #pragma unroll
             for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(m, n[k], p[(k + j) % L]);
-            const uint32_t m2 = wave::grp_bcast0<G>(((uint32_t)q[j] * n0inv) & kLimbMask, ln);
+            const uint32_t m2 = wave::grp_bcast0<G>((uint32_t)q[j] * n0inv, ln) & vmask;
 #pragma unroll
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(m2, n[k], q[(k + j) % L]);
             shift_row<G, L>(p, j, dmask);
@@ -234,6 +237,7 @@ PHE_DEV void pair_pass3(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
     constexpr int H = G * L;
     const uint32_t lane0 = kLimbMask & ~ln.not_low;
     const uint32_t dmask = kLimbMask & ln.not_top;
+    const uint32_t vmask = kLimbMask & (ln.not_top | ln.not_low);
     uint64_t p[L], q[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) p[k] = q[k] = 0;
@@ -250,11 +254,11 @@ PHE_DEV void pair_pass3(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
 #pragma unroll
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(ci, b0[k], q[(k + j) % L]);
             const uint32_t mraw = (uint32_t)p[j] * n0inv;
-            const uint32_t m = wave::grp_bcast0<G>(mraw & kLimbMask, ln);
+            const uint32_t m = wave::grp_bcast0<G>(mraw, ln) & vmask;
             q[j] += (uint64_t)(mraw & lane0);
 #pragma unroll
             for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(m, n[k], p[(k + j) % L]);
-            const uint32_t m2 = wave::grp_bcast0<G>(((uint32_t)q[j] * n0inv) & kLimbMask, ln);
+            const uint32_t m2 = wave::grp_bcast0<G>((uint32_t)q[j] * n0inv, ln) & vmask;
 #pragma unroll
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(m2, n[k], q[(k + j) % L]);
             shift_row<G, L>(p, j, dmask);
