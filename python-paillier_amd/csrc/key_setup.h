@@ -280,13 +280,13 @@ inline ModulusPack build_modulus(const Big& N_any, const Big* aux_src, int min_b
 
 // ---- split-modulus ("n-adic") arithmetic: constants of csrc/split_core.h -----------------------------------
 // Work modulo n^2 is done on pairs (X0, X1), x*R = X0 - n*X1 (mod n^2), with half-width Montgomery passes modulo n
-// only: R = 2^(29 H) >= 16 n, H = G*L limbs.  The widest pass adds three products per digit to a column
-// accumulator, so 3L * 2^58 < 2^64 bounds L by 21.
+// only: R = 2^(29 H) >= 16 n, H = G*L limbs.  A fused sweep adds three products per digit to a column accumulator
+// (3L * 2^58 < 2^64: L <= 21); wider lanes (L = 27) run the words of a pair product as single sweeps of two.
 static const int kS16[] = {1, 2, 3, 5, 7, 9, 14, 18};
 static const int kS8[] = {7, 9, 14, 18};
-static const int kS4[] = {9, 14, 18};
-static const int kS2[] = {9, 18};
-constexpr int kMaxSplitL = 21;
+static const int kS4[] = {9, 14, 18, 27};
+static const int kS2[] = {9, 18, 27};
+constexpr int kMaxSplitL = 31;  // two products per digit per sweep: 2L * 2^58 < 2^64 (fused sweeps, three products: L <= 21)
 
 inline Geometry pick_geometry_split(int n_bits, int prefer_group) {
     const int need = (n_bits + 4 + kRadixBits - 1) / kRadixBits;

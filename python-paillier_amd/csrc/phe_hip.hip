@@ -71,8 +71,10 @@ PHE_DECLARE_PART(g16b)
     }
 PHE_DECLARE_SPLIT_PART(s2a)
 PHE_DECLARE_SPLIT_PART(s2b)
+PHE_DECLARE_SPLIT_PART(s2c)
 PHE_DECLARE_SPLIT_PART(s4a)
 PHE_DECLARE_SPLIT_PART(s4b)
+PHE_DECLARE_SPLIT_PART(s4c)
 PHE_DECLARE_SPLIT_PART(s8a)
 PHE_DECLARE_SPLIT_PART(s8b)
 PHE_DECLARE_SPLIT_PART(s8c)
@@ -113,8 +115,10 @@ struct SplitPart {
 static const SplitPart kSplitParts[] = {
     {2, phe::s2a::occ_split, phe::s2a::launch_split, phe::s2a::occ_var_split, phe::s2a::launch_var_split},
     {2, phe::s2b::occ_split, phe::s2b::launch_split, phe::s2b::occ_var_split, phe::s2b::launch_var_split},
+    {2, phe::s2c::occ_split, phe::s2c::launch_split, phe::s2c::occ_var_split, phe::s2c::launch_var_split},
     {4, phe::s4a::occ_split, phe::s4a::launch_split, phe::s4a::occ_var_split, phe::s4a::launch_var_split},
     {4, phe::s4b::occ_split, phe::s4b::launch_split, phe::s4b::occ_var_split, phe::s4b::launch_var_split},
+    {4, phe::s4c::occ_split, phe::s4c::launch_split, phe::s4c::occ_var_split, phe::s4c::launch_var_split},
     {8, phe::s8a::occ_split, phe::s8a::launch_split, phe::s8a::occ_var_split, phe::s8a::launch_var_split},
     {8, phe::s8b::occ_split, phe::s8b::launch_split, phe::s8b::occ_var_split, phe::s8b::launch_var_split},
     {8, phe::s8c::occ_split, phe::s8c::launch_split, phe::s8c::occ_var_split, phe::s8c::launch_var_split},

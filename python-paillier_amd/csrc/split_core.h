@@ -20,8 +20,8 @@
 // decrypt are ~85 % squarings, so about half of the multiply-adds disappear.
 // tools/exp/split_model.py checks the algebra and the lazy-reduction bounds below with plain integers.
 //
-// Lazy bounds (R >= 16 n): X0 < 2n, X1 < 2n are closed under both operations (inputs up to 3n are fine); sums made
-// while converting inputs stay below R.  Limbs are almost-normalised (< 2^29 + 2^8) exactly as in mont_core.h, and
+// Lazy bounds (R >= 16 n): X0 < 2n, X1 < 2n are closed under both operations (X1 < 3n where a product is made of
+// single sweeps, see split_mul; inputs up to 3n are fine everywhere); sums made while converting inputs stay below R.  Limbs are almost-normalised (< 2^29 + 2^8) exactly as in mont_core.h, and
 // a column accumulator takes at most three products per digit for L digits: L <= 21 keeps it below 2^64 for any
 // operands.
 //
@@ -35,6 +35,11 @@
 #include "mont_core.h"
 
 namespace phe {
+
+// A fused sweep (pair_pass2 / pair_pass3) keeps two accumulator sets and three operand rows in registers (7L VGPRs)
+// and adds up to three products per digit to one accumulator: both stop at about L = 21 limbs per lane.  Wider lanes
+// run every word of a pair product as its own single-accumulator sweep (two products per digit, L <= 31).
+constexpr int kMaxFusedL = 21;
 
 // per-modulus constants (device pointers; H = G*L words of 29-bit limbs per row)
 struct SplitConsts {
@@ -127,6 +132,40 @@ PHE_DEV void montmac2(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)
             for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(m2, n[k], acc[(k + j) % L]);
             const uint64_t low = acc[j];
             const uint32_t recv = wave::grp_down1<G>((uint32_t)low & kLimbMask, ln);
+            if constexpr (L > 1) {
+                acc[(j + 1) % L] += low >> kRadixBits;
+                acc[j] = recv;
+            } else {
+                acc[0] = (low >> kRadixBits) + recv;
+            }
+        }
+    }
+    normalize_partial<G, L>(out, acc, ln);
+}
+
+// out = (addend + a*b + m2*n) / R;  a and the addend: H digits each in LDS (the addend is the quotient of a previous
+// montmul_q: the second word of a pair product when the sweeps are not fused)
+template <int G, int L>
+PHE_DEV void montmul_addend(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[L], const uint32_t* addend_row,
+                            const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln) {
+    constexpr int H = G * L;
+    const uint32_t dmask = kLimbMask & ln.not_top;
+    const uint32_t vmask = kLimbMask & (ln.not_top | ln.not_low);
+    uint64_t acc[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) acc[k] = addend_row[ln.g * L + k];
+#pragma unroll 1
+    for (int i = 0; i < H; i += L) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const uint32_t ai = a[i + j];
+#pragma unroll
+            for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(ai, b[k], acc[(k + j) % L]);
+            const uint32_t m2 = wave::grp_bcast0<G>((uint32_t)acc[j] * n0inv, ln) & vmask;
+#pragma unroll
+            for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(m2, n[k], acc[(k + j) % L]);
+            const uint64_t low = acc[j];
+            const uint32_t recv = wave::grp_down1_raw<G>((uint32_t)low) & dmask;
             if constexpr (L > 1) {
                 acc[(j + 1) % L] += low >> kRadixBits;
                 acc[j] = recv;
@@ -277,6 +316,23 @@ struct SplitLane {  // what every pass needs, loaded once per kernel
     uint32_t* row_c;  // H words: digits of X1 (quotient digits in split_exit)
 };
 
+// (z0, z1) = (a*b0 + m*n, m + a*b1 + m2*n) / R with a already in row_a: one fused sweep, or two single sweeps with the
+// quotient digits handed over through row_c when the lanes are too wide for the fused one
+template <int G, int L>
+PHE_DEV void pair_mul_plain(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t (&b0)[L], const uint32_t (&b1)[L],
+                            const SplitLane<G, L>& K, const Lanes<G>& ln) {
+    if constexpr (L <= kMaxFusedL) {
+        pair_pass2<G, L>(z0, z1, K.row_a, b0, b1, K.n, K.n0inv, ln);
+    } else {
+        uint32_t u[L];
+        montmul_q<G, L>(u, K.row_a, b0, K.row_c, K.n, K.n0inv, ln);
+        wave::lds_fence();
+        montmul_addend<G, L>(z1, K.row_a, b1, K.row_c, K.n, K.n0inv, ln);
+#pragma unroll
+        for (int k = 0; k < L; ++k) z0[k] = u[k];
+    }
+}
+
 template <int G, int L>
 PHE_DEV void split_square(uint32_t (&X0)[L], uint32_t (&X1)[L], const SplitLane<G, L>& K, const Lanes<G>& ln) {
     uint32_t d[L];
@@ -284,20 +340,31 @@ PHE_DEV void split_square(uint32_t (&X0)[L], uint32_t (&X1)[L], const SplitLane<
 #pragma unroll
     for (int k = 0; k < L; ++k) d[k] = X1[k];
     add_normalize<G, L>(d, X1, ln);  // 2*X1
-    pair_pass2<G, L>(X0, X1, K.row_a, X0, d, K.n, K.n0inv, ln);
+    pair_mul_plain<G, L>(X0, X1, X0, d, K, ln);
 }
 
 template <int G, int L>
 PHE_DEV void split_mul(uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t (&Y0)[L], const uint32_t (&Y1)[L],
                        const SplitLane<G, L>& K, const Lanes<G>& ln) {
-    wave::lds_fence();
+    if constexpr (L <= kMaxFusedL) {
+        wave::lds_fence();
 #pragma unroll
-    for (int k = 0; k < L; ++k) {
-        K.row_a[ln.g * L + k] = X0[k];
-        K.row_c[ln.g * L + k] = X1[k];
+        for (int k = 0; k < L; ++k) {
+            K.row_a[ln.g * L + k] = X0[k];
+            K.row_c[ln.g * L + k] = X1[k];
+        }
+        wave::lds_fence();
+        pair_pass3<G, L>(X0, X1, K.row_a, K.row_c, Y0, Y1, K.n, K.n0inv, ln);
+    } else {
+        // three single sweeps: X1*Y0, then (X0*Y0 with its quotient) and (quotient + X0*Y1); the second word stays
+        // below 3n instead of 2n, which every operation accepts
+        uint32_t t[L];
+        lds_put<L>(K.row_a, X1, ln.g);
+        montmul<G, L>(t, K.row_a, Y0, K.n, K.n0inv, ln);
+        lds_put<L>(K.row_a, X0, ln.g);
+        pair_mul_plain<G, L>(X0, X1, Y0, Y1, K, ln);
+        add_normalize<G, L>(X1, t, ln);
     }
-    wave::lds_fence();
-    pair_pass3<G, L>(X0, X1, K.row_a, K.row_c, Y0, Y1, K.n, K.n0inv, ln);
 }
 
 // the number in the 32-bit-word row src -> pair representation
@@ -312,9 +379,9 @@ PHE_DEV void split_conv(uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t* sr
         load_row<L>(d0, C.conv + (size_t)(2 * j) * H, ln.g);
         load_row<L>(d1, C.conv + (size_t)(2 * j + 1) * H, ln.g);
         if (j == 0) {
-            pair_pass2<G, L>(X0, X1, K.row_a, d0, d1, K.n, K.n0inv, ln);
+            pair_mul_plain<G, L>(X0, X1, d0, d1, K, ln);
         } else {
-            pair_pass2<G, L>(u, t, K.row_a, d0, d1, K.n, K.n0inv, ln);
+            pair_mul_plain<G, L>(u, t, d0, d1, K, ln);
             add_normalize<G, L>(X0, u, ln);
             add_normalize<G, L>(X1, t, ln);
         }
@@ -412,7 +479,14 @@ PHE_DEV void split_exit(uint32_t* out, int out_limbs, uint32_t (&X0)[L], uint32_
     lds_put<L>(K.row_a, X1, g);  // (its fences also order the quotient digits in row_c)
 #pragma unroll
     for (int k = 0; k < L; ++k) cst[k] = K.n[k] - ((g == 0u && k == 0) ? 1u : 0u);  // n is odd: no borrow
-    montmac2<G, L>(t, K.row_a, cst, K.row_c, cst, K.n, K.n0inv, ln);
+    if constexpr (L <= kMaxFusedL) {
+        montmac2<G, L>(t, K.row_a, cst, K.row_c, cst, K.n, K.n0inv, ln);
+    } else {
+        uint32_t t2[L];
+        montmul<G, L>(t, K.row_a, cst, K.n, K.n0inv, ln);
+        montmul<G, L>(t2, K.row_c, cst, K.n, K.n0inv, ln);
+        add_normalize<G, L>(t, t2, ln);
+    }
     if (mp != nullptr) {  // + mp * X0 / R: the plaintext term of (1 + n*mp), phe/paillier.py:134
         uint32_t w[L];
         load_u32_as_r29<L>(w, mp, mp_limbs, 0, g);

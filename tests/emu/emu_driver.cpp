@@ -118,6 +118,8 @@ static void run_mul(MulArgs A) {
         case 1618: { constexpr int GG = 16, LL = 18; CALL; break; }                   \
         case 209: { constexpr int GG = 2, LL = 9; CALL; break; }                      \
         case 218: { constexpr int GG = 2, LL = 18; CALL; break; }                     \
+        case 227: { constexpr int GG = 2, LL = 27; CALL; break; }                     \
+        case 427: { constexpr int GG = 4, LL = 27; CALL; break; }                     \
         case 409: { constexpr int GG = 4, LL = 9; CALL; break; }                      \
         case 414: { constexpr int GG = 4, LL = 14; CALL; break; }                     \
         case 418: { constexpr int GG = 4, LL = 18; CALL; break; }                     \
