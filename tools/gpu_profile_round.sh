@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-1 final: parity suite, smoke, bench (2048 / 3072 / ops), rocprofv3 kernel trace and PMC passes for the split-modulus engine
+# TAG=<name> bash tools/gpu_profile_round.sh (through gpurun): parity suite, smoke, bench (2048 / 3072 / ops), rocprofv3 kernel trace and PMC passes for the split-modulus engine
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out; R=$PWD
 timeout 1200 python -m pytest tests -m gpu -x -q > gpurun_out/pytest_gpu_${TAG:-r01}.log 2>&1; echo "pytest rc=$?"; tail -3 gpurun_out/pytest_gpu_${TAG:-r01}.log
