@@ -144,7 +144,7 @@ int phe_hip_stream_sync(phe_hip_ctx* ctx, void* stream);
 /* ---- diagnostics ----------------------------------------------------------------------------- */
 /* Runs the three DPP row primitives and the ballot on lane ids: out is (4, 64) uint32:
  * row 0 = row_down1(lane), row 1 = row_up1(lane), row 2 = row_bcast0(lane), row 3 = lane parity
- * ballot folded per lane.  Used by tests/test_gpu_prims.py to pin the emulator's semantics. */
+ * ballot folded per lane.  Used by tests/test_gpu_parity.py::test_wave_primitives to pin the emulator's semantics. */
 int phe_hip_selftest_prims(int device, uint32_t* out);
 
 #ifdef __cplusplus

@@ -11,7 +11,7 @@
 // (groups of 8 lanes add one v_and / a second DPP; see the templates below)
 //
 // tests/emu/wave_emu.h provides the same names on the host (fibers) so tests can run
-// mont_core.h on the CPU; tests/test_gpu_prims.py checks these semantics on the real GPU.
+// mont_core.h on the CPU; tests/test_gpu_parity.py::test_wave_primitives checks these semantics on the real GPU.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -4,7 +4,7 @@
 // GPU executes) can be exercised on a CPU-only box.  Cross-lane primitives exchange values
 // through a double-buffered mailbox and yield to the scheduler; all lanes must execute the same
 // sequence of cross-lane primitives (true for these kernels: control flow is wave-uniform).
-// Semantics mirror the DPP forms documented in wave_gfx950.h; tests/test_gpu_prims.py checks
+// Semantics mirror the DPP forms documented in wave_gfx950.h; tests/test_gpu_parity.py::test_wave_primitives checks
 // the real instructions against the same expectations on the GPU.
 #pragma once
 #include <stdint.h>
