@@ -60,6 +60,15 @@ def main():
     ok = np.array_equal(to_np(out[idx]), orc.add(n_arr, to_np(ca[idx]), to_np(cb[idx]), nthreads=8))
     res["raw_add"] = {"ops_per_s": B / t, "ms": t * 1e3, "bit_exact_sample": bool(ok),
                       "hbm_GBps_algorithmic": 3 * s2 * 4 * B / t / 1e9}
+    # ---- obfuscate (phe/paillier.py:603-624): c * r^n over an existing ciphertext ----
+    t = timed(lambda: ctx.obfuscate_dev(ca.data_ptr(), r.data_ptr(), out.data_ptr(), B, st))
+    ok = np.array_equal(to_np(out[idx]), orc.obfuscate(n_arr, to_np(ca[idx]), to_np(r[idx]), nthreads=8))
+    res["obfuscate"] = {"ops_per_s": B / t, "ms": t * 1e3, "bit_exact_sample": bool(ok)}
+    # ---- add a plaintext (phe/paillier.py:673-675): c * (1 + n*m) ----
+    t = timed(lambda: ctx.add_plain_dev(ca.data_ptr(), m.data_ptr(), out.data_ptr(), B, st))
+    ones = np.zeros((len(idx), s1), np.uint32); ones[:, 0] = 1
+    ok = np.array_equal(to_np(out[idx]), orc.add(n_arr, to_np(ca[idx]), orc.encrypt(n_arr, to_np(m[idx]), ones, nthreads=8), nthreads=8))
+    res["add_plain"] = {"ops_per_s": B / t, "ms": t * 1e3, "bit_exact_sample": bool(ok)}
     # ---- _raw_mul, positive scalars ----
     for name, bits in (("raw_mul_float56", 56), ("raw_mul_int64", 63)):
         e = rnd(2)
