@@ -109,6 +109,17 @@ int phe_hip_add_plain(phe_hip_ctx* ctx, const uint32_t* c, const uint32_t* m, ui
 int phe_hip_powmod(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, uint32_t* out,
                    size_t batch);
 
+/* out = prod_i base[i]^e[i] mod n^2         — the encrypted dot product sum_i k_i * E(x_i): what the reference
+ * computes as a chain of EncryptedNumber.__mul__ (phe/paillier.py:721-751 _raw_mul -> :751 powmod) and __add__
+ * (:705-719 _raw_add -> mulmod), e.g. np.dot over ciphertexts (phe/tests/math_test.py:44-58) and
+ * examples/logistic_regression_encrypted_model.py:170-177.  The product is one canonical residue, independent of
+ * the order of the factors, so chunks of the batch share one square-and-multiply ladder (Straus' interleaving) and
+ * the per-chunk products are joined by a pairwise mulmod tree.  base: (batch, ct_limbs) < n^2;
+ * e: (batch, exp_limbs); out: ONE row of ct_limbs words (1 for an empty batch).  Rows whose scalar is on the
+ * negative branch (:745-749) are handled by the host as a second product that is inverted once. */
+int phe_hip_multiexp(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, uint32_t* out,
+                     size_t batch);
+
 /* out[i] = a[i]^-1 mod n^2                  — phe.util.invert (phe/util.py:85-103) as used at
  * phe/paillier.py:747.  Montgomery's simultaneous inversion: a product tree of mulmod launches, ONE
  * scalar inversion of the root, and the tree walked back down.  On PHE_HIP_ENOINVERSE *bad_index
@@ -124,6 +135,9 @@ int phe_hip_add_plain_dev(phe_hip_ctx* ctx, const uint32_t* c, const uint32_t* m
 /* max_exp_bits: upper bound on the bit length of every e[i] (0 = 32*exp_limbs) */
 int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, int max_exp_bits,
                        uint32_t* out, size_t batch, void* stream);
+/* out: one row of ct_limbs words on the device, complete when `stream` has drained */
+int phe_hip_multiexp_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, int max_exp_bits,
+                         uint32_t* out, size_t batch, void* stream);
 
 /* phe_hip_invert on device buffers.  Synchronises `stream` internally (the root of the product tree makes one
  * round trip to the host); results are complete on return. */

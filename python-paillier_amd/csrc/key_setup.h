@@ -387,6 +387,15 @@ inline int pick_window(int exp_bits) {
     return 5;
 }
 
+// window of a shared multi-exponentiation ladder (split_core.h:multiexp_split_body): per element bits/chunk
+// squarings + bits/w + 2^w - 2 products, and the tables of a limb group are chunk * (2^w - 1) pairs
+inline int pick_multi_window(int exp_bits) {
+    if (exp_bits <= 4) return 1;
+    if (exp_bits <= 24) return 2;
+    if (exp_bits <= 110) return 3;
+    return 4;
+}
+
 inline Schedule build_schedule(const Big& e, int window = 0) {
     const int bits = big_bits(e);
     if (bits == 0) throw std::invalid_argument("exponent must be positive");

@@ -68,6 +68,8 @@ PHE_DECLARE_PART(g16b)
     int launch_split(int L, int mode, int blocks, hipStream_t st, const SplitArgs& A);            \
     int occ_var_split(int L);                                                                     \
     int launch_var_split(int L, int blocks, hipStream_t st, const SplitVarArgs& A);               \
+    int occ_multi_split(int L);                                                                   \
+    int launch_multi_split(int L, int blocks, hipStream_t st, const SplitMultiArgs& A);           \
     }
 PHE_DECLARE_SPLIT_PART(s2a)
 PHE_DECLARE_SPLIT_PART(s2b)
@@ -111,20 +113,34 @@ struct SplitPart {
     int (*launch_split)(int, int, int, hipStream_t, const SplitArgs&);
     int (*occ_var_split)(int);
     int (*launch_var_split)(int, int, hipStream_t, const SplitVarArgs&);
+    int (*occ_multi_split)(int);
+    int (*launch_multi_split)(int, int, hipStream_t, const SplitMultiArgs&);
 };
 static const SplitPart kSplitParts[] = {
-    {2, phe::s2a::occ_split, phe::s2a::launch_split, phe::s2a::occ_var_split, phe::s2a::launch_var_split},
-    {2, phe::s2b::occ_split, phe::s2b::launch_split, phe::s2b::occ_var_split, phe::s2b::launch_var_split},
-    {2, phe::s2c::occ_split, phe::s2c::launch_split, phe::s2c::occ_var_split, phe::s2c::launch_var_split},
-    {4, phe::s4a::occ_split, phe::s4a::launch_split, phe::s4a::occ_var_split, phe::s4a::launch_var_split},
-    {4, phe::s4b::occ_split, phe::s4b::launch_split, phe::s4b::occ_var_split, phe::s4b::launch_var_split},
-    {4, phe::s4c::occ_split, phe::s4c::launch_split, phe::s4c::occ_var_split, phe::s4c::launch_var_split},
-    {8, phe::s8a::occ_split, phe::s8a::launch_split, phe::s8a::occ_var_split, phe::s8a::launch_var_split},
-    {8, phe::s8b::occ_split, phe::s8b::launch_split, phe::s8b::occ_var_split, phe::s8b::launch_var_split},
-    {8, phe::s8c::occ_split, phe::s8c::launch_split, phe::s8c::occ_var_split, phe::s8c::launch_var_split},
-    {16, phe::s16a::occ_split, phe::s16a::launch_split, phe::s16a::occ_var_split, phe::s16a::launch_var_split},
-    {16, phe::s16b::occ_split, phe::s16b::launch_split, phe::s16b::occ_var_split, phe::s16b::launch_var_split},
-    {16, phe::s16c::occ_split, phe::s16c::launch_split, phe::s16c::occ_var_split, phe::s16c::launch_var_split},
+    {2, phe::s2a::occ_split, phe::s2a::launch_split, phe::s2a::occ_var_split, phe::s2a::launch_var_split,
+     phe::s2a::occ_multi_split, phe::s2a::launch_multi_split},
+    {2, phe::s2b::occ_split, phe::s2b::launch_split, phe::s2b::occ_var_split, phe::s2b::launch_var_split,
+     phe::s2b::occ_multi_split, phe::s2b::launch_multi_split},
+    {2, phe::s2c::occ_split, phe::s2c::launch_split, phe::s2c::occ_var_split, phe::s2c::launch_var_split,
+     phe::s2c::occ_multi_split, phe::s2c::launch_multi_split},
+    {4, phe::s4a::occ_split, phe::s4a::launch_split, phe::s4a::occ_var_split, phe::s4a::launch_var_split,
+     phe::s4a::occ_multi_split, phe::s4a::launch_multi_split},
+    {4, phe::s4b::occ_split, phe::s4b::launch_split, phe::s4b::occ_var_split, phe::s4b::launch_var_split,
+     phe::s4b::occ_multi_split, phe::s4b::launch_multi_split},
+    {4, phe::s4c::occ_split, phe::s4c::launch_split, phe::s4c::occ_var_split, phe::s4c::launch_var_split,
+     phe::s4c::occ_multi_split, phe::s4c::launch_multi_split},
+    {8, phe::s8a::occ_split, phe::s8a::launch_split, phe::s8a::occ_var_split, phe::s8a::launch_var_split,
+     phe::s8a::occ_multi_split, phe::s8a::launch_multi_split},
+    {8, phe::s8b::occ_split, phe::s8b::launch_split, phe::s8b::occ_var_split, phe::s8b::launch_var_split,
+     phe::s8b::occ_multi_split, phe::s8b::launch_multi_split},
+    {8, phe::s8c::occ_split, phe::s8c::launch_split, phe::s8c::occ_var_split, phe::s8c::launch_var_split,
+     phe::s8c::occ_multi_split, phe::s8c::launch_multi_split},
+    {16, phe::s16a::occ_split, phe::s16a::launch_split, phe::s16a::occ_var_split, phe::s16a::launch_var_split,
+     phe::s16a::occ_multi_split, phe::s16a::launch_multi_split},
+    {16, phe::s16b::occ_split, phe::s16b::launch_split, phe::s16b::occ_var_split, phe::s16b::launch_var_split,
+     phe::s16b::occ_multi_split, phe::s16b::launch_multi_split},
+    {16, phe::s16c::occ_split, phe::s16c::launch_split, phe::s16c::occ_var_split, phe::s16c::launch_var_split,
+     phe::s16c::occ_multi_split, phe::s16c::launch_multi_split},
 };
 #define PHE_SPLIT_BY_GROUP(G_, CALL2)                 \
     [&]() -> int {                                    \
@@ -247,6 +263,8 @@ struct phe_hip_ctx {
     size_t table_words = 0;
     uint32_t* scratch = nullptr;  // decrypt intermediates x_p | x_q
     size_t scratch_words = 0;
+    uint32_t* partial = nullptr;  // multi-exponentiation: one product per chunk, joined in place by a k_mulmod tree
+    size_t partial_words = 0;
     // staging for the host-pointer entry points
     uint32_t* stage[3] = {nullptr, nullptr, nullptr};
     size_t stage_words[3] = {0, 0, 0};
@@ -453,6 +471,39 @@ static int launch_var_split(phe_hip_ctx* ctx, const DevSplit& M, const uint32_t*
     return PHE_HIP_OK;
 }
 
+
+static int launch_multi_split(phe_hip_ctx* ctx, const DevSplit& M, const uint32_t* base, int base_limbs,
+                              const uint32_t* e, int exp_limbs, int max_bits, int chunk, uint32_t* out, int out_limbs,
+                              size_t batch, size_t n_out, hipStream_t stream) {
+    SplitMultiArgs A;
+    A.mod = M.c;
+    A.base = base;
+    A.base_limbs = base_limbs;
+    A.base_chunks = chunks_for(base_limbs, M.H);
+    A.exps = e;
+    A.exp_limbs = exp_limbs;
+    A.window = host::pick_multi_window(max_bits);
+    A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
+    A.chunk = chunk;
+    A.out = out;
+    A.out_limbs = out_limbs;
+    A.batch = batch;
+    A.n_out = n_out;
+    int per_cu = ctx->blocks_per_cu;
+    if (per_cu == 0) per_cu = PHE_SPLIT_BY_GROUP(M.G, occ_multi_split(M.L));
+    if (per_cu < 0) return fail(PHE_HIP_EINVAL, "unsupported split geometry");
+    const int blocks = grid_blocks(ctx, n_out, M.G, per_cu);
+    const size_t rows = (size_t)blocks * (size_t)(kBlock / M.G);
+    int rc = ensure_words(&ctx->table, &ctx->table_words,
+                          rows * (size_t)chunk * (((size_t)1 << A.window) - 1) * 2 * M.H);
+    if (rc) return rc;
+    A.table = ctx->table;
+    if (PHE_SPLIT_BY_GROUP(M.G, launch_multi_split(M.L, blocks, stream, A)) < 0)
+        return fail(PHE_HIP_EINVAL, "unsupported split geometry");
+    HIP_TRY(hipGetLastError());
+    return PHE_HIP_OK;
+}
+
 static int launch_var(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* base, int base_limbs,
                       const uint32_t* e, int exp_limbs, int max_bits, uint32_t* out, int out_limbs, size_t batch,
                       hipStream_t stream) {
@@ -645,8 +696,8 @@ void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
                         ctx->d_psplit_lat.blob, ctx->d_qsplit_lat.blob,
                         ctx->d_nsq_lat.blob, ctx->d_psq_lat.blob, ctx->d_qsq_lat.blob,
                         ctx->d_nsq.blob, ctx->d_psq.blob, ctx->d_qsq.blob, ctx->d_exp_n.ops, ctx->d_exp_p.ops,
-                        ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->scratch, ctx->stage[0], ctx->stage[1],
-                        ctx->stage[2]};
+                        ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->scratch, ctx->partial, ctx->stage[0],
+                        ctx->stage[1], ctx->stage[2]};
     for (uint32_t* b : bufs)
         if (b) (void)hipFree(b);
     delete ctx;
@@ -784,6 +835,64 @@ int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e
                       (hipStream_t)stream);
 }
 
+// prod_i base_i^e_i mod n^2 (the encrypted dot product): chunks of the batch go through k_multiexp_split (one shared
+// square-and-multiply ladder per chunk), the per-chunk products are joined in place by a pairwise k_mulmod tree.
+// Without a split geometry (or PHE_HIP_ENGINE=full) the per-element powers come from the powmod kernel (chunk = 1).
+int phe_hip_multiexp_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, int max_exp_bits,
+                         uint32_t* out, size_t batch, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (!out) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t s2 = (size_t)ctx->pub.s2;
+    if (batch == 0) {  // the empty product
+        HIP_TRY(hipMemsetAsync(out, 0, s2 * 4, st));
+        const uint32_t one = 1;
+        HIP_TRY(hipMemcpyAsync(out, &one, 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return PHE_HIP_OK;
+    }
+    if (!base || !e || exp_limbs < 1) return fail(PHE_HIP_EINVAL, "null buffer / exp_limbs");
+    if (max_exp_bits <= 0 || max_exp_bits > 32 * exp_limbs) max_exp_bits = 32 * exp_limbs;
+    const bool split = ctx->use_split && ctx->d_nsplit.G;
+    size_t chunk = 1;
+    if (split) {
+        // fill the resident groups of the throughput geometry first, then let chunks grow (cap 16: the tables of a
+        // group are chunk * (2^w - 1) pairs)
+        int per_cu = ctx->blocks_per_cu;
+        if (per_cu == 0) per_cu = PHE_SPLIT_BY_GROUP(ctx->d_nsplit.G, occ_multi_split(ctx->d_nsplit.L));
+        const size_t resident = (size_t)ctx->n_cus * (size_t)std::max(1, per_cu) * (size_t)(kBlock / ctx->d_nsplit.G);
+        chunk = std::min<size_t>(16, std::max<size_t>(1, batch / resident));
+        if (const char* ev = getenv("PHE_HIP_MULTI_CHUNK")) {
+            const int v = atoi(ev);
+            if (v >= 1 && v <= 64) chunk = (size_t)v;
+        }
+    }
+    size_t cur = (batch + chunk - 1) / chunk;
+    int rc = ensure_words(&ctx->partial, &ctx->partial_words, cur * s2);
+    if (rc) return rc;
+    uint32_t* P = ctx->partial;
+    if (split)
+        rc = launch_multi_split(ctx, pick_nsplit(ctx, cur), base, ctx->pub.s2, e, exp_limbs, max_exp_bits, (int)chunk, P,
+                                ctx->pub.s2, batch, cur, st);
+    else
+        rc = launch_var(ctx, pick_nsq(ctx, batch), base, ctx->pub.s2, e, exp_limbs, max_exp_bits, P, ctx->pub.s2, batch, st);
+    if (rc) return rc;
+    while (cur > 1) {
+        const size_t half = cur / 2;
+        rc = launch_mul(ctx, pick_nsq(ctx, half), P, s2, P + half * s2, s2, P, s2, ctx->pub.s2, half, st);
+        if (rc) return rc;
+        if (cur & 1) {  // the unpaired last row joins the next level
+            HIP_TRY(hipMemcpyAsync(P + half * s2, P + 2 * half * s2, s2 * 4, hipMemcpyDeviceToDevice, st));
+            cur = half + 1;
+        } else {
+            cur = half;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(out, P, s2 * 4, hipMemcpyDeviceToDevice, st));
+    return PHE_HIP_OK;
+}
+
 // ---- host-pointer entry points ------------------------------------------------------------------
 static int stage_in(phe_hip_ctx* ctx, int slot, const uint32_t* host_ptr, size_t words) {
     int rc = ensure_words(&ctx->stage[slot], &ctx->stage_words[slot], words);
@@ -888,6 +997,36 @@ int phe_hip_powmod(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, in
     if (!rc) rc = phe_hip_powmod_dev(ctx, ctx->stage[0], ctx->stage[1], exp_limbs, max_bits, ctx->stage[2], batch, nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));
+    return PHE_HIP_OK;
+}
+
+static int max_exp_bits_of(const uint32_t* e, int exp_limbs, size_t batch) {
+    int max_bits = 0;
+    for (size_t i = 0; i < batch; ++i) {
+        const uint32_t* row = e + i * (size_t)exp_limbs;
+        for (int k = exp_limbs - 1; k >= 0; --k)
+            if (row[k]) {
+                max_bits = std::max(max_bits, 32 * k + 32 - __builtin_clz(row[k]));
+                break;
+            }
+    }
+    return max_bits == 0 ? 1 : max_bits;
+}
+
+int phe_hip_multiexp(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, uint32_t* out, size_t batch) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (!out) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (batch && (!base || !e || exp_limbs < 1)) return fail(PHE_HIP_EINVAL, "null buffer / exp_limbs");
+    if (int rc = bind_device(ctx)) return rc;
+    const size_t s2 = (size_t)ctx->pub.s2;
+    int rc = stage_in(ctx, 0, batch ? base : nullptr, std::max<size_t>(1, batch) * s2);
+    if (!rc) rc = stage_in(ctx, 1, batch ? e : nullptr, std::max<size_t>(1, batch * (size_t)std::max(1, exp_limbs)));
+    if (!rc) rc = stage_in(ctx, 2, nullptr, s2);
+    if (!rc)
+        rc = phe_hip_multiexp_dev(ctx, ctx->stage[0], ctx->stage[1], exp_limbs, batch ? max_exp_bits_of(e, exp_limbs, batch) : 1,
+                                  ctx->stage[2], batch, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(out, ctx->stage[2], s2 * 4, hipMemcpyDeviceToHost));
     return PHE_HIP_OK;
 }
 

@@ -645,4 +645,91 @@ PHE_DEV void modexp_var_split_body(const SplitVarArgs& A, uint32_t* lds_row, uin
     }
 }
 
+// Multi-exponentiation  prod_i base_i ^ e_i  mod n^2 — the encrypted dot product sum_i k_i * E(x_i)
+// (phe/tests/math_test.py:44-58 np.dot over EncryptedNumbers; examples/logistic_regression_encrypted_model.py:170-177;
+// each term is phe/paillier.py:751 powmod(c_i, k_i, n^2), the terms are joined by :705-719 mulmod).  The product is a
+// canonical residue, so it does not depend on the order of the factors: one limb group takes a CHUNK of elements and
+// runs them through ONE square-and-multiply ladder (Straus' interleaving) — the w squarings per window are shared
+// by the whole chunk, each element contributes one product per window from its own 2^w-ary table.  Per element
+// that is (bits/chunk) squarings + bits/w + 2^w - 2 products instead of bits squarings + bits/w + 2^w - 2 products.
+// out row j = product over elements [j*chunk, (j+1)*chunk); rows at and beyond n_chunks receive 1 (the caller pads
+// the row count to a power of two and joins the rows with a pairwise k_mulmod tree).
+struct SplitMultiArgs {
+    SplitConsts mod;
+    const uint32_t* base;  // (batch, base_limbs)
+    int base_limbs;
+    int base_chunks;
+    const uint32_t* exps;  // (batch, exp_limbs)
+    int exp_limbs;
+    int window;     // w in 1..4
+    int n_windows;  // ceil(max_bits / w), >= 1
+    int chunk;      // elements per limb group and ladder
+    uint32_t* out;  // (n_out, out_limbs)
+    int out_limbs;
+    uint32_t* table;  // scratch: total_groups * chunk * (2^w - 1) * 2H words
+    uint64_t batch;
+    uint64_t n_out;   // >= ceil(batch / chunk)
+};
+
+template <int G, int L>
+PHE_DEV void multiexp_split_body(const SplitMultiArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots,
+                                 uint32_t lane) {
+    constexpr int H = G * L, S2 = 2 * H;
+    const Lanes<G> ln(lane);
+    const uint32_t g = ln.g;
+    SplitLane<G, L> K;
+    load_row<L>(K.n, A.mod.n, g);
+    K.n0inv = A.mod.n0inv;
+    K.row_a = lds_row;
+    K.row_c = lds_row + H;
+    const int per = (1 << A.window) - 1;  // table of one element: base^1 .. base^(2^w - 1)
+    uint32_t* tbl = A.table + (size_t)slot * (size_t)A.chunk * (size_t)per * S2;
+    const uint64_t n_iter = (A.n_out + total_slots - 1) / total_slots;
+    for (uint64_t it = 0; it < n_iter; ++it) {
+        uint64_t row = slot + it * (uint64_t)total_slots;
+        const bool live = row < A.n_out;
+        if (!live) row = A.n_out - 1;
+        const uint64_t first = row * (uint64_t)A.chunk;
+        // elements of this chunk that exist (0 for a padding row); every loop below runs `chunk` times in all
+        // groups so that the wavefront stays converged — missing elements repeat the last one with digit 0
+        const int count = first >= A.batch ? 0 : (int)((A.batch - first < (uint64_t)A.chunk) ? A.batch - first : A.chunk);
+        uint32_t X0[L], X1[L], Y0[L], Y1[L];
+        for (int el = 0; el < A.chunk; ++el) {
+            uint64_t item = first + (uint64_t)el;
+            if (item >= A.batch) item = A.batch - 1;
+            split_conv<G, L>(Y0, Y1, A.base + item * (uint64_t)A.base_limbs, A.base_limbs, A.base_chunks, A.mod, K, ln);
+            uint32_t* t = tbl + (size_t)el * (size_t)per * S2;
+            store_row<L>(t, Y0, g);
+            store_row<L>(t + H, Y1, g);
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                X0[k] = Y0[k];
+                X1[k] = Y1[k];
+            }
+            for (int j = 1; j < per; ++j) {
+                split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
+                store_row<L>(t + (size_t)j * S2, X0, g);
+                store_row<L>(t + (size_t)j * S2 + H, X1, g);
+            }
+        }
+        load_row<L>(X0, A.mod.e, g);
+        load_row<L>(X1, A.mod.e + H, g);
+        for (int wi = A.n_windows - 1; wi >= 0; --wi) {
+            if (wi != A.n_windows - 1)
+                for (int s = 0; s < A.window; ++s) split_square<G, L>(X0, X1, K, ln);
+            for (int el = 0; el < A.chunk; ++el) {
+                uint32_t d = 0;
+                if (el < count) d = exp_digit(A.exps + (first + (uint64_t)el) * (uint64_t)A.exp_limbs, A.exp_limbs, wi * A.window, A.window);
+                if (wave::ballot(d != 0) != 0) {  // wave-uniform: skip when every group has a zero digit
+                    const uint32_t* src = d ? tbl + ((size_t)el * (size_t)per + (d - 1)) * S2 : A.mod.e;
+                    load_row<L>(Y0, src, g);
+                    load_row<L>(Y1, src + H, g);
+                    split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
+                }
+            }
+        }
+        split_exit<G, L>(A.out + row * (uint64_t)A.out_limbs, A.out_limbs, X0, X1, nullptr, 0, A.mod, K, ln, live);
+    }
+}
+
 }  // namespace phe

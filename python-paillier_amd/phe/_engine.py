@@ -213,6 +213,43 @@ class Engine:
         self.ctx.sync()
         return out
 
+    @staticmethod
+    def _exp_limbs(exps):
+        """exponents (uint64 array or Python ints) -> (batch, width) uint32 limbs and the largest bit length"""
+        if isinstance(exps, np.ndarray):
+            return Engine._mag_limbs(exps)
+        exps = list(exps)
+        bits = max(1, max((e.bit_length() for e in exps), default=1))
+        return _native.ints_to_limbs(exps, (bits + 31) // 32), bits
+
+    def raw_dot(self, c, exps, neg):
+        """prod_i b_i^e_i mod n^2 with b_i = c_i, or invert(c_i, n^2) where neg[i] — the ciphertext of sum_i k_i * x_i
+        exactly as a chain of _raw_mul (phe/paillier.py:745-751: scalars at or above n - max_int take the inverted
+        base with exponent n - k) and _raw_add (:705-719) leaves it: the product of canonical residues does not
+        depend on the order of the factors.  One k_multiexp_split launch plus the k_mulmod tree over its chunk
+        products (include/phe_hip.h phe_hip_multiexp).  c: host limb array or DeviceArray.  Returns a Python int."""
+        limbs, bits = self._exp_limbs(exps)
+        neg = np.asarray(neg, dtype=bool)
+        if isinstance(c, DeviceArray):
+            base = c
+            if neg.any():
+                inv = DeviceArray(self.ctx, c.rows, self.ct_limbs)
+                self.ctx.invert_dev(c.ptr, inv.ptr, c.rows)
+                mask = DeviceArray.from_host(self.ctx, neg.astype(np.uint8), dtype=np.uint8)
+                base = DeviceArray(self.ctx, c.rows, self.ct_limbs)
+                self.ctx.select_rows_dev(c.ptr, inv.ptr, mask.ptr, base.ptr, self.ct_limbs, c.rows)
+            e = DeviceArray.from_host(self.ctx, limbs)
+            out = DeviceArray(self.ctx, 1, self.ct_limbs)
+            self.ctx.multiexp_dev(base.ptr, e.ptr, limbs.shape[1], bits, out.ptr, c.rows)
+            self.ctx.sync()
+            return self.to_ints(out.to_host())[0]
+        base = self._as_cipher(c)
+        if neg.any():
+            idx = np.nonzero(neg)[0]
+            base = base.copy()
+            base[idx] = self.ctx.invert(np.ascontiguousarray(base[idx]))
+        return self.to_ints(self.ctx.multiexp(base, limbs))[0]
+
     def powmod_n2(self, base, exps):
         exps = list(exps)
         width = max(1, (max(e.bit_length() for e in exps) + 31) // 32) if exps else 1

@@ -47,6 +47,8 @@ def lib():
         L.phe_hip_mulmod.argtypes = [vp, vp, vp, vp, sz]
         L.phe_hip_powmod.argtypes = [vp, vp, vp, ci, vp, sz]
         L.phe_hip_add_plain.argtypes = [vp, vp, vp, vp, sz]
+        L.phe_hip_multiexp.argtypes = [vp, vp, vp, ci, vp, sz]
+        L.phe_hip_multiexp_dev.argtypes = [vp, vp, vp, ci, ci, vp, sz, vp]
         L.phe_hip_add_plain_dev.argtypes = [vp, vp, vp, vp, sz, vp]
         L.phe_hip_invert.argtypes = [vp, vp, vp, sz, ctypes.POINTER(sz)]
         L.phe_hip_encrypt_dev.argtypes = [vp, vp, vp, vp, sz, vp]
@@ -75,6 +77,7 @@ EXPORTED_SYMBOLS = [
     "phe_hip_powmod_dev", "phe_hip_malloc", "phe_hip_free", "phe_hip_memcpy_h2d", "phe_hip_memcpy_d2h",
     "phe_hip_stream_sync", "phe_hip_selftest_prims", "phe_hip_memcpy_d2d", "phe_hip_invert_dev",
     "phe_hip_select_rows_dev", "phe_hip_add_plain", "phe_hip_add_plain_dev", "phe_hip_ctx_engine",
+    "phe_hip_multiexp", "phe_hip_multiexp_dev",
 ]
 
 
@@ -235,6 +238,16 @@ class Context:
         _check(lib().phe_hip_powmod(self._h, _ptr(base), _ptr(exps), exps.shape[1], _ptr(out), base.shape[0]))
         return out
 
+    def multiexp(self, base, exps):
+        """prod_i base[i]^exps[i] mod n^2 -> one row of ct_limbs words (1 for an empty batch)"""
+        base = _rows(base, self.ct_limbs, "base")
+        exps = np.ascontiguousarray(exps, dtype=np.uint32)
+        if exps.ndim != 2 or exps.shape[0] != base.shape[0]:
+            raise ValueError("exps must have shape (batch, exp_limbs)")
+        out = np.empty((1, self.ct_limbs), dtype=np.uint32)
+        _check(lib().phe_hip_multiexp(self._h, _ptr(base), _ptr(exps), max(1, exps.shape[1]), _ptr(out), base.shape[0]))
+        return out
+
     def invert(self, a):
         a = _rows(a, self.ct_limbs, "a")
         out = np.empty_like(a)
@@ -262,6 +275,9 @@ class Context:
 
     def powmod_dev(self, base_ptr, exp_ptr, exp_limbs, max_exp_bits, out_ptr, batch, stream=0):
         _check(lib().phe_hip_powmod_dev(self._h, base_ptr, exp_ptr, exp_limbs, max_exp_bits, out_ptr, batch, stream))
+
+    def multiexp_dev(self, base_ptr, exp_ptr, exp_limbs, max_exp_bits, out_ptr, batch, stream=0):
+        _check(lib().phe_hip_multiexp_dev(self._h, base_ptr, exp_ptr, exp_limbs, max_exp_bits, out_ptr, batch, stream))
 
     def invert_dev(self, a_ptr, out_ptr, batch, stream=0):
         bad = ctypes.c_size_t(0)

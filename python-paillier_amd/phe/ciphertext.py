@@ -414,5 +414,53 @@ class EncryptedVector(object):
         return vec.to_device() if device else vec
 
     def dot(self, plain):
-        """sum_i self[i] * plain[i] -> EncryptedNumber (np.dot over ciphertexts, phe/tests/math_test.py:44-58)."""
-        return (self * plain).sum()
+        """sum_i self[i] * plain[i] -> EncryptedNumber: np.dot over ciphertexts (phe/tests/math_test.py:44-58,
+        examples/logistic_regression_encrypted_model.py:170-177).  The ciphertext is bit-for-bit the one the chain of
+        `*` (phe/paillier.py:721-751) and `+` (:705-719, with :570-601 decrease_exponent_to aligning the terms to
+        the smallest exponent) produces — prod_i b_i^(e_i * BASE^delta_i) mod n^2, b_i = c_i or its inverse on the
+        negative branch — but formed as ONE multi-exponentiation (Engine.raw_dot) instead of a modexp per element,
+        a second one per misaligned element and log2(batch) product launches."""
+        pk = self.public_key
+        values = plain if isinstance(plain, (list, tuple, np.ndarray)) else [plain] * len(self)
+        if len(values) != len(self):
+            raise ValueError("vector lengths differ")
+        if len(self) == 0:
+            raise ValueError("empty vector")
+        if any(isinstance(v, (EncryptedNumber, EncryptedVector)) for v in (values if not isinstance(values, np.ndarray) else ())):
+            raise NotImplementedError('Good luck with that...')
+        eng = pk._get_engine()
+        signed = EncodedNumber.encode_signed(values) if eng.n_limbs >= 4 else None
+        if signed is not None:
+            mag, neg, kexp = signed
+        else:
+            if isinstance(values, np.ndarray) or not any(isinstance(v, EncodedNumber) for v in values):
+                encs, kexp = EncodedNumber.encode_many(pk, values)
+            else:
+                pairs = [v if isinstance(v, EncodedNumber) else EncodedNumber.encode(pk, v) for v in values]
+                if any(e.public_key != pk for e in pairs):
+                    raise ValueError("Attempted to multiply with numbers encoded against different public keys!")
+                encs, kexp = [e.encoding for e in pairs], [e.exponent for e in pairs]
+            threshold = pk.n - pk.max_int                     # phe/paillier.py:745: these take the inverted base
+            for e in encs:
+                if e < 0 or e >= pk.n:
+                    raise ValueError('Scalar out of bounds: %i' % e)
+            neg = np.fromiter((e >= threshold for e in encs), dtype=bool, count=len(encs))
+            mag = [pk.n - e if e >= threshold else e for e in encs]
+            kexp = np.asarray(kexp, dtype=np.int64)
+        total = self._exps + kexp
+        target = int(total.min())
+        delta = total - target                                 # rows above the common exponent: * BASE^delta (:599)
+        dmax = int(delta.max())
+        if dmax and pow(EncodedNumber.BASE, dmax) >= pk.n:
+            raise ValueError('Scalar out of bounds: %i' % pow(EncodedNumber.BASE, dmax))
+        log2b = int(round(EncodedNumber.LOG2_BASE))
+        if dmax == 0:
+            exps = mag
+        elif isinstance(mag, np.ndarray) and (1 << log2b) == EncodedNumber.BASE and \
+                int(mag.max()).bit_length() + log2b * dmax <= 64:
+            exps = mag << (delta * log2b).astype(np.uint64)
+        else:
+            mags = mag.tolist() if isinstance(mag, np.ndarray) else mag
+            powers = {d: pow(EncodedNumber.BASE, d) for d in np.unique(delta).tolist()}
+            exps = [m * powers[d] for m, d in zip(mags, delta.tolist())]
+        return EncryptedNumber(pk, eng.raw_dot(self._limbs, exps, neg), target)

@@ -170,6 +170,22 @@ static void run_var_split(SplitVarArgs A) {
     }
 }
 
+template <int G, int L>
+static void run_multi_split(SplitMultiArgs A) {
+    constexpr int S2 = 2 * G * L, kPer = 64 / G;
+    const int n_waves = waves_for(A.n_out, G);
+    const uint32_t total = (uint32_t)(kPer * n_waves);
+    std::vector<uint32_t> table((size_t)total * (size_t)A.chunk * (((size_t)1 << A.window) - 1) * S2);
+    A.table = table.data();
+    for (int w = 0; w < n_waves; ++w) {
+        std::vector<uint32_t> lds(kPer * (S2 + kLdsPad));
+        wave::run_wave([&](uint32_t lane) {
+            const uint32_t grp = lane / G;
+            multiexp_split_body<G, L>(A, lds.data() + grp * (S2 + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
+        });
+    }
+}
+
 static int g_prefer_group = 0;
 static int g_engine = 1;  // 1: split-modulus kernels where a geometry exists (the product default), 0: full-width only
 
@@ -410,6 +426,32 @@ int emu_powmod_n2(const uint32_t* n, int n_limbs, const uint32_t* base, const ui
         A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
         A.out = out; A.out_limbs = P.s2; A.batch = B;
         DISPATCH_GL(P.nsq.G, P.nsq.L, (run_var<GG, LL>(A)));
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// k_multiexp_split alone: out row j = prod of base[i]^exps[i] over the chunk [j*chunk, (j+1)*chunk), rows >= ceil(B/chunk)
+// are 1.  Returns 2 when the key has no split geometry (the product then takes powmod + the mulmod tree).
+int emu_multiexp_n2(const uint32_t* n, int n_limbs, const uint32_t* base, const uint32_t* exps, int exp_limbs,
+                    int chunk, uint32_t* out, uint64_t n_out, uint64_t B) {
+    try {
+        if (B == 0 || chunk < 1 || n_out * (uint64_t)chunk < B) throw std::invalid_argument("bad multiexp shape");
+        host::PublicPlan P = host::build_public(n, n_limbs, g_prefer_group);
+        if (!P.nsplit.G) return 2;
+        int max_bits = 1;
+        for (uint64_t i = 0; i < B; ++i)
+            max_bits = std::max(max_bits, host::big_bits(host::big_from(exps + i * exp_limbs, exp_limbs, exp_limbs)));
+        const host::SplitPack& M = P.nsplit;
+        SplitMultiArgs A;
+        memset(&A, 0, sizeof A);
+        A.mod = split_consts_of(M);
+        A.base = base; A.base_limbs = P.s2; A.base_chunks = chunks_for(P.s2, M.H);
+        A.exps = exps; A.exp_limbs = exp_limbs;
+        A.window = host::pick_multi_window(max_bits);
+        A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
+        A.chunk = chunk;
+        A.out = out; A.out_limbs = P.s2; A.batch = B; A.n_out = n_out;
+        DISPATCH_SPLIT(M.G, M.L, (run_multi_split<GG, LL>(A)));
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }

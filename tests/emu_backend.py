@@ -74,6 +74,23 @@ class EmuContext:
             return base.copy()
         return emu().powmod_n2(self._n_arr, np.ascontiguousarray(base), np.ascontiguousarray(exps))
 
+    def multiexp(self, base, exps):
+        # k_multiexp_split through the emulator (chunks of 3: exercises a ragged last chunk), then the pairwise
+        # product tree the library runs with k_mulmod
+        one = np.zeros((1, self.ct_limbs), np.uint32)
+        one[0, 0] = 1
+        if base.shape[0] == 0:
+            return one
+        base, exps = np.ascontiguousarray(base), np.ascontiguousarray(exps)
+        rows = emu().multiexp_n2(self._n_arr, base, exps, 3)
+        if rows is None:
+            rows = emu().powmod_n2(self._n_arr, base, exps)
+        while rows.shape[0] > 1:
+            half = rows.shape[0] // 2
+            merged = emu().mulmod(self._nsq_arr, np.ascontiguousarray(rows[:half]), np.ascontiguousarray(rows[half:2 * half]))
+            rows = np.concatenate([merged, rows[2 * half:]])
+        return rows
+
     def invert(self, a):
         # the product runs a mulmod product tree on the GPU plus one scalar inversion; the emulator
         # backend takes the scalar inverses directly (the tree itself is covered by the GPU tests)

@@ -92,6 +92,18 @@ class Emu:
                                       ctypes.c_uint64(base.shape[0])))
         return out
 
+    def multiexp_n2(self, n, base, exps, chunk, n_out=None):
+        """per-chunk products of base[i]^exps[i] mod n^2 the way k_multiexp_split forms them; None without a split geometry"""
+        B = base.shape[0]
+        n_out = n_out or -(-B // chunk)
+        out = np.zeros((n_out, base.shape[1]), dtype=np.uint32)
+        rc = self.L.emu_multiexp_n2(P(n), n.shape[0], P(base), P(exps), exps.shape[1], chunk, P(out),
+                                    ctypes.c_uint64(n_out), ctypes.c_uint64(B))
+        if rc == 2:
+            return None
+        self._ck(rc)
+        return out
+
     def modulus_geometry(self, N):
         GL = (ctypes.c_int * 2)()
         self._ck(self.L.emu_modulus_geometry(P(N), N.shape[0], GL))

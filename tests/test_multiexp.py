@@ -1,0 +1,216 @@
+"""The encrypted dot product as one multi-exponentiation (include/phe_hip.h phe_hip_multiexp, csrc/split_core.h
+multiexp_split_body, phe.EncryptedVector.dot).
+
+What it must equal: the ciphertext the reference leaves after the chain  sum_i (c_i * k_i)  —
+EncryptedNumber.__mul__ -> _raw_mul (phe/paillier.py:721-751, both branches), __add__ -> _add_encrypted (:677-703,
+exponent alignment through decrease_exponent_to :570-601) -> _raw_add (:705-719) — bit for bit.
+
+  * CPU (default run): the kernel body on the wave emulator against Python integers; the drop-in API on the
+    emulator backend against its own scalar chain (which tests/test_api.py pins to the golden vectors) and against
+    oracle/paillier_oracle.py's restatement of _raw_mul / _raw_add;
+  * -m gpu: the C-ABI against the libgmp oracle, and at 2^16 elements through the plaintext identity
+    D(prod c_i^k_i) = sum k_i m_i mod n.
+"""
+import functools
+import random
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PKG, load_golden
+
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+from oracle.paillier_oracle import PyPublic, int_to_limbs, ints_to_limbs, limbs_to_ints  # noqa: E402
+
+
+def H(x):
+    return int(x, 16)
+
+
+@pytest.fixture(scope="module")
+def emu():
+    from emu_lib import Emu
+    return Emu()
+
+
+@pytest.mark.parametrize("key_bits,group", [(256, 0), (1024, 0), (1024, 8), (2048, 0)])
+def test_chunk_products_through_emulator(emu, key_bits, group):
+    """k_multiexp_split's body: every chunk shares one ladder; ragged last chunk, padding rows, exponent 0 and 1,
+    bases 1 and n^2 - 1, all four window sizes"""
+    emu.set_engine(True)
+    emu.set_group(group)
+    g = load_golden(key_bits)
+    n_int = H(g["n"])
+    nsq = n_int * n_int
+    s1, s2 = key_bits // 32, key_bits // 16
+    rng = random.Random(key_bits + group)
+    shapes = [(7, 3, 64), (5, 1, 20), (9, 4, 130), (3, 8, 3)] if key_bits < 2048 else [(5, 2, 56)]
+    for batch, chunk, ebits in shapes:
+        bases = [rng.randrange(1, nsq) for _ in range(batch)]
+        exps = [rng.getrandbits(ebits) for _ in range(batch)]
+        exps[0], bases[1], bases[2] = 0, 1, nsq - 1
+        if batch > 3:
+            exps[3] = 1
+        n_out = -(-batch // chunk) + 1                      # one padding row: must come back as 1
+        rows = emu.multiexp_n2(int_to_limbs(n_int, s1), ints_to_limbs(bases, s2),
+                               ints_to_limbs(exps, max(1, -(-ebits // 32))), chunk, n_out)
+        want = []
+        for j in range(n_out):
+            v = 1
+            for i in range(j * chunk, min(batch, (j + 1) * chunk)):
+                v = v * pow(bases[i], exps[i], nsq) % nsq
+            want.append(v)
+        assert limbs_to_ints(rows) == want, (batch, chunk, ebits)
+    emu.set_group(0)
+
+
+def _chain(pub_oracle, cts, exps_c, encodings, exps_k):
+    """the reference's left-to-right chain on integers: _raw_mul per term, then _add_encrypted's alignment + _raw_add"""
+    nsq = pub_oracle.nsquare
+    acc, acc_e = None, None
+    for c, ec, k, ek in zip(cts, exps_c, encodings, exps_k):
+        t, te = pub_oracle.raw_mul(c, k), ec + ek
+        if acc is None:
+            acc, acc_e = t, te
+            continue
+        if acc_e > te:                                       # phe/paillier.py:695-700
+            acc, acc_e = pow(acc, 16 ** (acc_e - te), nsq), te
+        elif te > acc_e:
+            t = pow(t, 16 ** (te - acc_e), nsq)
+        acc = pub_oracle.raw_add(acc, t)
+    return acc, acc_e
+
+
+@pytest.mark.parametrize("engine", [True, False])
+def test_dot_equals_reference_chain(monkeypatch, emu, engine):
+    import emu_backend
+    emu_backend.install(monkeypatch)
+    emu_backend.emu().set_engine(engine)
+    from phe import paillier
+    from phe.encoding import EncodedNumber
+    g = load_golden(256)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    orc = PyPublic(pub.n)
+    rs = [H(e["r"]) for e in g["raw_encrypt"][:7]]
+    vals = np.array([0.5, -1.25, 3.0, 4.75, 1e-3, -7.0, 250.0])
+    vec = pub.encrypt_batch(vals, r_values=rs)
+    singles = [pub.encrypt(float(v), r_value=r) for v, r in zip(vals, rs)]
+    cases = [
+        np.array([2.0, -3.0, 0.5, 4.0, 1000.0, 0.25, -1e-2]),          # float64 array: mixed exponents and signs
+        np.array([3, -4, 0, 1, 12345, -1, 7], dtype=np.int64),          # int64 array: exponent 0, both branches, 0 and 1
+        [2, -3.5, 0.0, 1, 1e6, -0.125, 9],                              # list of Python numbers
+        [EncodedNumber.encode(pub, 2.5), 3, -1, EncodedNumber.encode(pub, -0.75), 0.5, 1, 2],   # ready-made encodings
+    ]
+    for w in cases:
+        got = vec.dot(w)
+        terms = [s * (x if isinstance(x, EncodedNumber) else (x.item() if hasattr(x, "item") else x))
+                 for s, x in zip(singles, w)]
+        chain = functools.reduce(lambda a, b: a + b, terms)
+        assert got.exponent == chain.exponent
+        assert got.ciphertext(False) == chain.ciphertext(False)        # bit for bit the scalar chain
+        encs = [x if isinstance(x, EncodedNumber) else EncodedNumber.encode(pub, x.item() if hasattr(x, "item") else x)
+                for x in w]
+        want, want_e = _chain(orc, [s.ciphertext(False) for s in singles], [s.exponent for s in singles],
+                              [e.encoding for e in encs], [e.exponent for e in encs])
+        assert (got.ciphertext(False), got.exponent) == (want, want_e)  # and the integer restatement of the reference
+        expect = sum(float(v) * (x.decode() if isinstance(x, EncodedNumber) else float(x)) for v, x in zip(vals, w))
+        assert abs(priv.decrypt(got) - expect) <= 1e-9 * max(1.0, abs(expect))
+        assert got._EncryptedNumber__is_obfuscated is False
+    assert vec.dot(2.0).ciphertext(False) == (vec * 2.0).sum().ciphertext(False)   # scalar broadcast
+    assert vec.dot(cases[0]).ciphertext(False) == (vec * cases[0]).sum().ciphertext(False)
+    with pytest.raises(ValueError):
+        vec.dot([1.0, 2.0])
+    with pytest.raises(NotImplementedError):
+        vec.dot(singles)
+    with pytest.raises(ValueError):
+        vec[:0].dot([])
+    emu_backend.emu().set_engine(True)
+
+
+# ---- GPU -------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def native():
+    from phe import _native
+    assert _native.device_count() >= 1
+    return _native
+
+
+def _ctx(native, g, private=False):
+    if private:
+        return native.Context(H(g["n"]), H(g["p"]), H(g["q"]), H(g["hp"]), H(g["hq"]), H(g["p_inverse"]),
+                              n_limbs=g["key_bits"] // 32)
+    return native.Context(H(g["n"]), n_limbs=g["key_bits"] // 32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("engine", ["split", "full"])
+@pytest.mark.parametrize("key_bits", [1024, 2048, 3072])
+def test_multiexp_vs_gmp_oracle(native, c_oracle, monkeypatch, key_bits, engine):
+    """phe_hip_multiexp against the per-element powmod of the libgmp oracle folded with Python integers: batches of
+    1 .. 700, exponents of 1 .. 200 bits (all window sizes), forced chunk sizes (ragged last chunk) and the automatic one"""
+    monkeypatch.setenv("PHE_HIP_ENGINE", engine)
+    g = load_golden(key_bits)
+    n_int = H(g["n"])
+    nsq = n_int * n_int
+    s1, s2 = key_bits // 32, key_bits // 16
+    n = native.int_to_limbs(n_int, s1)
+    ctx = _ctx(native, g)
+    rng = random.Random(key_bits)
+    one = np.zeros((1, s2), np.uint32)
+    one[0, 0] = 1
+    assert np.array_equal(ctx.multiexp(np.zeros((0, s2), np.uint32), np.zeros((0, 1), np.uint32)), one)
+    shapes = [(1, 64, "0"), (5, 3, "0"), (37, 56, "5"), (300, 64, "0"), (300, 130, "7"), (700, 20, "16"), (64, 200, "3")]
+    if key_bits == 3072:
+        shapes = shapes[:4]
+    for batch, ebits, chunk in shapes:
+        monkeypatch.setenv("PHE_HIP_MULTI_CHUNK", chunk)
+        bases = native.ints_to_limbs([rng.randrange(1, nsq) for _ in range(batch)], s2)
+        exps = [rng.getrandbits(ebits) for _ in range(batch)]
+        exps[0] = 0
+        e = native.ints_to_limbs(exps, max(1, -(-ebits // 32)))
+        e_full = native.ints_to_limbs(exps, s1)
+        terms = native.limbs_to_ints(c_oracle.mul(n, bases, e_full, nthreads=8))
+        want = functools.reduce(lambda a, b: a * b % nsq, terms, 1)
+        assert native.limbs_to_ints(ctx.multiexp(bases, e)) == [want], (batch, ebits, chunk)
+
+
+@pytest.mark.gpu
+def test_dot_large_batch_properties(native, c_oracle):
+    """2048-bit key, 2^16 ciphertexts (resident), int64 and float64 weights: the dot product decrypts to
+    sum k_i m_i, equals the `*` / sum() composition bit for bit, and a 512-element prefix equals the oracle chain"""
+    import phe
+    from phe import paillier
+    g = load_golden(2048)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    B = 1 << 16
+    rs = np.random.Generator(np.random.PCG64(99))
+    vals = rs.integers(-10 ** 6, 10 ** 6, B)
+    vec = pub.encrypt_batch(vals, device=True)
+    w_int = rs.integers(-2 ** 40, 2 ** 40, B)
+    got = vec.dot(w_int)
+    assert priv.decrypt(got) == int(np.dot(vals.astype(object), w_int.astype(object)))
+    assert got.ciphertext(False) == (vec * w_int).sum().ciphertext(False)
+    w_f = rs.standard_normal(B)
+    got_f = vec.dot(w_f)
+    assert got_f.ciphertext(False) == (vec * w_f).sum().ciphertext(False)
+    expect = float(np.dot(vals.astype(np.float64), w_f))
+    assert abs(priv.decrypt(got_f) - expect) <= 1e-6 * max(1.0, abs(expect))
+    # a prefix against the libgmp oracle
+    k = 512
+    n_int = pub.n
+    nsq = n_int * n_int
+    head = vec[:k].to_host()
+    c = head._limbs
+    mag = np.abs(w_int[:k]).astype(np.uint64)
+    neg = w_int[:k] < 0
+    n = native.int_to_limbs(n_int, 64)
+    scal = native.ints_to_limbs([n_int - int(m) if s else int(m) for m, s in zip(mag, neg)], 64)
+    terms = native.limbs_to_ints(c_oracle.mul(n, c, scal, nthreads=8))        # _raw_mul incl. the inverse branch
+    want = functools.reduce(lambda a, b: a * b % nsq, terms, 1)
+    assert head.dot(w_int[:k]).ciphertext(False) == want
+    assert isinstance(got, phe.EncryptedNumber)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Config 3 of BASELINE.json: 2048-bit key, 2^20 resident ciphertexts, homomorphic add (_raw_add = mulmod mod n^2)
 and scalar multiplication (_raw_mul: float-like 56-bit scalars, int64 scalars, and a 10 % negative mix that
-takes the inverse branch of phe/paillier.py:745-749).  Also config 4's per-GPU share (3072-bit encrypt).
+takes the inverse branch of phe/paillier.py:745-749), and the encrypted dot product (phe_hip_multiexp) against the
+powmod + product-tree composition it replaces.
 Prints one JSON object; every result is checked against the libgmp oracle on a strided sample."""
 import argparse
 import json
@@ -19,6 +20,7 @@ def main():
     ap.add_argument("--batch", type=int, default=1 << 20)
     ap.add_argument("--key-bits", type=int, default=2048)
     ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--chunk-sweep", action="store_true", help="time the dot product at forced chunk sizes (PHE_HIP_MULTI_CHUNK)")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -89,6 +91,44 @@ def main():
     ok = np.array_equal(ctx.mulmod(inv_host[:64], to_np(sub[:64]))[:, 0], np.ones(64, np.uint32))
     res["invert_10pct_subset"] = {"rows": int(len(neg_rows)), "seconds_incl_pcie": t_inv, "rows_per_s": len(neg_rows) / t_inv,
                                   "a_times_inverse_is_one": bool(ok)}
+    # ---- encrypted dot product sum_i k_i * E(x_i) (np.dot over ciphertexts): one multi-exponentiation against the
+    #      composition it replaces (powmod per element + log2(B) pairwise-product launches); same bits ----
+    one_row = torch.empty((1, s2), dtype=torch.int32, device=dev)
+    for name, bits in (("dot_float56", 56), ("dot_int64", 63)):
+        e = rnd(2)
+        e[:, 1] &= (0x00ffffff if bits == 56 else 0x7fffffff)
+        t = timed(lambda: ctx.multiexp_dev(ca.data_ptr(), e.data_ptr(), 2, bits, one_row.data_ptr(), B, st))
+
+        def composed():
+            ctx.powmod_dev(ca.data_ptr(), e.data_ptr(), 2, bits, out.data_ptr(), B, st)
+            cur = B
+            while cur > 1:                                   # B is a power of two here
+                half = cur // 2
+                ctx.mulmod_dev(out.data_ptr(), out.data_ptr() + half * s2 * 4, out.data_ptr(), half, st)
+                cur = half
+        t_old = timed(composed)
+        same = bool(torch.equal(out[0], one_row[0]))
+        k = 256                                              # prefix against the libgmp oracle
+        ctx.multiexp_dev(ca.data_ptr(), e.data_ptr(), 2, bits, one_row.data_ptr(), k, st)
+        torch.cuda.synchronize()
+        sc = np.zeros((k, s1), np.uint32); sc[:, :2] = to_np(e[:k])
+        terms = native.limbs_to_ints(orc.mul(n_arr, to_np(ca[:k]), sc, nthreads=8))
+        want = 1
+        for v in terms:
+            want = want * v % (n_int * n_int)
+        ok = native.limbs_to_ints(to_np(one_row))[0] == want
+        res[name] = {"elements_per_s": B / t, "ms": t * 1e3, "composed_powmod_plus_tree_ms": t_old * 1e3,
+                     "speedup_vs_composed": t_old / t, "same_bits_as_composed": same, "bit_exact_prefix_vs_oracle": bool(ok)}
+    if args.chunk_sweep:
+        e = rnd(2)
+        e[:, 1] &= 0x7fffffff
+        sweep = {}
+        for chunk in (1, 2, 4, 8, 16, 32):
+            os.environ["PHE_HIP_MULTI_CHUNK"] = str(chunk)
+            t = timed(lambda: ctx.multiexp_dev(ca.data_ptr(), e.data_ptr(), 2, 63, one_row.data_ptr(), B, st))
+            sweep[str(chunk)] = {"ms": t * 1e3, "elements_per_s": B / t}
+        os.environ.pop("PHE_HIP_MULTI_CHUNK", None)
+        res["dot_int64_chunk_sweep"] = sweep
     print(json.dumps(res))
 
 
