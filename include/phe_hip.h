@@ -126,6 +126,19 @@ int phe_hip_multiexp(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, 
  * is the first row with gcd(a, n^2) != 1 (the reference raises ZeroDivisionError for it). */
 int phe_hip_invert(phe_hip_ctx* ctx, const uint32_t* a, uint32_t* out, size_t batch, size_t* bad_index);
 
+/* ---- decimal wire format ---------------------------------------------------------------------
+ * The reference's interchange formats carry every ciphertext as str(int): docs/serialisation.rst:24-43
+ * ("values": [[str(ciphertext), exponent], ...]) and phe/command_line.py:120-131, :267-276 ({"v": str(c), "e": ...}).
+ * These entry points are the batch form of that str() / int(): rows of little-endian 32-bit words <-> rows of
+ * `width` ASCII digits, most significant first, left-padded with '0' (strip / add the padding on the host; the
+ * digits are exactly str(int)'s).  phe_hip_decimal_width(words) digits hold any number of `words` words.
+ * EINVAL (+ *bad_index = first offending row) for a character that is not a digit (int() raises ValueError) or a
+ * value that does not fit `words` words; EINVAL if a number needs more than `width` digits. */
+int phe_hip_decimal_width(int words);
+int phe_hip_to_decimal(phe_hip_ctx* ctx, const uint32_t* limbs, int words, char* digits, int width, size_t batch);
+int phe_hip_from_decimal(phe_hip_ctx* ctx, const char* digits, int width, uint32_t* limbs, int words, size_t batch,
+                         size_t* bad_index);
+
 /* ---- the hot path, device buffers (resident operands; asynchronous on `stream`) -------------- */
 int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch, void* stream);
 int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t* r, uint32_t* c_out, size_t batch, void* stream);
@@ -138,6 +151,12 @@ int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e
 /* out: one row of ct_limbs words on the device, complete when `stream` has drained */
 int phe_hip_multiexp_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, int max_exp_bits,
                          uint32_t* out, size_t batch, void* stream);
+
+/* the decimal conversions on device buffers; both synchronise `stream` (they report per-row errors) */
+int phe_hip_to_decimal_dev(phe_hip_ctx* ctx, const uint32_t* limbs, int words, char* digits, int width, size_t batch,
+                           void* stream);
+int phe_hip_from_decimal_dev(phe_hip_ctx* ctx, const char* digits, int width, uint32_t* limbs, int words, size_t batch,
+                             size_t* bad_index, void* stream);
 
 /* phe_hip_invert on device buffers.  Synchronises `stream` internally (the root of the product tree makes one
  * round trip to the host); results are complete on return. */

@@ -30,6 +30,7 @@
 #include "split_core.h"
 #include "decrypt_tail.h"
 #include "key_setup.h"
+#include "radix_conv.h"
 // clang-format on
 
 using namespace phe;
@@ -84,6 +85,16 @@ PHE_DECLARE_SPLIT_PART(s16a)
 PHE_DECLARE_SPLIT_PART(s16b)
 PHE_DECLARE_SPLIT_PART(s16c)
 #undef PHE_DECLARE_SPLIT_PART
+}  // namespace phe
+
+namespace phe {
+namespace radix {  // kernels_radix.hip
+size_t tile_bytes(int words);
+int launch_to_decimal(const uint32_t* limbs, int words, char* digits, int width, uint64_t batch, unsigned long long* bad,
+                      int max_blocks, hipStream_t st);
+int launch_from_decimal(const char* digits, int width, uint32_t* limbs, int words, uint64_t batch,
+                        unsigned long long* bad_char, unsigned long long* bad_size, int max_blocks, hipStream_t st);
+}  // namespace radix
 }  // namespace phe
 
 struct KernelPart {
@@ -263,6 +274,7 @@ struct phe_hip_ctx {
     size_t table_words = 0;
     uint32_t* scratch = nullptr;  // decrypt intermediates x_p | x_q
     size_t scratch_words = 0;
+    unsigned long long* flags = nullptr;  // radix conversion: first offending row per error kind (2 words)
     uint32_t* partial = nullptr;  // multi-exponentiation: one product per chunk, joined in place by a k_mulmod tree
     size_t partial_words = 0;
     // staging for the host-pointer entry points
@@ -696,7 +708,7 @@ void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
                         ctx->d_psplit_lat.blob, ctx->d_qsplit_lat.blob,
                         ctx->d_nsq_lat.blob, ctx->d_psq_lat.blob, ctx->d_qsq_lat.blob,
                         ctx->d_nsq.blob, ctx->d_psq.blob, ctx->d_qsq.blob, ctx->d_exp_n.ops, ctx->d_exp_p.ops,
-                        ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->scratch, ctx->partial, ctx->stage[0],
+                        ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->scratch, ctx->partial, (uint32_t*)ctx->flags, ctx->stage[0],
                         ctx->stage[1], ctx->stage[2]};
     for (uint32_t* b : bufs)
         if (b) (void)hipFree(b);
@@ -1161,6 +1173,90 @@ int phe_hip_select_rows_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t*
     const int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)ctx->n_cus * 8);
     k_select_rows<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(a, b, mask, out, limbs, (uint64_t)batch);
     HIP_TRY(hipGetLastError());
+    return PHE_HIP_OK;
+}
+
+// ---- decimal wire format (csrc/radix_conv.h, kernels_radix.hip) -------------------------------------------------
+static const size_t kMaxRadixTile = 160 * 1024;  // one LDS tile of 64 numbers must fit a CU
+
+static int radix_flags(phe_hip_ctx* ctx, hipStream_t st) {
+    if (!ctx->flags) HIP_TRY(hipMalloc((void**)&ctx->flags, 2 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(ctx->flags, 0xff, 2 * sizeof(unsigned long long), st));
+    return PHE_HIP_OK;
+}
+
+int phe_hip_decimal_width(int words) { return words < 1 ? 0 : phe::decimal_width(words); }
+
+int phe_hip_to_decimal_dev(phe_hip_ctx* ctx, const uint32_t* limbs, int words, char* digits, int width, size_t batch,
+                           void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!limbs || !digits || words < 1 || width < 1) return fail(PHE_HIP_EINVAL, "null buffer / words / width");
+    if (phe::radix::tile_bytes(words) > kMaxRadixTile) return fail(PHE_HIP_EINVAL, "number too wide for the conversion tile");
+    if (int rc = bind_device(ctx)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = radix_flags(ctx, st)) return rc;
+    if (phe::radix::launch_to_decimal(limbs, words, digits, width, batch, ctx->flags, ctx->n_cus * 8, st) < 0)
+        return fail(PHE_HIP_EHIP, "cannot size the conversion tile");
+    HIP_TRY(hipGetLastError());
+    unsigned long long bad[2];
+    HIP_TRY(hipMemcpyAsync(bad, ctx->flags, sizeof bad, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (bad[0] != ~0ull) return fail(PHE_HIP_EINVAL, "row " + std::to_string(bad[0]) + " needs more than `width` digits");
+    return PHE_HIP_OK;
+}
+
+int phe_hip_from_decimal_dev(phe_hip_ctx* ctx, const char* digits, int width, uint32_t* limbs, int words, size_t batch,
+                             size_t* bad_index, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!limbs || !digits || words < 1 || width < 1) return fail(PHE_HIP_EINVAL, "null buffer / words / width");
+    if (phe::radix::tile_bytes(words) > kMaxRadixTile) return fail(PHE_HIP_EINVAL, "number too wide for the conversion tile");
+    if (int rc = bind_device(ctx)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (int rc = radix_flags(ctx, st)) return rc;
+    if (phe::radix::launch_from_decimal(digits, width, limbs, words, batch, ctx->flags, ctx->flags + 1, ctx->n_cus * 8, st) < 0)
+        return fail(PHE_HIP_EHIP, "cannot size the conversion tile");
+    HIP_TRY(hipGetLastError());
+    unsigned long long bad[2];
+    HIP_TRY(hipMemcpyAsync(bad, ctx->flags, sizeof bad, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (bad[0] != ~0ull || bad[1] != ~0ull) {
+        const bool is_char = bad[0] <= bad[1];
+        if (bad_index) *bad_index = (size_t)(is_char ? bad[0] : bad[1]);
+        return fail(PHE_HIP_EINVAL, is_char ? "invalid literal: not a decimal digit" : "value does not fit the limb width");
+    }
+    return PHE_HIP_OK;
+}
+
+int phe_hip_to_decimal(phe_hip_ctx* ctx, const uint32_t* limbs, int words, char* digits, int width, size_t batch) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!limbs || !digits || words < 1 || width < 1) return fail(PHE_HIP_EINVAL, "null buffer / words / width");
+    if (int rc = bind_device(ctx)) return rc;
+    const size_t dwords = (batch * (size_t)width + 3) / 4;
+    int rc = stage_in(ctx, 0, limbs, batch * (size_t)words);
+    if (!rc) rc = stage_in(ctx, 1, nullptr, dwords);
+    if (!rc) rc = phe_hip_to_decimal_dev(ctx, ctx->stage[0], words, (char*)ctx->stage[1], width, batch, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(digits, ctx->stage[1], batch * (size_t)width, hipMemcpyDeviceToHost));
+    return PHE_HIP_OK;
+}
+
+int phe_hip_from_decimal(phe_hip_ctx* ctx, const char* digits, int width, uint32_t* limbs, int words, size_t batch,
+                         size_t* bad_index) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!limbs || !digits || words < 1 || width < 1) return fail(PHE_HIP_EINVAL, "null buffer / words / width");
+    if (int rc = bind_device(ctx)) return rc;
+    const size_t dwords = (batch * (size_t)width + 3) / 4;
+    int rc = stage_in(ctx, 1, nullptr, dwords);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(ctx->stage[1], digits, batch * (size_t)width, hipMemcpyHostToDevice));
+    rc = stage_in(ctx, 0, nullptr, batch * (size_t)words);
+    if (!rc) rc = phe_hip_from_decimal_dev(ctx, (const char*)ctx->stage[1], width, ctx->stage[0], words, batch, bad_index, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(limbs, ctx->stage[0], batch * (size_t)words * 4, hipMemcpyDeviceToHost));
     return PHE_HIP_OK;
 }
 

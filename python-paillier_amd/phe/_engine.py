@@ -250,6 +250,31 @@ class Engine:
             base[idx] = self.ctx.invert(np.ascontiguousarray(base[idx]))
         return self.to_ints(self.ctx.multiexp(base, limbs))[0]
 
+    # ---- the decimal wire format of ciphertext vectors (docs/serialisation.rst:24-43; str(int) / int(str) per
+    #      element in the reference) ---------------------------------------------------------------------------
+    def decimal_strings(self, c):
+        """ciphertext rows (host limb array or DeviceArray) -> list of str, exactly [str(int) ...]: the base
+        conversion runs on the device (csrc/radix_conv.h), the host only strips the '0' padding"""
+        if isinstance(c, DeviceArray):
+            digits = self.ctx.to_decimal_dev(c.ptr, c.cols, c.rows)
+        else:
+            digits = self.ctx.to_decimal(c)
+        width = digits.shape[1]
+        raw = digits.tobytes()
+        return [raw[i:i + width].lstrip(b"0").decode("ascii") or "0" for i in range(0, len(raw), width)]
+
+    def limbs_from_decimal(self, strings, words=None):
+        """list of decimal strings -> (rows, words) limb array (int(str) per element in the reference, then the
+        reduction the kernels expect is the caller's business).  ValueError for anything int() would reject here
+        (signs, spaces and underscores are not part of the wire format) or a value beyond `words` words."""
+        words = words or self.ct_limbs
+        if not strings:
+            return np.zeros((0, words), dtype=np.uint32)
+        width = max(1, max(len(s) for s in strings))
+        raw = b"".join(s.encode("ascii").rjust(width, b"0") for s in strings)
+        digits = np.frombuffer(raw, dtype=np.uint8).reshape(len(strings), width)
+        return self.ctx.from_decimal(digits, words)
+
     def powmod_n2(self, base, exps):
         exps = list(exps)
         width = max(1, (max(e.bit_length() for e in exps) + 31) // 32) if exps else 1

@@ -48,6 +48,11 @@ def lib():
         L.phe_hip_powmod.argtypes = [vp, vp, vp, ci, vp, sz]
         L.phe_hip_add_plain.argtypes = [vp, vp, vp, vp, sz]
         L.phe_hip_multiexp.argtypes = [vp, vp, vp, ci, vp, sz]
+        L.phe_hip_decimal_width.argtypes = [ci]
+        L.phe_hip_to_decimal.argtypes = [vp, vp, ci, vp, ci, sz]
+        L.phe_hip_from_decimal.argtypes = [vp, vp, ci, vp, ci, sz, ctypes.POINTER(sz)]
+        L.phe_hip_to_decimal_dev.argtypes = [vp, vp, ci, vp, ci, sz, vp]
+        L.phe_hip_from_decimal_dev.argtypes = [vp, vp, ci, vp, ci, sz, ctypes.POINTER(sz), vp]
         L.phe_hip_multiexp_dev.argtypes = [vp, vp, vp, ci, ci, vp, sz, vp]
         L.phe_hip_add_plain_dev.argtypes = [vp, vp, vp, vp, sz, vp]
         L.phe_hip_invert.argtypes = [vp, vp, vp, sz, ctypes.POINTER(sz)]
@@ -77,7 +82,8 @@ EXPORTED_SYMBOLS = [
     "phe_hip_powmod_dev", "phe_hip_malloc", "phe_hip_free", "phe_hip_memcpy_h2d", "phe_hip_memcpy_d2h",
     "phe_hip_stream_sync", "phe_hip_selftest_prims", "phe_hip_memcpy_d2d", "phe_hip_invert_dev",
     "phe_hip_select_rows_dev", "phe_hip_add_plain", "phe_hip_add_plain_dev", "phe_hip_ctx_engine",
-    "phe_hip_multiexp", "phe_hip_multiexp_dev",
+    "phe_hip_multiexp", "phe_hip_multiexp_dev", "phe_hip_decimal_width", "phe_hip_to_decimal",
+    "phe_hip_from_decimal", "phe_hip_to_decimal_dev", "phe_hip_from_decimal_dev",
 ]
 
 
@@ -246,6 +252,47 @@ class Context:
             raise ValueError("exps must have shape (batch, exp_limbs)")
         out = np.empty((1, self.ct_limbs), dtype=np.uint32)
         _check(lib().phe_hip_multiexp(self._h, _ptr(base), _ptr(exps), max(1, exps.shape[1]), _ptr(out), base.shape[0]))
+        return out
+
+    # ---- decimal wire format (include/phe_hip.h "decimal wire format") ----
+    @staticmethod
+    def decimal_width(words):
+        return lib().phe_hip_decimal_width(int(words))
+
+    def to_decimal(self, limbs):
+        """(rows, words) uint32 -> (rows, decimal_width(words)) uint8 ASCII digits, '0'-padded on the left"""
+        limbs = np.ascontiguousarray(limbs, dtype=np.uint32)
+        out = np.empty((limbs.shape[0], self.decimal_width(limbs.shape[1])), dtype=np.uint8)
+        _check(lib().phe_hip_to_decimal(self._h, _ptr(limbs), limbs.shape[1], _ptr(out), out.shape[1], limbs.shape[0]))
+        return out
+
+    def to_decimal_dev(self, limbs_ptr, words, rows):
+        """the same from a device-resident limb array: only the digits cross PCIe"""
+        width = self.decimal_width(words)
+        out = np.empty((rows, width), dtype=np.uint8)
+        if rows == 0:
+            return out
+        nbytes = (rows * width + 3) // 4 * 4
+        d = self.malloc(nbytes)
+        try:
+            _check(lib().phe_hip_to_decimal_dev(self._h, limbs_ptr, words, d, width, rows, 0))
+            self.d2h(out, d)
+        finally:
+            self.free(d, nbytes)
+        return out
+
+    def from_decimal(self, digits, words):
+        """(rows, width) uint8 ASCII digits (leading '0's allowed) -> (rows, words) uint32; ValueError like int()"""
+        digits = np.ascontiguousarray(digits, dtype=np.uint8)
+        out = np.empty((digits.shape[0], words), dtype=np.uint32)
+        bad = ctypes.c_size_t(0)
+        rc = lib().phe_hip_from_decimal(self._h, _ptr(digits), digits.shape[1], _ptr(out), words, digits.shape[0],
+                                        ctypes.byref(bad))
+        if rc == EINVAL:
+            err = ValueError("row %d: %s" % (bad.value, lib().phe_hip_last_error().decode()))
+            err.bad_index = bad.value
+            raise err
+        _check(rc)
         return out
 
     def invert(self, a):

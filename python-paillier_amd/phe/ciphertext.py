@@ -399,10 +399,12 @@ class EncryptedVector(object):
     def to_json(self, be_secure=True):
         """{"public_key": {"n": ...}, "values": [[str(ciphertext), exponent], ...]} — the reference's documented
         vector format; like EncryptedNumber.ciphertext() the rows are obfuscated first unless be_secure=False
-        (one launch over the vector instead of one modexp per element)."""
-        import json
-        return json.dumps({"public_key": {"n": self.public_key.n},
-                           "values": [[str(c), e] for c, e in zip(self.ciphertexts(be_secure), self.exponents)]})
+        (one launch over the vector instead of one modexp per element).  The decimal strings come from the device
+        (Engine.decimal_strings: the batch form of str(int)); the text is what json.dumps would write."""
+        eng = self.public_key._get_engine()
+        strings = eng.decimal_strings(self.limbs(be_secure))
+        body = ", ".join('["%s", %d]' % (c, e) for c, e in zip(strings, self._exps.tolist()))
+        return '{"public_key": {"n": %d}, "values": [%s]}' % (self.public_key.n, body)
 
     @classmethod
     def from_json(cls, text, device=False):
@@ -410,7 +412,11 @@ class EncryptedVector(object):
         from .keys import PaillierPublicKey
         doc = json.loads(text)
         public_key = PaillierPublicKey(n=int(doc["public_key"]["n"]))
-        vec = cls.from_ciphertexts(public_key, [int(v[0]) for v in doc["values"]], [int(v[1]) for v in doc["values"]])
+        eng = public_key._get_engine()
+        values = doc["values"]
+        texts = [v[0] if isinstance(v[0], str) else str(int(v[0])) for v in values]
+        limbs = eng.limbs_from_decimal(texts)                 # the batch form of int(str) per element
+        vec = cls(public_key, limbs, [int(v[1]) for v in values])
         return vec.to_device() if device else vec
 
     def dot(self, plain):

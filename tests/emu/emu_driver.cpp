@@ -10,6 +10,7 @@
 #include "../../python-paillier_amd/csrc/split_core.h"
 #include "../../python-paillier_amd/csrc/decrypt_tail.h"
 #include "../../python-paillier_amd/csrc/key_setup.h"
+#include "../../python-paillier_amd/csrc/radix_conv.h"
 // clang-format on
 #include <string.h>
 
@@ -454,6 +455,32 @@ int emu_multiexp_n2(const uint32_t* n, int n_limbs, const uint32_t* base, const 
         DISPATCH_SPLIT(M.G, M.L, (run_multi_split<GG, LL>(A)));
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// csrc/radix_conv.h on plain arrays: the per-number routines k_to_decimal / k_from_decimal run per thread
+struct PlainWords {
+    uint32_t* p;
+    uint32_t& operator()(int j) const { return p[j]; }
+};
+int emu_decimal_width(int words) { return decimal_width(words); }
+// returns the first row that does not fit `width` digits, or -1
+long long emu_to_decimal(const uint32_t* limbs, int words, char* digits, int width, uint64_t B) {
+    long long bad = -1;
+    std::vector<uint32_t> tmp((size_t)words);
+    for (uint64_t i = 0; i < B; ++i) {
+        memcpy(tmp.data(), limbs + i * (uint64_t)words, (size_t)words * 4);
+        if (!limbs_to_decimal(PlainWords{tmp.data()}, words, digits + i * (uint64_t)width, width) && bad < 0) bad = (long long)i;
+    }
+    return bad;
+}
+// returns 0, or 1 (not a digit) / 2 (too large) with *bad_row = the first offending row (the lower row wins)
+int emu_from_decimal(const char* digits, int width, uint32_t* limbs, int words, uint64_t B, uint64_t* bad_row) {
+    int status = 0;
+    for (uint64_t i = 0; i < B; ++i) {
+        const int st = decimal_to_limbs(digits + i * (uint64_t)width, width, PlainWords{limbs + i * (uint64_t)words}, words);
+        if (st && !status) { status = st; *bad_row = i; }
+    }
+    return status;
 }
 
 // geometry of the split-modulus kernels for modulus n (given as `limbs` words): GL_out = {G, L}; G = 0 if none

@@ -91,6 +91,17 @@ class EmuContext:
             rows = np.concatenate([merged, rows[2 * half:]])
         return rows
 
+    # decimal wire format: csrc/radix_conv.h through the emulator library (plain arrays instead of the LDS tile)
+    @staticmethod
+    def decimal_width(words):
+        return emu().L.emu_decimal_width(int(words))
+
+    def to_decimal(self, limbs):
+        return emu().to_decimal(limbs)
+
+    def from_decimal(self, digits, words):
+        return emu().from_decimal(digits, words)
+
     def invert(self, a):
         # the product runs a mulmod product tree on the GPU plus one scalar inversion; the emulator
         # backend takes the scalar inverses directly (the tree itself is covered by the GPU tests)

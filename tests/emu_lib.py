@@ -104,6 +104,29 @@ class Emu:
         self._ck(rc)
         return out
 
+    def to_decimal(self, limbs, width=None):
+        """csrc/radix_conv.h limbs_to_decimal per row -> (rows, width) uint8 ASCII digits, '0'-padded on the left"""
+        limbs = np.ascontiguousarray(limbs, dtype=np.uint32)
+        width = width or self.L.emu_decimal_width(limbs.shape[1])
+        out = np.zeros((limbs.shape[0], width), dtype=np.uint8)
+        self.L.emu_to_decimal.restype = ctypes.c_longlong
+        bad = self.L.emu_to_decimal(P(limbs), limbs.shape[1], P(out), width, ctypes.c_uint64(limbs.shape[0]))
+        if bad >= 0:
+            raise ValueError("row %d needs more than %d digits" % (bad, width))
+        return out
+
+    def from_decimal(self, digits, words):
+        """csrc/radix_conv.h decimal_to_limbs per row of ASCII digits -> (rows, words) uint32"""
+        digits = np.ascontiguousarray(digits, dtype=np.uint8)
+        out = np.zeros((digits.shape[0], words), dtype=np.uint32)
+        bad = ctypes.c_uint64(0)
+        st = self.L.emu_from_decimal(P(digits), digits.shape[1], P(out), words, ctypes.c_uint64(digits.shape[0]), ctypes.byref(bad))
+        if st:
+            err = ValueError("invalid literal: not a decimal digit" if st == 1 else "value does not fit the limb width")
+            err.bad_index = bad.value
+            raise err
+        return out
+
     def modulus_geometry(self, N):
         GL = (ctypes.c_int * 2)()
         self._ck(self.L.emu_modulus_geometry(P(N), N.shape[0], GL))
