@@ -158,6 +158,16 @@ int phe_hip_to_decimal_dev(phe_hip_ctx* ctx, const uint32_t* limbs, int words, c
 int phe_hip_from_decimal_dev(phe_hip_ctx* ctx, const char* digits, int width, uint32_t* limbs, int words, size_t batch,
                              size_t* bad_index, void* stream);
 
+/* The matrix form: out[r] = prod_i b_i^e[r][i] mod n^2 for r < rows — a plaintext matrix times an encrypted vector,
+ * i.e. `rows` of the dot products above over the SAME ciphertexts (examples/logistic_regression_encrypted_model.py:
+ * 170-177 scores every sample against one encrypted weight vector).  e: (rows, batch, exp_limbs); out: (rows, ct_limbs).
+ * b_i = base[i], or base_inv[i] (= base[i]^-1 mod n^2, e.g. from phe_hip_invert_dev) where neg[r*batch + i] != 0 —
+ * the reference's negative-scalar branch (phe/paillier.py:745-749) differs from row to row; base_inv and neg may
+ * both be NULL.  Needs the split-modulus engine (EINVAL otherwise: call phe_hip_multiexp_dev row by row). */
+int phe_hip_multiexp_rows_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* base_inv, const uint32_t* e,
+                              const uint8_t* neg, int exp_limbs, int max_exp_bits, uint32_t* out, size_t batch, size_t rows,
+                              void* stream);
+
 /* phe_hip_invert on device buffers.  Synchronises `stream` internally (the root of the product tree makes one
  * round trip to the host); results are complete on return. */
 int phe_hip_invert_dev(phe_hip_ctx* ctx, const uint32_t* a, uint32_t* out, size_t batch, size_t* bad_index, void* stream);

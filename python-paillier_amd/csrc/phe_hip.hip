@@ -484,30 +484,35 @@ static int launch_var_split(phe_hip_ctx* ctx, const DevSplit& M, const uint32_t*
 }
 
 
-static int launch_multi_split(phe_hip_ctx* ctx, const DevSplit& M, const uint32_t* base, int base_limbs,
-                              const uint32_t* e, int exp_limbs, int max_bits, int chunk, uint32_t* out, int out_limbs,
-                              size_t batch, size_t n_out, hipStream_t stream) {
+static int launch_multi_split(phe_hip_ctx* ctx, const DevSplit& M, const uint32_t* base, const uint32_t* base_inv,
+                              int base_limbs, const uint32_t* e, const uint8_t* neg, int exp_limbs, int max_bits, int chunk,
+                              int row_block, uint32_t* out, int out_limbs, size_t batch, size_t rows, hipStream_t stream) {
     SplitMultiArgs A;
     A.mod = M.c;
     A.base = base;
+    A.base_inv = base_inv;
     A.base_limbs = base_limbs;
     A.base_chunks = chunks_for(base_limbs, M.H);
     A.exps = e;
+    A.neg = neg;
     A.exp_limbs = exp_limbs;
     A.window = host::pick_multi_window(max_bits);
     A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
     A.chunk = chunk;
+    A.row_block = row_block;
     A.out = out;
     A.out_limbs = out_limbs;
     A.batch = batch;
-    A.n_out = n_out;
+    A.rows = rows;
+    A.n_chunks = (batch + (size_t)chunk - 1) / (size_t)chunk;
+    A.n_row_blocks = (rows + (size_t)row_block - 1) / (size_t)row_block;
     int per_cu = ctx->blocks_per_cu;
     if (per_cu == 0) per_cu = PHE_SPLIT_BY_GROUP(M.G, occ_multi_split(M.L));
     if (per_cu < 0) return fail(PHE_HIP_EINVAL, "unsupported split geometry");
-    const int blocks = grid_blocks(ctx, n_out, M.G, per_cu);
-    const size_t rows = (size_t)blocks * (size_t)(kBlock / M.G);
+    const int blocks = grid_blocks(ctx, (size_t)(A.n_chunks * A.n_row_blocks), M.G, per_cu);
+    const size_t groups = (size_t)blocks * (size_t)(kBlock / M.G);
     int rc = ensure_words(&ctx->table, &ctx->table_words,
-                          rows * (size_t)chunk * (((size_t)1 << A.window) - 1) * 2 * M.H);
+                          groups * (size_t)chunk * (((size_t)1 << A.window) - 1) * (base_inv ? 2 : 1) * 2 * M.H);
     if (rc) return rc;
     A.table = ctx->table;
     if (PHE_SPLIT_BY_GROUP(M.G, launch_multi_split(M.L, blocks, stream, A)) < 0)
@@ -847,62 +852,91 @@ int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e
                       (hipStream_t)stream);
 }
 
-// prod_i base_i^e_i mod n^2 (the encrypted dot product): chunks of the batch go through k_multiexp_split (one shared
-// square-and-multiply ladder per chunk), the per-chunk products are joined in place by a pairwise k_mulmod tree.
-// Without a split geometry (or PHE_HIP_ENGINE=full) the per-element powers come from the powmod kernel (chunk = 1).
-int phe_hip_multiexp_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, int max_exp_bits,
-                         uint32_t* out, size_t batch, void* stream) {
-    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
-    if (!out) return fail(PHE_HIP_EINVAL, "null buffer");
-    if (int rc = bind_device(ctx)) return rc;
-    hipStream_t st = (hipStream_t)stream;
+// out[r] = prod_i b_i^e[r][i] mod n^2, b_i = base_i or base_inv_i where neg[r][i] — `rows` encrypted dot products over
+// the same ciphertexts (rows = 1: phe_hip_multiexp).  Tasks (chunk of the batch, block of rows) go through
+// k_multiexp_split — tables built once per task, one shared square-and-multiply ladder per row — and the chunk products
+// of every row are joined in place by a pairwise k_mulmod tree over the chunk index.  Without a split geometry (or
+// PHE_HIP_ENGINE=full) a single row without negative entries takes the powmod kernel (chunk = 1) and the same tree.
+static int multiexp_rows_impl(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* base_inv, const uint32_t* e,
+                              const uint8_t* neg, int exp_limbs, int max_exp_bits, uint32_t* out, size_t batch, size_t rows,
+                              hipStream_t st) {
     const size_t s2 = (size_t)ctx->pub.s2;
-    if (batch == 0) {  // the empty product
-        HIP_TRY(hipMemsetAsync(out, 0, s2 * 4, st));
-        const uint32_t one = 1;
-        HIP_TRY(hipMemcpyAsync(out, &one, 4, hipMemcpyHostToDevice, st));
+    if (rows == 0) return PHE_HIP_OK;
+    if (batch == 0) {  // empty products
+        std::vector<uint32_t> ones(rows * s2, 0u);
+        for (size_t r = 0; r < rows; ++r) ones[r * s2] = 1u;
+        HIP_TRY(hipMemcpyAsync(out, ones.data(), rows * s2 * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
         return PHE_HIP_OK;
     }
     if (!base || !e || exp_limbs < 1) return fail(PHE_HIP_EINVAL, "null buffer / exp_limbs");
+    if (neg && !base_inv) return fail(PHE_HIP_EINVAL, "a sign mask needs the inverted bases");
     if (max_exp_bits <= 0 || max_exp_bits > 32 * exp_limbs) max_exp_bits = 32 * exp_limbs;
     const bool split = ctx->use_split && ctx->d_nsplit.G;
-    size_t chunk = 1;
+    if (!split && (rows != 1 || neg))
+        return fail(PHE_HIP_EINVAL, "the matrix form needs the split-modulus engine (call row by row on this key)");
+    size_t chunk = 1, row_block = 1;
     if (split) {
-        // fill the resident groups of the throughput geometry first, then let chunks grow (cap 16: the tables of a
-        // group are chunk * (2^w - 1) pairs)
+        // fill the resident groups of the throughput geometry first, then let chunks grow (cap 16: a group's tables
+        // are chunk * (2^w - 1) pairs) and rows share a task's tables
         int per_cu = ctx->blocks_per_cu;
         if (per_cu == 0) per_cu = PHE_SPLIT_BY_GROUP(ctx->d_nsplit.G, occ_multi_split(ctx->d_nsplit.L));
         const size_t resident = (size_t)ctx->n_cus * (size_t)std::max(1, per_cu) * (size_t)(kBlock / ctx->d_nsplit.G);
-        chunk = std::min<size_t>(16, std::max<size_t>(1, batch / resident));
+        chunk = std::min<size_t>(std::min<size_t>(16, batch), std::max<size_t>(1, batch * rows / resident));
         if (const char* ev = getenv("PHE_HIP_MULTI_CHUNK")) {
             const int v = atoi(ev);
             if (v >= 1 && v <= 64) chunk = (size_t)v;
         }
+        const size_t n_chunks = (batch + chunk - 1) / chunk;
+        row_block = std::min<size_t>(std::min<size_t>(64, rows), std::max<size_t>(1, n_chunks * rows / (2 * resident)));
+        if (const char* ev = getenv("PHE_HIP_MULTI_ROWBLOCK")) {
+            const int v = atoi(ev);
+            if (v >= 1 && v <= 1024) row_block = (size_t)v;
+        }
     }
     size_t cur = (batch + chunk - 1) / chunk;
-    int rc = ensure_words(&ctx->partial, &ctx->partial_words, cur * s2);
+    int rc = ensure_words(&ctx->partial, &ctx->partial_words, cur * rows * s2);
     if (rc) return rc;
     uint32_t* P = ctx->partial;
-    if (split)
-        rc = launch_multi_split(ctx, pick_nsplit(ctx, cur), base, ctx->pub.s2, e, exp_limbs, max_exp_bits, (int)chunk, P,
-                                ctx->pub.s2, batch, cur, st);
-    else
+    if (split) {
+        const size_t tasks = cur * ((rows + row_block - 1) / row_block);
+        rc = launch_multi_split(ctx, pick_nsplit(ctx, tasks), base, base_inv, ctx->pub.s2, e, neg, exp_limbs, max_exp_bits,
+                                (int)chunk, (int)row_block, P, ctx->pub.s2, batch, rows, st);
+    } else {
         rc = launch_var(ctx, pick_nsq(ctx, batch), base, ctx->pub.s2, e, exp_limbs, max_exp_bits, P, ctx->pub.s2, batch, st);
+    }
     if (rc) return rc;
+    const size_t block = rows * s2;  // words of one chunk index
     while (cur > 1) {
         const size_t half = cur / 2;
-        rc = launch_mul(ctx, pick_nsq(ctx, half), P, s2, P + half * s2, s2, P, s2, ctx->pub.s2, half, st);
+        rc = launch_mul(ctx, pick_nsq(ctx, half * rows), P, s2, P + half * block, s2, P, s2, ctx->pub.s2, half * rows, st);
         if (rc) return rc;
-        if (cur & 1) {  // the unpaired last row joins the next level
-            HIP_TRY(hipMemcpyAsync(P + half * s2, P + 2 * half * s2, s2 * 4, hipMemcpyDeviceToDevice, st));
+        if (cur & 1) {  // the unpaired last chunk joins the next level
+            HIP_TRY(hipMemcpyAsync(P + half * block, P + 2 * half * block, block * 4, hipMemcpyDeviceToDevice, st));
             cur = half + 1;
         } else {
             cur = half;
         }
     }
-    HIP_TRY(hipMemcpyAsync(out, P, s2 * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(out, P, block * 4, hipMemcpyDeviceToDevice, st));
     return PHE_HIP_OK;
+}
+
+int phe_hip_multiexp_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, int max_exp_bits,
+                         uint32_t* out, size_t batch, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (!out) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    return multiexp_rows_impl(ctx, base, nullptr, e, nullptr, exp_limbs, max_exp_bits, out, batch, 1, (hipStream_t)stream);
+}
+
+int phe_hip_multiexp_rows_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* base_inv, const uint32_t* e,
+                              const uint8_t* neg, int exp_limbs, int max_exp_bits, uint32_t* out, size_t batch, size_t rows,
+                              void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (!out) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    return multiexp_rows_impl(ctx, base, base_inv, e, neg, exp_limbs, max_exp_bits, out, batch, rows, (hipStream_t)stream);
 }
 
 // ---- host-pointer entry points ------------------------------------------------------------------

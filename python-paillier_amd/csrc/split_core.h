@@ -652,23 +652,34 @@ PHE_DEV void modexp_var_split_body(const SplitVarArgs& A, uint32_t* lds_row, uin
 // runs them through ONE square-and-multiply ladder (Straus' interleaving) — the w squarings per window are shared
 // by the whole chunk, each element contributes one product per window from its own 2^w-ary table.  Per element
 // that is (bits/chunk) squarings + bits/w + 2^w - 2 products instead of bits squarings + bits/w + 2^w - 2 products.
-// out row j = product over elements [j*chunk, (j+1)*chunk); rows at and beyond n_chunks receive 1 (the caller pads
-// the row count to a power of two and joins the rows with a pairwise k_mulmod tree).
+//
+// Matrix form (a plaintext matrix times an encrypted vector: `rows` dot products over the same ciphertexts): the
+// exponents are a (rows, batch) matrix, a task is (chunk j, block of row_block rows) and runs one ladder per row of
+// its block on the tables it built once.  Scalars on the reference's negative branch (phe/paillier.py:745-749:
+// inverted base, exponent n - k) differ from row to row, so the inverted ciphertexts come as a second base array
+// with their own tables and a (rows, batch) byte mask selects per entry.
+// out[(j * rows + r)] = product over the elements of chunk j with the exponents of row r; the caller joins the
+// chunks of every row with a pairwise k_mulmod tree (contiguous: the chunk index is the slow one).
 struct SplitMultiArgs {
     SplitConsts mod;
-    const uint32_t* base;  // (batch, base_limbs)
+    const uint32_t* base;      // (batch, base_limbs)
+    const uint32_t* base_inv;  // (batch, base_limbs) inverses mod n^2, or nullptr (then no entry is negative)
     int base_limbs;
     int base_chunks;
-    const uint32_t* exps;  // (batch, exp_limbs)
+    const uint32_t* exps;  // (rows, batch, exp_limbs)
+    const uint8_t* neg;    // (rows, batch): nonzero = take the inverted base; nullptr = none
     int exp_limbs;
     int window;     // w in 1..4
     int n_windows;  // ceil(max_bits / w), >= 1
     int chunk;      // elements per limb group and ladder
-    uint32_t* out;  // (n_out, out_limbs)
+    int row_block;  // rows a task runs on its tables
+    uint32_t* out;  // (n_chunks, rows, out_limbs)
     int out_limbs;
-    uint32_t* table;  // scratch: total_groups * chunk * (2^w - 1) * 2H words
+    uint32_t* table;  // scratch: total_groups * chunk * (2^w - 1) * (base_inv ? 2 : 1) * 2H words
     uint64_t batch;
-    uint64_t n_out;   // >= ceil(batch / chunk)
+    uint64_t rows;
+    uint64_t n_chunks;      // ceil(batch / chunk)
+    uint64_t n_row_blocks;  // ceil(rows / row_block)
 };
 
 template <int G, int L>
@@ -683,52 +694,68 @@ PHE_DEV void multiexp_split_body(const SplitMultiArgs& A, uint32_t* lds_row, uin
     K.row_a = lds_row;
     K.row_c = lds_row + H;
     const int per = (1 << A.window) - 1;  // table of one element: base^1 .. base^(2^w - 1)
-    uint32_t* tbl = A.table + (size_t)slot * (size_t)A.chunk * (size_t)per * S2;
-    const uint64_t n_iter = (A.n_out + total_slots - 1) / total_slots;
+    const int signs = A.base_inv ? 2 : 1;
+    uint32_t* tbl = A.table + (size_t)slot * (size_t)A.chunk * (size_t)per * (size_t)signs * S2;
+    const uint64_t n_tasks = A.n_chunks * A.n_row_blocks;
+    const uint64_t n_iter = (n_tasks + total_slots - 1) / total_slots;
     for (uint64_t it = 0; it < n_iter; ++it) {
-        uint64_t row = slot + it * (uint64_t)total_slots;
-        const bool live = row < A.n_out;
-        if (!live) row = A.n_out - 1;
-        const uint64_t first = row * (uint64_t)A.chunk;
-        // elements of this chunk that exist (0 for a padding row); every loop below runs `chunk` times in all
-        // groups so that the wavefront stays converged — missing elements repeat the last one with digit 0
-        const int count = first >= A.batch ? 0 : (int)((A.batch - first < (uint64_t)A.chunk) ? A.batch - first : A.chunk);
+        uint64_t task = slot + it * (uint64_t)total_slots;
+        const bool live_task = task < n_tasks;
+        if (!live_task) task = n_tasks - 1;
+        const uint64_t cj = task % A.n_chunks, rb = task / A.n_chunks;
+        const uint64_t first = cj * (uint64_t)A.chunk;
+        // elements of this chunk that exist; every loop below runs `chunk` times in all groups so that the
+        // wavefront stays converged — missing elements repeat the last one with digit 0
+        const int count = (int)((A.batch - first < (uint64_t)A.chunk) ? A.batch - first : (uint64_t)A.chunk);
         uint32_t X0[L], X1[L], Y0[L], Y1[L];
-        for (int el = 0; el < A.chunk; ++el) {
-            uint64_t item = first + (uint64_t)el;
-            if (item >= A.batch) item = A.batch - 1;
-            split_conv<G, L>(Y0, Y1, A.base + item * (uint64_t)A.base_limbs, A.base_limbs, A.base_chunks, A.mod, K, ln);
-            uint32_t* t = tbl + (size_t)el * (size_t)per * S2;
-            store_row<L>(t, Y0, g);
-            store_row<L>(t + H, Y1, g);
-#pragma unroll
-            for (int k = 0; k < L; ++k) {
-                X0[k] = Y0[k];
-                X1[k] = Y1[k];
-            }
-            for (int j = 1; j < per; ++j) {
-                split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
-                store_row<L>(t + (size_t)j * S2, X0, g);
-                store_row<L>(t + (size_t)j * S2 + H, X1, g);
-            }
-        }
-        load_row<L>(X0, A.mod.e, g);
-        load_row<L>(X1, A.mod.e + H, g);
-        for (int wi = A.n_windows - 1; wi >= 0; --wi) {
-            if (wi != A.n_windows - 1)
-                for (int s = 0; s < A.window; ++s) split_square<G, L>(X0, X1, K, ln);
+        for (int sg = 0; sg < signs; ++sg) {
+            const uint32_t* src = sg ? A.base_inv : A.base;
             for (int el = 0; el < A.chunk; ++el) {
-                uint32_t d = 0;
-                if (el < count) d = exp_digit(A.exps + (first + (uint64_t)el) * (uint64_t)A.exp_limbs, A.exp_limbs, wi * A.window, A.window);
-                if (wave::ballot(d != 0) != 0) {  // wave-uniform: skip when every group has a zero digit
-                    const uint32_t* src = d ? tbl + ((size_t)el * (size_t)per + (d - 1)) * S2 : A.mod.e;
-                    load_row<L>(Y0, src, g);
-                    load_row<L>(Y1, src + H, g);
+                uint64_t item = first + (uint64_t)el;
+                if (item >= A.batch) item = A.batch - 1;
+                split_conv<G, L>(Y0, Y1, src + item * (uint64_t)A.base_limbs, A.base_limbs, A.base_chunks, A.mod, K, ln);
+                uint32_t* t = tbl + ((size_t)sg * (size_t)A.chunk + (size_t)el) * (size_t)per * S2;
+                store_row<L>(t, Y0, g);
+                store_row<L>(t + H, Y1, g);
+#pragma unroll
+                for (int k = 0; k < L; ++k) {
+                    X0[k] = Y0[k];
+                    X1[k] = Y1[k];
+                }
+                for (int j = 1; j < per; ++j) {
                     split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
+                    store_row<L>(t + (size_t)j * S2, X0, g);
+                    store_row<L>(t + (size_t)j * S2 + H, X1, g);
                 }
             }
         }
-        split_exit<G, L>(A.out + row * (uint64_t)A.out_limbs, A.out_limbs, X0, X1, nullptr, 0, A.mod, K, ln, live);
+        for (int rr = 0; rr < A.row_block; ++rr) {
+            uint64_t r = rb * (uint64_t)A.row_block + (uint64_t)rr;
+            const bool live = live_task && r < A.rows;
+            if (r >= A.rows) r = A.rows - 1;
+            const uint64_t entry0 = r * A.batch + first;  // (row, first element of the chunk)
+            load_row<L>(X0, A.mod.e, g);
+            load_row<L>(X1, A.mod.e + H, g);
+            for (int wi = A.n_windows - 1; wi >= 0; --wi) {
+                if (wi != A.n_windows - 1)
+                    for (int s = 0; s < A.window; ++s) split_square<G, L>(X0, X1, K, ln);
+                for (int el = 0; el < A.chunk; ++el) {
+                    uint32_t d = 0, sg = 0;
+                    if (el < count) {
+                        d = exp_digit(A.exps + (entry0 + (uint64_t)el) * (uint64_t)A.exp_limbs, A.exp_limbs, wi * A.window, A.window);
+                        if (A.neg) sg = A.neg[entry0 + (uint64_t)el] ? 1u : 0u;
+                    }
+                    if (wave::ballot(d != 0) != 0) {  // wave-uniform: skip when every group has a zero digit
+                        const uint32_t* src =
+                            d ? tbl + (((size_t)sg * (size_t)A.chunk + (size_t)el) * (size_t)per + (d - 1)) * S2 : A.mod.e;
+                        load_row<L>(Y0, src, g);
+                        load_row<L>(Y1, src + H, g);
+                        split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
+                    }
+                }
+            }
+            split_exit<G, L>(A.out + (cj * A.rows + r) * (uint64_t)A.out_limbs, A.out_limbs, X0, X1, nullptr, 0, A.mod, K, ln, live);
+        }
     }
 }
 

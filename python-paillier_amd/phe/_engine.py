@@ -250,6 +250,47 @@ class Engine:
             base[idx] = self.ctx.invert(np.ascontiguousarray(base[idx]))
         return self.to_ints(self.ctx.multiexp(base, limbs))[0]
 
+    def raw_matvec(self, c, exps, neg):
+        """rows of raw_dot over the same ciphertexts: out[r] = prod_i b_i^exps[r][i] mod n^2, b_i = c_i or
+        invert(c_i, n^2) where neg[r][i] (include/phe_hip.h phe_hip_multiexp_rows_dev: the tables of a chunk of
+        ciphertexts serve a block of rows; the vector is inverted once with the simultaneous-inversion tree when any
+        entry is negative).  exps: (rows, batch) uint64 array or list of rows of Python ints; neg: (rows, batch) bool.
+        c: host limb array or DeviceArray; returns the same kind, (rows, ct_limbs)."""
+        neg = np.asarray(neg, dtype=bool)
+        rows, batch = neg.shape
+        if isinstance(exps, np.ndarray):
+            e64 = np.ascontiguousarray(exps, dtype=np.uint64)
+            bits = int(e64.max()).bit_length() if e64.size else 1
+            limbs = e64.view(np.uint32).reshape(rows, batch, 2)[:, :, :1 if bits <= 32 else 2].copy()
+        else:
+            bits = max(1, max((v.bit_length() for row in exps for v in row), default=1))
+            width = (bits + 31) // 32
+            limbs = np.stack([_native.ints_to_limbs(list(row), width) for row in exps]) if rows else np.zeros((0, batch, width), np.uint32)
+        bits = max(bits, 1)
+        on_dev = isinstance(c, DeviceArray)
+        any_neg = bool(neg.any())
+        info = self.ctx.info()
+        if not (info.get("emulated") or info.get("engine_pub") == "split"):
+            # keys without a split geometry: row by row on the single-row entry point
+            out = [self.raw_dot(c, exps[r] if isinstance(exps, np.ndarray) else list(exps[r]), neg[r]) for r in range(rows)]
+            host = self.cipher_limbs(out)
+            return DeviceArray.from_host(self.ctx, host) if on_dev else host
+        if on_dev:
+            inv = None
+            if any_neg:
+                inv = DeviceArray(self.ctx, c.rows, self.ct_limbs)
+                self.ctx.invert_dev(c.ptr, inv.ptr, c.rows)
+            e = DeviceArray.from_host(self.ctx, limbs.reshape(rows * batch, -1))
+            mask = DeviceArray.from_host(self.ctx, neg.astype(np.uint8).reshape(-1), dtype=np.uint8) if any_neg else None
+            out = DeviceArray(self.ctx, rows, self.ct_limbs)
+            self.ctx.multiexp_rows_dev(c.ptr, inv.ptr if inv else None, e.ptr, mask.ptr if mask else None, limbs.shape[2], bits,
+                                       out.ptr, batch, rows)
+            self.ctx.sync()
+            return out
+        base = self._as_cipher(c)
+        inv = self.ctx.invert(base) if any_neg else None
+        return self.ctx.multiexp_rows(base, inv, limbs, neg.astype(np.uint8) if any_neg else None)
+
     # ---- the decimal wire format of ciphertext vectors (docs/serialisation.rst:24-43; str(int) / int(str) per
     #      element in the reference) ---------------------------------------------------------------------------
     def decimal_strings(self, c):

@@ -54,6 +54,7 @@ def lib():
         L.phe_hip_to_decimal_dev.argtypes = [vp, vp, ci, vp, ci, sz, vp]
         L.phe_hip_from_decimal_dev.argtypes = [vp, vp, ci, vp, ci, sz, ctypes.POINTER(sz), vp]
         L.phe_hip_multiexp_dev.argtypes = [vp, vp, vp, ci, ci, vp, sz, vp]
+        L.phe_hip_multiexp_rows_dev.argtypes = [vp, vp, vp, vp, vp, ci, ci, vp, sz, sz, vp]
         L.phe_hip_add_plain_dev.argtypes = [vp, vp, vp, vp, sz, vp]
         L.phe_hip_invert.argtypes = [vp, vp, vp, sz, ctypes.POINTER(sz)]
         L.phe_hip_encrypt_dev.argtypes = [vp, vp, vp, vp, sz, vp]
@@ -82,7 +83,7 @@ EXPORTED_SYMBOLS = [
     "phe_hip_powmod_dev", "phe_hip_malloc", "phe_hip_free", "phe_hip_memcpy_h2d", "phe_hip_memcpy_d2h",
     "phe_hip_stream_sync", "phe_hip_selftest_prims", "phe_hip_memcpy_d2d", "phe_hip_invert_dev",
     "phe_hip_select_rows_dev", "phe_hip_add_plain", "phe_hip_add_plain_dev", "phe_hip_ctx_engine",
-    "phe_hip_multiexp", "phe_hip_multiexp_dev", "phe_hip_decimal_width", "phe_hip_to_decimal",
+    "phe_hip_multiexp", "phe_hip_multiexp_dev", "phe_hip_multiexp_rows_dev", "phe_hip_decimal_width", "phe_hip_to_decimal",
     "phe_hip_from_decimal", "phe_hip_to_decimal_dev", "phe_hip_from_decimal_dev",
 ]
 
@@ -101,6 +102,16 @@ def _raise(rc, bad_index=None):
 def _check(rc):
     if rc != OK:
         _raise(rc)
+
+
+def max_exp_bits(exps):
+    """largest bit length among exponent rows (..., exp_limbs) of little-endian uint32 words (at least 1)"""
+    flat = np.asarray(exps).reshape(-1, exps.shape[-1])
+    for k in range(flat.shape[1] - 1, -1, -1):
+        top = int(flat[:, k].max()) if flat.shape[0] else 0
+        if top:
+            return 32 * k + top.bit_length()
+    return 1
 
 
 def int_to_limbs(x, limbs):
@@ -325,6 +336,45 @@ class Context:
 
     def multiexp_dev(self, base_ptr, exp_ptr, exp_limbs, max_exp_bits, out_ptr, batch, stream=0):
         _check(lib().phe_hip_multiexp_dev(self._h, base_ptr, exp_ptr, exp_limbs, max_exp_bits, out_ptr, batch, stream))
+
+    def multiexp_rows_dev(self, base_ptr, inv_ptr, exp_ptr, neg_ptr, exp_limbs, max_exp_bits, out_ptr, batch, rows, stream=0):
+        _check(lib().phe_hip_multiexp_rows_dev(self._h, base_ptr, inv_ptr, exp_ptr, neg_ptr, exp_limbs, max_exp_bits,
+                                               out_ptr, batch, rows, stream))
+
+    def multiexp_rows(self, base, base_inv, exps, neg):
+        """host arrays: base (batch, ct_limbs), base_inv same or None, exps (rows, batch, exp_limbs), neg (rows, batch)
+        bytes or None -> (rows, ct_limbs).  Stages through device blocks (there is no host-pointer C entry for the
+        matrix form)."""
+        base = _rows(base, self.ct_limbs, "base")
+        exps = np.ascontiguousarray(exps, dtype=np.uint32)
+        rows, batch = exps.shape[0], base.shape[0]
+        out = np.empty((rows, self.ct_limbs), dtype=np.uint32)
+        held = []
+
+        def up(arr):
+            arr = np.ascontiguousarray(arr)
+            nbytes = max(4, (arr.nbytes + 3) // 4 * 4)
+            p = self.malloc(nbytes)
+            held.append((p, nbytes))
+            if arr.nbytes:
+                self.h2d(p, arr)
+            return p
+        try:
+            b = up(base)
+            bi = up(_rows(base_inv, self.ct_limbs, "base_inv")) if base_inv is not None else None
+            e = up(exps)
+            ng = up(np.ascontiguousarray(neg, dtype=np.uint8)) if neg is not None else None
+            o = self.malloc(max(4, out.nbytes))
+            held.append((o, max(4, out.nbytes)))
+            bits = max_exp_bits(exps)
+            self.multiexp_rows_dev(b, bi, e, ng, exps.shape[2], bits, o, batch, rows)
+            self.sync()
+            if out.nbytes:
+                self.d2h(out, o)
+        finally:
+            for p, nbytes in held:
+                self.free(p, nbytes)
+        return out
 
     def invert_dev(self, a_ptr, out_ptr, batch, stream=0):
         bad = ctypes.c_size_t(0)

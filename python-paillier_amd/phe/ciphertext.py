@@ -470,3 +470,43 @@ class EncryptedVector(object):
             powers = {d: pow(EncodedNumber.BASE, d) for d in np.unique(delta).tolist()}
             exps = [m * powers[d] for m, d in zip(mags, delta.tolist())]
         return EncryptedNumber(pk, eng.raw_dot(self._limbs, exps, neg), target)
+
+    def mean(self):
+        """np.mean over ciphertexts (phe/tests/math_test.py:50-58): sum() times the encoded 1/len"""
+        return self.sum() / len(self)
+
+    def matvec(self, matrix):
+        """matrix @ self for a plaintext (rows, len(self)) matrix -> EncryptedVector of `rows` dot products, each bit
+        for bit what `self.dot(matrix[r])` (hence the reference's chain of `*` and `+`) gives.  All rows go through
+        one launch of the matrix-form multi-exponentiation (Engine.raw_matvec): the tables built for a chunk of
+        ciphertexts serve a block of rows, and the negative-branch inverses are formed once for the whole vector —
+        e.g. scoring every sample against an encrypted weight vector,
+        examples/logistic_regression_encrypted_model.py:170-177."""
+        pk = self.public_key
+        eng = pk._get_engine()
+        W = np.asarray(matrix)
+        if W.ndim != 2 or W.shape[1] != len(self):
+            raise ValueError("matrix must have shape (rows, %d)" % len(self))
+        if len(self) == 0:
+            raise ValueError("empty vector")
+        rows = W.shape[0]
+        signed = EncodedNumber.encode_signed(np.ascontiguousarray(W)) if (eng.n_limbs >= 4 and rows) else None
+        if signed is None:                                   # object / exotic dtypes: row by row through dot()
+            return EncryptedVector.from_numbers(pk, [self.dot(list(row)) for row in W.tolist()]) if rows else self[:0]
+        mag, neg, kexp = (a.reshape(W.shape) for a in signed)
+        total = self._exps[None, :] + kexp
+        target = total.min(axis=1)
+        delta = total - target[:, None]
+        dmax = int(delta.max())
+        if dmax and pow(EncodedNumber.BASE, dmax) >= pk.n:
+            raise ValueError('Scalar out of bounds: %i' % pow(EncodedNumber.BASE, dmax))
+        log2b = int(round(EncodedNumber.LOG2_BASE))
+        if dmax == 0:
+            exps = mag
+        elif int(mag.max()).bit_length() + log2b * dmax <= 64:
+            exps = mag << (delta * log2b).astype(np.uint64)
+        else:
+            powers = {d: pow(EncodedNumber.BASE, d) for d in np.unique(delta).tolist()}
+            exps = [[m * powers[d] for m, d in zip(mrow, drow)] for mrow, drow in zip(mag.tolist(), delta.tolist())]
+        limbs = eng.raw_matvec(self._limbs, exps, neg)
+        return EncryptedVector(pk, limbs, target)

@@ -174,9 +174,9 @@ static void run_var_split(SplitVarArgs A) {
 template <int G, int L>
 static void run_multi_split(SplitMultiArgs A) {
     constexpr int S2 = 2 * G * L, kPer = 64 / G;
-    const int n_waves = waves_for(A.n_out, G);
+    const int n_waves = waves_for(A.n_chunks * A.n_row_blocks, G);
     const uint32_t total = (uint32_t)(kPer * n_waves);
-    std::vector<uint32_t> table((size_t)total * (size_t)A.chunk * (((size_t)1 << A.window) - 1) * S2);
+    std::vector<uint32_t> table((size_t)total * (size_t)A.chunk * (((size_t)1 << A.window) - 1) * (A.base_inv ? 2 : 1) * S2);
     A.table = table.data();
     for (int w = 0; w < n_waves; ++w) {
         std::vector<uint32_t> lds(kPer * (S2 + kLdsPad));
@@ -431,27 +431,30 @@ int emu_powmod_n2(const uint32_t* n, int n_limbs, const uint32_t* base, const ui
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
-// k_multiexp_split alone: out row j = prod of base[i]^exps[i] over the chunk [j*chunk, (j+1)*chunk), rows >= ceil(B/chunk)
-// are 1.  Returns 2 when the key has no split geometry (the product then takes powmod + the mulmod tree).
-int emu_multiexp_n2(const uint32_t* n, int n_limbs, const uint32_t* base, const uint32_t* exps, int exp_limbs,
-                    int chunk, uint32_t* out, uint64_t n_out, uint64_t B) {
+// k_multiexp_split alone: out[(j * rows + r)] = prod over the chunk [j*chunk, (j+1)*chunk) of b[i]^exps[r][i], b = base or
+// base_inv where neg[r][i] (base_inv / neg may be null).  Returns 2 when the key has no split geometry (the product
+// then takes powmod + the mulmod tree).
+int emu_multiexp_n2(const uint32_t* n, int n_limbs, const uint32_t* base, const uint32_t* base_inv, const uint32_t* exps,
+                    const uint8_t* neg, int exp_limbs, int chunk, int row_block, uint32_t* out, uint64_t rows, uint64_t B) {
     try {
-        if (B == 0 || chunk < 1 || n_out * (uint64_t)chunk < B) throw std::invalid_argument("bad multiexp shape");
+        if (B == 0 || rows == 0 || chunk < 1 || row_block < 1 || (neg && !base_inv)) throw std::invalid_argument("bad multiexp shape");
         host::PublicPlan P = host::build_public(n, n_limbs, g_prefer_group);
         if (!P.nsplit.G) return 2;
         int max_bits = 1;
-        for (uint64_t i = 0; i < B; ++i)
+        for (uint64_t i = 0; i < B * rows; ++i)
             max_bits = std::max(max_bits, host::big_bits(host::big_from(exps + i * exp_limbs, exp_limbs, exp_limbs)));
         const host::SplitPack& M = P.nsplit;
         SplitMultiArgs A;
         memset(&A, 0, sizeof A);
         A.mod = split_consts_of(M);
-        A.base = base; A.base_limbs = P.s2; A.base_chunks = chunks_for(P.s2, M.H);
-        A.exps = exps; A.exp_limbs = exp_limbs;
+        A.base = base; A.base_inv = base_inv; A.base_limbs = P.s2; A.base_chunks = chunks_for(P.s2, M.H);
+        A.exps = exps; A.neg = neg; A.exp_limbs = exp_limbs;
         A.window = host::pick_multi_window(max_bits);
         A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
-        A.chunk = chunk;
-        A.out = out; A.out_limbs = P.s2; A.batch = B; A.n_out = n_out;
+        A.chunk = chunk; A.row_block = row_block;
+        A.out = out; A.out_limbs = P.s2; A.batch = B; A.rows = rows;
+        A.n_chunks = (B + chunk - 1) / chunk;
+        A.n_row_blocks = (rows + row_block - 1) / row_block;
         DISPATCH_SPLIT(M.G, M.L, (run_multi_split<GG, LL>(A)));
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }

@@ -75,21 +75,31 @@ class EmuContext:
         return emu().powmod_n2(self._n_arr, np.ascontiguousarray(base), np.ascontiguousarray(exps))
 
     def multiexp(self, base, exps):
-        # k_multiexp_split through the emulator (chunks of 3: exercises a ragged last chunk), then the pairwise
-        # product tree the library runs with k_mulmod
-        one = np.zeros((1, self.ct_limbs), np.uint32)
-        one[0, 0] = 1
+        return self.multiexp_rows(base, None, np.ascontiguousarray(exps)[None], None)
+
+    def multiexp_rows(self, base, base_inv, exps, neg):
+        """(rows, ct_limbs): row r = prod_i b_i^exps[r][i].  k_multiexp_split through the emulator (chunks of 3: a ragged
+        last chunk; row blocks of 2), then the pairwise product tree over the chunk index that the library runs with
+        k_mulmod; without a split geometry the per-row powmod + tree (as Engine.raw_matvec does on such keys)."""
+        rows = exps.shape[0]
+        one = np.zeros((rows, self.ct_limbs), np.uint32)
+        one[:, 0] = 1
         if base.shape[0] == 0:
             return one
         base, exps = np.ascontiguousarray(base), np.ascontiguousarray(exps)
-        rows = emu().multiexp_n2(self._n_arr, base, exps, 3)
-        if rows is None:
-            rows = emu().powmod_n2(self._n_arr, base, exps)
-        while rows.shape[0] > 1:
-            half = rows.shape[0] // 2
-            merged = emu().mulmod(self._nsq_arr, np.ascontiguousarray(rows[:half]), np.ascontiguousarray(rows[half:2 * half]))
-            rows = np.concatenate([merged, rows[2 * half:]])
-        return rows
+        parts = emu().multiexp_n2(self._n_arr, base, exps, 3, base_inv=base_inv, neg=neg, row_block=2)
+        if parts is None:
+            parts = np.zeros((base.shape[0], rows, self.ct_limbs), np.uint32)
+            for r in range(rows):
+                b = base if neg is None else np.where(np.asarray(neg[r], bool)[:, None], base_inv, base)
+                parts[:, r] = emu().powmod_n2(self._n_arr, np.ascontiguousarray(b), np.ascontiguousarray(exps[r]))
+        while parts.shape[0] > 1:
+            half = parts.shape[0] // 2
+            a = np.ascontiguousarray(parts[:half]).reshape(half * rows, -1)
+            b = np.ascontiguousarray(parts[half:2 * half]).reshape(half * rows, -1)
+            merged = emu().mulmod(self._nsq_arr, a, b).reshape(half, rows, -1)
+            parts = np.concatenate([merged, parts[2 * half:]])
+        return parts[0]
 
     # decimal wire format: csrc/radix_conv.h through the emulator library (plain arrays instead of the LDS tile)
     @staticmethod

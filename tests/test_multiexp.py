@@ -38,8 +38,9 @@ def emu():
 
 @pytest.mark.parametrize("key_bits,group", [(256, 0), (1024, 0), (1024, 8), (2048, 0)])
 def test_chunk_products_through_emulator(emu, key_bits, group):
-    """k_multiexp_split's body: every chunk shares one ladder; ragged last chunk, padding rows, exponent 0 and 1,
-    bases 1 and n^2 - 1, all four window sizes"""
+    """k_multiexp_split's body: every chunk shares one ladder; ragged last chunk, exponent 0 and 1, bases 1 and
+    n^2 - 1, all four window sizes; matrix form (several exponent rows on the tables of one task, row blocks that do
+    not divide the row count) with per-entry selection of the inverted base"""
     emu.set_engine(True)
     emu.set_group(group)
     g = load_golden(key_bits)
@@ -47,6 +48,7 @@ def test_chunk_products_through_emulator(emu, key_bits, group):
     nsq = n_int * n_int
     s1, s2 = key_bits // 32, key_bits // 16
     rng = random.Random(key_bits + group)
+    n_arr = int_to_limbs(n_int, s1)
     shapes = [(7, 3, 64), (5, 1, 20), (9, 4, 130), (3, 8, 3)] if key_bits < 2048 else [(5, 2, 56)]
     for batch, chunk, ebits in shapes:
         bases = [rng.randrange(1, nsq) for _ in range(batch)]
@@ -54,16 +56,32 @@ def test_chunk_products_through_emulator(emu, key_bits, group):
         exps[0], bases[1], bases[2] = 0, 1, nsq - 1
         if batch > 3:
             exps[3] = 1
-        n_out = -(-batch // chunk) + 1                      # one padding row: must come back as 1
-        rows = emu.multiexp_n2(int_to_limbs(n_int, s1), ints_to_limbs(bases, s2),
-                               ints_to_limbs(exps, max(1, -(-ebits // 32))), chunk, n_out)
+        width = max(1, -(-ebits // 32))
+        parts = emu.multiexp_n2(n_arr, ints_to_limbs(bases, s2), ints_to_limbs(exps, width), chunk)
         want = []
-        for j in range(n_out):
+        for j in range(-(-batch // chunk)):
             v = 1
             for i in range(j * chunk, min(batch, (j + 1) * chunk)):
                 v = v * pow(bases[i], exps[i], nsq) % nsq
             want.append(v)
-        assert limbs_to_ints(rows) == want, (batch, chunk, ebits)
+        assert parts.shape == (len(want), 1, s2)
+        assert limbs_to_ints(parts[:, 0]) == want, (batch, chunk, ebits)
+    # matrix form
+    batch, rows, chunk, row_block, ebits = (7, 5, 3, 2, 40) if key_bits < 2048 else (3, 2, 2, 2, 24)
+    bases = [rng.randrange(1, nsq) for _ in range(batch)]
+    invs = [pow(b, -1, nsq) for b in bases]
+    ex = [[rng.getrandbits(ebits) for _ in range(batch)] for _ in range(rows)]
+    ex[0][1] = 0
+    neg = np.array([[rng.random() < 0.4 for _ in range(batch)] for _ in range(rows)], dtype=np.uint8)
+    e_arr = np.stack([ints_to_limbs(row, 2) for row in ex])
+    parts = emu.multiexp_n2(n_arr, ints_to_limbs(bases, s2), e_arr, chunk, base_inv=ints_to_limbs(invs, s2), neg=neg,
+                            row_block=row_block)
+    for j in range(-(-batch // chunk)):
+        for r in range(rows):
+            v = 1
+            for i in range(j * chunk, min(batch, (j + 1) * chunk)):
+                v = v * pow(invs[i] if neg[r][i] else bases[i], ex[r][i], nsq) % nsq
+            assert limbs_to_ints(parts[j, r:r + 1]) == [v], (j, r)
     emu.set_group(0)
 
 
@@ -128,6 +146,36 @@ def test_dot_equals_reference_chain(monkeypatch, emu, engine):
         vec.dot(singles)
     with pytest.raises(ValueError):
         vec[:0].dot([])
+    emu_backend.emu().set_engine(True)
+
+
+@pytest.mark.parametrize("engine", [True, False])
+def test_matvec_rows_equal_dot(monkeypatch, emu, engine):
+    """EncryptedVector.matvec: every row is bit for bit self.dot(row) (float rows with mixed exponents and signs, int
+    rows, an all-positive matrix that needs no inverses); mean() = sum() / len"""
+    import emu_backend
+    emu_backend.install(monkeypatch)
+    emu_backend.emu().set_engine(engine)
+    from phe import paillier
+    g = load_golden(256)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    vals = np.array([0.5, -1.25, 3.0, 4.75, 1e-3, -7.0, 250.0])
+    vec = pub.encrypt_batch(vals, r_values=[H(e["r"]) for e in g["raw_encrypt"][:7]])
+    rng = np.random.default_rng(1)
+    for W in (rng.standard_normal((5, 7)), rng.integers(-50, 50, (4, 7)), rng.integers(0, 9, (3, 7)),
+              np.array([[1e6, -1e-6, 0.0, 1.0, -1.0, 2.5, 0.125]])):
+        out = vec.matvec(W)
+        assert len(out) == W.shape[0]
+        for r in range(W.shape[0]):
+            d = vec.dot(W[r])
+            assert (out[r].ciphertext(False), out[r].exponent) == (d.ciphertext(False), d.exponent), r
+        got = priv.decrypt_batch(out)
+        assert np.allclose(got, W.astype(np.float64) @ vals, rtol=1e-9, atol=1e-9)
+    assert len(vec.matvec(np.zeros((0, 7)))) == 0
+    with pytest.raises(ValueError):
+        vec.matvec(np.zeros((2, 6)))
+    assert abs(priv.decrypt(vec.mean()) - vals.mean()) < 1e-9
     emu_backend.emu().set_engine(True)
 
 
@@ -214,3 +262,29 @@ def test_dot_large_batch_properties(native, c_oracle):
     want = functools.reduce(lambda a, b: a * b % nsq, terms, 1)
     assert head.dot(w_int[:k]).ciphertext(False) == want
     assert isinstance(got, phe.EncryptedNumber)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("forced", [None, ("5", "3"), ("1", "64"), ("16", "1")])
+def test_matvec_against_row_dots_and_plaintext(monkeypatch, forced):
+    """the matrix form through the C-ABI, host and device-resident vectors, automatic and forced (chunk, row block)
+    shapes incl. blocks that do not divide the row count: every row equals dot(row) bit for bit and decrypts to W @ x"""
+    from phe import paillier
+    if forced:
+        monkeypatch.setenv("PHE_HIP_MULTI_CHUNK", forced[0])
+        monkeypatch.setenv("PHE_HIP_MULTI_ROWBLOCK", forced[1])
+    g = load_golden(1024)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    rs = np.random.Generator(np.random.PCG64(17))
+    x = rs.standard_normal(93)
+    host = pub.encrypt_batch(x)
+    dev = host.to_device()
+    for W in (rs.standard_normal((41, 93)), rs.integers(-1000, 1000, (7, 93)), rs.integers(0, 1 << 40, (3, 93))):
+        a, b = host.matvec(W), dev.matvec(W)
+        assert b.on_device and a.ciphertexts(False) == b.ciphertexts(False) and a.exponents == b.exponents
+        for r in (0, W.shape[0] // 2, W.shape[0] - 1):
+            d = host.dot(W[r])
+            assert (a[r].ciphertext(False), a[r].exponent) == (d.ciphertext(False), d.exponent)
+        want = W.astype(np.float64) @ x
+        assert np.allclose(priv.decrypt_batch(b), want, rtol=1e-9, atol=1e-6)

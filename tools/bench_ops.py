@@ -119,6 +119,22 @@ def main():
         ok = native.limbs_to_ints(to_np(one_row))[0] == want
         res[name] = {"elements_per_s": B / t, "ms": t * 1e3, "composed_powmod_plus_tree_ms": t_old * 1e3,
                      "speedup_vs_composed": t_old / t, "same_bits_as_composed": same, "bit_exact_prefix_vs_oracle": bool(ok)}
+    # ---- matrix form: a (rows x features) plaintext matrix times an encrypted feature vector (the shape of
+    #      examples/logistic_regression_encrypted_model.py:170-177 with the roles of weights and samples swapped) ----
+    feat, nrows = 128, 8192
+    em = torch.randint(-2 ** 31, 2 ** 31, (nrows * feat, 2), dtype=torch.int32, device=dev, generator=gen)
+    em[:, 1] &= 0x00ffffff
+    outm = torch.empty((nrows, s2), dtype=torch.int32, device=dev)
+    t = timed(lambda: ctx.multiexp_rows_dev(ca.data_ptr(), None, em.data_ptr(), None, 2, 56, outm.data_ptr(), feat, nrows, st))
+
+    def looped(k):
+        for r in range(k):
+            ctx.multiexp_dev(ca.data_ptr(), em.data_ptr() + r * feat * 8, 2, 56, out.data_ptr() + r * s2 * 4, feat, st)
+    t_loop = timed(lambda: looped(256)) * (nrows / 256)
+    same = bool(torch.equal(outm[:256], out[:256]))
+    res["matvec_128x8192_float56"] = {"entries_per_s": feat * nrows / t, "rows_per_s": nrows / t, "ms": t * 1e3,
+                                      "row_by_row_dot_ms_extrapolated_from_256_rows": t_loop * 1e3, "speedup_vs_row_by_row": t_loop / t,
+                                      "same_bits_as_row_by_row": same}
     if args.chunk_sweep:
         e = rnd(2)
         e[:, 1] &= 0x7fffffff
