@@ -471,6 +471,27 @@ class EncryptedVector(object):
             exps = [m * powers[d] for m, d in zip(mags, delta.tolist())]
         return EncryptedNumber(pk, eng.raw_dot(self._limbs, exps, neg), target)
 
+    # numpy must not try to broadcast over the rows of a vector: `W @ vec`, `w @ vec`, `vec @ w` come here
+    __array_ufunc__ = None
+
+    def __matmul__(self, other):
+        """vec @ w (1-D plaintext) -> the dot product; vec @ M for a (len, cols) matrix -> M.T @ vec"""
+        other = np.asarray(other) if not isinstance(other, np.ndarray) else other
+        if other.ndim == 1:
+            return self.dot(other)
+        if other.ndim == 2:
+            return self.matvec(np.ascontiguousarray(other.T))
+        raise ValueError("matmul operand must be 1-D or 2-D")
+
+    def __rmatmul__(self, other):
+        """w @ vec -> the dot product; W @ vec for a (rows, len) matrix -> matvec(W)"""
+        other = np.asarray(other) if not isinstance(other, np.ndarray) else other
+        if other.ndim == 1:
+            return self.dot(other)
+        if other.ndim == 2:
+            return self.matvec(other)
+        raise ValueError("matmul operand must be 1-D or 2-D")
+
     def mean(self):
         """np.mean over ciphertexts (phe/tests/math_test.py:50-58): sum() times the encoded 1/len"""
         return self.sum() / len(self)

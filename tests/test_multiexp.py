@@ -173,6 +173,10 @@ def test_matvec_rows_equal_dot(monkeypatch, emu, engine):
         got = priv.decrypt_batch(out)
         assert np.allclose(got, W.astype(np.float64) @ vals, rtol=1e-9, atol=1e-9)
     assert len(vec.matvec(np.zeros((0, 7)))) == 0
+    W = rng.standard_normal((3, 7))
+    assert (W @ vec).ciphertexts(False) == vec.matvec(W).ciphertexts(False)            # numpy defers to the vector
+    assert (vec @ W.T).ciphertexts(False) == vec.matvec(W).ciphertexts(False)
+    assert (W[0] @ vec).ciphertext(False) == (vec @ W[0]).ciphertext(False) == vec.dot(W[0]).ciphertext(False)
     with pytest.raises(ValueError):
         vec.matvec(np.zeros((2, 6)))
     assert abs(priv.decrypt(vec.mean()) - vals.mean()) < 1e-9
@@ -288,3 +292,21 @@ def test_matvec_against_row_dots_and_plaintext(monkeypatch, forced):
             assert (a[r].ciphertext(False), a[r].exponent) == (d.ciphertext(False), d.exponent)
         want = W.astype(np.float64) @ x
         assert np.allclose(priv.decrypt_batch(b), want, rtol=1e-9, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_matvec_without_split_engine_goes_row_by_row(monkeypatch):
+    """PHE_HIP_ENGINE=full (or a key width without a split geometry): the C entry refuses the matrix form and
+    Engine.raw_matvec calls the single-row entry point per row — same bits as with the split engine"""
+    from phe import paillier
+    g = load_golden(1024)
+    rs = np.random.Generator(np.random.PCG64(5))
+    x, W = rs.standard_normal(21), rs.standard_normal((4, 21))
+    r_values = [int(v) for v in rs.integers(2, 1 << 62, 21)]
+    ref = paillier.PaillierPublicKey(H(g["n"])).encrypt_batch(x, r_values=r_values).matvec(W)
+    monkeypatch.setenv("PHE_HIP_ENGINE", "full")
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    assert pub._get_engine().ctx.info()["engine_pub"] != "split"
+    for vec in (pub.encrypt_batch(x, r_values=r_values), pub.encrypt_batch(x, r_values=r_values, device=True)):
+        out = vec.matvec(W)
+        assert out.ciphertexts(False) == ref.ciphertexts(False) and out.exponents == ref.exponents
