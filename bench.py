@@ -48,11 +48,12 @@ def mac32_counts(key_bits):
 
 def executed_mads(key_bits, info):
     """v_mad_u64_u32 lane-operations one encrypt / one decrypt really executes (29-bit limbs; schedule counted like
-    SURVEY's E(t): t squarings, ceil(t/6) + 16 products).  Split engine: a squaring is 4 H^2, a product 5 H^2, entry
+    SURVEY's E(t): t squarings, ceil(t/(w+1)) + 2^(w-1) products for the window w in use).  Split engine: a squaring is 4 H^2, a product 5 H^2, entry
     4 H^2 per input chunk (+5 H^2 when more than one), exit ~10 H^2 (csrc/split_core.h); full-width engine: 2 S^2 per
     Montgomery product."""
     E_sq = lambda t: t
-    E_mul = lambda t: -(-t // 6) + 16
+    # sliding windows of w = 6 bits (32 odd powers) from ~1000-bit exponents on, w = 5 (16) below: key_setup.h:pick_window
+    E_mul = lambda t: (-(-t // 7) + 32) if t > 900 else (-(-t // 6) + 16)
 
     def modexp(t, lane_limbs, split, in_bits, extra):
         G, L = divmod(lane_limbs, 100)

@@ -9,6 +9,7 @@
 //
 // Pure C++ (no HIP): also compiled into the CPU emulator used by tests/.
 #pragma once
+#include <stdlib.h>
 #include <stdint.h>
 
 #include <algorithm>
@@ -384,7 +385,11 @@ inline int pick_window(int exp_bits) {
     if (exp_bits <= 24) return 2;
     if (exp_bits <= 80) return 3;
     if (exp_bits <= 240) return 4;
-    return 5;
+    // measured on the batch-uniform exponents (tools/gpu_ab_window.sh, profiles/r01m_ab_window.txt): w = 6 beats w = 5
+    // from ~1000-bit exponents on (2048-bit n: +1.7 % encrypts/s, 3072-bit n: +2.4 %; the 1024 / 1536-bit p - 1 of
+    // decrypt: +0.3 % / +1.3 %); w = 7 gains a little more on n but loses on p - 1 and doubles the table again
+    if (exp_bits <= 900) return 5;
+    return 6;
 }
 
 // window of a shared multi-exponentiation ladder (split_core.h:multiexp_split_body): per element bits/chunk
@@ -401,6 +406,12 @@ inline Schedule build_schedule(const Big& e, int window = 0) {
     if (bits == 0) throw std::invalid_argument("exponent must be positive");
     Schedule s;
     s.window = window > 0 ? window : pick_window(bits);
+    if (window <= 0 && bits > 240) {  // the long batch-uniform exponents (n, p-1, q-1): PHE_HIP_WINDOW=4..7 overrides w = 5
+        if (const char* ev = getenv("PHE_HIP_WINDOW")) {
+            const int v = atoi(ev);
+            if (v >= 4 && v <= 7) s.window = v;
+        }
+    }
     s.tbl_entries = 1 << (s.window - 1);
     auto bit = [&](int i) -> uint32_t { return i < 0 ? 0u : (e[(size_t)(i >> 5)] >> (i & 31)) & 1u; };
     int i = bits - 1;

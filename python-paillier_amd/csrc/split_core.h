@@ -583,7 +583,7 @@ struct SplitVarArgs {
     int base_chunks;
     const uint32_t* exps;  // (batch, exp_limbs)
     int exp_limbs;
-    int window;      // w in 1..5
+    int window;      // w in 1..6 (key_setup.h:pick_window)
     int n_windows;   // ceil(max_bits / w), >= 1
     uint32_t* out;
     int out_limbs;
