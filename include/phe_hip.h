@@ -183,6 +183,10 @@ int phe_hip_memcpy_h2d(phe_hip_ctx* ctx, void* dst_dev, const void* src_host, si
 int phe_hip_memcpy_d2h(phe_hip_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 int phe_hip_memcpy_d2d(phe_hip_ctx* ctx, void* dst_dev, const void* src_dev, size_t bytes, void* stream);
 int phe_hip_stream_sync(phe_hip_ctx* ctx, void* stream);
+/* a stream that does not synchronise with the NULL stream: *_dev launches queued on it overlap the blocking copies
+ * above (hosts without a tensor library; with torch pass torch.cuda.current_stream().cuda_stream instead) */
+int phe_hip_stream_create(phe_hip_ctx* ctx, void** stream);
+int phe_hip_stream_destroy(phe_hip_ctx* ctx, void* stream);
 
 /* ---- diagnostics ----------------------------------------------------------------------------- */
 /* Runs the three DPP row primitives and the ballot on lane ids: out is (4, 64) uint32:

@@ -1325,6 +1325,24 @@ int phe_hip_memcpy_d2d(phe_hip_ctx* ctx, void* dst_dev, const void* src_dev, siz
     HIP_TRY(hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return PHE_HIP_OK;
 }
+// A stream that does not synchronise with the NULL stream: kernels queued on it keep running while the host uploads
+// the next operands with the blocking copies above (which are ordered on the NULL stream).
+int phe_hip_stream_create(phe_hip_ctx* ctx, void** stream) {
+    if (check_ctx(ctx) || !stream) return fail(PHE_HIP_EINVAL, "null argument");
+    if (int rc = bind_device(ctx)) return rc;
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream = (void*)st;
+    return PHE_HIP_OK;
+}
+int phe_hip_stream_destroy(phe_hip_ctx* ctx, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (!stream) return PHE_HIP_OK;
+    if (int rc = bind_device(ctx)) return rc;
+    HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return PHE_HIP_OK;
+}
+
 int phe_hip_stream_sync(phe_hip_ctx* ctx, void* stream) {
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
     if (int rc = bind_device(ctx)) return rc;

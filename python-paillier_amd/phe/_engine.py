@@ -213,6 +213,49 @@ class Engine:
         self.ctx.sync()
         return out
 
+    def __del__(self):
+        try:
+            st = self.__dict__.get("_stream")
+            if st:
+                self.ctx.stream_destroy(st)
+        except Exception:
+            pass
+
+    @staticmethod
+    def shifted_limbs(mag, shift_bits):
+        """(mag[i] << shift_bits[i]) as little-endian uint32 limb rows, without a Python integer per element: the
+        exponents k_i * BASE^delta_i of an aligned dot product (mag: uint64 magnitudes, shift_bits: int64 >= 0).
+        Returns (limbs (batch, width), largest bit length)."""
+        mag = np.ascontiguousarray(mag, dtype=np.uint64).reshape(-1)
+        sh = np.ascontiguousarray(shift_bits, dtype=np.int64).reshape(-1)
+        count = len(mag)
+        top = int(mag.max()) if count else 0
+        if top == 0:
+            return np.zeros((count, 1), dtype=np.uint32), 1
+        nz = mag != 0
+        # exact bit length of every magnitude: float64 log2 can be off by one near powers of two, so fix it up
+        bl = np.zeros(count, dtype=np.int64)
+        est = np.floor(np.log2(mag[nz].astype(np.float64))).astype(np.int64) + 1
+        est = np.minimum(est, 64)
+        m_nz = mag[nz]
+        too_big = (est > 1) & ((m_nz >> (est - 1).astype(np.uint64)) == 0)
+        est[too_big] -= 1
+        too_small = (est < 64) & ((m_nz >> np.minimum(est, 63).astype(np.uint64)) != 0)
+        est[too_small] += 1
+        bl[nz] = est
+        bits = int((bl + np.where(nz, sh, 0)).max())
+        width = max(1, (bits + 31) // 32)
+        out = np.zeros((count, width + 3), dtype=np.uint32)       # 3 spill words, cut off below
+        word = sh >> 5
+        bo = (sh & 31).astype(np.uint64)
+        lo = mag << bo                                            # low 64 bits of the shifted value
+        hi = np.where(bo == 0, np.uint64(0), mag >> ((np.uint64(64) - bo) & np.uint64(63)))   # the bits shifted out
+        rows = np.arange(count)
+        out[rows, word] = (lo & np.uint64(0xffffffff)).astype(np.uint32)
+        out[rows, word + 1] = (lo >> np.uint64(32)).astype(np.uint32)
+        out[rows, word + 2] = hi.astype(np.uint32)
+        return np.ascontiguousarray(out[:, :width]), max(bits, 1)
+
     @staticmethod
     def _exp_limbs(exps):
         """exponents (uint64 array or Python ints) -> (batch, width) uint32 limbs and the largest bit length"""
@@ -228,7 +271,7 @@ class Engine:
         base with exponent n - k) and _raw_add (:705-719) leaves it: the product of canonical residues does not
         depend on the order of the factors.  One k_multiexp_split launch plus the k_mulmod tree over its chunk
         products (include/phe_hip.h phe_hip_multiexp).  c: host limb array or DeviceArray.  Returns a Python int."""
-        limbs, bits = self._exp_limbs(exps)
+        limbs, bits = exps if isinstance(exps, tuple) else self._exp_limbs(exps)
         neg = np.asarray(neg, dtype=bool)
         if isinstance(c, DeviceArray):
             base = c
@@ -258,7 +301,9 @@ class Engine:
         c: host limb array or DeviceArray; returns the same kind, (rows, ct_limbs)."""
         neg = np.asarray(neg, dtype=bool)
         rows, batch = neg.shape
-        if isinstance(exps, np.ndarray):
+        if isinstance(exps, tuple):                              # (limb rows (rows*batch, width), bits): shifted_limbs
+            limbs, bits = exps[0].reshape(rows, batch, -1), exps[1]
+        elif isinstance(exps, np.ndarray):
             e64 = np.ascontiguousarray(exps, dtype=np.uint64)
             bits = int(e64.max()).bit_length() if e64.size else 1
             limbs = e64.view(np.uint32).reshape(rows, batch, 2)[:, :, :1 if bits <= 32 else 2].copy()
@@ -272,7 +317,7 @@ class Engine:
         info = self.ctx.info()
         if not (info.get("emulated") or info.get("engine_pub") == "split"):
             # keys without a split geometry: row by row on the single-row entry point
-            out = [self.raw_dot(c, exps[r] if isinstance(exps, np.ndarray) else list(exps[r]), neg[r]) for r in range(rows)]
+            out = [self.raw_dot(c, (np.ascontiguousarray(limbs[r]), bits), neg[r]) for r in range(rows)]
             host = self.cipher_limbs(out)
             return DeviceArray.from_host(self.ctx, host) if on_dev else host
         if on_dev:
@@ -339,22 +384,33 @@ class Engine:
         self.ctx.sync()
         return out
 
+    def _launch_stream(self):
+        """a non-blocking stream for pipelined launches (created on first use; 0 = NULL stream if the backend has none)"""
+        st = self.__dict__.get("_stream")
+        if st is None:
+            st = self.ctx.stream_create() if hasattr(self.ctx, "stream_create") else 0
+            self._stream = st
+        return st
+
     def raw_encrypt_fresh(self, m, device):
-        """raw_encrypt with freshly drawn obfuscators, in chunks: the draw of chunk k+1 (the kernel CSPRNG, host side)
-        overlaps the kernel of chunk k — launches are asynchronous, the only host/device rendezvous inside the loop is
-        the upload of the next operands.  m: (count, n_limbs) plaintext limbs.  Returns a DeviceArray or a host array."""
+        """raw_encrypt with freshly drawn obfuscators, in chunks: the draw (the kernel CSPRNG, host side) and the upload
+        of chunk k+1 overlap the kernel of chunk k — the kernels are queued on a non-blocking stream, so the blocking
+        copies (NULL stream) do not wait for them; the first chunk is half size to shorten the exposed prologue.
+        m: (count, n_limbs) plaintext limbs.  Returns a DeviceArray or a host array."""
         count = m.shape[0]
-        chunk = 1 << 16
+        st = self._launch_stream()
         out = DeviceArray(self.ctx, count, self.ct_limbs)
         keep = []                                         # operand buffers stay alive until the final sync
-        for lo in range(0, count, chunk):
+        lo, chunk = 0, 1 << 15                            # chunks are multiples of the groups in flight (32768 at 2048 bits)
+        while lo < count:
             hi = min(count, lo + chunk)
             r = random_lt_n_limbs(self.n, hi - lo, self.n_limbs, out=self.scratch("r", hi - lo, self.n_limbs))
             m_d = DeviceArray.from_host(self.ctx, m[lo:hi])
             r_d = DeviceArray.from_host(self.ctx, r)      # synchronous copy: the scratch buffer is free again
             keep += [m_d, r_d]
-            self.ctx.encrypt_dev(m_d.ptr, r_d.ptr, out.rows_view(lo, hi).ptr, hi - lo)
-        self.ctx.sync()
+            self.ctx.encrypt_dev(m_d.ptr, r_d.ptr, out.rows_view(lo, hi).ptr, hi - lo, st)
+            lo, chunk = hi, 1 << 16
+        self.ctx.sync(st)
         return out if device else out.to_host()
 
     def obfuscate_dev(self, c, r):

@@ -67,6 +67,8 @@ def lib():
         L.phe_hip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
         L.phe_hip_memcpy_d2h.argtypes = [vp, vp, vp, sz]
         L.phe_hip_stream_sync.argtypes = [vp, vp]
+        L.phe_hip_stream_create.argtypes = [vp, ctypes.POINTER(vp)]
+        L.phe_hip_stream_destroy.argtypes = [vp, vp]
         L.phe_hip_memcpy_d2d.argtypes = [vp, vp, vp, sz, vp]
         L.phe_hip_invert_dev.argtypes = [vp, vp, vp, sz, ctypes.POINTER(sz), vp]
         L.phe_hip_select_rows_dev.argtypes = [vp, vp, vp, vp, vp, ci, sz, vp]
@@ -84,7 +86,8 @@ EXPORTED_SYMBOLS = [
     "phe_hip_stream_sync", "phe_hip_selftest_prims", "phe_hip_memcpy_d2d", "phe_hip_invert_dev",
     "phe_hip_select_rows_dev", "phe_hip_add_plain", "phe_hip_add_plain_dev", "phe_hip_ctx_engine",
     "phe_hip_multiexp", "phe_hip_multiexp_dev", "phe_hip_multiexp_rows_dev", "phe_hip_decimal_width", "phe_hip_to_decimal",
-    "phe_hip_from_decimal", "phe_hip_to_decimal_dev", "phe_hip_from_decimal_dev",
+    "phe_hip_from_decimal", "phe_hip_to_decimal_dev", "phe_hip_from_decimal_dev", "phe_hip_stream_create",
+    "phe_hip_stream_destroy",
 ]
 
 
@@ -384,6 +387,16 @@ class Context:
 
     def select_rows_dev(self, a_ptr, b_ptr, mask_ptr, out_ptr, limbs, batch, stream=0):
         _check(lib().phe_hip_select_rows_dev(self._h, a_ptr, b_ptr, mask_ptr, out_ptr, limbs, batch, stream))
+
+    def stream_create(self):
+        """a stream whose launches overlap the blocking h2d / d2h copies (they are ordered on the NULL stream)"""
+        p = ctypes.c_void_p(None)
+        _check(lib().phe_hip_stream_create(self._h, ctypes.byref(p)))
+        return p.value
+
+    def stream_destroy(self, stream):
+        if self._h and self._h.value and stream:
+            lib().phe_hip_stream_destroy(self._h, stream)
 
     def sync(self, stream=0):
         _check(lib().phe_hip_stream_sync(self._h, stream))

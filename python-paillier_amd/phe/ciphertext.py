@@ -462,9 +462,8 @@ class EncryptedVector(object):
         log2b = int(round(EncodedNumber.LOG2_BASE))
         if dmax == 0:
             exps = mag
-        elif isinstance(mag, np.ndarray) and (1 << log2b) == EncodedNumber.BASE and \
-                int(mag.max()).bit_length() + log2b * dmax <= 64:
-            exps = mag << (delta * log2b).astype(np.uint64)
+        elif isinstance(mag, np.ndarray) and (1 << log2b) == EncodedNumber.BASE:
+            exps = eng.shifted_limbs(mag, delta * log2b)         # k_i * BASE^delta_i as limb rows, no Python ints
         else:
             mags = mag.tolist() if isinstance(mag, np.ndarray) else mag
             powers = {d: pow(EncodedNumber.BASE, d) for d in np.unique(delta).tolist()}
@@ -524,10 +523,7 @@ class EncryptedVector(object):
         log2b = int(round(EncodedNumber.LOG2_BASE))
         if dmax == 0:
             exps = mag
-        elif int(mag.max()).bit_length() + log2b * dmax <= 64:
-            exps = mag << (delta * log2b).astype(np.uint64)
-        else:
-            powers = {d: pow(EncodedNumber.BASE, d) for d in np.unique(delta).tolist()}
-            exps = [[m * powers[d] for m, d in zip(mrow, drow)] for mrow, drow in zip(mag.tolist(), delta.tolist())]
+        else:                                                    # k * BASE^delta as limb rows, no Python ints
+            exps = eng.shifted_limbs(mag.reshape(-1), (delta * log2b).reshape(-1))
         limbs = eng.raw_matvec(self._limbs, exps, neg)
         return EncryptedVector(pk, limbs, target)
