@@ -426,6 +426,29 @@ class Engine:
         self.ctx.sync()
         return out.to_host()
 
+    def raw_decrypt_dev_chunks(self, c, chunk=1 << 16):
+        """raw_decrypt of a resident vector as a generator of (lo, hi, plaintext limbs on the host): while the caller
+        works on one chunk (download + decoding), the kernels of the next one run — they are queued on the engine's
+        non-blocking stream right after the finished chunk is awaited, and the blocking download does not wait for them."""
+        st = self._launch_stream()
+        rows = c.rows
+        if rows <= chunk or not st:
+            if rows:
+                yield 0, rows, self.raw_decrypt_dev(c)
+            return
+        out = DeviceArray(self.ctx, rows, self.n_limbs)
+
+        def launch(lo):
+            hi = min(rows, lo + chunk)
+            self.ctx.decrypt_dev(c.rows_view(lo, hi).ptr, out.rows_view(lo, hi).ptr, hi - lo, st)
+            return hi
+        lo, hi = 0, launch(0)
+        while lo < rows:
+            self.ctx.sync(st)                                   # chunk [lo, hi) is complete
+            nxt = launch(hi) if hi < rows else hi
+            yield lo, hi, out.rows_view(lo, hi).to_host()
+            lo, hi = hi, nxt
+
     def raw_add_dev(self, a, b):
         out = DeviceArray(self.ctx, a.rows, self.ct_limbs)
         self.ctx.mulmod_dev(a.ptr, b.ptr, out.ptr, a.rows)

@@ -225,11 +225,18 @@ class PaillierPrivateKey(object):
         if self.public_key != vector.public_key:
             raise ValueError('encrypted_number was encrypted against a different key!')
         eng = self._get_engine()
+        plain_decode = Encoding is None or Encoding is EncodedNumber
         if vector.on_device:     # device pointers are valid across contexts of the same GPU
-            plain = eng.raw_decrypt_dev(vector.limbs(be_secure=False))
-        else:
-            plain = eng.raw_decrypt(vector.limbs(be_secure=False))
-        if Encoding is None or Encoding is EncodedNumber:
+            # chunks: the download and decoding of one chunk overlap the kernels of the next
+            out, exps = [], vector.exponent_array
+            for lo, hi, plain in eng.raw_decrypt_dev_chunks(vector.limbs(be_secure=False)):
+                if plain_decode:
+                    out += EncodedNumber.decode_limbs(self.public_key, plain, exps[lo:hi])
+                else:
+                    out += Encoding.decode_many(self.public_key, eng.to_ints(plain), exps[lo:hi].tolist())
+            return out
+        plain = eng.raw_decrypt(vector.limbs(be_secure=False))
+        if plain_decode:
             return EncodedNumber.decode_limbs(self.public_key, plain, vector.exponent_array)
         return Encoding.decode_many(self.public_key, eng.to_ints(plain), vector.exponents)
 

@@ -360,3 +360,24 @@ def test_device_resident_vector_matches_host_vector():
     after = un.ciphertexts()                              # be_secure -> obfuscate_dev over the vector
     assert before != after and all(un._obfuscated) and priv.decrypt_batch(un) == [1, 2, 3]
     assert dev.to_host().ciphertexts(False) == host.ciphertexts(False)
+
+
+@pytest.mark.gpu
+def test_decrypt_batch_pipelined_chunks():
+    """decrypt_batch of a resident vector runs in chunks (download + decoding of one chunk under the kernels of the
+    next): ragged chunking gives the same plaintexts as one launch, and a vector longer than the default chunk
+    round-trips exactly"""
+    g = load_golden(1024)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    rs = np.random.Generator(np.random.PCG64(8))
+    vals = rs.standard_normal((1 << 16) + 4321)
+    vec = pub.encrypt_batch(vals, device=True)
+    assert priv.decrypt_batch(vec) == vals.tolist()
+    eng = priv._get_engine()
+    whole = eng.raw_decrypt_dev(vec._limbs)
+    parts = list(eng.raw_decrypt_dev_chunks(vec._limbs, chunk=20000))
+    assert [(lo, hi) for lo, hi, _ in parts] == [(0, 20000), (20000, 40000), (40000, 60000), (60000, len(vals))]
+    assert np.array_equal(np.concatenate([p for _, _, p in parts]), whole)
+    ints = rs.integers(-10 ** 9, 10 ** 9, 70000)
+    assert priv.decrypt_batch(pub.encrypt_batch(ints, device=True)) == ints.tolist()
