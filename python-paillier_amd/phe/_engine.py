@@ -463,10 +463,15 @@ class Engine:
         return out
 
     def powmod_dev(self, base, exps):
-        exps = list(exps)
-        bits = max(1, max(e.bit_length() for e in exps))
-        width = (bits + 31) // 32
-        e = DeviceArray.from_host(self.ctx, _native.ints_to_limbs(exps, width))
+        """exps: Python ints, or (limb rows (batch, width), largest bit length) as shifted_limbs returns them"""
+        if isinstance(exps, tuple):
+            limbs, bits = exps
+        else:
+            exps = list(exps)
+            bits = max(1, max(e.bit_length() for e in exps))
+            limbs = _native.ints_to_limbs(exps, (bits + 31) // 32)
+        width = limbs.shape[1]
+        e = DeviceArray.from_host(self.ctx, limbs)
         out = DeviceArray(self.ctx, base.rows, self.ct_limbs)
         self.ctx.powmod_dev(base.ptr, e.ptr, width, bits, out.ptr, base.rows)
         self.ctx.sync()

@@ -260,15 +260,27 @@ class EncryptedVector(object):
         powers = {int(d): pow(EncodedNumber.BASE, int(d)) for d in np.unique(delta).tolist()}
         if max(powers.values()) >= pk.n:
             raise ValueError('Scalar out of bounds: %i' % max(powers.values()))
-        scal = [powers[d] for d in delta.tolist()]
         flags[rows] = False
         eng = pk._get_engine()
+        log2b = int(round(EncodedNumber.LOG2_BASE))
+        if (1 << log2b) == EncodedNumber.BASE and max(powers.values()) < pk.n - pk.max_int:
+            # BASE^delta = 1 << (log2b * delta): the exponents as limb rows, no Python integer per row
+            # (positive scalars below n - max_int: the plain powmod branch of _raw_mul, phe/paillier.py:751)
+            if self.on_device:
+                shifts = (old - new) * log2b                       # 0 for untouched rows: c^1 = c, still canonical
+                e = eng.shifted_limbs(np.ones(len(old), dtype=np.uint64), shifts)
+                return self._like(eng.powmod_dev(self._limbs, e), new, flags)
+            e, _ = eng.shifted_limbs(np.ones(len(rows), dtype=np.uint64), delta * log2b)
+            limbs = self._limbs.copy()
+            limbs[rows] = eng.ctx.powmod(np.ascontiguousarray(limbs[rows]), e)
+            return self._like(limbs, new, flags)
+        scal = [powers[d] for d in delta.tolist()]
         if self.on_device:
             # whole-vector launch: untouched rows are raised to the power 1 (c^1 = c, still canonical)
             exps = [1] * len(self)
             for i, sc in zip(rows.tolist(), scal):
                 exps[i] = sc
-            return self._like(eng.powmod_dev(self._limbs, exps), new, flags)
+            return self._like(eng.raw_mul_dev(self._limbs, exps), new, flags)   # both branches of _raw_mul
         limbs = self._limbs.copy()
         limbs[rows] = eng.raw_mul(np.ascontiguousarray(limbs[rows]), scal)
         return self._like(limbs, new, flags)
