@@ -413,6 +413,37 @@ class Engine:
         self.ctx.sync(st)
         return out if device else out.to_host()
 
+    def obfuscate_fresh_dev(self, c, rows=None):
+        """obfuscate_dev with freshly drawn obfuscators, chunked like raw_encrypt_fresh (draw and upload of the next
+        chunk under the kernels of the current one).  rows: indices that get a fresh r (None = all); the others get
+        r = 1 (c * 1^n = c, still canonical)."""
+        count = c.rows
+        st = self._launch_stream()
+        need = None
+        if rows is not None:
+            need = np.zeros(count, dtype=bool)
+            need[rows] = True
+        out = DeviceArray(self.ctx, count, self.ct_limbs)
+        keep = []
+        lo, chunk = 0, 1 << 15
+        while lo < count:
+            hi = min(count, lo + chunk)
+            if need is None:
+                r = random_lt_n_limbs(self.n, hi - lo, self.n_limbs, out=self.scratch("r", hi - lo, self.n_limbs))
+            else:
+                r = self.scratch("r", hi - lo, self.n_limbs)
+                r[:] = 0
+                r[:, 0] = 1
+                sel = np.nonzero(need[lo:hi])[0]
+                if len(sel):
+                    r[sel] = random_lt_n_limbs(self.n, len(sel), self.n_limbs)
+            r_d = DeviceArray.from_host(self.ctx, r)
+            keep.append(r_d)
+            self.ctx.obfuscate_dev(c.rows_view(lo, hi).ptr, r_d.ptr, out.rows_view(lo, hi).ptr, hi - lo, st)
+            lo, chunk = hi, 1 << 16
+        self.ctx.sync(st)
+        return out
+
     def obfuscate_dev(self, c, r):
         r = self.upload_plain(r)
         out = DeviceArray(self.ctx, c.rows, self.ct_limbs)

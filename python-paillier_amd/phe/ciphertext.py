@@ -219,6 +219,16 @@ class EncryptedVector(object):
         rows = np.arange(len(self)) if r_values is not None else np.nonzero(~self._obfuscated)[0]
         if len(rows) == 0:
             return self
+        if r_values is None and hasattr(eng.ctx, "obfuscate_dev"):
+            # fresh obfuscators as limb arrays straight from the CSPRNG (no Python integer per row)
+            if self.on_device:
+                self._limbs = eng.obfuscate_fresh_dev(self._limbs, None if len(rows) == len(self) else rows)
+            else:
+                from ._engine import random_lt_n_limbs
+                r = random_lt_n_limbs(pk.n, len(rows), eng.n_limbs)
+                self._limbs[rows] = eng.ctx.obfuscate(np.ascontiguousarray(self._limbs[rows]), r)
+            self._obfuscated[rows] = True
+            return self
         r = list(r_values) if r_values is not None else random_lt_n(pk.n, len(rows))
         if self.on_device:
             # one launch over the whole vector; rows that need nothing get r = 1 (c * 1^n = c)

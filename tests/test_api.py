@@ -381,3 +381,31 @@ def test_decrypt_batch_pipelined_chunks():
     assert np.array_equal(np.concatenate([p for _, _, p in parts]), whole)
     ints = rs.integers(-10 ** 9, 10 ** 9, 70000)
     assert priv.decrypt_batch(pub.encrypt_batch(ints, device=True)) == ints.tolist()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device", [True, False])
+def test_vector_obfuscation_draws_only_for_rows_that_need_it(device):
+    """EncryptedVector.obfuscate() without r_values: array-form obfuscators; rows already obfuscated keep their bits
+    (r = 1 on the device path), the others change, every row still decrypts to the same value — also across the chunk
+    boundaries of the pipelined device path"""
+    g = load_golden(1024)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    count = 40000 if device else 300
+    vals = np.arange(count, dtype=np.int64) - 7
+    vec = pub.encrypt_batch(vals, r_values=[1] * count, device=device)       # nude ciphertexts, not obfuscated
+    before = np.array(vec.to_host()._limbs)
+    vec._obfuscated[::3] = True                                              # pretend every third row is done
+    vec.obfuscate()
+    after = np.array(vec.to_host()._limbs)
+    same = (before == after).all(axis=1)
+    assert same[::3].all() and not same[1::3].any() and not same[2::3].any()
+    assert all(vec._obfuscated) and priv.decrypt_batch(vec) == vals.tolist()
+    again = np.array(vec.obfuscate().to_host()._limbs)                        # nothing left to do
+    assert np.array_equal(again, after)
+    k = min(count, 5000)
+    full = pub.encrypt_batch(vals[:k], r_values=[1] * k, device=device)
+    nude = np.array(full.to_host()._limbs)
+    assert not (np.array(full.obfuscate().to_host()._limbs) == nude).all(axis=1).any()
+    assert priv.decrypt_batch(full) == vals[:k].tolist()
