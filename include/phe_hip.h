@@ -139,6 +139,14 @@ int phe_hip_to_decimal(phe_hip_ctx* ctx, const uint32_t* limbs, int words, char*
 int phe_hip_from_decimal(phe_hip_ctx* ctx, const char* digits, int width, uint32_t* limbs, int words, size_t batch,
                          size_t* bad_index);
 
+/* ---- batched primality (key generation) ---------------------------------------------------------
+ * pass[i] = 1 iff n[i] is a strong probable prime to base[i] (Miller-Rabin), one modulus PER ROW — the test that
+ * getprimeover (phe/util.py:106-124: gmpy2.next_prime, or is_prime -> miller_rabin at :381-443) runs candidate after
+ * candidate, here over all sieved candidates of a search window (and, to confirm a hit, over many bases) in one
+ * launch.  n, base: (batch, limbs) little-endian words; n odd and > 3, 2 <= base <= n - 2 (EINVAL otherwise).
+ * Needs no context (no key); runs on `device`.  Host pointers. */
+int phe_hip_miller_rabin(int device, const uint32_t* n, const uint32_t* base, int limbs, uint8_t* pass, size_t batch);
+
 /* ---- the hot path, device buffers (resident operands; asynchronous on `stream`) -------------- */
 int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch, void* stream);
 int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t* r, uint32_t* c_out, size_t batch, void* stream);

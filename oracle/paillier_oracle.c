@@ -16,6 +16,8 @@
  *   phe/paillier.py:356-360  h_function                      -> orc_h_function
  *   phe/paillier.py:705-719  EncryptedNumber._raw_add        -> orc_raw_add
  *   phe/paillier.py:721-751  EncryptedNumber._raw_mul        -> orc_raw_mul
+ *   phe/util.py:106-124  getprimeover (gmpy2 branch :114-116: bit_set + next_prime) -> orc_next_prime
+ *                        (gmpy2.next_prime == mpz_nextprime), orc_probab_prime (mpz_probab_prime_p)
  *
  * The arithmetic engine is libgmp (GMP 6.2.1, /usr/lib/x86_64-linux-gnu/libgmp.so.10):
  * the very library gmpy2 (requirements.txt:2, gmpy2>=2.0.4 — not vendored under
@@ -368,4 +370,25 @@ int orc_mul_batch(const uint32_t *n, size_t n_limbs, const uint32_t *c, const ui
     pub_clear(&pub);
     return rc;
 }
+/* phe/util.py:114-116: the smallest (probable) prime above `start`; 1 if it does not fit `limbs` words */
+int orc_next_prime(const uint32_t *start, uint32_t *out, size_t limbs) {
+    mpz_t a, p;
+    mpz_inits(a, p, NULL);
+    limbs_to_mpz(a, start, limbs);
+    mpz_nextprime(p, a);
+    const int too_big = mpz_sizeinbase(p, 2) > 32 * limbs;
+    if (!too_big) mpz_to_limbs(out, limbs, p);
+    mpz_clears(a, p, NULL);
+    return too_big;
+}
+/* 2 = certainly prime, 1 = probably prime, 0 = composite (mpz_probab_prime_p with `reps` rounds) */
+int orc_probab_prime(const uint32_t *n, size_t limbs, int reps) {
+    mpz_t a;
+    mpz_init(a);
+    limbs_to_mpz(a, n, limbs);
+    const int r = mpz_probab_prime_p(a, reps);
+    mpz_clear(a);
+    return r;
+}
+
 const char *orc_gmp_version(void) { return gmp_version; }

@@ -163,6 +163,8 @@ class COracle:
         L.orc_add_batch.argtypes = [_u32p, sz, _u32p, _u32p, _u32p, sz, ctypes.c_int]
         L.orc_mul_batch.argtypes = [_u32p, sz, _u32p, _u32p, sz, _u32p, sz, ctypes.c_int,
                                     ctypes.POINTER(ctypes.c_size_t)]
+        L.orc_next_prime.argtypes = [_u32p, _u32p, sz]
+        L.orc_probab_prime.argtypes = [_u32p, sz, ctypes.c_int]
         L.orc_gmp_version.restype = ctypes.c_char_p
         self.L = L
 
@@ -190,6 +192,18 @@ class COracle:
         if rc:
             raise ZeroDivisionError("invert() no inverse exists")
         return limbs_to_int(out)
+
+    def next_prime(self, start):
+        """gmpy2.next_prime(start) (phe/util.py:116): the smallest probable prime above `start`"""
+        limbs = start.bit_length() // 32 + 2
+        out = np.zeros(limbs, np.uint32)
+        if self.L.orc_next_prime(int_to_limbs(start, limbs), out, limbs):
+            raise OverflowError("next prime does not fit")
+        return limbs_to_int(out)
+
+    def is_probable_prime(self, n, reps=25):
+        limbs = max(1, (n.bit_length() + 31) // 32)
+        return self.L.orc_probab_prime(int_to_limbs(n, limbs), limbs, reps) > 0
 
     def private_constants(self, n, p, q, n_limbs, pq_limbs):
         outs = [np.zeros(pq_limbs, np.uint32) for _ in range(5)]

@@ -31,6 +31,7 @@
 #include "decrypt_tail.h"
 #include "key_setup.h"
 #include "radix_conv.h"
+#include "primality.h"
 // clang-format on
 
 using namespace phe;
@@ -95,6 +96,12 @@ int launch_to_decimal(const uint32_t* limbs, int words, char* digits, int width,
 int launch_from_decimal(const char* digits, int width, uint32_t* limbs, int words, uint64_t batch,
                         unsigned long long* bad_char, unsigned long long* bad_size, int max_blocks, hipStream_t st);
 }  // namespace radix
+}  // namespace phe
+
+namespace phe {
+namespace mr {  // kernels_mr.hip
+int launch(int L, int blocks, hipStream_t st, const MillerRabinArgs& A);
+}  // namespace mr
 }  // namespace phe
 
 struct KernelPart {
@@ -1291,6 +1298,58 @@ int phe_hip_from_decimal(phe_hip_ctx* ctx, const char* digits, int width, uint32
     if (!rc) rc = phe_hip_from_decimal_dev(ctx, (const char*)ctx->stage[1], width, ctx->stage[0], words, batch, bad_index, nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(limbs, ctx->stage[0], batch * (size_t)words * 4, hipMemcpyDeviceToHost));
+    return PHE_HIP_OK;
+}
+
+// ---- batched Miller-Rabin, one modulus per row (csrc/primality.h, kernels_mr.hip) ---------------------------------
+int phe_hip_miller_rabin(int device, const uint32_t* n, const uint32_t* base, int limbs, uint8_t* pass, size_t batch) {
+    if (batch == 0) return PHE_HIP_OK;
+    if (!n || !base || !pass || limbs < 1) return fail(PHE_HIP_EINVAL, "null buffer / limbs");
+    const host::Geometry geo = host::pick_geometry(32 * limbs, 0, 16);
+    if (geo.G != 16) return fail(PHE_HIP_EINVAL, "candidates too wide for the compiled 16-lane kernels");
+    for (size_t i = 0; i < batch; ++i) {  // n odd and > 3, 2 <= base <= n - 2 (what the callers' small-number paths leave)
+        const host::Big N = host::big_from(n + i * (size_t)limbs, limbs, limbs);
+        host::Big a = host::big_from(base + i * (size_t)limbs, limbs, limbs);
+        host::Big two((size_t)limbs, 0u);
+        two[0] = 2;
+        if ((N[0] & 1u) == 0u || host::big_bits(N) < 3)
+            return fail(PHE_HIP_EINVAL, "row " + std::to_string(i) + ": candidate must be odd and > 3");
+        if (host::big_cmp(a, two) < 0) return fail(PHE_HIP_EINVAL, "row " + std::to_string(i) + ": base must be >= 2");
+        host::big_add_inplace(a, two);  // base + 2 <= n, no overflow of the width because base < 2^(32 limbs) - 2 is implied below
+        if (host::big_cmp(a, two) < 0 || host::big_cmp(a, N) > 0)
+            return fail(PHE_HIP_EINVAL, "row " + std::to_string(i) + ": base must be <= n - 2");
+    }
+    HIP_TRY(hipSetDevice(device));
+    uint32_t *d_n = nullptr, *d_b = nullptr;
+    uint8_t* d_p = nullptr;
+    const size_t words = batch * (size_t)limbs;
+    auto cleanup = [&]() {
+        if (d_n) (void)hipFree(d_n);
+        if (d_b) (void)hipFree(d_b);
+        if (d_p) (void)hipFree(d_p);
+    };
+    hipError_t e = hipMalloc((void**)&d_n, words * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_b, words * 4);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_p, batch);
+    if (e == hipSuccess) e = hipMemcpy(d_n, n, words * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_b, base, words * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        MillerRabinArgs A;
+        A.n = d_n;
+        A.base = d_b;
+        A.limbs = limbs;
+        A.pass = d_p;
+        A.batch = batch;
+        const int blocks = (int)std::min<size_t>((batch + 15) / 16, 65535);
+        if (phe::mr::launch(geo.L, blocks, nullptr, A) < 0) {
+            cleanup();
+            return fail(PHE_HIP_EINVAL, "unsupported limb-group geometry");
+        }
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(pass, d_p, batch, hipMemcpyDeviceToHost);
+    cleanup();
+    if (e != hipSuccess) return fail(PHE_HIP_EHIP, std::string("miller_rabin: ") + hipGetErrorString(e));
     return PHE_HIP_OK;
 }
 

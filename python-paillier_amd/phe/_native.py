@@ -68,6 +68,7 @@ def lib():
         L.phe_hip_memcpy_d2h.argtypes = [vp, vp, vp, sz]
         L.phe_hip_stream_sync.argtypes = [vp, vp]
         L.phe_hip_stream_create.argtypes = [vp, ctypes.POINTER(vp)]
+        L.phe_hip_miller_rabin.argtypes = [ci, vp, vp, ci, vp, sz]
         L.phe_hip_stream_destroy.argtypes = [vp, vp]
         L.phe_hip_memcpy_d2d.argtypes = [vp, vp, vp, sz, vp]
         L.phe_hip_invert_dev.argtypes = [vp, vp, vp, sz, ctypes.POINTER(sz), vp]
@@ -87,7 +88,7 @@ EXPORTED_SYMBOLS = [
     "phe_hip_select_rows_dev", "phe_hip_add_plain", "phe_hip_add_plain_dev", "phe_hip_ctx_engine",
     "phe_hip_multiexp", "phe_hip_multiexp_dev", "phe_hip_multiexp_rows_dev", "phe_hip_decimal_width", "phe_hip_to_decimal",
     "phe_hip_from_decimal", "phe_hip_to_decimal_dev", "phe_hip_from_decimal_dev", "phe_hip_stream_create",
-    "phe_hip_stream_destroy",
+    "phe_hip_stream_destroy", "phe_hip_miller_rabin",
 ]
 
 
@@ -443,6 +444,18 @@ class Context:
 
     def d2d(self, dst_ptr, src_ptr, nbytes, stream=0):
         _check(lib().phe_hip_memcpy_d2d(self._h, dst_ptr, src_ptr, nbytes, stream))
+
+
+def miller_rabin(n, base, device=0):
+    """pass[i] = n[i] is a strong probable prime to base[i]; (batch, limbs) uint32 rows -> bool array.
+    One launch, one modulus per row (include/phe_hip.h "batched primality")."""
+    n = np.ascontiguousarray(n, dtype=np.uint32)
+    base = np.ascontiguousarray(base, dtype=np.uint32)
+    if n.ndim != 2 or base.shape != n.shape:
+        raise ValueError("n and base must be (batch, limbs) arrays of the same shape")
+    out = np.zeros(n.shape[0], dtype=np.uint8)
+    _check(lib().phe_hip_miller_rabin(int(device), _ptr(n), _ptr(base), n.shape[1], _ptr(out), n.shape[0]))
+    return out.astype(bool)
 
 
 def selftest_prims(device=0):

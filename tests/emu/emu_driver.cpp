@@ -11,6 +11,7 @@
 #include "../../python-paillier_amd/csrc/decrypt_tail.h"
 #include "../../python-paillier_amd/csrc/key_setup.h"
 #include "../../python-paillier_amd/csrc/radix_conv.h"
+#include "../../python-paillier_amd/csrc/primality.h"
 // clang-format on
 #include <string.h>
 
@@ -187,6 +188,19 @@ static void run_multi_split(SplitMultiArgs A) {
     }
 }
 
+template <int G, int L>
+static void run_miller_rabin(MillerRabinArgs A) {
+    constexpr int S = G * L, kPer = 64 / G;
+    const int n_waves = waves_for(A.batch, G, 4);
+    const uint32_t total = (uint32_t)(kPer * n_waves);
+    for (int w = 0; w < n_waves; ++w) {
+        std::vector<uint32_t> lds(kPer * (S + kLdsPad));
+        wave::run_wave([&](uint32_t lane) {
+            const uint32_t grp = lane / G;
+            miller_rabin_body<G, L>(A, lds.data() + grp * (S + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
+        });
+    }
+}
 static int g_prefer_group = 0;
 static int g_engine = 1;  // 1: split-modulus kernels where a geometry exists (the product default), 0: full-width only
 
@@ -456,6 +470,20 @@ int emu_multiexp_n2(const uint32_t* n, int n_limbs, const uint32_t* base, const 
         A.n_chunks = (B + chunk - 1) / chunk;
         A.n_row_blocks = (rows + row_block - 1) / row_block;
         DISPATCH_SPLIT(M.G, M.L, (run_multi_split<GG, LL>(A)));
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// csrc/primality.h: strong-probable-prime test of n[i] to base[i] (rows of `limbs` 32-bit words), one modulus per row;
+// 16-lane groups like the product (kernels_mr.hip).  Returns 2 if no compiled geometry covers 32*limbs + 4 bits.
+int emu_miller_rabin(const uint32_t* n, const uint32_t* base, int limbs, uint8_t* pass, uint64_t B) {
+    try {
+        if (B == 0) return 0;
+        const host::Geometry geo = host::pick_geometry(32 * limbs, 0, 16);
+        if (geo.G != 16) return 2;
+        MillerRabinArgs A;
+        A.n = n; A.base = base; A.limbs = limbs; A.pass = pass; A.batch = B;
+        DISPATCH_GL(geo.G, geo.L, (run_miller_rabin<GG, LL>(A)));
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }

@@ -127,9 +127,15 @@ class EmuContext:
         return self._native.ints_to_limbs(out, self.ct_limbs)
 
 
+def _emu_miller_rabin(n, base, device=0):
+    return emu().miller_rabin(n, base)
+
+
 def install(monkeypatch=None):
     from phe import _native
     if monkeypatch is not None:
         monkeypatch.setattr(_native, "Context", EmuContext)
+        monkeypatch.setattr(_native, "miller_rabin", _emu_miller_rabin)
     else:
         _native.Context = EmuContext
+        _native.miller_rabin = _emu_miller_rabin

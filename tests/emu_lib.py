@@ -109,6 +109,17 @@ class Emu:
         self._ck(rc)
         return out
 
+    def miller_rabin(self, n, base):
+        """csrc/primality.h: strong-probable-prime test of n[i] to base[i]; rows of 32-bit words -> bool array"""
+        n = np.ascontiguousarray(n, dtype=np.uint32)
+        base = np.ascontiguousarray(base, dtype=np.uint32)
+        out = np.zeros(n.shape[0], dtype=np.uint8)
+        rc = self.L.emu_miller_rabin(P(n), P(base), n.shape[1], P(out), ctypes.c_uint64(n.shape[0]))
+        if rc == 2:
+            raise ValueError("no 16-lane geometry for %d-bit candidates" % (32 * n.shape[1]))
+        self._ck(rc)
+        return out.astype(bool)
+
     def to_decimal(self, limbs, width=None):
         """csrc/radix_conv.h limbs_to_decimal per row -> (rows, width) uint8 ASCII digits, '0'-padded on the left"""
         limbs = np.ascontiguousarray(limbs, dtype=np.uint32)
