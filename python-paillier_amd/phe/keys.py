@@ -22,14 +22,34 @@ from .codec import EncodedNumber
 DEFAULT_KEYSIZE = 3072
 
 
+def _gpu_prime_search_available():
+    """the batched Miller-Rabin launch needs the real library and a device (the test emulator has neither)"""
+    try:
+        from . import _native
+        return hasattr(_native.Context, "encrypt_dev") and _native.device_count() > 0
+    except Exception:
+        return False
+
+
 def generate_paillier_keypair(private_keyring=None, n_length=DEFAULT_KEYSIZE):
     """New (PaillierPublicKey, PaillierPrivateKey) with an n of exactly n_length bits (phe/paillier.py:37-68)."""
     half = n_length // 2
+    draw_pair = None
+    if half >= 256 and _gpu_prime_search_available():
+        # both primes of a try from ONE pair of launches (phe/primes.py: the smallest probable prime above a random
+        # start with the top bit set — the gmpy2 branch of getprimeover, phe/util.py:113-116)
+        from . import primes
+        draw_pair = lambda: primes.getprimeover_batch(half, 2)
     while True:
-        p = util.getprimeover(half)
-        q = p
-        while q == p:
-            q = util.getprimeover(half)
+        if draw_pair is not None:
+            p, q = draw_pair()
+            if p == q:
+                continue
+        else:
+            p = util.getprimeover(half)
+            q = p
+            while q == p:
+                q = util.getprimeover(half)
         n = p * q
         if n.bit_length() == n_length:
             break

@@ -116,3 +116,22 @@ def test_prime_search_and_keypairs_on_gpu(c_oracle):
         assert c_oracle.is_probable_prime(priv.p) and c_oracle.is_probable_prime(priv.q)
         vals = [0.5, -3.25, 12345.0]
         assert priv.decrypt_batch(pub.encrypt_batch(np.array(vals))) == vals
+
+
+@pytest.mark.gpu
+def test_generate_paillier_keypair_uses_the_batched_search(c_oracle):
+    """the reference's entry point (phe/paillier.py:37-68) on a GPU box: same contract, primes from phe.primes"""
+    import time
+    from phe import keys, paillier
+    assert keys._gpu_prime_search_available()
+    t0 = time.perf_counter()
+    pub, priv = paillier.generate_paillier_keypair(n_length=2048)
+    elapsed = time.perf_counter() - t0
+    assert pub.n.bit_length() == 2048 and priv.p * priv.q == pub.n and priv.p != priv.q
+    assert priv.p.bit_length() == priv.q.bit_length() == 1024
+    assert c_oracle.is_probable_prime(priv.p) and c_oracle.is_probable_prime(priv.q)
+    assert priv.decrypt(pub.encrypt(-12.5)) == -12.5
+    ring = paillier.PaillierPrivateKeyring()
+    pub2, priv2 = paillier.generate_paillier_keypair(ring, 1024)
+    assert ring[pub2] == priv2 and pub2.n.bit_length() == 1024
+    assert elapsed < 5.0
