@@ -160,8 +160,15 @@ class PaillierPrivateKey(object):
         self.psquare = self.p * self.p
         self.qsquare = self.q * self.q
         self.p_inverse = util.invert(self.p, self.q)
-        self.hp = self.h_function(self.p, self.psquare)
-        self.hq = self.h_function(self.q, self.qsquare)
+        if public_key.g == public_key.n + 1:
+            # h_function in closed form: g = 1 + n and n^2 = 0 (mod p^2), so g^(p-1) = 1 + (p-1) n = 1 + p (-q mod p)
+            # (mod p^2), L(.) = -q mod p and hp = (-q)^-1 mod p — the value phe/paillier.py:356-360 computes with a
+            # modular exponentiation (pinned to the reference's numbers by tests/test_api.py and the golden fixtures)
+            self.hp = util.invert((-self.q) % self.p, self.p)
+            self.hq = util.invert((-self.p) % self.q, self.q)
+        else:
+            self.hp = self.h_function(self.p, self.psquare)
+            self.hq = self.h_function(self.q, self.qsquare)
         self._engine = None
 
     @staticmethod
