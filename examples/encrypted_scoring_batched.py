@@ -6,12 +6,14 @@ its weights and intercept and hands them to Bob; Bob computes, for each of his s
 `intercept + sum_i x_i * w_i` (`Bob.encrypted_score`, :170-177 — one `*` and one `+` per feature, per sample) and sends
 the scores back; Alice decrypts them and thresholds at 0.  Here Bob's whole evaluation is ONE call:
 
-    scores = encrypted_model.matvec(X1)        # X1 = [X | 1]: the intercept rides along as a weight of a constant feature
+    scores = encrypted_model.matvec(X1)        # X1 = [X | 1] as a scipy CSR matrix: the intercept rides along as the
+                                               # weight of a constant feature
 
-i.e. one launch of the matrix-form multi-exponentiation (a chunk of encrypted weights builds its window tables once
-and serves a block of samples), and Alice's side is one `encrypt_batch` and one `decrypt_batch`.  Every score is, bit
-for bit, the ciphertext the reference's chain of `*` and `+` gives on the augmented sample [x | 1] (the reference adds
-the intercept unscaled, which changes ciphertext bits and exponent but not the decrypted score).
+i.e. two launches of the table-lookup multi-exponentiation (the window tables of every encrypted weight once, then one
+square-and-multiply ladder per sample over its nonzero features only — the features Bob.encrypted_score walks), and
+Alice's side is one `encrypt_batch` and one `decrypt_batch`.  Every score is, bit for bit, the ciphertext the
+reference's chain of `*` and `+` gives on the stored entries of [x | 1] (the reference adds the intercept unscaled,
+which changes ciphertext bits and exponent but not the decrypted score).
 
 The reference downloads the Enron spam corpus; there is no network here, so the data is a synthetic two-class problem
 of the same shape (sparse non-negative counts).  python examples/encrypted_scoring_batched.py [key_length] [samples] [features]
@@ -21,6 +23,7 @@ import sys
 import time
 
 import numpy as np
+import scipy.sparse as sp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "python-paillier_amd"))
@@ -74,8 +77,10 @@ class Bob:
         self.model = encrypted_model
 
     def encrypted_evaluate(self, X):
-        X1 = np.c_[X, np.ones(len(X))]
-        return self.model.matvec(X1)             # all samples, all features: one matrix-form multi-exponentiation
+        # like the reference's Bob, only the NONZERO features of a sample enter its score (plus the constant one that
+        # carries the intercept): a CSR matrix goes through the table-lookup multi-exponentiation, all samples at once
+        X1 = sp.hstack([sp.csr_matrix(X), np.ones((len(X), 1))], format="csr")
+        return self.model.matvec(X1)
 
 
 def run(key_length=1024, n_samples=512, n_features=128, device=None, verbose=True):

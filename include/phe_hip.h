@@ -176,6 +176,18 @@ int phe_hip_multiexp_rows_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint
                               const uint8_t* neg, int exp_limbs, int max_exp_bits, uint32_t* out, size_t batch, size_t rows,
                               void* stream);
 
+/* The same `rows` products when the matrix is SPARSE or has many rows: out[r] = prod over the entries of row r of
+ * b[col]^exp — entries in CSR order (row_ptr: rows + 1 offsets, cols / e / neg: one item per entry), or dense rows of
+ * `batch` entries when row_ptr and cols are NULL.  This is the loop of Bob.encrypted_score,
+ * examples/logistic_regression_encrypted_model.py:170-177 (`_, idx = x.nonzero(); for i in idx: score += x[0, i] * w[i]`),
+ * for all samples at once: the 2^w-ary tables of every ciphertext (and of base_inv, if given) are built once, then one
+ * limb group runs ONE ladder per row over that row's entries only.  order (optional): the rows sorted by entry count,
+ * so that the groups of a wavefront get ladders of similar length.  Needs the split-modulus engine. */
+int phe_hip_multiexp_csr_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* base_inv, size_t batch,
+                             const uint64_t* row_ptr, const uint32_t* cols, const uint32_t* e, const uint8_t* neg,
+                             int exp_limbs, int max_exp_bits, const uint32_t* order, uint32_t* out, size_t rows,
+                             void* stream);
+
 /* phe_hip_invert on device buffers.  Synchronises `stream` internally (the root of the product tree makes one
  * round trip to the host); results are complete on return. */
 int phe_hip_invert_dev(phe_hip_ctx* ctx, const uint32_t* a, uint32_t* out, size_t batch, size_t* bad_index, void* stream);

@@ -72,6 +72,8 @@ PHE_DECLARE_PART(g16b)
     int launch_var_split(int L, int blocks, hipStream_t st, const SplitVarArgs& A);               \
     int occ_multi_split(int L);                                                                   \
     int launch_multi_split(int L, int blocks, hipStream_t st, const SplitMultiArgs& A);           \
+    int launch_multi_tables(int L, int blocks, hipStream_t st, const SplitTableArgs& A);          \
+    int launch_multi_lookup(int L, int blocks, hipStream_t st, const SplitLookupArgs& A);         \
     }
 PHE_DECLARE_SPLIT_PART(s2a)
 PHE_DECLARE_SPLIT_PART(s2b)
@@ -133,32 +135,46 @@ struct SplitPart {
     int (*launch_var_split)(int, int, hipStream_t, const SplitVarArgs&);
     int (*occ_multi_split)(int);
     int (*launch_multi_split)(int, int, hipStream_t, const SplitMultiArgs&);
+    int (*launch_multi_tables)(int, int, hipStream_t, const SplitTableArgs&);
+    int (*launch_multi_lookup)(int, int, hipStream_t, const SplitLookupArgs&);
 };
 static const SplitPart kSplitParts[] = {
     {2, phe::s2a::occ_split, phe::s2a::launch_split, phe::s2a::occ_var_split, phe::s2a::launch_var_split,
-     phe::s2a::occ_multi_split, phe::s2a::launch_multi_split},
+     phe::s2a::occ_multi_split, phe::s2a::launch_multi_split, phe::s2a::launch_multi_tables,
+     phe::s2a::launch_multi_lookup},
     {2, phe::s2b::occ_split, phe::s2b::launch_split, phe::s2b::occ_var_split, phe::s2b::launch_var_split,
-     phe::s2b::occ_multi_split, phe::s2b::launch_multi_split},
+     phe::s2b::occ_multi_split, phe::s2b::launch_multi_split, phe::s2b::launch_multi_tables,
+     phe::s2b::launch_multi_lookup},
     {2, phe::s2c::occ_split, phe::s2c::launch_split, phe::s2c::occ_var_split, phe::s2c::launch_var_split,
-     phe::s2c::occ_multi_split, phe::s2c::launch_multi_split},
+     phe::s2c::occ_multi_split, phe::s2c::launch_multi_split, phe::s2c::launch_multi_tables,
+     phe::s2c::launch_multi_lookup},
     {4, phe::s4a::occ_split, phe::s4a::launch_split, phe::s4a::occ_var_split, phe::s4a::launch_var_split,
-     phe::s4a::occ_multi_split, phe::s4a::launch_multi_split},
+     phe::s4a::occ_multi_split, phe::s4a::launch_multi_split, phe::s4a::launch_multi_tables,
+     phe::s4a::launch_multi_lookup},
     {4, phe::s4b::occ_split, phe::s4b::launch_split, phe::s4b::occ_var_split, phe::s4b::launch_var_split,
-     phe::s4b::occ_multi_split, phe::s4b::launch_multi_split},
+     phe::s4b::occ_multi_split, phe::s4b::launch_multi_split, phe::s4b::launch_multi_tables,
+     phe::s4b::launch_multi_lookup},
     {4, phe::s4c::occ_split, phe::s4c::launch_split, phe::s4c::occ_var_split, phe::s4c::launch_var_split,
-     phe::s4c::occ_multi_split, phe::s4c::launch_multi_split},
+     phe::s4c::occ_multi_split, phe::s4c::launch_multi_split, phe::s4c::launch_multi_tables,
+     phe::s4c::launch_multi_lookup},
     {8, phe::s8a::occ_split, phe::s8a::launch_split, phe::s8a::occ_var_split, phe::s8a::launch_var_split,
-     phe::s8a::occ_multi_split, phe::s8a::launch_multi_split},
+     phe::s8a::occ_multi_split, phe::s8a::launch_multi_split, phe::s8a::launch_multi_tables,
+     phe::s8a::launch_multi_lookup},
     {8, phe::s8b::occ_split, phe::s8b::launch_split, phe::s8b::occ_var_split, phe::s8b::launch_var_split,
-     phe::s8b::occ_multi_split, phe::s8b::launch_multi_split},
+     phe::s8b::occ_multi_split, phe::s8b::launch_multi_split, phe::s8b::launch_multi_tables,
+     phe::s8b::launch_multi_lookup},
     {8, phe::s8c::occ_split, phe::s8c::launch_split, phe::s8c::occ_var_split, phe::s8c::launch_var_split,
-     phe::s8c::occ_multi_split, phe::s8c::launch_multi_split},
+     phe::s8c::occ_multi_split, phe::s8c::launch_multi_split, phe::s8c::launch_multi_tables,
+     phe::s8c::launch_multi_lookup},
     {16, phe::s16a::occ_split, phe::s16a::launch_split, phe::s16a::occ_var_split, phe::s16a::launch_var_split,
-     phe::s16a::occ_multi_split, phe::s16a::launch_multi_split},
+     phe::s16a::occ_multi_split, phe::s16a::launch_multi_split, phe::s16a::launch_multi_tables,
+     phe::s16a::launch_multi_lookup},
     {16, phe::s16b::occ_split, phe::s16b::launch_split, phe::s16b::occ_var_split, phe::s16b::launch_var_split,
-     phe::s16b::occ_multi_split, phe::s16b::launch_multi_split},
+     phe::s16b::occ_multi_split, phe::s16b::launch_multi_split, phe::s16b::launch_multi_tables,
+     phe::s16b::launch_multi_lookup},
     {16, phe::s16c::occ_split, phe::s16c::launch_split, phe::s16c::occ_var_split, phe::s16c::launch_var_split,
-     phe::s16c::occ_multi_split, phe::s16c::launch_multi_split},
+     phe::s16c::occ_multi_split, phe::s16c::launch_multi_split, phe::s16c::launch_multi_tables,
+     phe::s16c::launch_multi_lookup},
 };
 #define PHE_SPLIT_BY_GROUP(G_, CALL2)                 \
     [&]() -> int {                                    \
@@ -282,6 +298,8 @@ struct phe_hip_ctx {
     uint32_t* scratch = nullptr;  // decrypt intermediates x_p | x_q
     size_t scratch_words = 0;
     unsigned long long* flags = nullptr;  // radix conversion: first offending row per error kind (2 words)
+    uint32_t* lookup = nullptr;  // multi-exponentiation: the 2^w-ary tables of a whole vector (phe_hip_multiexp_csr_dev)
+    size_t lookup_words = 0;
     uint32_t* partial = nullptr;  // multi-exponentiation: one product per chunk, joined in place by a k_mulmod tree
     size_t partial_words = 0;
     // staging for the host-pointer entry points
@@ -720,7 +738,7 @@ void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
                         ctx->d_psplit_lat.blob, ctx->d_qsplit_lat.blob,
                         ctx->d_nsq_lat.blob, ctx->d_psq_lat.blob, ctx->d_qsq_lat.blob,
                         ctx->d_nsq.blob, ctx->d_psq.blob, ctx->d_qsq.blob, ctx->d_exp_n.ops, ctx->d_exp_p.ops,
-                        ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->scratch, ctx->partial, (uint32_t*)ctx->flags, ctx->stage[0],
+                        ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->scratch, ctx->partial, ctx->lookup, (uint32_t*)ctx->flags, ctx->stage[0],
                         ctx->stage[1], ctx->stage[2]};
     for (uint32_t* b : bufs)
         if (b) (void)hipFree(b);
@@ -944,6 +962,73 @@ int phe_hip_multiexp_rows_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint
     if (!out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
     return multiexp_rows_impl(ctx, base, base_inv, e, neg, exp_limbs, max_exp_bits, out, batch, rows, (hipStream_t)stream);
+}
+
+// out[r] = prod over the entries of row r of b[col]^exp (csrc/split_core.h: multiexp_tables_body + multiexp_lookup_body):
+// the 2^w-ary tables of the whole vector once, then one ladder per row over that row's entries only.
+int phe_hip_multiexp_csr_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* base_inv, size_t batch,
+                             const uint64_t* row_ptr, const uint32_t* cols, const uint32_t* e, const uint8_t* neg,
+                             int exp_limbs, int max_exp_bits, const uint32_t* order, uint32_t* out, size_t rows,
+                             void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (rows == 0) return PHE_HIP_OK;
+    if (!out || !base || batch == 0) return fail(PHE_HIP_EINVAL, "null buffer / empty vector");
+    if (!e || exp_limbs < 1) return fail(PHE_HIP_EINVAL, "null buffer / exp_limbs");
+    if ((cols != nullptr) != (row_ptr != nullptr)) return fail(PHE_HIP_EINVAL, "row_ptr and cols come together (both NULL = dense rows)");
+    if (neg && !base_inv) return fail(PHE_HIP_EINVAL, "a sign mask needs the inverted bases");
+    if (max_exp_bits <= 0 || max_exp_bits > 32 * exp_limbs) max_exp_bits = 32 * exp_limbs;
+    if (int rc = bind_device(ctx)) return rc;
+    if (!(ctx->use_split && ctx->d_nsplit.G))
+        return fail(PHE_HIP_EINVAL, "the table form needs the split-modulus engine (call phe_hip_multiexp_dev row by row on this key)");
+    hipStream_t st = (hipStream_t)stream;
+    const int w = host::pick_multi_window(max_exp_bits);
+    const size_t per = ((size_t)1 << w) - 1, signs = base_inv ? 2 : 1;
+    {   // tables: one limb group per (ciphertext, sign)
+        // one geometry for both kernels (the table rows are H = G*L limbs of that geometry); the ladders are the bulk of
+        // the work and their parallelism is `rows`: 16-lane groups (half the time per product) until the rows alone
+        // fill the throughput geometry's resident groups halfway
+        const DevSplit& M = (ctx->has_lat_pub && rows <= (size_t)ctx->n_cus * 64) ? ctx->d_nsplit_lat : ctx->d_nsplit;
+        int rc = ensure_words(&ctx->lookup, &ctx->lookup_words, batch * signs * per * 2 * (size_t)M.H);
+        if (rc) return rc;
+        SplitTableArgs T;
+        T.mod = M.c;
+        T.base = base;
+        T.base_inv = base_inv;
+        T.base_limbs = ctx->pub.s2;
+        T.base_chunks = chunks_for(ctx->pub.s2, M.H);
+        T.window = w;
+        T.table = ctx->lookup;
+        T.batch = batch;
+        const int blocks = grid_blocks(ctx, batch * signs, M.G, 2);
+        if (PHE_SPLIT_BY_GROUP(M.G, launch_multi_tables(M.L, blocks, st, T)) < 0)
+            return fail(PHE_HIP_EINVAL, "unsupported split geometry");
+        HIP_TRY(hipGetLastError());
+        const DevSplit& M2 = M;
+        SplitLookupArgs A;
+        A.mod = M2.c;
+        A.table = ctx->lookup;
+        A.signs = (int)signs;
+        A.row_ptr = row_ptr;
+        A.cols = cols;
+        A.exps = e;
+        A.neg = neg;
+        A.order = order;
+        A.exp_limbs = exp_limbs;
+        A.window = w;
+        A.n_windows = std::max(1, (max_exp_bits + w - 1) / w);
+        A.out = out;
+        A.out_limbs = ctx->pub.s2;
+        A.batch = batch;
+        A.rows = rows;
+        int per_cu = ctx->blocks_per_cu;
+        if (per_cu == 0) per_cu = PHE_SPLIT_BY_GROUP(M2.G, occ_multi_split(M2.L));
+        if (per_cu < 0) return fail(PHE_HIP_EINVAL, "unsupported split geometry");
+        const int blocks2 = grid_blocks(ctx, rows, M2.G, per_cu);
+        if (PHE_SPLIT_BY_GROUP(M2.G, launch_multi_lookup(M2.L, blocks2, st, A)) < 0)
+            return fail(PHE_HIP_EINVAL, "unsupported split geometry");
+        HIP_TRY(hipGetLastError());
+    }
+    return PHE_HIP_OK;
 }
 
 // ---- host-pointer entry points ------------------------------------------------------------------

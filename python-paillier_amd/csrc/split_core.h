@@ -759,4 +759,131 @@ PHE_DEV void multiexp_split_body(const SplitMultiArgs& A, uint32_t* lds_row, uin
     }
 }
 
+// ---- multi-exponentiation on ONE table set for the whole vector ---------------------------------------------------
+// A plaintext matrix with many rows, or sparse rows (examples/logistic_regression_encrypted_model.py:170-177 walks the
+// NONZERO features of a sample: `_, idx = x.nonzero(); for i in idx: score += x[0, i] * self.weights[i]`), makes the
+// per-task tables of multiexp_split_body a waste: the same few ciphertexts are expanded again and again.  Here the
+// 2^w-ary tables of EVERY ciphertext of the vector (and of its inverse, if any entry is negative) are built once
+// (multiexp_tables_body: one limb group per ciphertext) and a limb group then runs ONE ladder for a whole matrix row,
+// over that row's entries only — (column, exponent, sign) triples in CSR order, or the dense row — with one table
+// lookup and one pair product per entry and window.  The result of a row is final: no product tree.
+// Rows are visited in the caller's `order` (rows sorted by their entry count) so that the 64/G groups of a wavefront
+// have ladders of similar length; every inner loop runs to the wavefront's longest row and is predicated per group.
+struct SplitTableArgs {
+    SplitConsts mod;
+    const uint32_t* base;      // (batch, base_limbs)
+    const uint32_t* base_inv;  // (batch, base_limbs) or nullptr
+    int base_limbs;
+    int base_chunks;
+    int window;       // w: the table of one ciphertext is base^1 .. base^(2^w - 1)
+    uint32_t* table;  // (batch, signs, 2^w - 1, 2H)
+    uint64_t batch;
+};
+
+template <int G, int L>
+PHE_DEV void multiexp_tables_body(const SplitTableArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots,
+                                  uint32_t lane) {
+    constexpr int H = G * L, S2 = 2 * H;
+    const Lanes<G> ln(lane);
+    const uint32_t g = ln.g;
+    SplitLane<G, L> K;
+    load_row<L>(K.n, A.mod.n, g);
+    K.n0inv = A.mod.n0inv;
+    K.row_a = lds_row;
+    K.row_c = lds_row + H;
+    const int per = (1 << A.window) - 1;
+    const int signs = A.base_inv ? 2 : 1;
+    const uint64_t n_items = A.batch * (uint64_t)signs;
+    const uint64_t n_iter = (n_items + total_slots - 1) / total_slots;
+    for (uint64_t it = 0; it < n_iter; ++it) {
+        uint64_t item = slot + it * (uint64_t)total_slots;
+        const bool live = item < n_items;
+        if (!live) item = n_items - 1;
+        const uint64_t col = item / (uint64_t)signs;
+        const int sg = (int)(item - col * (uint64_t)signs);
+        const uint32_t* src = (sg ? A.base_inv : A.base) + col * (uint64_t)A.base_limbs;
+        uint32_t X0[L], X1[L], Y0[L], Y1[L];
+        split_conv<G, L>(Y0, Y1, src, A.base_limbs, A.base_chunks, A.mod, K, ln);
+        uint32_t* t = A.table + item * (uint64_t)per * S2;
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            X0[k] = Y0[k];
+            X1[k] = Y1[k];
+        }
+        for (int j = 0; j < per; ++j) {
+            if (j) split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
+            if (live) {
+                store_row<L>(t + (size_t)j * S2, X0, g);
+                store_row<L>(t + (size_t)j * S2 + H, X1, g);
+            }
+        }
+    }
+}
+
+struct SplitLookupArgs {
+    SplitConsts mod;
+    const uint32_t* table;    // multiexp_tables_body's output
+    int signs;                // 1 or 2 (inverse tables present)
+    const uint64_t* row_ptr;  // (rows + 1) entry offsets, or nullptr: dense rows of `batch` entries each
+    const uint32_t* cols;     // (entries) column of every entry, or nullptr: dense (column = position in the row)
+    const uint32_t* exps;     // (entries, exp_limbs)
+    const uint8_t* neg;       // (entries) nonzero = inverted base, or nullptr
+    const uint32_t* order;    // (rows) visiting order, or nullptr
+    int exp_limbs;
+    int window;
+    int n_windows;
+    uint32_t* out;  // (rows, out_limbs)
+    int out_limbs;
+    uint64_t batch;
+    uint64_t rows;
+};
+
+template <int G, int L>
+PHE_DEV void multiexp_lookup_body(const SplitLookupArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots,
+                                  uint32_t lane) {
+    constexpr int H = G * L, S2 = 2 * H;
+    const Lanes<G> ln(lane);
+    const uint32_t g = ln.g;
+    SplitLane<G, L> K;
+    load_row<L>(K.n, A.mod.n, g);
+    K.n0inv = A.mod.n0inv;
+    K.row_a = lds_row;
+    K.row_c = lds_row + H;
+    const int per = (1 << A.window) - 1;
+    const uint64_t n_iter = (A.rows + total_slots - 1) / total_slots;
+    for (uint64_t it = 0; it < n_iter; ++it) {
+        uint64_t pos = slot + it * (uint64_t)total_slots;
+        const bool live = pos < A.rows;
+        if (!live) pos = A.rows - 1;
+        const uint64_t r = A.order ? (uint64_t)A.order[pos] : pos;
+        const uint64_t first = A.row_ptr ? A.row_ptr[r] : r * A.batch;
+        const uint64_t count = A.row_ptr ? A.row_ptr[r + 1] - first : A.batch;
+        uint32_t X0[L], X1[L], Y0[L], Y1[L];
+        load_row<L>(X0, A.mod.e, g);
+        load_row<L>(X1, A.mod.e + H, g);
+        for (int wi = A.n_windows - 1; wi >= 0; --wi) {
+            if (wi != A.n_windows - 1)
+                for (int s = 0; s < A.window; ++s) split_square<G, L>(X0, X1, K, ln);
+            for (uint64_t el = 0; wave::ballot(el < count) != 0; ++el) {  // to the wavefront's longest row
+                uint32_t d = 0;
+                uint64_t tbl_item = 0;
+                if (el < count) {
+                    const uint64_t entry = first + el;
+                    d = exp_digit(A.exps + entry * (uint64_t)A.exp_limbs, A.exp_limbs, wi * A.window, A.window);
+                    const uint64_t col = A.cols ? (uint64_t)A.cols[entry] : el;
+                    const uint64_t sg = (A.neg && A.neg[entry]) ? 1u : 0u;
+                    tbl_item = col * (uint64_t)A.signs + sg;
+                }
+                if (wave::ballot(d != 0) != 0) {
+                    const uint32_t* src = d ? A.table + (tbl_item * (uint64_t)per + (d - 1)) * S2 : A.mod.e;
+                    load_row<L>(Y0, src, g);
+                    load_row<L>(Y1, src + H, g);
+                    split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
+                }
+            }
+        }
+        split_exit<G, L>(A.out + r * (uint64_t)A.out_limbs, A.out_limbs, X0, X1, nullptr, 0, A.mod, K, ln, live);
+    }
+}
+
 }  // namespace phe

@@ -336,6 +336,45 @@ class Engine:
         inv = self.ctx.invert(base) if any_neg else None
         return self.ctx.multiexp_rows(base, inv, limbs, neg.astype(np.uint8) if any_neg else None)
 
+    def has_split_engine(self):
+        info = self.ctx.info()
+        return bool(info.get("emulated") or info.get("engine_pub") == "split")
+
+    def raw_matvec_csr(self, c, row_ptr, cols, exps, neg, rows):
+        """out[r] = prod over the entries of row r of b[col]^exp (b = c[col], or its inverse where neg[entry]): the
+        table-lookup form of raw_matvec (include/phe_hip.h phe_hip_multiexp_csr_dev) — tables of the whole vector
+        once, then one ladder per row over its entries only.  row_ptr / cols: CSR (None, None = dense rows);
+        exps: (limb rows (entries, width), bits) as shifted_limbs returns them; neg: (entries,) bool or None.
+        Rows are visited longest first.  c: host limb array or DeviceArray; returns the same kind."""
+        limbs, bits = exps
+        any_neg = neg is not None and bool(np.asarray(neg).any())
+        order = None
+        if row_ptr is not None:
+            row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+            counts = np.diff(row_ptr.astype(np.int64))
+            order = np.argsort(-counts, kind="stable").astype(np.uint32)
+        if isinstance(c, DeviceArray):
+            inv = None
+            if any_neg:
+                inv = DeviceArray(self.ctx, c.rows, self.ct_limbs)
+                self.ctx.invert_dev(c.ptr, inv.ptr, c.rows)
+            dev = lambda a, dt: DeviceArray.from_host(self.ctx, np.ascontiguousarray(a, dtype=dt).reshape(-1), dtype=dt)
+            e = DeviceArray.from_host(self.ctx, limbs)
+            rp = DeviceArray.from_host(self.ctx, row_ptr.view(np.uint32).reshape(-1, 2)) if row_ptr is not None else None
+            cl = DeviceArray.from_host(self.ctx, np.ascontiguousarray(cols, dtype=np.uint32)) if cols is not None else None
+            ng = dev(np.asarray(neg).astype(np.uint8), np.uint8) if any_neg else None
+            od = DeviceArray.from_host(self.ctx, order) if order is not None else None
+            out = DeviceArray(self.ctx, rows, self.ct_limbs)
+            ptr = lambda a: a.ptr if a is not None else None
+            self.ctx.multiexp_csr_dev(c.ptr, ptr(inv), c.rows, ptr(rp), ptr(cl), e.ptr, ptr(ng), limbs.shape[1], bits, ptr(od),
+                                      out.ptr, rows)
+            self.ctx.sync()
+            return out
+        base = self._as_cipher(c)
+        inv = self.ctx.invert(base) if any_neg else None
+        return self.ctx.multiexp_csr(base, inv, row_ptr, cols, limbs, np.asarray(neg).astype(np.uint8) if any_neg else None,
+                                     order, rows)
+
     # ---- the decimal wire format of ciphertext vectors (docs/serialisation.rst:24-43; str(int) / int(str) per
     #      element in the reference) ---------------------------------------------------------------------------
     def decimal_strings(self, c):

@@ -55,6 +55,7 @@ def lib():
         L.phe_hip_from_decimal_dev.argtypes = [vp, vp, ci, vp, ci, sz, ctypes.POINTER(sz), vp]
         L.phe_hip_multiexp_dev.argtypes = [vp, vp, vp, ci, ci, vp, sz, vp]
         L.phe_hip_multiexp_rows_dev.argtypes = [vp, vp, vp, vp, vp, ci, ci, vp, sz, sz, vp]
+        L.phe_hip_multiexp_csr_dev.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp, ci, ci, vp, vp, sz, vp]
         L.phe_hip_add_plain_dev.argtypes = [vp, vp, vp, vp, sz, vp]
         L.phe_hip_invert.argtypes = [vp, vp, vp, sz, ctypes.POINTER(sz)]
         L.phe_hip_encrypt_dev.argtypes = [vp, vp, vp, vp, sz, vp]
@@ -86,7 +87,7 @@ EXPORTED_SYMBOLS = [
     "phe_hip_powmod_dev", "phe_hip_malloc", "phe_hip_free", "phe_hip_memcpy_h2d", "phe_hip_memcpy_d2h",
     "phe_hip_stream_sync", "phe_hip_selftest_prims", "phe_hip_memcpy_d2d", "phe_hip_invert_dev",
     "phe_hip_select_rows_dev", "phe_hip_add_plain", "phe_hip_add_plain_dev", "phe_hip_ctx_engine",
-    "phe_hip_multiexp", "phe_hip_multiexp_dev", "phe_hip_multiexp_rows_dev", "phe_hip_decimal_width", "phe_hip_to_decimal",
+    "phe_hip_multiexp", "phe_hip_multiexp_dev", "phe_hip_multiexp_rows_dev", "phe_hip_multiexp_csr_dev", "phe_hip_decimal_width", "phe_hip_to_decimal",
     "phe_hip_from_decimal", "phe_hip_to_decimal_dev", "phe_hip_from_decimal_dev", "phe_hip_stream_create",
     "phe_hip_stream_destroy", "phe_hip_miller_rabin",
 ]
@@ -344,6 +345,45 @@ class Context:
     def multiexp_rows_dev(self, base_ptr, inv_ptr, exp_ptr, neg_ptr, exp_limbs, max_exp_bits, out_ptr, batch, rows, stream=0):
         _check(lib().phe_hip_multiexp_rows_dev(self._h, base_ptr, inv_ptr, exp_ptr, neg_ptr, exp_limbs, max_exp_bits,
                                                out_ptr, batch, rows, stream))
+
+    def multiexp_csr_dev(self, base_ptr, inv_ptr, batch, row_ptr, cols_ptr, exp_ptr, neg_ptr, exp_limbs, max_exp_bits,
+                         order_ptr, out_ptr, rows, stream=0):
+        _check(lib().phe_hip_multiexp_csr_dev(self._h, base_ptr, inv_ptr, batch, row_ptr, cols_ptr, exp_ptr, neg_ptr,
+                                              exp_limbs, max_exp_bits, order_ptr, out_ptr, rows, stream))
+
+    def multiexp_csr(self, base, base_inv, row_ptr, cols, exps, neg, order, rows):
+        """host arrays -> (rows, ct_limbs): the table-lookup multi-exponentiation (phe_hip_multiexp_csr_dev) staged through
+        device blocks.  row_ptr / cols None = dense rows; exps: (entries, exp_limbs); neg: (entries,) bytes or None."""
+        base = _rows(base, self.ct_limbs, "base")
+        exps = np.ascontiguousarray(exps, dtype=np.uint32)
+        out = np.empty((rows, self.ct_limbs), dtype=np.uint32)
+        held = []
+
+        def up(arr, dtype):
+            if arr is None:
+                return None
+            arr = np.ascontiguousarray(arr, dtype=dtype)
+            nbytes = max(4, (arr.nbytes + 3) // 4 * 4)
+            p = self.malloc(nbytes)
+            held.append((p, nbytes))
+            if arr.nbytes:
+                self.h2d(p, arr)
+            return p
+        try:
+            b = up(base, np.uint32)
+            bi = up(_rows(base_inv, self.ct_limbs, "base_inv"), np.uint32) if base_inv is not None else None
+            rp, cl = up(row_ptr, np.uint64), up(cols, np.uint32)
+            e, ng, od = up(exps, np.uint32), up(neg, np.uint8), up(order, np.uint32)
+            o = self.malloc(max(4, out.nbytes))
+            held.append((o, max(4, out.nbytes)))
+            self.multiexp_csr_dev(b, bi, base.shape[0], rp, cl, e, ng, exps.shape[1], max_exp_bits(exps), od, o, rows)
+            self.sync()
+            if out.nbytes:
+                self.d2h(out, o)
+        finally:
+            for p, nbytes in held:
+                self.free(p, nbytes)
+        return out
 
     def multiexp_rows(self, base, base_inv, exps, neg):
         """host arrays: base (batch, ct_limbs), base_inv same or None, exps (rows, batch, exp_limbs), neg (rows, batch)

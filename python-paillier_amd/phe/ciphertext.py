@@ -518,19 +518,54 @@ class EncryptedVector(object):
         return self.sum() / len(self)
 
     def matvec(self, matrix):
-        """matrix @ self for a plaintext (rows, len(self)) matrix -> EncryptedVector of `rows` dot products, each bit
-        for bit what `self.dot(matrix[r])` (hence the reference's chain of `*` and `+`) gives.  All rows go through
-        one launch of the matrix-form multi-exponentiation (Engine.raw_matvec): the tables built for a chunk of
-        ciphertexts serve a block of rows, and the negative-branch inverses are formed once for the whole vector —
-        e.g. scoring every sample against an encrypted weight vector,
-        examples/logistic_regression_encrypted_model.py:170-177."""
+        """matrix @ self for a plaintext (rows, len(self)) matrix — numpy array or scipy.sparse matrix — ->
+        EncryptedVector of `rows` dot products, each bit for bit what `self.dot(matrix[r])` (hence the reference's chain
+        of `*` and `+`) gives; for a sparse matrix the chain over the STORED entries of the row, which is what
+        Bob.encrypted_score walks (examples/logistic_regression_encrypted_model.py:170-177: `_, idx = x.nonzero()`).
+        Sparse matrices and dense ones with many rows go through the table-lookup multi-exponentiation
+        (Engine.raw_matvec_csr: the window tables of every ciphertext once, then one ladder per row over its entries);
+        few dense rows over a long vector through the chunked form (Engine.raw_matvec).  Negative-branch inverses are
+        formed once for the whole vector.  A row without entries is the ciphertext 1 (an encryption of 0)."""
         pk = self.public_key
         eng = pk._get_engine()
+        if len(self) == 0:
+            raise ValueError("empty vector")
+        log2b = int(round(EncodedNumber.LOG2_BASE))
+        pow2_base = (1 << log2b) == EncodedNumber.BASE
+        sparse = hasattr(matrix, "tocsr") and not isinstance(matrix, np.ndarray)
+        if sparse and eng.n_limbs >= 4 and pow2_base and eng.has_split_engine():
+            csr = matrix.tocsr()
+            if csr.shape[1] != len(self):
+                raise ValueError("matrix must have shape (rows, %d)" % len(self))
+            rows = csr.shape[0]
+            data = np.ascontiguousarray(csr.data)
+            signed = EncodedNumber.encode_signed(data) if len(data) else None
+            indptr = np.asarray(csr.indptr, dtype=np.int64)
+            cols = np.asarray(csr.indices, dtype=np.int64)
+            if signed is not None or len(data) == 0:
+                base_exp = int(self._exps.min())
+                if len(data) == 0:
+                    mag = np.zeros(0, np.uint64); neg = np.zeros(0, bool); total = np.zeros(0, np.int64)
+                else:
+                    mag, neg, kexp = signed
+                    total = self._exps[cols] + kexp
+                counts = np.diff(indptr)
+                target = np.full(rows, base_exp, dtype=np.int64)
+                filled = np.nonzero(counts)[0]
+                if len(filled):
+                    target[filled] = np.minimum.reduceat(total, indptr[filled])
+                delta = total - np.repeat(target, counts)
+                dmax = int(delta.max()) if len(delta) else 0
+                if dmax and pow(EncodedNumber.BASE, dmax) >= pk.n:
+                    raise ValueError('Scalar out of bounds: %i' % pow(EncodedNumber.BASE, dmax))
+                exps = eng.shifted_limbs(mag, delta * log2b)
+                limbs = eng.raw_matvec_csr(self._limbs, indptr, cols, exps, neg, rows)
+                return EncryptedVector(pk, limbs, target)
+        if sparse:
+            matrix = matrix.toarray()
         W = np.asarray(matrix)
         if W.ndim != 2 or W.shape[1] != len(self):
             raise ValueError("matrix must have shape (rows, %d)" % len(self))
-        if len(self) == 0:
-            raise ValueError("empty vector")
         rows = W.shape[0]
         signed = EncodedNumber.encode_signed(np.ascontiguousarray(W)) if (eng.n_limbs >= 4 and rows) else None
         if signed is None:                                   # object / exotic dtypes: row by row through dot()
@@ -542,7 +577,12 @@ class EncryptedVector(object):
         dmax = int(delta.max())
         if dmax and pow(EncodedNumber.BASE, dmax) >= pk.n:
             raise ValueError('Scalar out of bounds: %i' % pow(EncodedNumber.BASE, dmax))
-        log2b = int(round(EncodedNumber.LOG2_BASE))
+        # many rows over a vector whose tables fit comfortably (<= 1 GiB): build them once for all rows
+        table_bytes = len(self) * 2 * 15 * 2 * 4 * (eng.ct_limbs + 32)
+        if pow2_base and rows >= 64 and table_bytes <= (1 << 30) and eng.has_split_engine():
+            exps = eng.shifted_limbs(mag.reshape(-1), (delta * log2b).reshape(-1))
+            limbs = eng.raw_matvec_csr(self._limbs, None, None, exps, neg.reshape(-1), rows)
+            return EncryptedVector(pk, limbs, target)
         if dmax == 0:
             exps = mag
         else:                                                    # k * BASE^delta as limb rows, no Python ints

@@ -189,6 +189,33 @@ static void run_multi_split(SplitMultiArgs A) {
 }
 
 template <int G, int L>
+static void run_multi_tables(SplitTableArgs A) {
+    constexpr int S2 = 2 * G * L, kPer = 64 / G;
+    const int n_waves = waves_for(A.batch * (A.base_inv ? 2 : 1), G);
+    const uint32_t total = (uint32_t)(kPer * n_waves);
+    for (int w = 0; w < n_waves; ++w) {
+        std::vector<uint32_t> lds(kPer * (S2 + kLdsPad));
+        wave::run_wave([&](uint32_t lane) {
+            const uint32_t grp = lane / G;
+            multiexp_tables_body<G, L>(A, lds.data() + grp * (S2 + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
+        });
+    }
+}
+template <int G, int L>
+static void run_multi_lookup(SplitLookupArgs A) {
+    constexpr int S2 = 2 * G * L, kPer = 64 / G;
+    const int n_waves = waves_for(A.rows, G);
+    const uint32_t total = (uint32_t)(kPer * n_waves);
+    for (int w = 0; w < n_waves; ++w) {
+        std::vector<uint32_t> lds(kPer * (S2 + kLdsPad));
+        wave::run_wave([&](uint32_t lane) {
+            const uint32_t grp = lane / G;
+            multiexp_lookup_body<G, L>(A, lds.data() + grp * (S2 + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
+        });
+    }
+}
+
+template <int G, int L>
 static void run_miller_rabin(MillerRabinArgs A) {
     constexpr int S = G * L, kPer = 64 / G;
     const int n_waves = waves_for(A.batch, G, 4);
@@ -470,6 +497,39 @@ int emu_multiexp_n2(const uint32_t* n, int n_limbs, const uint32_t* base, const 
         A.n_chunks = (B + chunk - 1) / chunk;
         A.n_row_blocks = (rows + row_block - 1) / row_block;
         DISPATCH_SPLIT(M.G, M.L, (run_multi_split<GG, LL>(A)));
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// k_multiexp_tables + k_multiexp_lookup: out[r] = prod over the entries of row r of b[col]^exp, b = base or base_inv where
+// neg[entry]; row_ptr/cols null = dense rows of B entries.  Returns 2 without a split geometry.
+int emu_multiexp_csr(const uint32_t* n, int n_limbs, const uint32_t* base, const uint32_t* base_inv, uint64_t B,
+                     const uint64_t* row_ptr, const uint32_t* cols, const uint32_t* exps, const uint8_t* neg, int exp_limbs,
+                     uint64_t entries, const uint32_t* order, uint32_t* out, uint64_t rows) {
+    try {
+        if (B == 0 || rows == 0 || (neg && !base_inv)) throw std::invalid_argument("bad multiexp shape");
+        host::PublicPlan P = host::build_public(n, n_limbs, g_prefer_group);
+        if (!P.nsplit.G) return 2;
+        int max_bits = 1;
+        for (uint64_t i = 0; i < entries; ++i)
+            max_bits = std::max(max_bits, host::big_bits(host::big_from(exps + i * exp_limbs, exp_limbs, exp_limbs)));
+        const host::SplitPack& M = P.nsplit;
+        const int w = host::pick_multi_window(max_bits);
+        const int signs = base_inv ? 2 : 1;
+        std::vector<uint32_t> table((size_t)B * signs * (((size_t)1 << w) - 1) * 2 * M.H);
+        SplitTableArgs T;
+        memset(&T, 0, sizeof T);
+        T.mod = split_consts_of(M);
+        T.base = base; T.base_inv = base_inv; T.base_limbs = P.s2; T.base_chunks = chunks_for(P.s2, M.H);
+        T.window = w; T.table = table.data(); T.batch = B;
+        DISPATCH_SPLIT(M.G, M.L, (run_multi_tables<GG, LL>(T)));
+        SplitLookupArgs A;
+        memset(&A, 0, sizeof A);
+        A.mod = T.mod; A.table = table.data(); A.signs = signs;
+        A.row_ptr = row_ptr; A.cols = cols; A.exps = exps; A.neg = neg; A.order = order;
+        A.exp_limbs = exp_limbs; A.window = w; A.n_windows = std::max(1, (max_bits + w - 1) / w);
+        A.out = out; A.out_limbs = P.s2; A.batch = B; A.rows = rows;
+        DISPATCH_SPLIT(M.G, M.L, (run_multi_lookup<GG, LL>(A)));
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }

@@ -101,6 +101,14 @@ class EmuContext:
             parts = np.concatenate([merged, parts[2 * half:]])
         return parts[0]
 
+    def multiexp_csr(self, base, base_inv, row_ptr, cols, exps, neg, order, rows):
+        base, exps = np.ascontiguousarray(base), np.ascontiguousarray(exps)
+        out = emu().multiexp_csr(self._n_arr, base, exps, base_inv=base_inv, neg=neg, row_ptr=row_ptr, cols=cols, order=order,
+                                 rows=rows)
+        if out is None:
+            raise ValueError("the table form needs the split-modulus engine")
+        return out
+
     # decimal wire format: csrc/radix_conv.h through the emulator library (plain arrays instead of the LDS tile)
     @staticmethod
     def decimal_width(words):

@@ -109,6 +109,32 @@ class Emu:
         self._ck(rc)
         return out
 
+    def multiexp_csr(self, n, base, exps, base_inv=None, neg=None, row_ptr=None, cols=None, order=None, rows=None):
+        """k_multiexp_tables + k_multiexp_lookup: (rows, ct_limbs).  exps: (entries, exp_limbs); dense when row_ptr is
+        None (entries = rows * batch).  None without a split geometry."""
+        base = np.ascontiguousarray(base, dtype=np.uint32)
+        exps = np.ascontiguousarray(exps, dtype=np.uint32)
+        B = base.shape[0]
+        if row_ptr is not None:
+            row_ptr = np.ascontiguousarray(row_ptr, dtype=np.uint64)
+            rows = len(row_ptr) - 1
+        else:
+            rows = rows or exps.shape[0] // B
+        out = np.zeros((rows, base.shape[1]), dtype=np.uint32)
+        opt = lambda a, dt: P(np.ascontiguousarray(a, dtype=dt)) if a is not None else None
+        keep = [opt(base_inv, np.uint32), opt(cols, np.uint32), opt(neg, np.uint8), opt(order, np.uint32)]
+        arrs = [np.ascontiguousarray(a, dtype=dt) if a is not None else None
+                for a, dt in ((base_inv, np.uint32), (cols, np.uint32), (neg, np.uint8), (order, np.uint32))]
+        ptr = [P(a) if a is not None else None for a in arrs]
+        rc = self.L.emu_multiexp_csr(P(n), n.shape[0], P(base), ptr[0], ctypes.c_uint64(B),
+                                     P(row_ptr) if row_ptr is not None else None, ptr[1], P(exps), ptr[2], exps.shape[1],
+                                     ctypes.c_uint64(exps.shape[0]), ptr[3], P(out), ctypes.c_uint64(rows))
+        del keep
+        if rc == 2:
+            return None
+        self._ck(rc)
+        return out
+
     def miller_rabin(self, n, base):
         """csrc/primality.h: strong-probable-prime test of n[i] to base[i]; rows of 32-bit words -> bool array"""
         n = np.ascontiguousarray(n, dtype=np.uint32)

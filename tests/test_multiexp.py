@@ -183,6 +183,82 @@ def test_matvec_rows_equal_dot(monkeypatch, emu, engine):
     emu_backend.emu().set_engine(True)
 
 
+@pytest.mark.parametrize("key_bits", [256, 1024])
+def test_table_lookup_form_through_emulator(emu, key_bits):
+    """k_multiexp_tables + k_multiexp_lookup: CSR rows of different lengths (one of them empty) visited longest first,
+    per-entry selection of the inverted base; dense rows without inverses"""
+    emu.set_engine(True)
+    g = load_golden(key_bits)
+    n_int = H(g["n"])
+    nsq = n_int * n_int
+    s1, s2 = key_bits // 32, key_bits // 16
+    rng = random.Random(key_bits)
+    B, nnz = 7, [3, 0, 7, 1, 5, 2]
+    bases = [rng.randrange(1, nsq) for _ in range(B)]
+    invs = [pow(b, -1, nsq) for b in bases]
+    cols, ex, ng = [], [], []
+    for k in nnz:
+        cs = rng.sample(range(B), k)
+        cols += cs
+        ex += [rng.getrandbits(rng.choice([1, 20, 56])) for _ in cs]
+        ng += [rng.random() < 0.4 for _ in cs]
+    row_ptr = np.cumsum([0] + nnz).astype(np.uint64)
+    order = np.argsort(-np.array(nnz), kind="stable").astype(np.uint32)
+    out = emu.multiexp_csr(int_to_limbs(n_int, s1), ints_to_limbs(bases, s2), ints_to_limbs(ex, 2),
+                           base_inv=ints_to_limbs(invs, s2), neg=np.array(ng, dtype=np.uint8), row_ptr=row_ptr,
+                           cols=np.array(cols, dtype=np.uint32), order=order)
+    want, k = [], 0
+    for cnt in nnz:
+        v = 1
+        for _ in range(cnt):
+            v = v * pow(invs[cols[k]] if ng[k] else bases[cols[k]], ex[k], nsq) % nsq
+            k += 1
+        want.append(v)
+    assert limbs_to_ints(out) == want
+    dense = [[rng.getrandbits(40) for _ in range(B)] for _ in range(4)]
+    out = emu.multiexp_csr(int_to_limbs(n_int, s1), ints_to_limbs(bases, s2),
+                           np.concatenate([ints_to_limbs(r, 2) for r in dense]), rows=4)
+    assert limbs_to_ints(out) == [functools.reduce(lambda a, b: a * b % nsq, [pow(b, e, nsq) for b, e in zip(bases, r)], 1)
+                                  for r in dense]
+
+
+def test_sparse_and_tall_matrices_take_the_table_form(monkeypatch, emu):
+    """EncryptedVector.matvec with a scipy.sparse matrix (the stored entries of a row, as Bob.encrypted_score walks them)
+    and with a dense matrix of many rows: every row bit for bit the dot product over its entries; an empty row is 1"""
+    import scipy.sparse as sp
+    import emu_backend
+    emu_backend.install(monkeypatch)
+    emu_backend.emu().set_engine(True)
+    from phe import paillier
+    g = load_golden(256)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    vals = np.array([0.5, -1.25, 3.0, 4.75, 1e-3, -7.0, 250.0])
+    vec = pub.encrypt_batch(vals, r_values=[H(e["r"]) for e in g["raw_encrypt"][:7]])
+    rng = np.random.default_rng(2)
+    D = rng.standard_normal((6, 7))
+    D[rng.random((6, 7)) < 0.6] = 0.0
+    D[1, :] = 0.0
+    for M in (sp.csr_matrix(D), sp.coo_matrix(D), sp.csr_matrix(np.rint(D * 10).astype(np.int64))):
+        dense = M.toarray()
+        out = vec.matvec(M)
+        for r in range(6):
+            nz = np.nonzero(dense[r])[0]
+            if len(nz) == 0:
+                assert out[r].ciphertext(False) == 1 and priv.decrypt(out[r]) == 0
+                continue
+            sub = paillier.EncryptedVector.from_numbers(pub, [vec[int(i)] for i in nz])
+            d = sub.dot(dense[r][nz])
+            assert (out[r].ciphertext(False), out[r].exponent) == (d.ciphertext(False), d.exponent), r
+        assert np.allclose(priv.decrypt_batch(out), dense.astype(np.float64) @ vals, rtol=1e-9, atol=1e-12)
+    W = rng.integers(-20, 20, (70, 7))                       # >= 64 rows: dense rows on the shared tables
+    out = vec.matvec(W)
+    for r in (0, 33, 69):
+        d = vec.dot(W[r])
+        assert (out[r].ciphertext(False), out[r].exponent) == (d.ciphertext(False), d.exponent)
+    assert np.allclose(priv.decrypt_batch(out), W.astype(np.float64) @ vals, rtol=1e-9)
+
+
 # ---- GPU -------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def native():
@@ -310,3 +386,36 @@ def test_matvec_without_split_engine_goes_row_by_row(monkeypatch):
     for vec in (pub.encrypt_batch(x, r_values=r_values), pub.encrypt_batch(x, r_values=r_values, device=True)):
         out = vec.matvec(W)
         assert out.ciphertexts(False) == ref.ciphertexts(False) and out.exponents == ref.exponents
+
+
+@pytest.mark.gpu
+def test_sparse_matvec_on_gpu():
+    """scipy.sparse rows (5 % dense, ragged, some empty) and a tall dense matrix through phe_hip_multiexp_csr_dev, host and
+    device-resident vectors: equal to the chunked matrix form row for row, and to W @ x after decryption"""
+    import scipy.sparse as sp
+    from phe import paillier
+    g = load_golden(1024)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    rs = np.random.Generator(np.random.PCG64(23))
+    x = rs.standard_normal(400)
+    host = pub.encrypt_batch(x)
+    dev = host.to_device()
+    D = rs.standard_normal((300, 400))
+    D[rs.random((300, 400)) < 0.95] = 0.0
+    D[7, :] = 0.0
+    S = sp.csr_matrix(D)
+    a, b = host.matvec(S), dev.matvec(S)
+    assert b.on_device and a.ciphertexts(False) == b.ciphertexts(False) and a.exponents == b.exponents
+    assert a[7].ciphertext(False) == 1
+    assert np.allclose(priv.decrypt_batch(b), D @ x, rtol=1e-9, atol=1e-9)
+    for r in (0, 150, 299):
+        nz = np.nonzero(D[r])[0]
+        sub = paillier.EncryptedVector.from_numbers(pub, [host[int(i)] for i in nz])
+        d = sub.dot(D[r][nz])
+        assert (a[r].ciphertext(False), a[r].exponent) == (d.ciphertext(False), d.exponent)
+    W = rs.integers(-1000, 1000, (130, 400))                 # tall and dense: the table form; 5 rows: the chunked form
+    tall = dev.matvec(W)
+    few = dev.matvec(W[:5])
+    assert tall[:5].ciphertexts(False) == few.ciphertexts(False)
+    assert np.allclose(priv.decrypt_batch(tall), W.astype(np.float64) @ x, rtol=1e-9, atol=1e-6)

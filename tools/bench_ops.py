@@ -135,6 +135,27 @@ def main():
     res["matvec_128x8192_float56"] = {"entries_per_s": feat * nrows / t, "rows_per_s": nrows / t, "ms": t * 1e3,
                                       "row_by_row_dot_ms_extrapolated_from_256_rows": t_loop * 1e3, "speedup_vs_row_by_row": t_loop / t,
                                       "same_bits_as_row_by_row": same}
+    # the same matrix on one table set for the whole vector (phe_hip_multiexp_csr_dev, dense rows), and a SPARSE matrix:
+    # 8192 samples x 4096 features, 100 stored entries per row (bag-of-words shaped), CSR
+    t = timed(lambda: ctx.multiexp_csr_dev(ca.data_ptr(), None, feat, None, None, em.data_ptr(), None, 2, 56, None,
+                                           outm.data_ptr(), nrows, st))
+    res["matvec_128x8192_float56_table_form"] = {"entries_per_s": feat * nrows / t, "rows_per_s": nrows / t, "ms": t * 1e3,
+                                                  "same_bits_as_chunked_form": bool(torch.equal(outm[:256], out[:256]))}
+    ncols, per_row = 4096, 100
+    row_ptr = torch.arange(0, (nrows + 1) * per_row, per_row, dtype=torch.int64, device=dev)
+    cols = torch.randint(0, ncols, (nrows * per_row,), dtype=torch.int32, device=dev, generator=gen)
+    es = torch.randint(-2 ** 31, 2 ** 31, (nrows * per_row, 2), dtype=torch.int32, device=dev, generator=gen)
+    es[:, 1] &= 0x00ffffff
+    outs = torch.empty((nrows, s2), dtype=torch.int32, device=dev)
+    t = timed(lambda: ctx.multiexp_csr_dev(ca.data_ptr(), None, ncols, row_ptr.data_ptr(), cols.data_ptr(), es.data_ptr(), None,
+                                           2, 56, None, outs.data_ptr(), nrows, st))
+    # row 0 against the single-row entry point on the gathered ciphertexts
+    idx0 = cols[:per_row].long()
+    gathered = ca[idx0].contiguous()
+    ctx.multiexp_dev(gathered.data_ptr(), es.data_ptr(), 2, 56, one_row.data_ptr(), per_row, st)
+    torch.cuda.synchronize()
+    res["matvec_sparse_8192x4096_100_per_row"] = {"entries_per_s": nrows * per_row / t, "rows_per_s": nrows / t, "ms": t * 1e3,
+                                                   "row0_same_bits_as_single_row_entry": bool(torch.equal(outs[0], one_row[0]))}
     if args.chunk_sweep:
         e = rnd(2)
         e[:, 1] &= 0x7fffffff
