@@ -182,7 +182,8 @@ int phe_hip_multiexp_rows_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint
  * examples/logistic_regression_encrypted_model.py:170-177 (`_, idx = x.nonzero(); for i in idx: score += x[0, i] * w[i]`),
  * for all samples at once: the 2^w-ary tables of every ciphertext (and of base_inv, if given) are built once, then one
  * limb group runs ONE ladder per row over that row's entries only.  order (optional): the rows sorted by entry count,
- * so that the groups of a wavefront get ladders of similar length.  Needs the split-modulus engine. */
+ * so that the groups of a wavefront get ladders of similar length.  cols must be < batch (not checked: the arrays
+ * live on the device).  Needs the split-modulus engine. */
 int phe_hip_multiexp_csr_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* base_inv, size_t batch,
                              const uint64_t* row_ptr, const uint32_t* cols, const uint32_t* e, const uint8_t* neg,
                              int exp_limbs, int max_exp_bits, const uint32_t* order, uint32_t* out, size_t rows,

@@ -15,6 +15,11 @@ from ._engine import random_lt_n, random_lt_n_limbs
 from .codec import EncodedNumber
 
 
+# matvec on a host vector gathers the columns a sparse matrix actually stores once the window tables of the whole
+# vector would exceed this many bytes (tests lower it)
+TABLE_COMPACT_BYTES = 64 << 20
+
+
 class EncryptedNumber(object):
     def __init__(self, public_key, ciphertext, exponent=0):
         from .keys import PaillierPublicKey
@@ -559,7 +564,18 @@ class EncryptedVector(object):
                 if dmax and pow(EncodedNumber.BASE, dmax) >= pk.n:
                     raise ValueError('Scalar out of bounds: %i' % pow(EncodedNumber.BASE, dmax))
                 exps = eng.shifted_limbs(mag, delta * log2b)
-                limbs = eng.raw_matvec_csr(self._limbs, indptr, cols, exps, neg, rows)
+                base = self._limbs
+                # the tables cover every ciphertext handed over: keep them to the columns that are actually stored
+                # (host vectors: a gather; resident vectors are used whole, up to 8 GiB of tables)
+                per_col = 2 * 15 * 2 * 4 * (eng.ct_limbs + 32)
+                if not self.on_device and len(cols) and len(self) * per_col > TABLE_COMPACT_BYTES:
+                    used, remap = np.unique(cols, return_inverse=True)
+                    if len(used) < len(self):
+                        base, cols = np.ascontiguousarray(base[used]), remap
+                if base.shape[0] * per_col > (8 << 30):
+                    raise MemoryError("matvec: window tables for %d ciphertexts would not fit the table budget; "
+                                      "slice the matrix by columns" % base.shape[0])
+                limbs = eng.raw_matvec_csr(base, indptr, cols, exps, neg, rows)
                 return EncryptedVector(pk, limbs, target)
         if sparse:
             matrix = matrix.toarray()

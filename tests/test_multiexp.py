@@ -251,6 +251,17 @@ def test_sparse_and_tall_matrices_take_the_table_form(monkeypatch, emu):
             d = sub.dot(dense[r][nz])
             assert (out[r].ciphertext(False), out[r].exponent) == (d.ciphertext(False), d.exponent), r
         assert np.allclose(priv.decrypt_batch(out), dense.astype(np.float64) @ vals, rtol=1e-9, atol=1e-12)
+    from phe import ciphertext
+    monkeypatch.setattr(ciphertext, "TABLE_COMPACT_BYTES", 0)         # host vectors: tables only for the stored columns
+    E = D.copy()
+    E[:, [0, 3, 5]] = 0.0
+    compact = vec.matvec(sp.csr_matrix(E))
+    for r in range(6):
+        nz = np.nonzero(E[r])[0]
+        if len(nz):
+            sub = paillier.EncryptedVector.from_numbers(pub, [vec[int(i)] for i in nz])
+            assert compact[r].ciphertext(False) == sub.dot(E[r][nz]).ciphertext(False)
+    assert np.allclose(priv.decrypt_batch(compact), E @ vals, rtol=1e-9, atol=1e-12)
     W = rng.integers(-20, 20, (70, 7))                       # >= 64 rows: dense rows on the shared tables
     out = vec.matvec(W)
     for r in (0, 33, 69):
