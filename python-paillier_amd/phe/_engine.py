@@ -452,6 +452,47 @@ class Engine:
         self.ctx.sync(st)
         return out if device else out.to_host()
 
+    # ---- offline / online split: obfuscators r^n mod n^2 made ahead of time -------------------------------------------
+    # r^n is the expensive factor of an encryption and does not depend on the plaintext (phe/paillier.py:137 draws r
+    # and exponentiates at encryption time).  A pool of them, each used ONCE, turns the online part of encrypt_batch /
+    # obfuscate into one product per element: c = (1 + n m) * r^n — the same value raw_encrypt(m, r) returns for that r.
+    def fill_obfuscator_pool(self, count):
+        """draw `count` fresh r in [1, n) and keep r^n mod n^2 in HBM (raw_encrypt of the plaintext 0: 1 + n*0 = 1)"""
+        if count <= 0:
+            return self.obfuscators_available()
+        zeros = np.zeros((count, self.n_limbs), dtype=np.uint32)
+        block = self.raw_encrypt_fresh(zeros, device=True)
+        self.__dict__.setdefault("_obf_pool", []).append([block, 0])
+        return self.obfuscators_available()
+
+    def obfuscators_available(self):
+        return sum(b.rows - used for b, used in self.__dict__.get("_obf_pool", []))
+
+    def take_obfuscators(self, count):
+        """`count` unused obfuscators as one DeviceArray (views where possible), or None if the pool is short;
+        they are consumed: nothing is handed out twice"""
+        pool = self.__dict__.get("_obf_pool", [])
+        if count <= 0 or self.obfuscators_available() < count:
+            return None
+        parts, need = [], count
+        while need:
+            block, used = pool[0]
+            k = min(need, block.rows - used)
+            parts.append(block.rows_view(used, used + k))
+            pool[0][1] = used + k
+            need -= k
+            if pool[0][1] == block.rows:
+                pool.pop(0)
+        if len(parts) == 1:
+            return parts[0]
+        out = DeviceArray(self.ctx, count, self.ct_limbs)
+        lo = 0
+        for part in parts:
+            self.ctx.d2d(out.ptr + lo * self.ct_limbs * 4, part.ptr, part.nbytes)
+            lo += part.rows
+        self.ctx.sync()
+        return out
+
     def obfuscate_fresh_dev(self, c, rows=None):
         """obfuscate_dev with freshly drawn obfuscators, chunked like raw_encrypt_fresh (draw and upload of the next
         chunk under the kernels of the current one).  rows: indices that get a fresh r (None = all); the others get

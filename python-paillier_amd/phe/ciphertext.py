@@ -226,7 +226,10 @@ class EncryptedVector(object):
             return self
         if r_values is None and hasattr(eng.ctx, "obfuscate_dev"):
             # fresh obfuscators as limb arrays straight from the CSPRNG (no Python integer per row)
-            if self.on_device:
+            pooled = eng.take_obfuscators(len(self)) if (self.on_device and len(rows) == len(self)) else None
+            if pooled is not None:
+                self._limbs = eng.raw_add_dev(self._limbs, pooled)       # c * r^n with r^n made ahead of time, used once
+            elif self.on_device:
                 self._limbs = eng.obfuscate_fresh_dev(self._limbs, None if len(rows) == len(self) else rows)
             else:
                 from ._engine import random_lt_n_limbs

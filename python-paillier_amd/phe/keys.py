@@ -115,6 +115,17 @@ class PaillierPublicKey(object):
         c = self.raw_encrypt(encoding.encoding, r_value or 1)   # r_value == 0 => obfuscator 1, not obfuscated
         return EncryptedNumber(self, c, encoding.exponent)
 
+    # ---- offline / online split ------------------------------------------------------------------------
+    def precompute_obfuscators(self, count):
+        """Make `count` obfuscators r^n mod n^2 (fresh r from the OS CSPRNG) ahead of time and keep them in HBM.
+        encrypt_batch without r_values and EncryptedVector.obfuscate() then consume them — one product per element
+        instead of a modular exponentiation — and fall back to drawing on the spot when the pool is short.  Every
+        obfuscator is used once.  Returns the number available."""
+        return self._get_engine().fill_obfuscator_pool(int(count))
+
+    def obfuscators_available(self):
+        return self._get_engine().obfuscators_available()
+
     # ---- batched API ------------------------------------------------------------------------------
     def raw_encrypt_batch(self, plaintexts, r_values=None):
         """List of ints -> list of int ciphertexts; r_values=None draws fresh obfuscators."""
@@ -141,7 +152,13 @@ class PaillierPublicKey(object):
         else:
             m, exps = EncodedNumber.encode_many(self, values, precision)
         count = len(exps)
-        if fresh and isinstance(m, np.ndarray) and hasattr(eng.ctx, "encrypt_dev"):
+        obf = eng.take_obfuscators(count) if (fresh and isinstance(m, np.ndarray) and hasattr(eng.ctx, "encrypt_dev")) else None
+        if obf is not None:
+            # online part only: (1 + n m) * r^n with r^n from the pool made by precompute_obfuscators (each used once)
+            limbs = eng.add_plain_dev(obf, m)
+            if not device:
+                limbs = limbs.to_host()
+        elif fresh and isinstance(m, np.ndarray) and hasattr(eng.ctx, "encrypt_dev"):
             limbs = eng.raw_encrypt_fresh(m, device)
         else:
             r = random_lt_n_limbs(self.n, count, eng.n_limbs) if fresh else list(r_values)

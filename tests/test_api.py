@@ -409,3 +409,40 @@ def test_vector_obfuscation_draws_only_for_rows_that_need_it(device):
     nude = np.array(full.to_host()._limbs)
     assert not (np.array(full.obfuscate().to_host()._limbs) == nude).all(axis=1).any()
     assert priv.decrypt_batch(full) == vals[:k].tolist()
+
+
+@pytest.mark.gpu
+def test_obfuscator_pool_offline_online_split():
+    """precompute_obfuscators: r^n made ahead of time; encrypt_batch / obfuscate then cost one product per element and
+    give exactly raw_encrypt(m, r) for the pooled r^n; every obfuscator is consumed once; a short pool falls back"""
+    from phe import _native
+    g = load_golden(1024)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    nsq = pub.nsquare
+    vals = np.arange(3000, dtype=np.int64) - 1500
+    assert pub.obfuscators_available() == 0
+    assert pub.precompute_obfuscators(3000) == 3000
+    eng = pub._get_engine()
+    first = _native.limbs_to_ints(eng._obf_pool[0][0].rows_view(0, 4).to_host())
+    assert all(1 < f < nsq for f in first) and len(set(first)) == 4
+    vec = pub.encrypt_batch(vals[:1000], device=True)
+    assert pub.obfuscators_available() == 2000 and all(vec._obfuscated) and vec.on_device
+    for c, m, f in zip(vec.ciphertexts(False)[:4], vals[:4].tolist(), first):
+        assert c == (1 + pub.n * (m % pub.n)) % nsq * f % nsq            # = raw_encrypt(m, r) for the pooled r^n
+    assert priv.decrypt_batch(vec) == vals[:1000].tolist()
+    host = pub.encrypt_batch(vals[:500].astype(np.float64))
+    assert pub.obfuscators_available() == 1500 and not host.on_device
+    assert priv.decrypt_batch(host) == vals[:500].astype(np.float64).tolist()
+    big = pub.encrypt_batch(vals[:2000], device=True)                     # more than the pool holds: drawn on the spot
+    assert pub.obfuscators_available() == 1500 and priv.decrypt_batch(big) == vals[:2000].tolist()
+    un = pub.encrypt_batch(vals[:1500], r_values=[1] * 1500, device=True)
+    nude = un.ciphertexts(False)
+    un.obfuscate()
+    assert pub.obfuscators_available() == 0 and all(un._obfuscated)
+    assert all(a != b for a, b in zip(nude, un.ciphertexts(False))) and priv.decrypt_batch(un) == vals[:1500].tolist()
+    pub.precompute_obfuscators(100)
+    pub.precompute_obfuscators(100)
+    mixed = pub.encrypt_batch(vals[:150], device=True)                     # spans two pool blocks
+    assert pub.obfuscators_available() == 50 and priv.decrypt_batch(mixed) == vals[:150].tolist()
+    assert len(set(mixed.ciphertexts(False))) == 150

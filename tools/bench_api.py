@@ -37,5 +37,11 @@ dot = timed("vec.dot(w) (device)", lambda: vec.dot(w))
 back = timed("decrypt_batch (device vector)", lambda: priv.decrypt_batch(vec))
 hvec = timed("encrypt_batch(float64, host arrays)", lambda: pub.encrypt_batch(x))
 timed("decrypt_batch (host vector)", lambda: priv.decrypt_batch(hvec))
+t0 = time.perf_counter()
+pub.precompute_obfuscators(2 * B)
+res["precompute_obfuscators (offline)"] = {"seconds": time.perf_counter() - t0, "per_s": 2 * B / (time.perf_counter() - t0)}
+pvec = timed("encrypt_batch from the obfuscator pool (online, device=True)", lambda: pub.encrypt_batch(x, device=True))
+phost = timed("encrypt_batch from the obfuscator pool (online, host arrays)", lambda: pub.encrypt_batch(x))
+res["pool_roundtrip"] = priv.decrypt_batch(pvec) == x.tolist() and priv.decrypt_batch(phost) == x.tolist()
 res["checks"] = {"roundtrip": back == x.tolist(), "dot_close": bool(abs(priv.decrypt(dot) - float(x @ w)) < 1e-6 * B)}
 print(json.dumps(res))
