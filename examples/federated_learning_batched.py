@@ -61,10 +61,18 @@ class Hospital:
         return float(np.mean((X_test @ self.w - y_test) ** 2))
 
 
-def run(key_length=2048, n_rounds=N_ROUNDS, verbose=True):
+def run(key_length=2048, n_rounds=N_ROUNDS, verbose=True, precompute=False):
+    """precompute=True: the obfuscators r^n of every encryption of the run are made ahead of time in ONE launch
+    (PaillierPublicKey.precompute_obfuscators: the offline half of Paillier encryption); the rounds then only pay the
+    online product per gradient entry.  The decrypted aggregates — hence the models — are the same either way."""
     parts, X_test, y_test = load_split(N_HOSPITALS)
     public_key, private_key = paillier.generate_paillier_keypair(n_length=key_length)
     hospitals = [Hospital(X, y, public_key) for X, y in parts]
+    if precompute and hasattr(public_key, "precompute_obfuscators") and hasattr(public_key._get_engine().ctx, "encrypt_dev"):
+        t_off = time.perf_counter()
+        public_key.precompute_obfuscators(n_rounds * len(hospitals) * parts[0][0].shape[1])
+        if verbose:
+            print("offline: %d obfuscators in %.3f s" % (public_key.obfuscators_available(), time.perf_counter() - t_off))
     t0 = time.perf_counter()
     for _ in range(n_rounds):
         total = hospitals[0].encrypted_gradient()
@@ -98,3 +106,4 @@ if __name__ == "__main__":
     bits = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
     print("local-only test MSE:", ", ".join("%.2f" % e for e in local_only()))
     run(bits)
+    run(bits, precompute=True)
