@@ -298,6 +298,10 @@ struct phe_hip_ctx {
     uint32_t* scratch = nullptr;  // decrypt intermediates x_p | x_q
     size_t scratch_words = 0;
     unsigned long long* flags = nullptr;  // radix conversion: first offending row per error kind (2 words)
+    uint32_t* table2 = nullptr;  // window tables of the q half when the two halves of a small decrypt run concurrently
+    size_t table2_words = 0;
+    hipStream_t aux_stream = nullptr;  // created on first use
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t* lookup = nullptr;  // multi-exponentiation: the 2^w-ary tables of a whole vector (phe_hip_multiexp_csr_dev)
     size_t lookup_words = 0;
     uint32_t* partial = nullptr;  // multi-exponentiation: one product per chunk, joined in place by a k_mulmod tree
@@ -449,13 +453,14 @@ static int chunks_for(int limbs32, int H) { return std::max(1, (32 * limbs32 + 2
 template <int MODE>
 static int launch_split(phe_hip_ctx* ctx, const DevSplit& M, const DevSchedule& E, const uint32_t* base, int base_limbs,
                         const uint32_t* post, int post_limbs, uint32_t* out, int out_limbs, size_t batch,
-                        hipStream_t stream) {
+                        hipStream_t stream, bool second_table = false) {
     int per_cu = ctx->blocks_per_cu;
     if (per_cu == 0) per_cu = PHE_SPLIT_BY_GROUP(M.G, occ_split(M.L, MODE));
     if (per_cu < 0) return fail(PHE_HIP_EINVAL, "unsupported split geometry");
     const int blocks = grid_blocks(ctx, batch, M.G, per_cu);
     const size_t rows = (size_t)blocks * (size_t)(kBlock / M.G);
-    int rc = ensure_words(&ctx->table, &ctx->table_words, rows * (size_t)E.tbl_entries * 2 * M.H);
+    uint32_t** tbl = second_table ? &ctx->table2 : &ctx->table;
+    int rc = ensure_words(tbl, second_table ? &ctx->table2_words : &ctx->table_words, rows * (size_t)E.tbl_entries * 2 * M.H);
     if (rc) return rc;
     SplitArgs A;
     A.mod = M.c;
@@ -471,7 +476,7 @@ static int launch_split(phe_hip_ctx* ctx, const DevSplit& M, const DevSchedule& 
     A.post_chunks = chunks_for(post_limbs, M.H);
     A.out = out;
     A.out_limbs = out_limbs;
-    A.table = ctx->table;
+    A.table = *tbl;
     A.batch = batch;
     if (PHE_SPLIT_BY_GROUP(M.G, launch_split(M.L, MODE, blocks, stream, A)) < 0)
         return fail(PHE_HIP_EINVAL, "unsupported split geometry");
@@ -738,10 +743,13 @@ void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
                         ctx->d_psplit_lat.blob, ctx->d_qsplit_lat.blob,
                         ctx->d_nsq_lat.blob, ctx->d_psq_lat.blob, ctx->d_qsq_lat.blob,
                         ctx->d_nsq.blob, ctx->d_psq.blob, ctx->d_qsq.blob, ctx->d_exp_n.ops, ctx->d_exp_p.ops,
-                        ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->scratch, ctx->partial, ctx->lookup, (uint32_t*)ctx->flags, ctx->stage[0],
+                        ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->table2, ctx->scratch, ctx->partial, ctx->lookup, (uint32_t*)ctx->flags, ctx->stage[0],
                         ctx->stage[1], ctx->stage[2]};
     for (uint32_t* b : bufs)
         if (b) (void)hipFree(b);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     delete ctx;
 }
 
@@ -818,6 +826,24 @@ int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t
     const bool lat = ctx->has_lat_priv && small_batch(ctx, batch);
     const DevSplit& sp_p = lat ? ctx->d_psplit_lat : ctx->d_psplit;
     const DevSplit& sp_q = lat ? ctx->d_qsplit_lat : ctx->d_qsplit;
+    if (lat && ctx->use_split && sp_p.G && sp_q.G) {
+        // a small batch cannot fill the GPU and each half is a chain of ~key_bits/2 dependent squarings: run the two
+        // halves side by side (the q half on an internal stream with its own window tables), join before the tail
+        if (!ctx->aux_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+        }
+        // size both table buffers before anything is in flight (growing one synchronises the device)
+        HIP_TRY(hipEventRecord(ctx->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+        rc = launch_split<kModeHalfDecrypt>(ctx, sp_q, ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0, xq, S, batch, ctx->aux_stream, true);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->aux_stream));
+        rc = launch_split<kModeHalfDecrypt>(ctx, sp_p, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0, xp, S, batch, st);
+        if (rc) return rc;
+        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
+    } else {
     if (ctx->use_split && sp_p.G)
         rc = launch_split<kModeHalfDecrypt>(ctx, sp_p, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0, xp, S, batch, st);
     else
@@ -830,6 +856,7 @@ int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t
         rc = launch_uniform<kModeHalfDecrypt>(ctx, lat ? ctx->d_qsq_lat : ctx->d_qsq, ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0,
                                               xq, S, batch, st);
     if (rc) return rc;
+    }
     TailArgs T;
     T.k = ctx->d_tail.k;
     T.xp = xp;

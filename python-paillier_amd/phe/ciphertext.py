@@ -78,8 +78,13 @@ class EncryptedNumber(object):
     def obfuscate(self):
         pk = self.public_key
         eng = pk._get_engine()
-        r = pk.get_random_lt_n()
-        self.__ciphertext = eng.to_ints(eng.obfuscate([self.__ciphertext % pk.nsquare], [r]))[0]
+        pooled = eng.take_obfuscators(1) if hasattr(eng.ctx, "encrypt_dev") else None
+        if pooled is not None:
+            # an obfuscator r^n made ahead of time (PaillierPublicKey.precompute_obfuscators), used once: one product
+            self.__ciphertext = eng.to_ints(eng.raw_add([self.__ciphertext % pk.nsquare], pooled.to_host()))[0]
+        else:
+            r = pk.get_random_lt_n()
+            self.__ciphertext = eng.to_ints(eng.obfuscate([self.__ciphertext % pk.nsquare], [r]))[0]
         self.__is_obfuscated = True
 
     # ---- addition -----------------------------------------------------------------------------------

@@ -108,6 +108,16 @@ class PaillierPublicKey(object):
         if r_value is None:
             # fresh obfuscator: one fused launch (1 + n*m) * r^n, flagged obfuscated like
             # encrypt_encoded + obfuscate() in the reference (phe/paillier.py:189-193)
+            eng = self._get_engine()
+            obf = eng.take_obfuscators(1) if hasattr(eng.ctx, "encrypt_dev") else None
+            if obf is not None:
+                # an obfuscator made ahead of time (precompute_obfuscators), used once: r^n * (1 + n m), one small launch
+                if not isinstance(encoding.encoding, int):
+                    raise TypeError('Expected int type plaintext but got: %s' % type(encoding.encoding))
+                limbs = eng.add_plain_dev(obf, eng.plain_limbs([encoding.encoding % self.n]))
+                number = EncryptedNumber(self, eng.to_ints(limbs.to_host())[0], encoding.exponent)
+                number._EncryptedNumber__is_obfuscated = True
+                return number
             c = self.raw_encrypt(encoding.encoding, self.get_random_lt_n())
             number = EncryptedNumber(self, c, encoding.exponent)
             number._EncryptedNumber__is_obfuscated = True

@@ -441,6 +441,15 @@ def test_obfuscator_pool_offline_online_split():
     un.obfuscate()
     assert pub.obfuscators_available() == 0 and all(un._obfuscated)
     assert all(a != b for a, b in zip(nude, un.ciphertexts(False))) and priv.decrypt_batch(un) == vals[:1500].tolist()
+    pub.precompute_obfuscators(3)
+    peek = _native.limbs_to_ints(eng._obf_pool[0][0].rows_view(0, 1).to_host())[0]
+    one = pub.encrypt(2.5)                                                 # scalar API: obfuscate() takes from the pool too
+    nude = pub.encrypt(2.5, r_value=1)
+    assert pub.obfuscators_available() == 2 and one.ciphertext(False) == nude.ciphertext(False) * peek % nsq
+    assert priv.decrypt(one) == 2.5 and one._EncryptedNumber__is_obfuscated
+    (one + one).ciphertext()                                               # be_secure: another pooled obfuscator
+    assert pub.obfuscators_available() == 1
+    pub._get_engine().take_obfuscators(1)
     pub.precompute_obfuscators(100)
     pub.precompute_obfuscators(100)
     mixed = pub.encrypt_batch(vals[:150], device=True)                     # spans two pool blocks
