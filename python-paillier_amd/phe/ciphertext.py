@@ -352,6 +352,14 @@ class EncryptedVector(object):
                 plain = EncodedNumber.signed_to_limbs(pk, mag << shift.astype(np.uint64), neg, eng.n_limbs)
                 limbs = eng.add_plain_dev(a._limbs, plain) if self.on_device else eng.add_plain(a._limbs, plain)
                 return self._like(limbs, target)
+            if int((bits + shift).max()) < min(pk.max_int.bit_length(), 32 * (eng.n_limbs - 1)):
+                # wider than 64 bits after the shift (the plaintext's exponent is well above the ciphertext's):
+                # the shifted mantissas as limb rows, n - value for the negative ones — still no Python integer per row
+                a = self.decrease_exponent_to(target)
+                wide, _ = eng.shifted_limbs(mag, shift)
+                plain = EncodedNumber.signed_limbs_to_plain(pk, wide, neg, eng.n_limbs)
+                limbs = eng.add_plain_dev(a._limbs, plain) if self.on_device else eng.add_plain(a._limbs, plain)
+                return self._like(limbs, target)
         values = values.tolist() if isinstance(values, np.ndarray) else values
         encs, exps = [], []
         for v, e in zip(values, self.exponents):

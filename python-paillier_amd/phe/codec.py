@@ -178,6 +178,29 @@ class EncodedNumber(object):
             out[i] = np.frombuffer((n - int(mag[i])).to_bytes(4 * n_limbs, "little"), dtype=np.uint32)
         return out
 
+    @staticmethod
+    def signed_limbs_to_plain(public_key, mag_limbs, neg, n_limbs):
+        """(-1)^neg * value mod n for magnitudes given as (len, w) little-endian uint32 rows (w < n_limbs, every
+        value <= max_int: the caller has checked the bit lengths) -> (len, n_limbs) rows: value, or n - value."""
+        mag_limbs = np.ascontiguousarray(mag_limbs, dtype=np.uint32)
+        count, w = mag_limbs.shape
+        out = np.zeros((count, n_limbs), dtype=np.uint32)
+        out[:, :w] = mag_limbs
+        rows = np.nonzero(np.asarray(neg, dtype=bool) & mag_limbs.any(axis=1))[0]
+        if len(rows):
+            n_arr = np.frombuffer(public_key.n.to_bytes(4 * n_limbs, "little"), dtype=np.uint32).astype(np.int64)
+            res = np.broadcast_to(n_arr, (len(rows), n_limbs)).copy()
+            res[:, :w] -= mag_limbs[rows].astype(np.int64)
+            borrow = np.zeros(len(rows), dtype=np.int64)
+            for j in range(n_limbs):                              # the borrow dies out right above the magnitude's limbs
+                col = res[:, j] - borrow
+                borrow = (col < 0).astype(np.int64)
+                res[:, j] = col + (borrow << 32)
+                if j >= w and not borrow.any():
+                    break
+            out[rows] = res.astype(np.uint32)
+        return out
+
     @classmethod
     def decode_limbs(cls, public_key, limbs, exponents):
         """Plaintext rows (len, n_limbs) + exponents -> list of numbers, element-wise identical to

@@ -294,6 +294,32 @@ def test_encrypted_vector(keys):
     assert [priv.decrypt(x) for x in singles_rec] == vals.tolist()
 
 
+def test_plaintext_array_with_much_larger_exponents_adds_like_the_scalar_path(backend):
+    """vec + ndarray where the plaintexts' natural exponents sit far above the ciphertexts': the shifted mantissas exceed
+    64 bits and are formed as limb rows (codec.signed_limbs_to_plain) — bit for bit EncryptedNumber.__add__ per element"""
+    import random
+    from phe import _native
+    from phe.codec import EncodedNumber
+    g = load_golden(1024)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    rng = np.random.default_rng(3)
+    x = rng.random(12) * 1e-6
+    w = rng.standard_normal(12) * 1e3
+    w[0], w[1] = 0.0, -1e3
+    vec = pub.encrypt_batch(x, r_values=[int(v) for v in rng.integers(2, 1 << 60, 12)])
+    out = vec + w
+    for i, single in enumerate(vec.to_numbers()):
+        ref = single + float(w[i])
+        assert (out[i].ciphertext(False), out[i].exponent) == (ref.ciphertext(False), ref.exponent), i
+    assert np.allclose(priv.decrypt_batch(out), x + w)
+    r = random.Random(1)
+    vals = [r.getrandbits(r.choice([1, 40, 64, 65, 100, 130])) for _ in range(200)] + [0, 1, (1 << 64) - 1, 1 << 64, 1 << 96]
+    neg = np.array([r.random() < 0.5 for _ in vals])
+    got = EncodedNumber.signed_limbs_to_plain(pub, _native.ints_to_limbs(vals, 5), neg, 32)
+    assert _native.limbs_to_ints(got) == [(pub.n - v) if (s and v) else v for v, s in zip(vals, neg)]
+
+
 def test_array_operands_take_the_same_path_as_lists(keys):
     """numpy operands are encoded without a Python integer per element (codec array forms); the ciphertext bits must
     be the ones the element-by-element path produces."""
