@@ -404,6 +404,8 @@ class EncryptedVector(object):
     def __sub__(self, other):
         if isinstance(other, EncryptedVector):
             return self + (other * -1)
+        if isinstance(other, np.ndarray) and other.dtype.kind in "fi":
+            return self + (-other)                                # stays on the array path of __add__
         if isinstance(other, (list, tuple, np.ndarray)):
             return self + [-v for v in (other.tolist() if isinstance(other, np.ndarray) else other)]
         return self + (-other)
