@@ -129,7 +129,20 @@ class EncodedNumber(object):
         value = (-1)^negative * magnitude * BASE^exponent, element-wise the int_rep / exponent `encode` picks
         (phe/encoding.py:160-199).  None when the array form does not apply (other dtypes, precision / max_exponent
         given, BASE not a power of two): the caller then encodes element by element."""
-        if not isinstance(values, np.ndarray) or precision is not None or max_exponent is not None:
+        if precision is not None or max_exponent is not None:
+            return None
+        if isinstance(values, (list, tuple)) and len(values):
+            # a homogeneous list of Python floats, or of Python ints that fit int64, encodes like the array of the same
+            # dtype (mixed lists do not: an int and the float of the same value get different exponents)
+            kind = type(values[0])
+            if kind is float and all(type(v) is float for v in values):
+                values = np.array(values, dtype=np.float64)
+            elif kind is int and all(type(v) is int for v in values):
+                try:
+                    values = np.array(values, dtype=np.int64)
+                except OverflowError:
+                    return None
+        if not isinstance(values, np.ndarray):
             return None
         log2b = int(round(cls.LOG2_BASE))
         if (1 << log2b) != cls.BASE or log2b + cls.FLOAT_MANTISSA_BITS > 62:

@@ -47,8 +47,14 @@ def test_encode_arrays_equal_scalar_encode(pk):
         assert not exps.any()
         got = _native.limbs_to_ints(E.signed_to_limbs(pk, mag, neg, 64))
         assert got == [E.encode(pk, int(v)).encoding for v in arr.tolist()]
-    # what the array form declines (the caller then encodes element by element)
-    assert E.encode_signed([1.0, 2.0]) is None and E.encode_signed(x, precision=1e-3) is None
+    # homogeneous Python lists encode like the array of the same dtype; what the array form declines (mixed lists:
+    # an int and the float of the same value get different exponents; precision / max_exponent) goes element by element
+    for lst in ([1.0, -2.5, 1e-9, 0.0], [3, -4, 0, 2 ** 62]):
+        mag, neg, exps = E.encode_signed(lst)
+        got = _native.limbs_to_ints(E.signed_to_limbs(pk, mag, neg, 64))
+        assert [(E.encode(pk, v).encoding, E.encode(pk, v).exponent) for v in lst] == list(zip(got, exps.tolist()))
+    assert E.encode_signed([1, 2.0]) is None and E.encode_signed([2 ** 70, 1]) is None and E.encode_signed([True, False]) is None
+    assert E.encode_signed([np.float64(1.0), 2.0]) is None and E.encode_signed(x, precision=1e-3) is None
     assert E.encode_signed(np.array([1.0, 2.0], dtype=np.float32)) is None and E.encode_signed(x, max_exponent=-3) is None
     with pytest.raises(ValueError):
         E.encode_signed(np.array([1.0, np.inf]))
