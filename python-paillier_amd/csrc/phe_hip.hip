@@ -844,18 +844,18 @@ int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t
         if (rc) return rc;
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
     } else {
-    if (ctx->use_split && sp_p.G)
-        rc = launch_split<kModeHalfDecrypt>(ctx, sp_p, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0, xp, S, batch, st);
-    else
-        rc = launch_uniform<kModeHalfDecrypt>(ctx, lat ? ctx->d_psq_lat : ctx->d_psq, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0,
-                                              xp, S, batch, st);
-    if (rc) return rc;
-    if (ctx->use_split && sp_q.G)
-        rc = launch_split<kModeHalfDecrypt>(ctx, sp_q, ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0, xq, S, batch, st);
-    else
-        rc = launch_uniform<kModeHalfDecrypt>(ctx, lat ? ctx->d_qsq_lat : ctx->d_qsq, ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0,
-                                              xq, S, batch, st);
-    if (rc) return rc;
+        if (ctx->use_split && sp_p.G)
+            rc = launch_split<kModeHalfDecrypt>(ctx, sp_p, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0, xp, S, batch, st);
+        else
+            rc = launch_uniform<kModeHalfDecrypt>(ctx, lat ? ctx->d_psq_lat : ctx->d_psq, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0,
+                                                  xp, S, batch, st);
+        if (rc) return rc;
+        if (ctx->use_split && sp_q.G)
+            rc = launch_split<kModeHalfDecrypt>(ctx, sp_q, ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0, xq, S, batch, st);
+        else
+            rc = launch_uniform<kModeHalfDecrypt>(ctx, lat ? ctx->d_qsq_lat : ctx->d_qsq, ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0,
+                                                  xq, S, batch, st);
+        if (rc) return rc;
     }
     TailArgs T;
     T.k = ctx->d_tail.k;
