@@ -803,9 +803,20 @@ int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t
     if (batch == 0) return PHE_HIP_OK;
     if (!c_in || !r || !c_out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
-    if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G)
+    if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G) {
+        if (c_in != c_out && !getenv("PHE_HIP_FUSED_OBFUSCATE")) {
+            // r^n with the encrypt instantiation (no plaintext factor), then one k_mulmod by the ciphertext: the fused
+            // kModeObfuscate instantiation spills inside its ladder (PMC: 94 KB written per element against 20 KB) and
+            // runs ~5 % slower than encrypt for 0.2 % more arithmetic (profiles/r01p_rocprofv3_pmc_ops.txt)
+            int rc = launch_split<kModeEncrypt>(ctx, sp, ctx->d_exp_n, r, ctx->pub.s1, nullptr, ctx->pub.s1, c_out, ctx->pub.s2,
+                                                batch, (hipStream_t)stream);
+            if (rc) return rc;
+            const size_t s2 = (size_t)ctx->pub.s2;
+            return launch_mul(ctx, pick_nsq(ctx, batch), c_out, s2, c_in, s2, c_out, s2, ctx->pub.s2, batch, (hipStream_t)stream);
+        }
         return launch_split<kModeObfuscate>(ctx, sp, ctx->d_exp_n, r, ctx->pub.s1, c_in, ctx->pub.s2, c_out, ctx->pub.s2,
                                             batch, (hipStream_t)stream);
+    }
     return launch_uniform<kModeObfuscate>(ctx, pick_nsq(ctx, batch), ctx->d_exp_n, r, ctx->pub.s1, c_in, ctx->pub.s2, c_out,
                                           ctx->pub.s2, batch, (hipStream_t)stream);
 }

@@ -565,7 +565,8 @@ PHE_DEV void modexp_split_body(const SplitArgs& A, uint32_t* lds_row, uint32_t s
         // ---- the op's final factor and the way out of the pair representation --------------------------------
         const uint32_t* mp = nullptr;
         if (MODE == kModeEncrypt) {
-            mp = A.post + item * (uint64_t)A.post_limbs;  // nude ciphertext 1 + n*m folded into split_exit
+            // nude ciphertext 1 + n*m folded into split_exit (no plaintexts given: the bare power base^e)
+            mp = A.post ? A.post + item * (uint64_t)A.post_limbs : nullptr;
         } else if (MODE == kModeObfuscate) {
             split_conv<G, L>(Y0, Y1, A.post + item * (uint64_t)A.post_limbs, A.post_limbs, A.post_chunks, A.mod, K, ln);
             split_mul<G, L>(X0, X1, Y0, Y1, K, ln);

@@ -238,3 +238,19 @@ def test_other_key_sizes_roundtrip(native, c_oracle, key_bits):
     c = ctx.encrypt(m, r)
     assert np.array_equal(c, c_oracle.encrypt(native.int_to_limbs(n_int, s1), m, r, nthreads=8))
     assert np.array_equal(ctx.decrypt(c), m)
+
+
+def test_obfuscate_composed_and_fused_forms_agree(native, c_oracle, monkeypatch):
+    """phe_hip_obfuscate: r^n by the encrypt instantiation followed by one k_mulmod (default) and the fused
+    kModeObfuscate instantiation (PHE_HIP_FUSED_OBFUSCATE, and in-place calls) give the oracle's bits"""
+    g = load_golden(2048)
+    n_int = H(g["n"])
+    n = native.int_to_limbs(n_int, 64)
+    ctx = make_ctx(native, g, private=False)
+    rng = random.Random(77)
+    c = native.ints_to_limbs([rng.randrange(1, n_int * n_int) for _ in range(70)], 128)
+    r = native.ints_to_limbs([rng.randrange(1, n_int) for _ in range(70)], 64)
+    want = c_oracle.obfuscate(n, c, r, nthreads=8)
+    assert np.array_equal(ctx.obfuscate(c, r), want)
+    monkeypatch.setenv("PHE_HIP_FUSED_OBFUSCATE", "1")
+    assert np.array_equal(ctx.obfuscate(c, r), want)
