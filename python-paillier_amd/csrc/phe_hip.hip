@@ -806,8 +806,8 @@ int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t
     if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G) {
         if (c_in != c_out && !getenv("PHE_HIP_FUSED_OBFUSCATE")) {
             // r^n with the encrypt instantiation (no plaintext factor), then one k_mulmod by the ciphertext: the fused
-            // kModeObfuscate instantiation spills inside its ladder (PMC: 94 KB written per element against 20 KB) and
-            // runs ~5 % slower than encrypt for 0.2 % more arithmetic (profiles/r01p_rocprofv3_pmc_ops.txt)
+            // kModeObfuscate instantiation spills more (PMC: 94 KB written per element against 20 KB,
+            // profiles/r01p_rocprofv3_pmc_ops.txt) and measured 559.7 k/s against 566.6 k/s for this form on the same box
             int rc = launch_split<kModeEncrypt>(ctx, sp, ctx->d_exp_n, r, ctx->pub.s1, nullptr, ctx->pub.s1, c_out, ctx->pub.s2,
                                                 batch, (hipStream_t)stream);
             if (rc) return rc;
