@@ -439,18 +439,29 @@ class Engine:
         count = m.shape[0]
         st = self._launch_stream()
         out = DeviceArray(self.ctx, count, self.ct_limbs)
+        host = None if device else np.empty((count, self.ct_limbs), dtype=np.uint32)
         keep = []                                         # operand buffers stay alive until the final sync
-        lo, chunk = 0, 1 << 15                            # chunks are multiples of the groups in flight (32768 at 2048 bits)
+        lo, chunk, prev = 0, 1 << 15, None                # chunks are multiples of the groups in flight (32768 at 2048 bits)
         while lo < count:
             hi = min(count, lo + chunk)
             r = random_lt_n_limbs(self.n, hi - lo, self.n_limbs, out=self.scratch("r", hi - lo, self.n_limbs))
             m_d = DeviceArray.from_host(self.ctx, m[lo:hi])
             r_d = DeviceArray.from_host(self.ctx, r)      # synchronous copy: the scratch buffer is free again
             keep += [m_d, r_d]
+            if host is not None and st:
+                self.ctx.sync(st)                         # the previous chunk is complete (its successor starts right away)
             self.ctx.encrypt_dev(m_d.ptr, r_d.ptr, out.rows_view(lo, hi).ptr, hi - lo, st)
+            if host is not None and st and prev is not None:
+                self.ctx.d2h(host[prev[0]:prev[1]], out.rows_view(*prev).ptr)     # download under this chunk's kernel
+            prev = (lo, hi)
             lo, chunk = hi, 1 << 16
         self.ctx.sync(st)
-        return out if device else out.to_host()
+        if host is None:
+            return out
+        if st and prev is not None:
+            self.ctx.d2h(host[prev[0]:prev[1]], out.rows_view(*prev).ptr)
+            return host
+        return out.to_host()
 
     # ---- offline / online split: obfuscators r^n mod n^2 made ahead of time -------------------------------------------
     # r^n is the expensive factor of an encryption and does not depend on the plaintext (phe/paillier.py:137 draws r
@@ -559,6 +570,38 @@ class Engine:
             nxt = launch(hi) if hi < rows else hi
             yield lo, hi, out.rows_view(lo, hi).to_host()
             lo, hi = hi, nxt
+
+    def raw_decrypt_host_chunks(self, c, chunk=1 << 16):
+        """raw_decrypt_dev_chunks for a HOST limb array: the upload of chunk k+1 and the download + decoding of chunk k
+        both happen while kernels run (uploads and downloads are blocking copies on the NULL stream, the kernels are
+        queued on the engine's non-blocking stream)."""
+        st = self._launch_stream()
+        rows = c.shape[0]
+        if rows <= chunk or not st:
+            if rows:
+                yield 0, rows, self.raw_decrypt(c)
+            return
+        bounds = [(lo, min(rows, lo + chunk)) for lo in range(0, rows, chunk)]
+        inputs, outputs = {}, {}
+
+        def stage(k):
+            lo, hi = bounds[k]
+            inputs[k] = DeviceArray.from_host(self.ctx, c[lo:hi])
+            outputs[k] = DeviceArray(self.ctx, hi - lo, self.n_limbs)
+
+        def launch(k):
+            lo, hi = bounds[k]
+            self.ctx.decrypt_dev(inputs[k].ptr, outputs[k].ptr, hi - lo, st)
+        stage(0)
+        launch(0)
+        for k, (lo, hi) in enumerate(bounds):
+            if k + 1 < len(bounds):
+                stage(k + 1)                                     # upload under the kernels of chunk k
+            self.ctx.sync(st)                                    # chunk k is complete
+            if k + 1 < len(bounds):
+                launch(k + 1)
+            yield lo, hi, outputs.pop(k).to_host()               # download + the caller's decoding under chunk k+1
+            inputs.pop(k)
 
     def raw_add_dev(self, a, b):
         out = DeviceArray(self.ctx, a.rows, self.ct_limbs)

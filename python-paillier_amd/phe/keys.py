@@ -280,10 +280,13 @@ class PaillierPrivateKey(object):
             raise ValueError('encrypted_number was encrypted against a different key!')
         eng = self._get_engine()
         plain_decode = Encoding is None or Encoding is EncodedNumber
-        if vector.on_device:     # device pointers are valid across contexts of the same GPU
-            # chunks: the download and decoding of one chunk overlap the kernels of the next
+        if vector.on_device or hasattr(eng.ctx, "decrypt_dev"):
+            # chunks: the download and decoding of one chunk (and, for a host vector, the upload of the next) overlap
+            # the kernels; device pointers are valid across contexts of the same GPU
             out, exps = [], vector.exponent_array
-            for lo, hi, plain in eng.raw_decrypt_dev_chunks(vector.limbs(be_secure=False)):
+            limbs = vector.limbs(be_secure=False)
+            chunks = eng.raw_decrypt_dev_chunks(limbs) if vector.on_device else eng.raw_decrypt_host_chunks(limbs)
+            for lo, hi, plain in chunks:
                 if plain_decode:
                     out += EncodedNumber.decode_limbs(self.public_key, plain, exps[lo:hi])
                 else:
