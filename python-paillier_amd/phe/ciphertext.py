@@ -186,6 +186,31 @@ class EncryptedVector(object):
         eng = public_key._get_engine()
         return cls(public_key, eng.cipher_limbs(ciphertexts), exponents)
 
+    @classmethod
+    def concatenate(cls, vectors):
+        """One vector from several under the same key (e.g. the shards a batch was encrypted in): limbs, exponents and
+        obfuscation flags in order.  Resident if every part is resident (device-to-device copies), else on the host."""
+        vectors = list(vectors)
+        if not vectors:
+            raise ValueError("need at least one vector")
+        pk = vectors[0].public_key
+        if any(v.public_key != pk for v in vectors):
+            raise ValueError("vectors were encrypted against different public keys")
+        exps = np.concatenate([v._exps for v in vectors])
+        flags = np.concatenate([v._obfuscated for v in vectors])
+        if all(v.on_device for v in vectors):
+            eng = pk._get_engine()
+            out = DeviceArray(eng.ctx, len(exps), eng.ct_limbs)
+            lo = 0
+            for v in vectors:
+                if len(v):
+                    eng.ctx.d2d(out.ptr + lo * eng.ct_limbs * 4, v._limbs.ptr, v._limbs.nbytes)
+                lo += len(v)
+            eng.ctx.sync()
+            return cls(pk, out, exps, flags)
+        host = [v._limbs.to_host() if v.on_device else v._limbs for v in vectors]
+        return cls(pk, np.concatenate(host), exps, flags)
+
     def to_device(self):
         if self.on_device:
             return self

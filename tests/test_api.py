@@ -320,6 +320,24 @@ def test_plaintext_array_with_much_larger_exponents_adds_like_the_scalar_path(ba
     assert _native.limbs_to_ints(got) == [(pub.n - v) if (s and v) else v for v, s in zip(vals, neg)]
 
 
+def test_concatenate_vectors(keys):
+    g, pub, priv = keys
+    rs = [H(e["r"]) for e in g["raw_encrypt"][:6]]
+    a = pub.encrypt_batch(np.array([0.5, -1.25, 3.0]), r_values=rs[:3])
+    b = pub.encrypt_batch([7, -8], r_values=rs[3:5])
+    c = pub.encrypt_batch([1.5])                                         # fresh: obfuscated
+    whole = paillier.EncryptedVector.concatenate([a, b, a[:0], c])
+    assert len(whole) == 6 and whole.ciphertexts(False)[:5] == a.ciphertexts(False) + b.ciphertexts(False)
+    assert whole.exponents == a.exponents + b.exponents + c.exponents
+    assert whole._obfuscated.tolist() == [False] * 5 + [True]
+    assert priv.decrypt_batch(whole) == [0.5, -1.25, 3.0, 7, -8, 1.5]
+    other = paillier.PaillierPublicKey(H(load_golden(1024)["n"]))
+    with pytest.raises(ValueError):
+        paillier.EncryptedVector.concatenate([a, other.encrypt_batch([1], r_values=[1])])
+    with pytest.raises(ValueError):
+        paillier.EncryptedVector.concatenate([])
+
+
 def test_array_operands_take_the_same_path_as_lists(keys):
     """numpy operands are encoded without a Python integer per element (codec array forms); the ciphertext bits must
     be the ones the element-by-element path produces."""
@@ -386,6 +404,10 @@ def test_device_resident_vector_matches_host_vector():
     after = un.ciphertexts()                              # be_secure -> obfuscate_dev over the vector
     assert before != after and all(un._obfuscated) and priv.decrypt_batch(un) == [1, 2, 3]
     assert dev.to_host().ciphertexts(False) == host.ciphertexts(False)
+    joined = paillier.EncryptedVector.concatenate([dev[:10], dev[10:], dev[:3]])
+    assert joined.on_device and joined.ciphertexts(False) == host.ciphertexts(False) + host.ciphertexts(False)[:3]
+    mixed_join = paillier.EncryptedVector.concatenate([dev[:5], host[5:]])
+    assert not mixed_join.on_device and mixed_join.ciphertexts(False) == host.ciphertexts(False)
 
 
 @pytest.mark.gpu
