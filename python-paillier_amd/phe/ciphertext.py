@@ -78,7 +78,13 @@ class EncryptedNumber(object):
     def obfuscate(self):
         pk = self.public_key
         eng = pk._get_engine()
-        pooled = eng.take_obfuscators(1) if hasattr(eng.ctx, "encrypt_dev") else None
+        pooled = None
+        if hasattr(eng.ctx, "encrypt_dev"):
+            from . import keys
+            pooled = eng.take_obfuscators(1)
+            if pooled is None and keys.SCALAR_POOL_REFILL:
+                eng.fill_obfuscator_pool(keys.SCALAR_POOL_REFILL)          # see keys.SCALAR_POOL_REFILL
+                pooled = eng.take_obfuscators(1)
         if pooled is not None:
             # an obfuscator r^n made ahead of time (PaillierPublicKey.precompute_obfuscators), used once: one product
             self.__ciphertext = eng.to_ints(eng.raw_add([self.__ciphertext % pk.nsquare], pooled.to_host()))[0]

@@ -20,6 +20,9 @@ from ._engine import Engine, random_lt_n, random_lt_n_limbs
 from .codec import EncodedNumber
 
 DEFAULT_KEYSIZE = 3072
+# scalar encrypt() / obfuscate() refill the obfuscator pool with this many r^n per launch when it runs dry (0 = one
+# exponentiation per call, as the reference does): 4096 rows still fit the latency geometry of one launch
+SCALAR_POOL_REFILL = 4096
 
 
 def _gpu_prime_search_available():
@@ -109,7 +112,14 @@ class PaillierPublicKey(object):
             # fresh obfuscator: one fused launch (1 + n*m) * r^n, flagged obfuscated like
             # encrypt_encoded + obfuscate() in the reference (phe/paillier.py:189-193)
             eng = self._get_engine()
-            obf = eng.take_obfuscators(1) if hasattr(eng.ctx, "encrypt_dev") else None
+            obf = None
+            if hasattr(eng.ctx, "encrypt_dev"):
+                obf = eng.take_obfuscators(1)
+                if obf is None and SCALAR_POOL_REFILL:
+                    # one scalar encryption is one latency-bound exponentiation on an otherwise idle GPU: draw and
+                    # exponentiate a launch-full of obfuscators in the same ~time and keep the rest for the next calls
+                    eng.fill_obfuscator_pool(SCALAR_POOL_REFILL)
+                    obf = eng.take_obfuscators(1)
             if obf is not None:
                 # an obfuscator made ahead of time (precompute_obfuscators), used once: r^n * (1 + n m), one small launch
                 if not isinstance(encoding.encoding, int):

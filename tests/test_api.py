@@ -503,3 +503,25 @@ def test_obfuscator_pool_offline_online_split():
     mixed = pub.encrypt_batch(vals[:150], device=True)                     # spans two pool blocks
     assert pub.obfuscators_available() == 50 and priv.decrypt_batch(mixed) == vals[:150].tolist()
     assert len(set(mixed.ciphertexts(False))) == 150
+
+
+@pytest.mark.gpu
+def test_scalar_encrypt_refills_the_pool_by_the_launch(monkeypatch):
+    """pub.encrypt() with an empty pool exponentiates a launch-full of obfuscators instead of one (same latency on an idle
+    GPU) and serves the next calls from it; SCALAR_POOL_REFILL = 0 restores one exponentiation per call"""
+    from phe import keys
+    g = load_golden(1024)
+    monkeypatch.setattr(keys, "SCALAR_POOL_REFILL", 64)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    a = pub.encrypt(1.25)
+    assert pub.obfuscators_available() == 63 and a._EncryptedNumber__is_obfuscated and priv.decrypt(a) == 1.25
+    cts = {pub.encrypt(7).ciphertext(False) for _ in range(63)}
+    assert len(cts) == 63 and pub.obfuscators_available() == 0
+    b = pub.encrypt(7, r_value=1)
+    b.obfuscate()                                                          # refills as well
+    assert pub.obfuscators_available() == 63 and priv.decrypt(b) == 7
+    monkeypatch.setattr(keys, "SCALAR_POOL_REFILL", 0)
+    pub2 = paillier.PaillierPublicKey(H(g["n"]))
+    c = pub2.encrypt(-3)
+    assert pub2.obfuscators_available() == 0 and priv.decrypt(c) == -3
