@@ -262,7 +262,13 @@ class EncryptedVector(object):
             return self
         if r_values is None and hasattr(eng.ctx, "obfuscate_dev"):
             # fresh obfuscators as limb arrays straight from the CSPRNG (no Python integer per row)
-            pooled = eng.take_obfuscators(len(self)) if (self.on_device and len(rows) == len(self)) else None
+            pooled = None
+            if self.on_device and len(rows) == len(self):
+                from . import keys
+                pooled = eng.take_obfuscators(len(self))
+                if pooled is None and len(self) <= keys.SCALAR_POOL_REFILL // 4:
+                    eng.fill_obfuscator_pool(keys.SCALAR_POOL_REFILL)
+                    pooled = eng.take_obfuscators(len(self))
             if pooled is not None:
                 self._limbs = eng.raw_add_dev(self._limbs, pooled)       # c * r^n with r^n made ahead of time, used once
             elif self.on_device:

@@ -172,7 +172,12 @@ class PaillierPublicKey(object):
         else:
             m, exps = EncodedNumber.encode_many(self, values, precision)
         count = len(exps)
-        obf = eng.take_obfuscators(count) if (fresh and isinstance(m, np.ndarray) and hasattr(eng.ctx, "encrypt_dev")) else None
+        obf = None
+        if fresh and isinstance(m, np.ndarray) and hasattr(eng.ctx, "encrypt_dev"):
+            obf = eng.take_obfuscators(count)
+            if obf is None and 0 < count <= SCALAR_POOL_REFILL // 4:
+                eng.fill_obfuscator_pool(SCALAR_POOL_REFILL)       # a small batch is as latency-bound as a scalar call
+                obf = eng.take_obfuscators(count)
         if obf is not None:
             # online part only: (1 + n m) * r^n with r^n from the pool made by precompute_obfuscators (each used once)
             limbs = eng.add_plain_dev(obf, m)
