@@ -254,3 +254,32 @@ def test_obfuscate_composed_and_fused_forms_agree(native, c_oracle, monkeypatch)
     assert np.array_equal(ctx.obfuscate(c, r), want)
     monkeypatch.setenv("PHE_HIP_FUSED_OBFUSCATE", "1")
     assert np.array_equal(ctx.obfuscate(c, r), want)
+
+
+def test_argument_errors_come_back_as_status_codes(native):
+    """the C-ABI never throws: bad arguments are PHE_HIP_EINVAL (+ message) -> ValueError in the binding"""
+    g = load_golden(1024)
+    ctx = make_ctx(native, g, private=False)
+    lib = native.lib()
+    one = np.zeros((1, 64), np.uint32)
+    one[0, 0] = 1
+    d = ctx.malloc(4096)
+    try:
+        # a sign mask without inverted bases; CSR arrays that do not come together; null output
+        assert lib.phe_hip_multiexp_rows_dev(ctx._h, d, None, d, d, 1, 32, d, 1, 1, None) == native.EINVAL
+        assert b"inverted" in lib.phe_hip_last_error()
+        assert lib.phe_hip_multiexp_csr_dev(ctx._h, d, None, 1, d, None, d, None, 1, 32, None, d, 1, None) == native.EINVAL
+        assert lib.phe_hip_multiexp_dev(ctx._h, d, d, 1, 32, None, 1, None) == native.EINVAL
+        assert lib.phe_hip_to_decimal_dev(ctx._h, d, 0, d, 10, 1, None) == native.EINVAL
+        assert lib.phe_hip_decrypt_dev(ctx._h, d, d, 1, None) == native.EINVAL          # public context
+        assert b"private" in lib.phe_hip_last_error()
+        assert lib.phe_hip_encrypt_dev(None, d, d, d, 1, None) == native.EINVAL
+    finally:
+        ctx.free(d, 4096)
+    with pytest.raises(ValueError):
+        ctx.encrypt(np.zeros((2, 32), np.uint32), np.zeros((3, 32), np.uint32))          # batch sizes differ
+    with pytest.raises(ValueError):
+        native.miller_rabin(np.array([[9]], np.uint32), np.array([[8]], np.uint32))      # base > n - 2
+    # zero-length batches are fine everywhere
+    assert ctx.multiexp(np.zeros((0, 64), np.uint32), np.zeros((0, 1), np.uint32)).tolist() == one.tolist()
+    assert ctx.to_decimal(np.zeros((0, 64), np.uint32)).shape[0] == 0
