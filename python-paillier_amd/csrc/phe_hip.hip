@@ -940,12 +940,14 @@ static int multiexp_rows_impl(phe_hip_ctx* ctx, const uint32_t* base, const uint
         return fail(PHE_HIP_EINVAL, "the matrix form needs the split-modulus engine (call row by row on this key)");
     size_t chunk = 1, row_block = 1;
     if (split) {
-        // fill the resident groups of the throughput geometry first, then let chunks grow (cap 16: a group's tables
-        // are chunk * (2^w - 1) pairs) and rows share a task's tables
+        // fill the resident groups of the throughput geometry first, then let chunks grow (a group's tables are
+        // chunk * (2^w - 1) pairs) and rows share a task's tables
         int per_cu = ctx->blocks_per_cu;
         if (per_cu == 0) per_cu = PHE_SPLIT_BY_GROUP(ctx->d_nsplit.G, occ_multi_split(ctx->d_nsplit.L));
         const size_t resident = (size_t)ctx->n_cus * (size_t)std::max(1, per_cu) * (size_t)(kBlock / ctx->d_nsplit.G);
-        chunk = std::min<size_t>(std::min<size_t>(16, batch), std::max<size_t>(1, batch * rows / resident));
+        // (cap 32 once the batch offers two full rounds of 32-element chunks: +3.6 % measured at 2^20 elements)
+        const size_t cap = (batch * rows >= 64 * resident) ? 32 : 16;
+        chunk = std::min<size_t>(std::min<size_t>(cap, batch), std::max<size_t>(1, batch * rows / resident));
         if (const char* ev = getenv("PHE_HIP_MULTI_CHUNK")) {
             const int v = atoi(ev);
             if (v >= 1 && v <= 64) chunk = (size_t)v;
