@@ -3,7 +3,7 @@ whatever the inputs, the array forms must equal the element-by-element definitio
 import sys
 
 import numpy as np
-from hypothesis import given, settings, strategies as st
+from hypothesis import Phase, given, settings, strategies as st
 
 from conftest import PKG, load_golden
 
@@ -101,3 +101,45 @@ def test_miller_rabin_rows_equal_the_textbook_round(pairs):
         return False
     got = _emu().miller_rabin(_native.ints_to_limbs(ns, 2), _native.ints_to_limbs(bases, 2))
     assert got.tolist() == [spp(n, a) for n, a in zip(ns, bases)]
+
+
+# magnitudes a 256-bit test key can align (an exponent gap of more than ~60 makes BASE^gap exceed n: ValueError in the
+# scalar API and in the vector API alike)
+_finite = st.floats(allow_nan=False, allow_infinity=False, width=64, min_value=-1e6, max_value=1e6).filter(
+    lambda v: v == 0 or abs(v) > 1e-6)
+_scalar = st.one_of(_finite, st.integers(-10 ** 9, 10 ** 9))
+
+
+@settings(max_examples=12, deadline=None, phases=[Phase.explicit, Phase.reuse, Phase.generate])
+@given(st.lists(st.tuples(_finite, _scalar, _scalar), min_size=1, max_size=5), st.booleans())
+def test_vector_operators_equal_the_scalar_operators(rows, as_array):
+    """EncryptedVector +, -, *, dot on the emulator backend against EncryptedNumber's operators (the drop-in scalar API,
+    pinned to the reference by tests/test_api.py): same ciphertext bits, same exponents, element by element"""
+    import emu_backend
+    emu_backend.install()
+    from phe import paillier
+    g = load_golden(256)
+    pub = paillier.PaillierPublicKey(int(g["n"], 16))
+    xs = [r[0] for r in rows]
+    ws = [r[1] for r in rows]
+    vs = [r[2] for r in rows]
+    r_values = list(range(3, 3 + len(rows)))
+    vec = pub.encrypt_batch(np.array(xs), r_values=r_values)
+    singles = [pub.encrypt(float(x), r_value=r) for x, r in zip(xs, r_values)]
+    homogeneous = len({type(w) for w in ws}) == 1
+    w_operand = np.array(ws) if (as_array and homogeneous) else ws
+    v_operand = np.array(vs) if (as_array and len({type(v) for v in vs}) == 1) else vs
+
+    def same(vector, numbers):
+        assert vector.ciphertexts(False) == [x.ciphertext(False) for x in numbers]
+        assert vector.exponents == [x.exponent for x in numbers]
+    same(vec * w_operand, [s * w for s, w in zip(singles, ws)])
+    same(vec + v_operand, [s + v for s, v in zip(singles, vs)])
+    same(vec - v_operand, [s - v for s, v in zip(singles, vs)])
+    prod = vec * w_operand
+    same(vec + prod, [s + s * w for s, w in zip(singles, ws)])
+    chain = None
+    for s, w in zip(singles, ws):
+        chain = s * w if chain is None else chain + s * w
+    d = vec.dot(w_operand)
+    assert (d.ciphertext(False), d.exponent) == (chain.ciphertext(False), chain.exponent)
