@@ -235,6 +235,11 @@ class EncryptedVector(object):
         return len(self._exps)
 
     def __getitem__(self, i):
+        if isinstance(i, (list, np.ndarray)):
+            # index / boolean-mask selection like numpy's (a gather: the result lives on the host)
+            idx = np.asarray(i)
+            host = self._limbs.to_host() if self.on_device else self._limbs
+            return self._like(np.ascontiguousarray(host[idx]), self._exps[idx], self._obfuscated[idx])
         if isinstance(i, slice):
             lo, hi, step = i.indices(len(self))
             if self.on_device and step == 1:

@@ -331,6 +331,9 @@ def test_concatenate_vectors(keys):
     assert whole.exponents == a.exponents + b.exponents + c.exponents
     assert whole._obfuscated.tolist() == [False] * 5 + [True]
     assert priv.decrypt_batch(whole) == [0.5, -1.25, 3.0, 7, -8, 1.5]
+    picked = whole[[4, 0, 0]]
+    assert picked.ciphertexts(False) == [whole.ciphertexts(False)[k] for k in (4, 0, 0)] and picked.exponents == [0, a.exponents[0]] + [a.exponents[0]]
+    assert priv.decrypt_batch(whole[np.array([True, False, True, False, False, True])]) == [0.5, 3.0, 1.5]
     other = paillier.PaillierPublicKey(H(load_golden(1024)["n"]))
     with pytest.raises(ValueError):
         paillier.EncryptedVector.concatenate([a, other.encrypt_batch([1], r_values=[1])])
