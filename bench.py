@@ -1,29 +1,42 @@
 #!/usr/bin/env python3
-"""bench.py — BASELINE.json's metric on the config it is quoted on.
+"""bench.py — BASELINE.json's metric on the config it is quoted on, plus the other configs' legs.
 
 Metric : "Paillier 2048-bit encrypts/sec + decrypts/sec per node (bit-exact)"
 Config : configs[1] — 2048-bit key, 1M-plaintext batch encrypt + decrypt on 1 MI355X (per GPU; weak scaling).
 
-A "step" is one pass of raw_encrypt over the batch (`value` = encrypts/s, the number the >=10x target is
-stated in); the same K steps of raw_decrypt are timed as a second region and reported under "decrypt".
-Inputs (plaintexts m, obfuscators r, and for decrypt the ciphertexts) are resident in HBM before the
-timed region starts.  One process per GPU; N>1 is launched by torch.distributed.run and ranks only meet
-at the barriers (the batch is embarrassingly sharded: no data-path collective).
+    python bench.py --gpus N --steps K --warmup W
 
-Also printed in the same JSON line:
-  roofline     — dominant kernel (k_modexp_split<4,18,encrypt> at 2048 bits): algorithmic MAC32 (SURVEY.md 8(d):
-                 the canonical full-width Montgomery count) per launch / average launch duration measured with
-                 HIP events on the launch stream, against the integer-VALU peak calibrated by csrc/microbench.hip
-                 (profiles/microbench_*.json).  The split-modulus kernels execute fewer multiply-adds than that
-                 canonical count (csrc/split_core.h), so `frac` can exceed 1; `executed` gives the multiply-adds
-                 the kernel really issues and their fraction of the same peak.
-  cpu_baseline — the libgmp oracle (what gmpy2 executes) on all host cores over a bounded sample of the same
-                 workload, rank 0 at N=1 only.
+N > 1: one process per GPU.  Started by `torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in the environment) the
+script is a rank; started bare with --gpus N > 1 it re-launches ITSELF under `torch.distributed.run --nproc-per-node N`
+(127.0.0.1 rendezvous, backend nccl = RCCL), so both ways of calling it give N ranks and `n_gpus: N`.
+
+A "step" is one pass of raw_encrypt over the batch (`value` = encrypts/s, whole job); the same K steps of raw_decrypt
+are timed as a second region ("decrypt").  Operands are resident in HBM before every timed region.  Ranks only meet
+at the barriers (the batch is embarrassingly sharded: no data-path collective in configs[1]).
+
+The same JSON line also carries
+  ops          — configs[2]: _raw_add, _raw_mul by float-like 56-bit / int64 scalars and with 10 % negative scalars
+                 (the inverse branch of phe/paillier.py:745-749), obfuscate — each over the whole batch, with its own
+                 roofline entry and a strided sample checked against the libgmp oracle;
+  config4      — configs[3] (N > 1, or --config4): a 3072-bit key, one shard of 2^20 plaintexts per GPU (8M on 8 GPUs),
+                 the ciphertext shards concatenated on every GPU by ONE RCCL all-gather (phe.sharding.all_gather_rows);
+                 shard-boundary rows + a strided sample against the oracle;
+  roofline     — dominant kernel (k_modexp_split<4,18,encrypt>): `frac` = multiply-adds the kernel EXECUTES
+                 (v_mad_u64_u32 lane-operations, exact count from profiles/executed_mads_r*.json, cross-checked with the
+                 PMC SQ_INSTS_VALU of profiles/) per second / integer-VALU peak — a fraction of the hardware limit, <= 1.
+                 `canonical_frac` prices the same time with SURVEY.md 8(d)'s algorithmic MAC32 count (full-width
+                 Montgomery): the split-modulus kernels need fewer multiplies than that, so it exceeds `frac`.
+  cpu_baseline — the libgmp oracle (what gmpy2 executes) on all host cores over a bounded sample, rank 0 at N=1 only.
+
+`--selftest-emu` (CPU contract test only, tests/test_bench_contract.py): gloo + the CPU wave emulator of tests/emu on a
+256-bit key and a handful of rows, to check the launch / sharding / JSON plumbing without a GPU.  Not a measurement.
 """
 import argparse
 import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -36,21 +49,37 @@ for p in (ROOT, PKG):
 METRIC = "Paillier 2048-bit encrypts/sec + decrypts/sec per node (bit-exact)"
 
 
+# ---- bookkeeping (checked on CPU by tests/test_bench_contract.py) -------------------------------------------------
+def _E(t):
+    """modmuls of a t-bit exponentiation, canonical (t squarings, w = 5 sliding window, 16-entry table)"""
+    return t + -(-t // 6) + 16
+
+
+def _mont(s):
+    return 2 * s * s + s
+
+
 def mac32_counts(key_bits):
-    """Algorithmic multiply-accumulates per op, exactly SURVEY.md 8(d)."""
+    """Algorithmic multiply-accumulates per encrypt / decrypt, exactly SURVEY.md 8(d)."""
     s2, s1, sh = key_bits // 16, key_bits // 32, key_bits // 64
-    mont = lambda s: 2 * s * s + s
-    E = lambda t: t + -(-t // 6) + 16
-    enc = s1 * s1 + (E(key_bits) + 3) * mont(s2)
-    dec = 2 * mont(s1) + 2 * (E(key_bits // 2) + 2) * mont(s1) + 3 * sh * sh + 4 * mont(sh)
+    enc = s1 * s1 + (_E(key_bits) + 3) * _mont(s2)
+    dec = 2 * _mont(s1) + 2 * (_E(key_bits // 2) + 2) * _mont(s1) + 3 * sh * sh + 4 * _mont(sh)
     return enc, dec
 
 
+def mac32_ops(key_bits):
+    """SURVEY.md 8(d) for configs[2]: add(k) = 2 s2^2, mul_t(k) = (E(t)+2) MontMul(s2); obfuscate = encrypt's
+    exponentiation with one more product in place of the s1^2 plaintext term."""
+    s2 = key_bits // 16
+    return {"raw_add": 2 * s2 * s2, "raw_mul_float56": (_E(56) + 2) * _mont(s2), "raw_mul_int64": (_E(63) + 2) * _mont(s2),
+            "obfuscate": (_E(key_bits) + 4) * _mont(s2)}
+
+
 def executed_mads(key_bits, info):
-    """v_mad_u64_u32 lane-operations one encrypt / one decrypt really executes (29-bit limbs; schedule counted like
-    SURVEY's E(t): t squarings, ceil(t/(w+1)) + 2^(w-1) products for the window w in use).  Split engine: a squaring is 4 H^2, a product 5 H^2, entry
+    """MODEL of the v_mad_u64_u32 lane-operations one encrypt / one decrypt executes (29-bit limbs; t squarings,
+    ceil(t/(w+1)) + 2^(w-1) products for the window w in use).  Split engine: a squaring is 4 H^2, a product 5 H^2, entry
     4 H^2 per input chunk (+5 H^2 when more than one), exit ~10 H^2 (csrc/split_core.h); full-width engine: 2 S^2 per
-    Montgomery product."""
+    Montgomery product.  Only the fallback when profiles/executed_mads_r*.json has no exact count for the geometry."""
     E_sq = lambda t: t
     # sliding windows of w = 6 bits (32 odd powers) from ~1000-bit exponents on, w = 5 (16) below: key_setup.h:pick_window
     E_mul = lambda t: (-(-t // 7) + 32) if t > 900 else (-(-t // 6) + 16)
@@ -66,6 +95,26 @@ def executed_mads(key_bits, info):
     enc = modexp(key_bits, info["lane_limbs_pub"], info["engine_pub"] == "split", key_bits, 2)
     dec = 2 * modexp(key_bits // 2, info["lane_limbs_priv"], info["engine_priv"] == "split", 2 * key_bits, 0)
     return enc, dec
+
+
+def counted_mads(key_bits, info=None):
+    """EXACT executed multiply-adds per element from the newest profiles/executed_mads_r*.json (tools/count_executed_mads.py:
+    every wave::mad64 call of the device headers counted by the CPU wave emulator on full wavefronts) -> (dict, file),
+    or (None, None) when there is no count for this key size / geometry."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "executed_mads_r*.json")))
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                rec = json.load(f)["keys"][str(key_bits)]
+        except Exception:
+            continue
+        if info is not None and info.get("engine_pub") == "split":
+            if list(divmod(info["lane_limbs_pub"], 100)) != list(rec.get("split_geometry_GL", [])):
+                continue
+        elif info is not None and not info.get("emulated"):
+            continue
+        return rec, os.path.basename(path)
+    return None, None
 
 
 def valu_peak_mac32(n_cus=256, clock_hz=2.4e9):
@@ -93,14 +142,27 @@ def valu_peak_mac32(n_cus=256, clock_hz=2.4e9):
 def measured_traffic_per_unit(kernel_key):
     """HBM bytes per ciphertext from the newest committed PMC run (profiles/hbm_traffic_r*.json), or None."""
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "hbm_traffic_r*.json")))
-    if not files:
-        return None, None
-    try:
-        with open(files[-1]) as f:
-            t = json.load(f)[kernel_key]
-        return (t["fetch_bytes"] + t["write_bytes"]) / float(t["batch"]), os.path.basename(files[-1])
-    except Exception:
-        return None, None
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                t = json.load(f)[kernel_key]
+            return (t["fetch_bytes"] + t["write_bytes"]) / float(t["batch"]), os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
+
+
+def pmc_valu_per_unit(kernel_key):
+    """SQ_INSTS_VALU wave-instructions per element of the newest committed PMC summary that has them -> (value, file)"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "hbm_traffic_r*.json")))
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                t = json.load(f)[kernel_key]
+            return float(t["sq_insts_valu"]) / float(t["batch"]), os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
 
 
 def host_cores():
@@ -118,85 +180,294 @@ def host_cores():
     return n
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1 << 20, help="plaintexts per GPU per step")
-    ap.add_argument("--key-bits", type=int, default=2048, choices=[1024, 2048, 3072])
+    ap.add_argument("--key-bits", type=int, default=2048, choices=[256, 1024, 2048, 3072])
     ap.add_argument("--cpu-sample", type=int, default=0, help="elements for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ops", action="store_true", help="skip the configs[2] leg")
+    ap.add_argument("--config4", action="store_true", help="run the configs[3] leg at N=1 too (always on for N>1)")
+    ap.add_argument("--no-config4", action="store_true")
+    ap.add_argument("--config4-key-bits", type=int, default=3072, choices=[256, 1024, 2048, 3072])
+    ap.add_argument("--config4-total", type=int, default=0, help="plaintexts of the whole configs[3] job (0 = 2^20 per GPU)")
+    ap.add_argument("--oracle-sample", type=int, default=4096, help="strided rows of the timed batch checked against libgmp")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
-    args = ap.parse_args()
+    ap.add_argument("--selftest-emu", action="store_true", help="CPU contract test: gloo + wave emulator, not a measurement")
+    return ap.parse_args(argv)
+
+
+def relaunch_under_torchrun(args):
+    """`bench.py --gpus N` started bare: become N ranks (one per GPU) by re-launching under torch.distributed.run."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on these hosts (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+# ---- the two backends: where operands live and how a launch is issued / timed -----------------------------------------
+class HipBackend:
+    """The product path: operands are torch tensors in HBM (torch = device memory + streams + torch.distributed, nothing
+    else), every operation is one call through the C-ABI's device-pointer entry points on torch's current stream."""
+    name, dist_backend = "hip", "nccl"
+
+    def __init__(self, local_rank):
+        import torch
+        self.torch = torch
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        self.local_rank = local_rank
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def context(self, n, p=None, q=None, hp=None, hq=None, pinv=None, n_limbs=None):
+        from phe import _native as native
+        return native.Context(n, p, q, hp, hq, pinv, device=self.local_rank, n_limbs=n_limbs)
+
+    def rand(self, rows, cols, seed):
+        gen = self.torch.Generator(device=self.dev)
+        gen.manual_seed(seed)
+        return self.torch.randint(-2 ** 31, 2 ** 31, (rows, cols), dtype=self.torch.int32, device=self.dev, generator=gen)
+
+    def empty(self, rows, cols):
+        return self.torch.empty((rows, cols), dtype=self.torch.int32, device=self.dev)
+
+    def cat(self, parts):
+        return self.torch.cat(parts).contiguous()
+
+    def roll(self, t):
+        return self.torch.roll(t, 1, 0).contiguous()
+
+    def mask_every(self, rows, step):
+        m = self.torch.zeros(rows, dtype=self.torch.uint8, device=self.dev)
+        m[::step] = 1
+        return m
+
+    def np(self, t):
+        import numpy as np
+        return t.cpu().numpy().view(np.uint32) if t.dtype == self.torch.int32 else t.cpu().numpy()
+
+    def take(self, t, idx):
+        return t[self.torch.as_tensor(idx, device=self.dev, dtype=self.torch.long)]
+
+    def equal(self, a, b):
+        return bool(self.torch.equal(a, b))
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+    def as_tensor(self, t):
+        return t
+
+    def scalar_tensor(self, values):
+        return self.torch.tensor(values, dtype=self.torch.float64, device=self.dev)
+
+    def events(self, k):
+        E = self.torch.cuda.Event
+        return [(E(enable_timing=True), E(enable_timing=True)) for _ in range(k)]
+
+    def record(self, ev):
+        ev.record()
+
+    def elapsed_ms(self, a, b):
+        return a.elapsed_time(b)
+
+    # one launch each (device pointers + torch's current stream)
+    def encrypt(self, ctx, m, r, c, rows):
+        ctx.encrypt_dev(m.data_ptr(), r.data_ptr(), c.data_ptr(), rows, self.stream)
+
+    def decrypt(self, ctx, c, m, rows):
+        ctx.decrypt_dev(c.data_ptr(), m.data_ptr(), rows, self.stream)
+
+    def mulmod(self, ctx, a, b, out, rows):
+        ctx.mulmod_dev(a.data_ptr(), b.data_ptr(), out.data_ptr(), rows, self.stream)
+
+    def powmod(self, ctx, base, e, bits, out, rows):
+        ctx.powmod_dev(base.data_ptr(), e.data_ptr(), e.shape[1], bits, out.data_ptr(), rows, self.stream)
+
+    def obfuscate(self, ctx, c, r, out, rows):
+        ctx.obfuscate_dev(c.data_ptr(), r.data_ptr(), out.data_ptr(), rows, self.stream)
+
+    def invert(self, ctx, a, out, rows):
+        ctx.invert_dev(a.data_ptr(), out.data_ptr(), rows, self.stream)
+
+    def select_rows(self, ctx, a, b, mask, out, rows):
+        ctx.select_rows_dev(a.data_ptr(), b.data_ptr(), mask.data_ptr(), out.data_ptr(), a.shape[1], rows, self.stream)
+
+
+class EmuSelftestBackend:
+    """CPU contract test only (--selftest-emu): numpy operands, the wave emulator of tests/emu behind the same method
+    names, wall-clock 'events'.  Exists so that the launch / sharding / JSON plumbing is testable without a GPU."""
+    name, dist_backend = "selftest-emu", "gloo"
+
+    def __init__(self, local_rank):
+        import numpy as np
+        self.npmod = np
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import emu_backend
+        self.EmuContext = emu_backend.EmuContext
+        self.local_rank = local_rank
+
+    def context(self, n, p=None, q=None, hp=None, hq=None, pinv=None, n_limbs=None):
+        return self.EmuContext(n, p, q, hp, hq, pinv, n_limbs=n_limbs)
+
+    def rand(self, rows, cols, seed):
+        rng = self.npmod.random.Generator(self.npmod.random.PCG64(seed))
+        return rng.integers(0, 2 ** 32, (rows, cols), dtype=self.npmod.uint64).astype(self.npmod.uint32)
+
+    def empty(self, rows, cols):
+        return self.npmod.zeros((rows, cols), dtype=self.npmod.uint32)
+
+    def cat(self, parts):
+        return self.npmod.ascontiguousarray(self.npmod.concatenate(parts))
+
+    def roll(self, t):
+        return self.npmod.ascontiguousarray(self.npmod.roll(t, 1, 0))
+
+    def mask_every(self, rows, step):
+        m = self.npmod.zeros(rows, dtype=self.npmod.uint8)
+        m[::step] = 1
+        return m
+
+    def np(self, t):
+        return t
+
+    def take(self, t, idx):
+        return self.npmod.ascontiguousarray(t[self.npmod.asarray(idx, dtype=self.npmod.int64)])
+
+    def equal(self, a, b):
+        return bool(self.npmod.array_equal(a, b))
+
+    def sync(self):
+        pass
+
+    def as_tensor(self, t):
+        import torch
+        return torch.from_numpy(self.npmod.ascontiguousarray(t).view(self.npmod.int32))
+
+    def scalar_tensor(self, values):
+        import torch
+        return torch.tensor(values, dtype=torch.float64)
+
+    def events(self, k):
+        return [([0.0], [0.0]) for _ in range(k)]
+
+    def record(self, ev):
+        ev[0] = time.perf_counter()
+
+    def elapsed_ms(self, a, b):
+        return (b[0] - a[0]) * 1e3
+
+    def encrypt(self, ctx, m, r, c, rows):
+        c[:rows] = ctx.encrypt(m[:rows], r[:rows])
+
+    def decrypt(self, ctx, c, m, rows):
+        m[:rows] = ctx.decrypt(c[:rows])
+
+    def mulmod(self, ctx, a, b, out, rows):
+        out[:rows] = ctx.mulmod(a[:rows], b[:rows])
+
+    def powmod(self, ctx, base, e, bits, out, rows):
+        out[:rows] = ctx.powmod(base[:rows], e[:rows])
+
+    def obfuscate(self, ctx, c, r, out, rows):
+        out[:rows] = ctx.obfuscate(c[:rows], r[:rows])
+
+    def invert(self, ctx, a, out, rows):
+        out[:rows] = ctx.invert(a[:rows])
+
+    def select_rows(self, ctx, a, b, mask, out, rows):
+        out[:rows] = self.npmod.where(mask[:rows, None] != 0, b[:rows], a[:rows])
+
+
+def clamp_operands(m, r, s1, n_int):
+    """random words -> m < n, 1 <= r < n (n has exactly 32*s1 bits in every fixture key)"""
+    top = (n_int >> (32 * (s1 - 1)))                     # the top word of n: >= 2^31
+    assert top >= 1 << 31
+    m[:, s1 - 1] = 0
+    r[:, s1 - 1] &= 0x3fffffff
+    r[:, 0] |= 1
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args)
 
     import numpy as np
-    import torch
     import torch.distributed as dist
     from phe import _native as native
+    from phe.sharding import all_gather_rows, shard_bounds
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is used" % (args.gpus, world), file=sys.stderr)
     use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run (also with 1 rank)
-    torch.cuda.set_device(local_rank)
+    be = (EmuSelftestBackend if args.selftest_emu else HipBackend)(local_rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if be.name == "hip":
+            dist.init_process_group(backend="nccl", device_id=be.dev)
+        else:
+            dist.init_process_group(backend="gloo")
 
-    with open(os.path.join(ROOT, "tests", "golden", "paillier_%d.json" % args.key_bits)) as f:
-        g = json.load(f)
-    H = lambda k: int(g[k], 16)
-    n_int = H("n")
+    def golden(bits):
+        with open(os.path.join(ROOT, "tests", "golden", "paillier_%d.json" % bits)) as f:
+            g = json.load(f)
+        return {k: int(g[k], 16) for k in ("n", "p", "q", "hp", "hq", "p_inverse")}
+
+    key = golden(args.key_bits)
+    n_int = key["n"]
     s1, s2 = args.key_bits // 32, args.key_bits // 16
-    ctx = native.Context(n_int, H("p"), H("q"), H("hp"), H("hq"), H("p_inverse"), device=local_rank, n_limbs=s1)
-    if args.blocks_per_cu:
+    ctx = be.context(n_int, key["p"], key["q"], key["hp"], key["hq"], key["p_inverse"], n_limbs=s1)
+    if args.blocks_per_cu and hasattr(ctx, "set_blocks_per_cu"):
         ctx.set_blocks_per_cu(args.blocks_per_cu)
 
     # ---- synthetic inputs, generated on the device (resident in HBM before any timed region) ----
     B = args.batch
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    m = torch.randint(-2 ** 31, 2 ** 31, (B, s1), dtype=torch.int32, device=dev, generator=gen)
-    r = torch.randint(-2 ** 31, 2 ** 31, (B, s1), dtype=torch.int32, device=dev, generator=gen)
-    m[:, s1 - 1] = 0                      # m < n (n has exactly key_bits bits)
-    r[:, s1 - 1] &= 0x3fffffff            # r < n
-    r[:, 0] |= 1                          # r != 0
-    c = torch.empty((B, s2), dtype=torch.int32, device=dev)
-    m_back = torch.empty((B, s1), dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    def enc_step():
-        ctx.encrypt_dev(m.data_ptr(), r.data_ptr(), c.data_ptr(), B, stream)
-
-    def dec_step():
-        ctx.decrypt_dev(c.data_ptr(), m_back.data_ptr(), B, stream)
+    m = be.rand(B, s1, 1234 + 2 * rank)
+    r = be.rand(B, s1, 1235 + 2 * rank)
+    clamp_operands(m, r, s1, n_int)
+    c = be.empty(B, s2)
+    m_back = be.empty(B, s1)
 
     def barrier():
-        torch.cuda.synchronize()
+        be.sync()
         if use_dist:
             dist.barrier()
 
+    def max_over_ranks(values):
+        if not use_dist:
+            return list(values)
+        t = be.scalar_tensor(list(values))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(x) for x in t.tolist()]
+
     def timed(step_fn, steps):
-        """K steps bracketed by barrier + synchronize on both sides; also per-launch HIP-event durations."""
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        """K steps bracketed by barrier + synchronize on both sides (max over ranks); also per-launch event durations."""
+        evs = be.events(steps)
         barrier()
         t0 = time.perf_counter()
         for a, b in evs:
-            a.record()
+            be.record(a)
             step_fn()
-            b.record()
+            be.record(b)
         barrier()
-        dt = time.perf_counter() - t0
-        if use_dist:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        launch_ms = [a.elapsed_time(b) for a, b in evs]
-        return dt, launch_ms
+        dt = max_over_ranks([time.perf_counter() - t0])[0]
+        return dt, [be.elapsed_ms(a, b) for a, b in evs]
 
+    enc_step = lambda: be.encrypt(ctx, m, r, c, B)
+    dec_step = lambda: be.decrypt(ctx, c, m_back, B)
     for _ in range(args.warmup):
         enc_step()
     enc_dt, enc_launch_ms = timed(enc_step, args.steps)
@@ -205,99 +476,269 @@ def main():
     dec_dt, dec_launch_ms = timed(dec_step, args.steps)
 
     # ---- bit-exactness of what was just timed -------------------------------------------------
-    roundtrip_ok = bool(torch.equal(m_back, m))
-    sample_ok = None
-    cpu = None
+    roundtrip_ok = be.equal(m_back, m)
+    cores = host_cores()
+    orc = None
     if rank == 0:
-        from oracle.paillier_oracle import COracle
+        from oracle.paillier_oracle import COracle             # the CHECKER (and the cpu_baseline leg), never the product
         orc = COracle()
-        idx = torch.arange(0, B, max(1, B // 64), device=dev)[:64]
-        to_np = lambda t: t.cpu().numpy().view(np.uint32)
-        n_arr = native.int_to_limbs(n_int, s1)
-        want = orc.encrypt(n_arr, to_np(m[idx]), to_np(r[idx]), nthreads=host_cores())
-        sample_ok = bool(np.array_equal(to_np(c[idx]), want))
-        if world == 1 and not args.no_cpu_baseline:
-            cores = host_cores()
-            pq = s1 // 2
-            p_arr, q_arr = native.int_to_limbs(H("p"), pq), native.int_to_limbs(H("q"), pq)
+    n_arr = native.int_to_limbs(n_int, s1)
 
-            def cpu_timed(fn, target_s):
-                """Time fn(count) on a bounded sample: a short probe sizes the sample for ~target_s seconds."""
-                probe = min(B, max(cores, 2 * cores))
-                t0 = time.perf_counter()
-                fn(probe)
-                rate = probe / max(time.perf_counter() - t0, 1e-6)
-                count = int(min(B, max(probe, args.cpu_sample or rate * target_s)))
-                t0 = time.perf_counter()
-                res = fn(count)
-                return count, time.perf_counter() - t0, res
+    def strided(rows, count):
+        return sorted(set(range(0, rows, max(1, rows // max(1, count)))))[:count]
 
-            ne, t_enc, ch = cpu_timed(lambda k: orc.encrypt(n_arr, to_np(m[:k]), to_np(r[:k]), nthreads=cores), 12.0)
-            cpu_ok = bool(np.array_equal(ch, to_np(c[:ne])))
-            nd, t_dec, dh = cpu_timed(lambda k: orc.decrypt(n_arr, p_arr, q_arr, to_np(c[:k]), nthreads=cores), 6.0)
-            cpu_ok = cpu_ok and bool(np.array_equal(dh, to_np(m[:nd])))
-            cpu = {"value": ne / t_enc, "unit": "encrypts/s", "cores": cores, "kind": "port",
-                   "sample": "first %d of the same (m, r) batch through oracle/paillier_oracle.c "
-                             "(libgmp %s mpz_powm = what gmpy2.powmod executes), %d threads, %.1f s; "
-                             "decrypt: first %d ciphertexts, %.1f s" % (ne, orc.gmp_version, cores, t_enc, nd, t_dec),
-                   "decrypts_per_s": nd / t_dec, "matches_gpu": cpu_ok}
+    sample_ok, sample_rows = None, 0
+    if rank == 0:
+        idx = strided(B, args.oracle_sample)
+        want = orc.encrypt(n_arr, be.np(be.take(m, idx)), be.np(be.take(r, idx)), nthreads=cores)
+        sample_ok = bool(np.array_equal(be.np(be.take(c, idx)), want))
+        sample_rows = len(idx)
 
+    # ---- configs[2]: homomorphic add, scalar multiplication (both branches), obfuscate ----------------------------
+    ops, ops_ok = None, True
+    if not args.no_ops:
+        ops = {}
+        c2 = be.roll(c)
+        out = be.empty(B, s2)
+        idx = strided(B, 96)
+        warm_rows = min(B, 4096)
+
+        def run_op(name, fn, reps, check, note=None):
+            fn(warm_rows)                                       # first-launch costs (module load, scratch) stay outside
+            barrier()
+            evs = be.events(reps)
+            t0 = time.perf_counter()
+            for a, b in evs:
+                be.record(a)
+                fn(B)
+                be.record(b)
+            barrier()
+            dt = max_over_ranks([time.perf_counter() - t0])[0]
+            ok = check() if rank == 0 else None
+            ops[name] = {"value": world * B * reps / dt, "unit": "ops/s", "reps": reps, "ms_per_pass": dt / reps * 1e3,
+                         "launch_ms_avg": sum(be.elapsed_ms(a, b) for a, b in evs) / reps,
+                         "bit_exact_strided_sample_vs_gmp_oracle": ok, "rows_checked": len(idx) if rank == 0 else None}
+            if note:
+                ops[name]["note"] = note
+            return ok is not False
+
+        ca_s = lambda: be.np(be.take(c, idx))
+        ops_ok &= run_op("raw_add", lambda k: be.mulmod(ctx, c, c2, out, k), 20 if be.name == "hip" else 1,
+                         lambda: bool(np.array_equal(be.np(be.take(out, idx)),
+                                                     orc.add(n_arr, ca_s(), be.np(be.take(c2, idx)), nthreads=cores))))
+        scal = {}
+        for name, bits, seed in (("raw_mul_float56", 56, 77), ("raw_mul_int64", 63, 78)):
+            e = be.rand(B, 2, seed + 10 * rank)
+            e[:, 1] &= (0x00ffffff if bits == 56 else 0x7fffffff)
+            scal[name] = e
+
+            def check(e=e):
+                sc = np.zeros((len(idx), s1), np.uint32)
+                sc[:, :2] = be.np(be.take(e, idx))
+                return bool(np.array_equal(be.np(be.take(out, idx)), orc.mul(n_arr, ca_s(), sc, nthreads=cores)))
+            ops_ok &= run_op(name, lambda k, e=e, bits=bits: be.powmod(ctx, c, e, bits, out, k), 3 if be.name == "hip" else 1, check)
+        # 10 % negative scalars: those rows take invert(c, n^2) as the base and n - s as the exponent (phe/paillier.py:745-749);
+        # composed as Engine.raw_mul_signed_dev composes it: one simultaneous inversion of the vector, a per-row select, one powmod
+        e = scal["raw_mul_float56"]
+        neg = be.mask_every(B, 10)
+        inv, base = be.empty(B, s2), be.empty(B, s2)
+
+        def neg_mul(k):
+            be.invert(ctx, c, inv, k)
+            be.select_rows(ctx, c, inv, neg, base, k)
+            be.powmod(ctx, base, e, 56, out, k)
+
+        def check_neg():
+            sc = native.limbs_to_ints(np.ascontiguousarray(be.np(be.take(e, idx))))
+            sc = [(n_int - v) if (i % 10 == 0 and v) else v for i, v in zip(idx, sc)]      # negative scalar -v is the residue n - v
+            got = be.np(be.take(out, idx))
+            return bool(np.array_equal(got, orc.mul(n_arr, ca_s(), native.ints_to_limbs(sc, s1), nthreads=cores)))
+        ops_ok &= run_op("raw_mul_float56_neg10pct", neg_mul, 2 if be.name == "hip" else 1, check_neg,
+                         "simultaneous inversion of the whole vector (3 modmuls per row + 1 host inversion) + select + powmod")
+        ops_ok &= run_op("obfuscate", lambda k: be.obfuscate(ctx, c, r, out, k), 1,
+                         lambda: bool(np.array_equal(be.np(be.take(out, idx)),
+                                                     orc.obfuscate(n_arr, ca_s(), be.np(be.take(r, idx)), nthreads=cores))))
+        del c2, out, inv, base
+
+    # ---- configs[3]: a shard per GPU under a 3072-bit key + ONE all-gather of the ciphertext shards ---------------
+    cfg4, cfg4_ok = None, True
+    if (world > 1 or args.config4) and not args.no_config4:
+        k4 = golden(args.config4_key_bits)
+        t1, t2 = args.config4_key_bits // 32, args.config4_key_bits // 16
+        ctx4 = be.context(k4["n"], n_limbs=t1)
+        total = args.config4_total or world * (1 << 20)
+        lo, hi = shard_bounds(total, world, rank)
+        rows = hi - lo
+        blk = 1 << 16
+
+        def operands(first, count):
+            """rows [first, first+count) of the job's (m, r): a function of the row index only (a seeded stream per 2^16-row
+            block), so that any rank — and the checker — can regenerate any row"""
+            ms, rs = [], []
+            for b in range(first // blk, (first + count - 1) // blk + 1):
+                mb, rb = be.rand(blk, t1, 400000 + 2 * b), be.rand(blk, t1, 400001 + 2 * b)
+                a, z = max(first, b * blk) - b * blk, min(first + count, (b + 1) * blk) - b * blk
+                ms.append(mb[a:z])
+                rs.append(rb[a:z])
+            mm, rr = be.cat(ms), be.cat(rs)
+            clamp_operands(mm, rr, t1, k4["n"])
+            return mm, rr
+
+        m4, r4 = operands(lo, rows) if rows else (be.empty(0, t1), be.empty(0, t1))
+        c4 = be.empty(rows, t2)
+        be.encrypt(ctx4, m4, r4, c4, min(rows, 4096))           # first-launch costs outside the timed region
+        barrier()
+        t0 = time.perf_counter()
+        be.encrypt(ctx4, m4, r4, c4, rows)
+        barrier()
+        t_enc = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        full = all_gather_rows(be.as_tensor(c4), total) if use_dist else be.as_tensor(c4)
+        barrier()
+        t_gather = time.perf_counter() - t0
+        t_enc, t_gather = max_over_ranks([t_enc, t_gather])
+        if rank == 0:
+            bounds = [shard_bounds(total, world, k) for k in range(world)]
+            idx = sorted(set([0, total - 1] + [b[0] for b in bounds if b[0] < total] + [max(0, b[1] - 1) for b in bounds] +
+                             list(range(0, total, max(1, total // 48)))))
+            ms, rs = zip(*[operands(i, 1) for i in idx])
+            want = orc.encrypt(native.int_to_limbs(k4["n"], t1), be.np(be.cat(list(ms))), be.np(be.cat(list(rs))), nthreads=cores)
+            got = full[idx].cpu().numpy().view(np.uint32)
+            cfg4_ok = bool(np.array_equal(got, want))
+            cfg4 = {"workload": "configs[3]: %d-bit key, %d plaintexts sharded over %d GPU(s) (%d per GPU), ONE all-gather "
+                                "of the ciphertext shards (phe.sharding.all_gather_rows, backend %s)"
+                                % (args.config4_key_bits, total, world, rows, be.dist_backend if use_dist else "none: 1 rank"),
+                    "total": total, "rows_per_gpu": rows,
+                    "encrypt": {"seconds": t_enc, "value": total / t_enc, "unit": "encrypts/s"},
+                    "all_gather": {"seconds": t_gather, "bytes_received_per_gpu": total * t2 * 4,
+                                   "GBps_per_gpu": total * t2 * 4 / t_gather / 1e9 if use_dist else None},
+                    "end_to_end_encrypts_per_s": total / (t_enc + t_gather),
+                    "bit_exact_boundaries_and_sample_vs_gmp_oracle": cfg4_ok, "rows_checked": len(idx),
+                    "geometry": ctx4.info()}
+        del full, c4, m4, r4
+
+    # ---- CPU baseline: the libgmp oracle on all host cores, bounded sample, rank 0 at N = 1 only -------------------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        pq = s1 // 2
+        p_arr, q_arr = native.int_to_limbs(key["p"], pq), native.int_to_limbs(key["q"], pq)
+
+        def cpu_timed(fn, target_s):
+            """Time fn(count) on a bounded sample: a short probe sizes the sample for ~target_s seconds."""
+            probe = min(B, max(cores, 2 * cores))
+            t0 = time.perf_counter()
+            fn(probe)
+            rate = probe / max(time.perf_counter() - t0, 1e-6)
+            count = int(min(B, max(probe, args.cpu_sample or rate * target_s)))
+            t0 = time.perf_counter()
+            res = fn(count)
+            return count, time.perf_counter() - t0, res
+
+        m_h, r_h, c_h = be.np(m), be.np(r), be.np(c)
+        ne, t_enc_cpu, ch = cpu_timed(lambda k: orc.encrypt(n_arr, m_h[:k], r_h[:k], nthreads=cores), 12.0)
+        cpu_ok = bool(np.array_equal(ch, c_h[:ne]))
+        nd, t_dec_cpu, dh = cpu_timed(lambda k: orc.decrypt(n_arr, p_arr, q_arr, c_h[:k], nthreads=cores), 6.0)
+        cpu_ok = cpu_ok and bool(np.array_equal(dh, m_h[:nd]))
+        cpu = {"value": ne / t_enc_cpu, "unit": "encrypts/s", "cores": cores, "kind": "port",
+               "sample": "first %d of the same (m, r) batch through oracle/paillier_oracle.c "
+                         "(libgmp %s mpz_powm = what gmpy2.powmod executes), %d threads, %.1f s; "
+                         "decrypt: first %d ciphertexts, %.1f s" % (ne, orc.gmp_version, cores, t_enc_cpu, nd, t_dec_cpu),
+               "decrypts_per_s": nd / t_dec_cpu, "matches_gpu": cpu_ok}
+
+    ok = roundtrip_ok and sample_ok is not False and ops_ok and cfg4_ok
     if rank == 0:
         enc_mac, dec_mac = mac32_counts(args.key_bits)
         peak, sustained, peak_src = valu_peak_mac32()
         info = ctx.info()
+        split = info.get("engine_pub") == "split"
         kname = lambda limbs, eng, mode: "k_modexp_%s<%d,%d,%s>" % (("split" if eng == "split" else "uniform",) + divmod(limbs, 100) + (mode,))
-        enc_kernel = kname(info["lane_limbs_pub"], info["engine_pub"], "encrypt")
-        dec_kernel = kname(info["lane_limbs_priv"], info["engine_priv"], "half_decrypt")
+        if "lane_limbs_pub" in info:
+            enc_kernel = kname(info["lane_limbs_pub"], info["engine_pub"], "encrypt")
+            dec_kernel = kname(info["lane_limbs_priv"], info["engine_priv"], "half_decrypt")
+            model_enc, model_dec = executed_mads(args.key_bits, info)
+        else:
+            enc_kernel, dec_kernel, model_enc, model_dec = "emulator", "emulator", None, None
+        counted, counted_src = counted_mads(args.key_bits, info)
+        enc_exec = counted["encrypt"] if counted else model_enc
+        dec_exec = counted["decrypt"] if counted else model_dec
+        exec_src = ("exact: wave::mad64 calls counted by the CPU wave emulator, %s" % counted_src) if counted else \
+            "model (bench.py:executed_mads): no exact count committed for this geometry"
         traffic_unit, traffic_src = measured_traffic_per_unit(enc_kernel) if args.key_bits == 2048 else (None, None)
-        enc_exec, dec_exec = executed_mads(args.key_bits, info)
+        valu_unit, valu_src = pmc_valu_per_unit(enc_kernel) if args.key_bits == 2048 else (None, None)
         enc_kernel_s = sum(enc_launch_ms) / len(enc_launch_ms) * 1e-3
         dec_kernel_s = sum(dec_launch_ms) / len(dec_launch_ms) * 1e-3
-        achieved = enc_mac * B / enc_kernel_s
         value = world * B * args.steps / enc_dt
+        rate = lambda per_unit, seconds: per_unit * B / seconds if per_unit else None
+        frac = lambda per_unit, seconds: per_unit * B / seconds / peak if per_unit else None
+        roofline = {
+            "bound": "valu_int32", "kernel": enc_kernel + " (radix 2^29)",
+            "achieved": rate(enc_exec, enc_kernel_s) / 1e12 if enc_exec else None, "peak": peak / 1e12, "unit": "Tmad/s (v_mad_u64_u32 lane-operations = MAC32)",
+            "frac": frac(enc_exec, enc_kernel_s),
+            "frac_note": "multiply-adds the kernel EXECUTES per second / nominal integer-VALU peak (<= 1 by construction)",
+            "executed_mad_per_encrypt": enc_exec, "executed_source": exec_src,
+            "frac_of_sustained_mad_rate": (rate(enc_exec, enc_kernel_s) / sustained) if (sustained and enc_exec) else None,
+            "canonical_mac32_per_encrypt": enc_mac, "canonical_achieved": enc_mac * B / enc_kernel_s / 1e12,
+            "canonical_frac": enc_mac * B / enc_kernel_s / peak,
+            "canonical_note": "SURVEY.md 8(d) algorithmic MAC32 (full-width Montgomery) x batch / launch time / peak: exceeds "
+                              "`frac` because the split-modulus kernels execute fewer multiply-adds than the canonical algorithm",
+            "pmc_valu_lane_ops_per_encrypt": valu_unit * 64 if valu_unit else None,
+            "mad_share_of_valu_instructions": (enc_exec / (valu_unit * 64)) if (valu_unit and enc_exec) else None,
+            "pmc_source": valu_src,
+            "traffic": (traffic_unit * B) if traffic_unit else None,
+            "traffic_note": ("HBM+MALL bytes per launch = %.0f B/encrypt (PMC FETCH_SIZE x2 + WRITE_SIZE, %s) x batch; "
+                             "algorithmic bytes are %d B/encrypt" % (traffic_unit, traffic_src, (2 * s1 + s2) * 4))
+            if traffic_unit else "no PMC run committed for this kernel",
+            "launch_ms_avg": enc_kernel_s * 1e3,
+            "peak_source": "256 CUs x 4 SIMD x 64 lanes x 2.4 GHz / 4 cycles per v_mad_u64_u32 (half-rate, calibrated)",
+            "peak_sustained_microbench": (sustained / 1e12) if sustained else None, "microbench": peak_src,
+            "hbm_algorithmic_GBps": (2 * s1 + s2) * 4 * B / enc_kernel_s / 1e9, "hbm_peak_GBps": 8000.0,
+            "decrypt": {"kernel": "2 x %s + k_decrypt_tail" % dec_kernel,
+                        "achieved": rate(dec_exec, dec_kernel_s) / 1e12 if dec_exec else None, "frac": frac(dec_exec, dec_kernel_s),
+                        "executed_mad_per_decrypt": dec_exec, "canonical_mac32_per_decrypt": dec_mac,
+                        "canonical_frac": dec_mac * B / dec_kernel_s / peak, "launch_ms_avg": dec_kernel_s * 1e3},
+        }
+        if ops:
+            canon = mac32_ops(args.key_bits)
+            exec_key = {"raw_add": "raw_add", "raw_mul_float56": "raw_mul_56bit", "raw_mul_int64": "raw_mul_63bit",
+                        "obfuscate": "obfuscate"}
+            for name, rec in ops.items():
+                per_gpu = rec["value"] / world
+                ck = "raw_mul_float56" if name.startswith("raw_mul_float56") else name
+                ex = counted.get(exec_key[ck]) if counted else None
+                rec["roofline"] = {"bound": "valu_int32", "canonical_mac32_per_op": canon[ck],
+                                   "canonical_frac": canon[ck] * per_gpu / peak,
+                                   "executed_mad_per_op": ex, "frac": (ex * per_gpu / peak) if ex else None}
+            add_bytes = 3 * s2 * 4
+            ops["raw_add"]["roofline"].update(hbm_algorithmic_GBps=add_bytes * ops["raw_add"]["value"] / world / 1e9,
+                                              hbm_frac=add_bytes * ops["raw_add"]["value"] / world / 8e12)
         out = {
             "metric": METRIC, "value": value, "unit": "encrypts/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": enc_dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u32 (29-bit limbs, v_mad_u64_u32 with 64-bit accumulate)",
-            "data": "synthetic",
+            "data": "synthetic" if be.name == "hip" else "synthetic, SELFTEST on the CPU wave emulator — not a measurement",
+            "rccl_ranks": dist.get_world_size() if use_dist else 1, "backend": be.dist_backend if use_dist else "single process",
             "config": {"workload": "configs[1]: %d-bit key, %d-plaintext batch per GPU, raw_encrypt then raw_decrypt, "
                                    "operands resident in HBM" % (args.key_bits, B),
                        "key_bits": args.key_bits, "batch_per_gpu": B, "parallelism": "batch-sharded x%d" % world,
                        "geometry": info},
             "decrypt": {"value": world * B * args.steps / dec_dt, "unit": "decrypts/s",
                         "ms_per_step": dec_dt / args.steps * 1e3},
-            "bit_exact": {"roundtrip_full_batch": roundtrip_ok, "strided_sample_vs_gmp_oracle": sample_ok},
-            "roofline": {
-                "bound": "valu_int32", "kernel": enc_kernel + " (radix 2^29)",
-                "achieved": achieved / 1e12, "peak": peak / 1e12, "unit": "TMAC32/s", "frac": achieved / peak,
-                "achieved_note": "SURVEY.md 8(d) canonical MAC32 per encrypt (full-width Montgomery) x batch / launch time",
-                "executed": {"mad_per_encrypt": enc_exec, "rate_Tmad_per_s": enc_exec * B / enc_kernel_s / 1e12,
-                             "frac_of_peak": enc_exec * B / enc_kernel_s / peak,
-                             "note": "v_mad_u64_u32 lane-operations the kernel really issues (29-bit limbs)"},
-                "traffic": (traffic_unit * B) if traffic_unit else None,
-                "traffic_note": ("HBM+MALL bytes per launch = %.0f B/encrypt (PMC FETCH_SIZE x2 + WRITE_SIZE, %s) x batch; "
-                                 "algorithmic bytes are %d B/encrypt" % (traffic_unit, traffic_src, (2 * s1 + s2) * 4))
-                if traffic_unit else "no PMC run committed for this kernel",
-                "mac32_per_encrypt": enc_mac, "launch_ms_avg": enc_kernel_s * 1e3,
-                "peak_source": "256 CUs x 4 SIMD x 64 lanes x 2.4 GHz / 4 cycles per v_mad_u64_u32 (half-rate, calibrated)",
-                "peak_sustained_microbench": (sustained / 1e12) if sustained else None, "microbench": peak_src,
-                "hbm_algorithmic_GBps": (2 * s1 + s2) * 4 * B / enc_kernel_s / 1e9, "hbm_peak_GBps": 8000.0,
-                "decrypt": {"kernel": "2 x %s + k_decrypt_tail" % dec_kernel,
-                            "achieved": dec_mac * B / dec_kernel_s / 1e12, "frac": dec_mac * B / dec_kernel_s / peak,
-                            "mac32_per_decrypt": dec_mac, "launch_ms_avg": dec_kernel_s * 1e3,
-                            "executed": {"mad_per_decrypt": dec_exec, "rate_Tmad_per_s": dec_exec * B / dec_kernel_s / 1e12,
-                                         "frac_of_peak": dec_exec * B / dec_kernel_s / peak}},
-            },
+            "bit_exact": {"roundtrip_full_batch": roundtrip_ok, "strided_sample_vs_gmp_oracle": sample_ok,
+                          "strided_sample_rows": sample_rows},
+            "roofline": roofline,
+            "ops": ops, "config4": cfg4,
             "cpu_baseline": cpu,
         }
         if cpu:
             out["speedup_vs_cpu_all_cores"] = {"encrypt": value / cpu["value"],
                                                "decrypt": out["decrypt"]["value"] / cpu["decrypts_per_s"]}
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if use_dist:
+        flag = max_over_ranks([0.0 if ok else 1.0])[0]
+        ok = flag == 0.0
         dist.barrier()
         dist.destroy_process_group()
-    if not roundtrip_ok or sample_ok is False:
+    if not ok:
         sys.exit(1)
 
 

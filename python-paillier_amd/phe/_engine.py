@@ -13,6 +13,7 @@ hot functions of the reference on *batches* of Python ints or uint32 limb arrays
 There is no CPU implementation behind these: if lib/libphe_hip.so or a GPU is missing, they raise.
 """
 import os
+import threading
 
 import numpy as np
 
@@ -98,8 +99,13 @@ def random_lt_n_limbs(n, count, limbs, out=None):
         out[rows] = fresh
 
 
+# Every public Engine method runs under the engine's re-entrant lock (see _native.serialised).  A key's engine owns
+# shared state: the obfuscator pool, whose entries must never be handed out twice (two ciphertexts sharing r^n reveal
+# m1 - m2), the host staging buffers, the native context's window tables and launch stream.
+@_native.serialised
 class Engine:
     def __init__(self, n, p=None, q=None, hp=None, hq=None, p_inverse=None, device=None):
+        self._lock = threading.RLock()
         self.n = n
         self.nsquare = n * n
         self.max_int = n // 3 - 1
@@ -233,6 +239,7 @@ class Engine:
         if top == 0:
             return np.zeros((count, 1), dtype=np.uint32), 1
         nz = mag != 0
+        sh = np.where(nz, sh, 0)              # a zero stays zero whatever its shift: it must not size or index the rows
         # exact bit length of every magnitude: float64 log2 can be off by one near powers of two, so fix it up
         bl = np.zeros(count, dtype=np.int64)
         est = np.floor(np.log2(mag[nz].astype(np.float64))).astype(np.int64) + 1
@@ -243,7 +250,7 @@ class Engine:
         too_small = (est < 64) & ((m_nz >> np.minimum(est, 63).astype(np.uint64)) != 0)
         est[too_small] += 1
         bl[nz] = est
-        bits = int((bl + np.where(nz, sh, 0)).max())
+        bits = int((bl + sh).max())
         width = max(1, (bits + 31) // 32)
         out = np.zeros((count, width + 3), dtype=np.uint32)       # 3 spill words, cut off below
         word = sh >> 5
@@ -564,12 +571,17 @@ class Engine:
             hi = min(rows, lo + chunk)
             self.ctx.decrypt_dev(c.rows_view(lo, hi).ptr, out.rows_view(lo, hi).ptr, hi - lo, st)
             return hi
-        lo, hi = 0, launch(0)
-        while lo < rows:
-            self.ctx.sync(st)                                   # chunk [lo, hi) is complete
-            nxt = launch(hi) if hi < rows else hi
-            yield lo, hi, out.rows_view(lo, hi).to_host()
-            lo, hi = hi, nxt
+        try:
+            lo, hi = 0, launch(0)
+            while lo < rows:
+                self.ctx.sync(st)                               # chunk [lo, hi) is complete
+                nxt = launch(hi) if hi < rows else hi
+                yield lo, hi, out.rows_view(lo, hi).to_host()
+                lo, hi = hi, nxt
+        finally:
+            # a consumer that stops early (e.g. OverflowError while decoding a row) drops the generator with the next
+            # chunk's kernels still writing into `out`: wait for them before the block returns to the size-keyed pool
+            self.ctx.sync(st)
 
     def raw_decrypt_host_chunks(self, c, chunk=1 << 16):
         """raw_decrypt_dev_chunks for a HOST limb array: the upload of chunk k+1 and the download + decoding of chunk k
@@ -592,16 +604,19 @@ class Engine:
         def launch(k):
             lo, hi = bounds[k]
             self.ctx.decrypt_dev(inputs[k].ptr, outputs[k].ptr, hi - lo, st)
-        stage(0)
-        launch(0)
-        for k, (lo, hi) in enumerate(bounds):
-            if k + 1 < len(bounds):
-                stage(k + 1)                                     # upload under the kernels of chunk k
-            self.ctx.sync(st)                                    # chunk k is complete
-            if k + 1 < len(bounds):
-                launch(k + 1)
-            yield lo, hi, outputs.pop(k).to_host()               # download + the caller's decoding under chunk k+1
-            inputs.pop(k)
+        try:
+            stage(0)
+            launch(0)
+            for k, (lo, hi) in enumerate(bounds):
+                if k + 1 < len(bounds):
+                    stage(k + 1)                                 # upload under the kernels of chunk k
+                self.ctx.sync(st)                                # chunk k is complete
+                if k + 1 < len(bounds):
+                    launch(k + 1)
+                yield lo, hi, outputs.pop(k).to_host()           # download + the caller's decoding under chunk k+1
+                inputs.pop(k)
+        finally:
+            self.ctx.sync(st)                                    # see raw_decrypt_dev_chunks: nothing in flight on release
 
     def raw_add_dev(self, a, b):
         out = DeviceArray(self.ctx, a.rows, self.ct_limbs)

@@ -6,7 +6,10 @@ an exception is raised.  Status codes map onto the exception types the reference
 EINVAL -> ValueError, EHIP -> RuntimeError.
 """
 import ctypes
+import functools
+import inspect
 import os
+import threading
 
 import numpy as np
 
@@ -161,10 +164,38 @@ def limbs_for_bits(bits):
     return max(1, (bits + 31) // 32)
 
 
+def serialised(cls):
+    """Class decorator: every public method runs under the instance's re-entrant lock `self._lock`.  ctypes drops the
+    GIL inside each native call and a native context (its window tables, launch streams, the size-keyed block pool)
+    is not thread-safe, while the reference's functions are stateless and callable from any thread — so calls on one
+    key are serialised here instead of being left to the caller."""
+    for name, fn in list(vars(cls).items()):
+        if name.startswith("_") or not inspect.isfunction(fn):
+            continue
+        if inspect.isgeneratorfunction(fn):
+            def wrap(fn):
+                @functools.wraps(fn)
+                def locked_gen(self, *a, **kw):
+                    with self._lock:                      # held until the generator is exhausted, closed or collected
+                        yield from fn(self, *a, **kw)
+                return locked_gen
+        else:
+            def wrap(fn):
+                @functools.wraps(fn)
+                def locked(self, *a, **kw):
+                    with self._lock:
+                        return fn(self, *a, **kw)
+                return locked
+        setattr(cls, name, wrap(fn))
+    return cls
+
+
+@serialised
 class Context:
     """One key on one device.  `n` (and optionally p, q, hp, hq, p_inverse) are Python ints."""
 
     def __init__(self, n, p=None, q=None, hp=None, hq=None, p_inverse=None, device=0, n_limbs=None):
+        self._lock = threading.RLock()
         L = lib()
         self.n = int(n)
         self.n_limbs = n_limbs or limbs_for_bits(self.n.bit_length())

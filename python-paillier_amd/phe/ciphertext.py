@@ -20,6 +20,14 @@ from .codec import EncodedNumber
 TABLE_COMPACT_BYTES = 64 << 20
 
 
+def _check_alignment_factor(public_key, factor):
+    """The reference aligns exponents with `self * pow(BASE, delta)` (phe/paillier.py:599): the factor goes through
+    EncodedNumber.encode, which rejects integers above max_int (phe/encoding.py:194-196) — the vector forms raise the
+    same error at the same bound instead of letting a factor in (max_int, n) through."""
+    if factor > public_key.max_int:
+        raise ValueError('Integer needs to be within +/- %d but got %d' % (public_key.max_int, factor))
+
+
 class EncryptedNumber(object):
     def __init__(self, public_key, ciphertext, exponent=0):
         from .keys import PaillierPublicKey
@@ -323,8 +331,7 @@ class EncryptedVector(object):
         pk = self.public_key
         delta = (old - new)[rows]
         powers = {int(d): pow(EncodedNumber.BASE, int(d)) for d in np.unique(delta).tolist()}
-        if max(powers.values()) >= pk.n:
-            raise ValueError('Scalar out of bounds: %i' % max(powers.values()))
+        _check_alignment_factor(pk, max(powers.values()))
         flags[rows] = False
         eng = pk._get_engine()
         log2b = int(round(EncodedNumber.LOG2_BASE))
@@ -544,8 +551,8 @@ class EncryptedVector(object):
         target = int(total.min())
         delta = total - target                                 # rows above the common exponent: * BASE^delta (:599)
         dmax = int(delta.max())
-        if dmax and pow(EncodedNumber.BASE, dmax) >= pk.n:
-            raise ValueError('Scalar out of bounds: %i' % pow(EncodedNumber.BASE, dmax))
+        if dmax:
+            _check_alignment_factor(pk, pow(EncodedNumber.BASE, dmax))
         log2b = int(round(EncodedNumber.LOG2_BASE))
         if dmax == 0:
             exps = mag
@@ -621,8 +628,8 @@ class EncryptedVector(object):
                     target[filled] = np.minimum.reduceat(total, indptr[filled])
                 delta = total - np.repeat(target, counts)
                 dmax = int(delta.max()) if len(delta) else 0
-                if dmax and pow(EncodedNumber.BASE, dmax) >= pk.n:
-                    raise ValueError('Scalar out of bounds: %i' % pow(EncodedNumber.BASE, dmax))
+                if dmax:
+                    _check_alignment_factor(pk, pow(EncodedNumber.BASE, dmax))
                 exps = eng.shifted_limbs(mag, delta * log2b)
                 base = self._limbs
                 # the tables cover every ciphertext handed over: keep them to the columns that are actually stored
@@ -651,8 +658,8 @@ class EncryptedVector(object):
         target = total.min(axis=1)
         delta = total - target[:, None]
         dmax = int(delta.max())
-        if dmax and pow(EncodedNumber.BASE, dmax) >= pk.n:
-            raise ValueError('Scalar out of bounds: %i' % pow(EncodedNumber.BASE, dmax))
+        if dmax:
+            _check_alignment_factor(pk, pow(EncodedNumber.BASE, dmax))
         # many rows over a vector whose tables fit comfortably (<= 1 GiB): build them once for all rows
         table_bytes = len(self) * 2 * 15 * 2 * 4 * (eng.ct_limbs + 32)
         if pow2_base and rows >= 64 and table_bytes <= (1 << 30) and eng.has_split_engine():

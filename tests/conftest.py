@@ -10,6 +10,16 @@ PKG = os.path.join(ROOT, "python-paillier_amd")
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# Property tests are deterministic: the same examples every run (no example database, no random seed), so that
+# "N passed" is reproducible.  Loaded before any test module creates its settings objects, which inherit from it.
+try:
+    from hypothesis import settings as _hyp_settings
+    _hyp_settings.register_profile("repo", derandomize=True, database=None, deadline=None)
+    _hyp_settings.load_profile("repo")
+except ImportError:                                                # hypothesis is optional on a bare box
+    pass
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

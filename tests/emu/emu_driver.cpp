@@ -235,6 +235,13 @@ extern "C" {
 
 void emu_set_engine(int e) { g_engine = e ? 1 : 0; }
 
+// multiply-add lane-operations (wave::mad64 calls) since the last reset, over all 64 lanes of every emulated wave
+uint64_t emu_mad_count(int reset) {
+    const uint64_t v = wave::mad_counter();
+    if (reset) wave::mad_counter() = 0;
+    return v;
+}
+
 const char* emu_last_error() { return g_err.c_str(); }
 
 void emu_set_group(int g) { g_prefer_group = (g == 2 || g == 4 || g == 8 || g == 16) ? g : 0; }

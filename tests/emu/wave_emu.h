@@ -194,6 +194,15 @@ inline void lds_fence() {
     yield_all();
 }
 
-inline uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
+// every mad64 is one v_mad_u64_u32 lane-operation on the device: counted here so that tools/count_executed_mads.py can
+// state EXACTLY how many multiply-adds a kernel issues per element (bench.py's roofline.executed), not a hand model
+inline uint64_t& mad_counter() {
+    static thread_local uint64_t count = 0;
+    return count;
+}
+inline uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) {
+    ++mad_counter();
+    return (uint64_t)a * b + c;
+}
 
 }  // namespace wave

@@ -528,3 +528,93 @@ def test_scalar_encrypt_refills_the_pool_by_the_launch(monkeypatch):
     pub2 = paillier.PaillierPublicKey(H(g["n"]))
     c = pub2.encrypt(-3)
     assert pub2.obfuscators_available() == 0 and priv.decrypt(c) == -3
+
+
+# ---- round-2 regressions ------------------------------------------------------------------------
+def test_zero_weight_against_mixed_exponents(backend):
+    """A zero weight / plaintext placed against ciphertexts whose exponents are far apart used to size the aligned
+    exponent rows from the non-zero rows only (Engine.shifted_limbs) and crash; the reference's chain of * and + gives
+    the non-zero term.  dot, dense matvec and vec + ndarray all go through that helper."""
+    g = load_golden(1024)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    xs = [1e10, 1e-10]
+    vec = pub.encrypt_batch(np.array(xs), r_values=[5, 7])
+    singles = [pub.encrypt(x, r_value=r) for x, r in zip(xs, (5, 7))]
+    for w in ([0, 1], [0.0, 1.0], np.array([0.0, 1.0]), np.array([0, 3])):
+        d = vec.dot(w)
+        ws = w.tolist() if isinstance(w, np.ndarray) else w
+        chain = singles[0] * ws[0] + singles[1] * ws[1]
+        assert (d.ciphertext(False), d.exponent) == (chain.ciphertext(False), chain.exponent)
+        assert priv.decrypt(d) == pytest.approx(xs[1] * ws[1], rel=1e-12)
+    W = np.array([[0.0, 1.0], [2.0, 0.0], [0.0, 0.0]])
+    got = vec.matvec(W)
+    want = [vec.dot(row) for row in W]
+    assert got.ciphertexts(False) == [x.ciphertext(False) for x in want] and got.exponents == [x.exponent for x in want]
+    far = pub.encrypt_batch(np.array([1e-60, 2.0]), r_values=[5, 7])
+    s = far + np.array([0.0, 1.0])
+    ref = [pub.encrypt(1e-60, r_value=5) + 0.0, pub.encrypt(2.0, r_value=7) + 1.0]
+    assert s.ciphertexts(False) == [x.ciphertext(False) for x in ref] and s.exponents == [x.exponent for x in ref]
+
+
+def test_alignment_factor_is_bounded_by_max_int_like_the_scalar_path(backend):
+    """decrease_exponent_to multiplies by BASE**delta THROUGH EncodedNumber.encode (phe/paillier.py:599,
+    phe/encoding.py:194-196): a factor in (max_int, n) is a ValueError in the reference and in the scalar drop-in; the
+    vector forms must raise it too, not return a ciphertext.  Such a factor exists when bit_length(n) = 1 (mod 4):
+    a 253-bit modulus here (the checks run on the host, before any kernel)."""
+    n = (1 << 252) + 0x1234567
+    pub = paillier.PaillierPublicKey(n)
+    base = phe.EncodedNumber.BASE
+    d = 63
+    assert pub.max_int < base ** d < pub.n and base ** (d - 1) <= pub.max_int
+    one = np.zeros((2, 16), dtype=np.uint32)
+    one[:, 0] = 1
+    x = paillier.EncryptedNumber(pub, 1, 0)
+    vec = phe.EncryptedVector(pub, one, [0, 0])
+    with pytest.raises(ValueError, match="Integer needs to be within"):
+        x.decrease_exponent_to(-d)
+    with pytest.raises(ValueError, match="Integer needs to be within"):
+        vec.decrease_exponent_to(-d)
+    with pytest.raises(ValueError, match="Integer needs to be within"):
+        vec.decrease_exponent_to([0, -d])
+    lifted = phe.EncryptedVector(pub, one, [0, -d])
+    with pytest.raises(ValueError, match="Integer needs to be within"):
+        lifted.dot([1, 1])
+    with pytest.raises(ValueError, match="Integer needs to be within"):
+        lifted.matvec(np.array([[1, 1], [2, 3]]))
+    with pytest.raises(ValueError, match="Integer needs to be within"):
+        lifted + lifted[::-1]
+    with pytest.raises(ValueError, match="Integer needs to be within"):
+        x + paillier.EncryptedNumber(pub, 1, -d)
+
+
+def test_obfuscator_pool_is_handed_out_once_across_threads():
+    """Engine.take_obfuscators under concurrent callers: no pool row is ever returned twice (two ciphertexts sharing
+    r^n reveal m1 - m2).  Host logic only: the pool block is a stand-in with the DeviceArray view interface."""
+    import threading
+    from phe import _engine
+
+    class Block:
+        def __init__(self, lo, hi):
+            self.lo, self.hi, self.rows = lo, hi, hi - lo
+
+        def rows_view(self, lo, hi):
+            return Block(self.lo + lo, self.lo + hi)
+
+    eng = _engine.Engine.__new__(_engine.Engine)
+    eng._lock = threading.RLock()
+    eng._obf_pool = [[Block(0, 20000), 0]]
+    taken, barrier = [[] for _ in range(8)], threading.Barrier(8)
+
+    def worker(k):
+        barrier.wait()
+        while True:
+            part = eng.take_obfuscators(1)
+            if part is None:
+                return
+            taken[k].append(part.lo)
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    flat = sorted(x for part in taken for x in part)
+    assert flat == list(range(20000))

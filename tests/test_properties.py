@@ -3,7 +3,7 @@ whatever the inputs, the array forms must equal the element-by-element definitio
 import sys
 
 import numpy as np
-from hypothesis import Phase, given, settings, strategies as st
+from hypothesis import Phase, example, given, settings, strategies as st
 
 from conftest import PKG, load_golden
 
@@ -37,6 +37,9 @@ def _emu():
 
 @FAST
 @given(st.lists(st.tuples(st.integers(0, 2 ** 64 - 1), st.integers(0, 200)), min_size=1, max_size=40))
+@example([(0, 96), (1, 0)])                 # round-1 regression: a zero magnitude carrying the largest shift
+@example([(0, 64), (1, 0)])
+@example([(0, 200), (2 ** 64 - 1, 31), (0, 0)])
 def test_shifted_limbs_is_a_left_shift(pairs):
     mags, shifts = zip(*pairs)
     limbs, bits = Engine.shifted_limbs(np.array(mags, dtype=np.uint64), np.array(shifts, dtype=np.int64))

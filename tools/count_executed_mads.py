@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Exact multiply-add counts of the kernels, from the code itself.
+
+Every `wave::mad64` call of the device headers is one `v_mad_u64_u32` lane-operation on gfx950.  The CPU wave emulator
+(tests/emu: the SAME headers compiled for the host) counts those calls, so running one full wavefront's worth of
+elements through it gives the multiply-adds a kernel EXECUTES per element — lane-operations, the unit of the VALU
+roofline — without a hand model.  bench.py reads the committed result (profiles/executed_mads_r*.json) for
+`roofline.executed` / `roofline.frac`; profiles/README.md says how it relates to the PMC count SQ_INSTS_VALU.
+
+    python tools/count_executed_mads.py --out profiles/executed_mads_r02.json [--key-bits 1024 2048 3072]
+
+TEST/MEASUREMENT INFRASTRUCTURE: runs on the CPU box (no GPU), never imported by the product path."""
+import argparse
+import ctypes
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "python-paillier_amd")):
+    sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--key-bits", type=int, nargs="+", default=[1024, 2048, 3072])
+    ap.add_argument("--elements", type=int, default=64, help="elements per run: a multiple of 64/G for every geometry")
+    args = ap.parse_args()
+    from emu_lib import Emu
+    from phe import _native as native
+    emu = Emu()
+    emu.L.emu_mad_count.restype = ctypes.c_uint64
+    count = lambda: int(emu.L.emu_mad_count(1))
+    out = {"unit": "v_mad_u64_u32 lane-operations per element (wave::mad64 calls counted by the CPU wave emulator on "
+                   "full wavefronts; 29-bit limbs)", "elements_per_run": args.elements, "keys": {}}
+    for bits in args.key_bits:
+        g = json.load(open(os.path.join(ROOT, "tests", "golden", "paillier_%d.json" % bits)))
+        H = lambda k: int(g[k], 16)
+        n, p, q = H("n"), H("p"), H("q")
+        s1, s2, sh = bits // 32, bits // 16, bits // 64
+        rng = random.Random(bits)
+        B = args.elements
+        n_arr = native.int_to_limbs(n, s1)
+        nsq_arr = native.int_to_limbs(n * n, s2)
+        m = native.ints_to_limbs([rng.randrange(n) for _ in range(B)], s1)
+        r = native.ints_to_limbs([rng.randrange(1, n) for _ in range(B)], s1)
+        res = {"split_geometry_GL": list(emu.split_geometry(n_arr))}
+        t0 = time.time()
+        count()
+        c = emu.encrypt(n_arr, m, r)
+        res["encrypt"] = count() / B
+        assert native.limbs_to_ints(c[:1])[0] == (1 + n * native.limbs_to_ints(m[:1])[0]) * pow(
+            native.limbs_to_ints(r[:1])[0], n, n * n) % (n * n)
+        emu.obfuscate(n_arr, c, r)
+        res["obfuscate"] = count() / B
+        key = [native.int_to_limbs(v, sh) for v in (p, q, H("hp"), H("hq"), H("p_inverse"))]
+        back = emu.decrypt(*key, s1, c)
+        res["decrypt"] = count() / B
+        assert np.array_equal(back, m)
+        emu.mulmod(nsq_arr, c, np.ascontiguousarray(c[::-1]))
+        res["raw_add"] = count() / B
+        emu.add_plain(n_arr, c, m)
+        res["add_plain"] = count() / B
+        for name, ebits in (("raw_mul_56bit", 56), ("raw_mul_63bit", 63)):
+            e = native.ints_to_limbs([rng.getrandbits(ebits) | (1 << (ebits - 1)) for _ in range(B)], 2)
+            emu.powmod_n2(n_arr, c, e)
+            res[name] = count() / B
+        res["seconds"] = round(time.time() - t0, 1)
+        out["keys"][str(bits)] = res
+        print(bits, res, flush=True)
+    text = json.dumps(out, indent=1)
+    if args.out:
+        with open(args.out, "w") as f:
+            f.write(text + "\n")
+    else:
+        print(text)
+
+
+if __name__ == "__main__":
+    main()
