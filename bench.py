@@ -292,6 +292,13 @@ class HipBackend:
     def powmod(self, ctx, base, e, bits, out, rows):
         ctx.powmod_dev(base.data_ptr(), e.data_ptr(), e.shape[1], bits, out.data_ptr(), rows, self.stream)
 
+    def montmul(self, ctx, a, b, b_is_row, out, rows):
+        ctx.montmul_dev(a.data_ptr(), b.data_ptr(), b_is_row, out.data_ptr(), rows, self.stream)
+
+    def upload(self, arr):
+        import numpy as np
+        return self.torch.from_numpy(np.ascontiguousarray(arr).view(np.int32)).to(self.dev)
+
     def obfuscate(self, ctx, c, r, out, rows):
         ctx.obfuscate_dev(c.data_ptr(), r.data_ptr(), out.data_ptr(), rows, self.stream)
 
@@ -526,6 +533,33 @@ def main():
         ops_ok &= run_op("raw_add", lambda k: be.mulmod(ctx, c, c2, out, k), 20 if be.name == "hip" else 1,
                          lambda: bool(np.array_equal(be.np(be.take(out, idx)),
                                                      orc.add(n_arr, ca_s(), be.np(be.take(c2, idx)), nthreads=cores))))
+        if hasattr(be, "montmul") and hasattr(ctx, "montmul_dev"):
+            # resident vectors: ONE Montgomery product per addition, the missing powers of R ("debt") settled by one product
+            # with a constant when the residues are needed (phe/ciphertext.py).  Timed as the chain c2 + 8 x c: 8 additions
+            # + 1 settling product, the result checked as plain residues c2 * c^8 mod n^2.
+            chain = 8
+            R = 1 << ctx.mont_radix_bits()
+            const = be.upload(native.ints_to_limbs([pow(R, chain + 1, n_int * n_int)], s2))
+            tmp = be.empty(B, s2)
+
+            def lazy_chain(k):
+                src = c2
+                for i in range(chain):
+                    dst = tmp if i % 2 == 0 else out
+                    be.montmul(ctx, src, c, False, dst, k)
+                    src = dst
+                be.montmul(ctx, src, const, True, tmp if src is out else out, k)
+
+            def check_lazy():
+                final = tmp if chain % 2 == 0 else out               # the settle wrote the buffer the chain did not end in
+                sc = np.zeros((len(idx), s1), np.uint32)
+                sc[:, 0] = chain
+                want = orc.add(n_arr, orc.mul(n_arr, ca_s(), sc, nthreads=cores), be.np(be.take(c2, idx)), nthreads=cores)
+                return bool(np.array_equal(be.np(be.take(final, idx)), want))
+            ops_ok &= run_op("raw_add_resident_chain", lazy_chain, 4, check_lazy,
+                             "per pass: 8 additions at one Montgomery product each + 1 settling product; `value` counts passes")
+            ops["raw_add_resident_chain"]["additions_per_s"] = ops["raw_add_resident_chain"]["value"] * chain
+            del tmp
         scal = {}
         for name, bits, seed in (("raw_mul_float56", 56, 77), ("raw_mul_int64", 63, 78)):
             e = be.rand(B, 2, seed + 10 * rank)
@@ -703,6 +737,15 @@ def main():
                         "obfuscate": "obfuscate"}
             for name, rec in ops.items():
                 per_gpu = rec["value"] / world
+                if name == "raw_add_resident_chain":
+                    adds = rec["additions_per_s"] / world
+                    half = (counted["raw_add"] / 2) if counted else None      # one of the two products of the plain form
+                    rec["roofline"] = {"bound": "valu_int32", "canonical_mac32_per_op": canon["raw_add"],
+                                       "canonical_frac": canon["raw_add"] * adds / peak,
+                                       "executed_mad_per_op": half * 9 / 8 if half else None,
+                                       "frac": (half * 9 / 8 * adds / peak) if half else None,
+                                       "hbm_algorithmic_GBps": 3 * s2 * 4 * 9 / 8 * adds / 1e9}
+                    continue
                 ck = "raw_mul_float56" if name.startswith("raw_mul_float56") else name
                 ex = counted.get(exec_key[ck]) if counted else None
                 rec["roofline"] = {"bound": "valu_int32", "canonical_mac32_per_op": canon[ck],

@@ -153,6 +153,14 @@ int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t
 int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t batch, void* stream);
 int phe_hip_mulmod_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t batch, void* stream);
 int phe_hip_add_plain_dev(phe_hip_ctx* ctx, const uint32_t* c, const uint32_t* m, uint32_t* out, size_t batch, void* stream);
+/* Chains of homomorphic additions on resident vectors (EncryptedNumber._raw_add, phe/paillier.py:705-719, is one
+ * mulmod(a, b, n^2) = two Montgomery products here): out[i] = a[i] * b[i] * R^-1 mod n^2, canonical — ONE product.
+ * R = 2^bits with bits from phe_hip_mont_radix_bits (fixed per context).  b_is_row != 0: b is a single row used for
+ * every i (e.g. R^(d+1) mod n^2, which turns a value carrying d missing factors of R back into the plain residue).
+ * The caller keeps count of the missing powers of R (the host mirror does, per vector: phe/ciphertext.py). */
+int phe_hip_montmul_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, int b_is_row, uint32_t* out, size_t batch,
+                        void* stream);
+int phe_hip_mont_radix_bits(phe_hip_ctx* ctx, int* bits);
 /* max_exp_bits: upper bound on the bit length of every e[i] (0 = 32*exp_limbs) */
 int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, int max_exp_bits,
                        uint32_t* out, size_t batch, void* stream);

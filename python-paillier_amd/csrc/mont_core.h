@@ -470,9 +470,11 @@ struct MulArgs {
                                             // the product is taken with 1 + n*m — E(a) * g^m, the "add a plaintext" of
                                             // EncryptedNumber._add_encoded (phe/paillier.py:673-675); needs mod.aux
     uint64_t batch;
+    int one_product;                        // mul_io.h: 1 = a*b*R^-1 mod N (one Montgomery product) instead of a*b mod N
+    int vec_ok;                             // mul_io.h: every row pointer and stride is 16-byte aligned
 };
 
-template <int G, int L>
+template <int G, int L, bool ONE = false>
 PHE_DEV void mulmod_body(const MulArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots, uint32_t lane) {
     const Lanes<G> ln(lane);
     const uint32_t g = ln.g;
@@ -499,8 +501,10 @@ PHE_DEV void mulmod_body(const MulArgs& A, uint32_t* lds_row, uint32_t slot, uin
         }
         lds_put<L>(lds_row, x, g);
         montmul<G, L>(x, lds_row, y, n, n0inv, ln);   // a*b/R
-        lds_put<L>(lds_row, x, g);
-        montmul<G, L>(x, lds_row, r2, n, n0inv, ln);  // a*b
+        if constexpr (!ONE) {  // ONE: a*b*R^-1, one Montgomery product (A.one_product; see mul_io.h)
+            lds_put<L>(lds_row, x, g);
+            montmul<G, L>(x, lds_row, r2, n, n0inv, ln);  // a*b
+        }
         canonicalize<G, L>(x, n, ln);
         store_r29_as_u32<G, L>(A.out + item * A.out_stride, A.limbs, x, lds_row, g, live);
     }

@@ -582,9 +582,13 @@ static int launch_var(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* bas
 
 static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, size_t a_stride, const uint32_t* b,
                       size_t b_stride, uint32_t* out, size_t out_stride, int limbs, size_t batch,
-                      hipStream_t stream, int b_plain_limbs = 0) {
+                      hipStream_t stream, int b_plain_limbs = 0, int one_product = 0) {
     MulArgs A;
     A.b_plain_limbs = b_plain_limbs;
+    A.one_product = one_product;
+    // 16-byte chunks (mul_io.h) when every row starts on a 16-byte boundary; otherwise word by word
+    A.vec_ok = ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15u) == 0 && a_stride % 4 == 0 && b_stride % 4 == 0 &&
+                out_stride % 4 == 0 && limbs % 4 == 0 && b_plain_limbs % 4 == 0) ? 1 : 0;
     A.mod = M.c;
     A.a = a;
     A.b = b;
@@ -890,6 +894,24 @@ int phe_hip_mulmod_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, u
     if (int rc = bind_device(ctx)) return rc;
     const size_t s2 = (size_t)ctx->pub.s2;
     return launch_mul(ctx, pick_nsq(ctx, batch), a, s2, b, s2, out, s2, ctx->pub.s2, batch, (hipStream_t)stream);
+}
+
+int phe_hip_montmul_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, int b_is_row, uint32_t* out, size_t batch,
+                        void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!a || !b || !out) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    const size_t s2 = (size_t)ctx->pub.s2;
+    // always the throughput geometry: R must not depend on the batch size
+    return launch_mul(ctx, ctx->d_nsq, a, s2, b, b_is_row ? 0 : s2, out, s2, ctx->pub.s2, batch, (hipStream_t)stream, 0, 1);
+}
+
+int phe_hip_mont_radix_bits(phe_hip_ctx* ctx, int* bits) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (!bits) return fail(PHE_HIP_EINVAL, "null pointer");
+    *bits = phe::kRadixBits * ctx->d_nsq.S;
+    return PHE_HIP_OK;
 }
 
 int phe_hip_add_plain_dev(phe_hip_ctx* ctx, const uint32_t* c, const uint32_t* m, uint32_t* out, size_t batch, void* stream) {

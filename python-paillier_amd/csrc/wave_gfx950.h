@@ -100,6 +100,18 @@ PHE_DEV void lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Asynchronous 16-byte copy global -> LDS without a register round trip (global_load_lds_dwordx4, "LDS-DMA"): lane l
+// of the wave lands at lds_wave_base + 16*l bytes — the destination is wave-uniform base + lane*16, the SOURCE is per
+// lane.  Lanes for which `active` is false copy nothing.  The data may be read after wait_async_copies().
+PHE_DEV void async_copy16_to_lds(const uint32_t* gsrc, uint32_t* lds_wave_base, bool active) {
+    if (active)
+        __builtin_amdgcn_global_load_lds(gsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+PHE_DEV void wait_async_copies() {
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched (gfx9 encoding)
+    lds_fence();
+}
+
 // 32x32+64 -> 64 multiply-accumulate: v_mad_u64_u32 with a full 64-bit addend.  The radix-2^29 core
 // keeps every accumulator below 2^64 by construction, so the carry-out is never needed.
 PHE_DEV uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }

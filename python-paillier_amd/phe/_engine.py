@@ -624,6 +624,47 @@ class Engine:
         self.ctx.sync()
         return out
 
+    # ---- chains of additions on resident vectors: one Montgomery product per addition ("Montgomery debt") -------------
+    # _raw_add is mulmod(a, b, n^2) (phe/paillier.py:705-719): on the device two Montgomery products, a*b/R and then *R^2/R.
+    # A resident vector may instead hold x * R^-d mod n^2 for a vector-wide integer d (its debt): the product of two such
+    # rows by ONE Montgomery product is (x_a x_b) * R^-(d_a + d_b + 1), and one product with the constant R^(d+1) mod n^2
+    # gives the plain residues back when they are needed (download, decrypt, scalar multiplication, ...).  A chain of k
+    # additions costs k + 1 products instead of 2k; what leaves the vector is the same canonical residue as before.
+    def lazy_products(self):
+        """True when the backend offers the one-product entry (include/phe_hip.h phe_hip_montmul_dev)"""
+        return hasattr(self.ctx, "montmul_dev") and hasattr(self.ctx, "malloc")
+
+    def _mont_radix(self):
+        R = self.__dict__.get("_mont_R")
+        if R is None:
+            R = self._mont_R = 1 << self.ctx.mont_radix_bits()
+        return R
+
+    def _mont_const_row(self, power):
+        """the row R^power mod n^2 on the device (cached per power)"""
+        rows = self.__dict__.setdefault("_mont_rows", {})
+        row = rows.get(power)
+        if row is None:
+            if len(rows) > 256:
+                rows.clear()
+            row = rows[power] = DeviceArray.from_host(self.ctx, self.cipher_limbs([pow(self._mont_radix(), power, self.nsquare)]))
+        return row
+
+    def montmul_dev(self, a, b):
+        """row-wise a * b / R mod n^2 (canonical): the debts of the operands add up, plus one"""
+        out = DeviceArray(self.ctx, a.rows, self.ct_limbs)
+        self.ctx.montmul_dev(a.ptr, b.ptr, False, out.ptr, a.rows)
+        self.ctx.sync()
+        return out
+
+    def scale_dev(self, a, power):
+        """row-wise a * R^power mod n^2 by one product with the constant R^(power + 1): power = d settles a debt of d,
+        a negative power takes a row further into debt (to meet a partner's)"""
+        out = DeviceArray(self.ctx, a.rows, self.ct_limbs)
+        self.ctx.montmul_dev(a.ptr, self._mont_const_row(power + 1).ptr, True, out.ptr, a.rows)
+        self.ctx.sync()
+        return out
+
     def add_plain_dev(self, c, plaintexts):
         m = self.upload_plain([v % self.n for v in plaintexts] if not isinstance(plaintexts, np.ndarray) else plaintexts)
         out = DeviceArray(self.ctx, c.rows, self.ct_limbs)

@@ -66,6 +66,8 @@ def lib():
         L.phe_hip_decrypt_dev.argtypes = [vp, vp, vp, sz, vp]
         L.phe_hip_mulmod_dev.argtypes = [vp, vp, vp, vp, sz, vp]
         L.phe_hip_powmod_dev.argtypes = [vp, vp, vp, ci, ci, vp, sz, vp]
+        L.phe_hip_montmul_dev.argtypes = [vp, vp, vp, ci, vp, sz, vp]
+        L.phe_hip_mont_radix_bits.argtypes = [vp, ctypes.POINTER(ci)]
         L.phe_hip_malloc.argtypes = [vp, sz, ctypes.POINTER(vp)]
         L.phe_hip_free.argtypes = [vp, vp]
         L.phe_hip_memcpy_h2d.argtypes = [vp, vp, vp, sz]
@@ -92,7 +94,7 @@ EXPORTED_SYMBOLS = [
     "phe_hip_select_rows_dev", "phe_hip_add_plain", "phe_hip_add_plain_dev", "phe_hip_ctx_engine",
     "phe_hip_multiexp", "phe_hip_multiexp_dev", "phe_hip_multiexp_rows_dev", "phe_hip_multiexp_csr_dev", "phe_hip_decimal_width", "phe_hip_to_decimal",
     "phe_hip_from_decimal", "phe_hip_to_decimal_dev", "phe_hip_from_decimal_dev", "phe_hip_stream_create",
-    "phe_hip_stream_destroy", "phe_hip_miller_rabin",
+    "phe_hip_stream_destroy", "phe_hip_miller_rabin", "phe_hip_montmul_dev", "phe_hip_mont_radix_bits",
 ]
 
 
@@ -363,6 +365,15 @@ class Context:
 
     def mulmod_dev(self, a_ptr, b_ptr, out_ptr, batch, stream=0):
         _check(lib().phe_hip_mulmod_dev(self._h, a_ptr, b_ptr, out_ptr, batch, stream))
+
+    def montmul_dev(self, a_ptr, b_ptr, b_is_row, out_ptr, batch, stream=0):
+        """out[i] = a[i] * b[i] / R mod n^2 (ONE Montgomery product; R = 2^mont_radix_bits()); b_is_row: one row b for all i"""
+        _check(lib().phe_hip_montmul_dev(self._h, a_ptr, b_ptr, 1 if b_is_row else 0, out_ptr, batch, stream))
+
+    def mont_radix_bits(self):
+        bits = ctypes.c_int(0)
+        _check(lib().phe_hip_mont_radix_bits(self._h, ctypes.byref(bits)))
+        return bits.value
 
     def add_plain_dev(self, c_ptr, m_ptr, out_ptr, batch, stream=0):
         _check(lib().phe_hip_add_plain_dev(self._h, c_ptr, m_ptr, out_ptr, batch, stream))

@@ -151,16 +151,30 @@ class EncryptedVector(object):
     host numpy array or a device-resident DeviceArray (`device=True` / `.to_device()`), in which case every
     operation below runs on HBM-resident operands and only plaintext-sized data crosses PCIe."""
 
-    def __init__(self, public_key, limbs, exponents, obfuscated=False):
+    def __init__(self, public_key, limbs, exponents, obfuscated=False, _debt=0):
         self.public_key = public_key
         self.on_device = isinstance(limbs, DeviceArray)
-        self._limbs = limbs if self.on_device else np.ascontiguousarray(limbs, dtype=np.uint32)
+        self._store = limbs if self.on_device else np.ascontiguousarray(limbs, dtype=np.uint32)
+        # resident vectors only: the rows hold x * R^-debt mod n^2 (Engine "Montgomery debt": chains of additions at one
+        # Montgomery product each); anything that looks at `_limbs` settles the debt first, so the lazy form never leaves
+        self._debt = int(_debt) if self.on_device else 0
         self._exps = np.array(exponents if isinstance(exponents, np.ndarray) else list(exponents), dtype=np.int64).reshape(-1)
-        shape = self._limbs.shape
+        shape = self._store.shape
         if len(shape) != 2 or shape[0] != len(self._exps):
             raise ValueError("limbs must be (batch, ct_limbs) with one exponent per row")
         flags = obfuscated if isinstance(obfuscated, np.ndarray) else np.full(len(self._exps), bool(obfuscated))
         self._obfuscated = flags.astype(bool)
+
+    @property
+    def _limbs(self):
+        if self._debt:
+            self._store = self.public_key._get_engine().scale_dev(self._store, self._debt)
+            self._debt = 0
+        return self._store
+
+    @_limbs.setter
+    def _limbs(self, value):
+        self._store, self._debt = value, 0
 
     @property
     def exponents(self):
@@ -326,8 +340,9 @@ class EncryptedVector(object):
         rows = np.nonzero(new < old)[0]
         flags = self._obfuscated.copy()
         if len(rows) == 0:
-            limbs = self._limbs if self.on_device else self._limbs.copy()
-            return self._like(limbs, new, flags)
+            if self.on_device:                                # same rows, same debt: nothing to settle
+                return EncryptedVector(self.public_key, self._store, new, flags, _debt=self._debt)
+            return self._like(self._limbs.copy(), new, flags)
         pk = self.public_key
         delta = (old - new)[rows]
         powers = {int(d): pow(EncodedNumber.BASE, int(d)) for d in np.unique(delta).tolist()}
@@ -380,6 +395,10 @@ class EncryptedVector(object):
                 other = other.to_device() if self.on_device else other.to_host()
             a, target = self._aligned(other._exps)
             b = other.decrease_exponent_to(target)
+            eng = pk._get_engine()
+            if self.on_device and eng.lazy_products():
+                # one Montgomery product; the missing powers of R are settled when the residues are looked at
+                return EncryptedVector(pk, eng.montmul_dev(a._store, b._store), target, _debt=a._debt + b._debt + 1)
             return self._like(self._raw_add(a._limbs, b._limbs), target)
         # plain operand(s): scalar broadcast or sequence; encode with max_exponent = own exponent per row
         values = other if isinstance(other, (list, tuple, np.ndarray)) else [other] * len(self)
@@ -470,6 +489,23 @@ class EncryptedVector(object):
         pk = self.public_key
         eng = pk._get_engine()
         cur = self.decrease_exponent_to(int(self._exps.min()))
+        if self.on_device and eng.lazy_products():
+            # the pairwise tree at ONE Montgomery product per node: a level turns rows of debt d into rows of debt 2d + 1
+            # (an odd row out is taken to the same debt by a product with a constant); settled once, at the root
+            store, debt, exp = cur._store, cur._debt, int(cur._exps[0])
+            while store.rows > 1:
+                half = store.rows // 2
+                merged = eng.montmul_dev(store.rows_view(0, half), store.rows_view(half, 2 * half))
+                if store.rows % 2:
+                    odd = eng.scale_dev(store.rows_view(2 * half, 2 * half + 1), -(debt + 1))
+                    grown = DeviceArray(eng.ctx, half + 1, store.cols)
+                    eng.ctx.d2d(grown.ptr, merged.ptr, merged.nbytes)
+                    eng.ctx.d2d(grown.ptr + merged.nbytes, odd.ptr, odd.nbytes)
+                    eng.ctx.sync()
+                    merged = grown
+                store, debt = merged, 2 * debt + 1
+            root = eng.scale_dev(store, debt) if debt else store
+            return EncryptedNumber(pk, eng.to_ints(root.to_host())[0], exp)
         limbs, exp = cur._limbs, int(cur._exps[0])
         if self.on_device:
             while limbs.rows > 1:

@@ -7,6 +7,7 @@
 #include "wave_emu.h"
 // clang-format off
 #include "../../python-paillier_amd/csrc/mont_core.h"
+#include "../../python-paillier_amd/csrc/mul_io.h"
 #include "../../python-paillier_amd/csrc/split_core.h"
 #include "../../python-paillier_amd/csrc/decrypt_tail.h"
 #include "../../python-paillier_amd/csrc/key_setup.h"
@@ -93,17 +94,51 @@ static void run_var(VarArgs A) {
     }
 }
 
+static int g_mul_io = 1;  // 1: mul_io.h (the kernels' body), 0: mont_core.h:mulmod_body (the reference form)
+
+static bool rows_vec_ok(const MulArgs& A) {
+    auto al = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
+    return al(A.a) && al(A.b) && al(A.out) && A.a_stride % 4 == 0 && A.b_stride % 4 == 0 && A.out_stride % 4 == 0 &&
+           A.limbs % 4 == 0 && A.b_plain_limbs % 4 == 0;
+}
+
+// the element-wise product the way k_mulmod runs it: the staged body (mul_io.h) where the geometry offers it and the rows
+// are aligned, the plain one otherwise; returns which one ran
+static int g_last_mul_staged = 0;
 template <int G, int L>
 static void run_mul(MulArgs A) {
+    using IO = RowIO<G, L>;
     constexpr int S = G * L, kPer = 64 / G;
     const int n_waves = waves_for(A.batch, G);
     const uint32_t total = (uint32_t)(kPer * n_waves);
+    A.vec_ok = rows_vec_ok(A) ? 1 : 0;
+    const bool staged = g_mul_io && IO::kUse && A.vec_ok;
+    g_last_mul_staged = staged ? 1 : 0;
     for (int w = 0; w < n_waves; ++w) {
-        std::vector<uint32_t> lds(kPer * (S + kLdsPad));
-        wave::run_wave([&](uint32_t lane) {
-            const uint32_t grp = lane / G;
-            mulmod_body<G, L>(A, lds.data() + grp * (S + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
-        });
+        if (staged) {
+            // one wave: its groups' digit rows | its staging area (a | b) | R^2, 16-byte aligned like the kernels' LDS
+            std::vector<Words4> lds(((size_t)kPer * IO::kRow + 2 * IO::kStageWave + IO::kConstWords) / 4 + 1);
+            uint32_t* base = (uint32_t*)lds.data();
+            for (size_t i = 0; i < lds.size() * 4; ++i) base[i] = 0xdeadbeefu;   // LDS is not zero on the device either
+            uint32_t* r2_row = base + kPer * IO::kRow + 2 * IO::kStageWave;
+            for (int k = 0; k < S; ++k) r2_row[k] = A.mod.r2[k];
+            wave::run_wave([&](uint32_t lane) {
+                const uint32_t grp = lane / G;
+                if (A.one_product)
+                    mul_io_body<G, L, true>(A, base + grp * IO::kRow, base + kPer * IO::kRow, r2_row, (uint32_t)w * kPer + grp, total, lane);
+                else
+                    mul_io_body<G, L, false>(A, base + grp * IO::kRow, base + kPer * IO::kRow, r2_row, (uint32_t)w * kPer + grp, total, lane);
+            });
+        } else {
+            std::vector<uint32_t> lds(kPer * (S + kLdsPad));
+            wave::run_wave([&](uint32_t lane) {
+                const uint32_t grp = lane / G;
+                if (A.one_product)
+                    mulmod_body<G, L, true>(A, lds.data() + grp * (S + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
+                else
+                    mulmod_body<G, L, false>(A, lds.data() + grp * (S + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
+            });
+        }
     }
 }
 
@@ -234,6 +269,8 @@ static int g_engine = 1;  // 1: split-modulus kernels where a geometry exists (t
 extern "C" {
 
 void emu_set_engine(int e) { g_engine = e ? 1 : 0; }
+void emu_set_mul_io(int e) { g_mul_io = e ? 1 : 0; }
+int emu_last_mul_staged() { return g_last_mul_staged; }
 
 // multiply-add lane-operations (wave::mad64 calls) since the last reset, over all 64 lanes of every emulated wave
 uint64_t emu_mad_count(int reset) {
@@ -361,6 +398,23 @@ int emu_mulmod(const uint32_t* N, int limbs, const uint32_t* a, const uint32_t* 
         memset(&A, 0, sizeof A);
         A.mod = consts_of(M); A.a = a; A.b = b; A.limbs = limbs; A.out = out; A.batch = B;
         A.a_stride = A.b_stride = A.out_stride = (size_t)limbs;
+        DISPATCH_GL(M.G, M.L, (run_mul<GG, LL>(A)));
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// one Montgomery product per row: out = a*b*R^-1 mod N, canonical (R = 2^(29*S) of the geometry, returned through
+// radix_bits); broadcast_b != 0: one row b for the whole batch
+int emu_montmul_rows(const uint32_t* N, int limbs, const uint32_t* a, const uint32_t* b, int broadcast_b, uint32_t* out,
+                     uint64_t B, int* radix_bits) {
+    try {
+        host::ModulusPack M = host::build_modulus(host::big_from(N, limbs, limbs), nullptr, 32 * limbs, g_prefer_group);
+        if (radix_bits) *radix_bits = kRadixBits * M.S;
+        if (B == 0) return 0;
+        MulArgs A;
+        memset(&A, 0, sizeof A);
+        A.mod = consts_of(M); A.a = a; A.b = b; A.limbs = limbs; A.out = out; A.batch = B; A.one_product = 1;
+        A.a_stride = A.out_stride = (size_t)limbs; A.b_stride = broadcast_b ? 0 : (size_t)limbs;
         DISPATCH_GL(M.G, M.L, (run_mul<GG, LL>(A)));
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }

@@ -194,6 +194,16 @@ inline void lds_fence() {
     yield_all();
 }
 
+// LDS-DMA stand-in: lane l's 16 bytes land at lds_wave_base + 16*l (copied at once: any completion time before the wait
+// is a legal behaviour of the device instruction)
+inline void async_copy16_to_lds(const uint32_t* gsrc, uint32_t* lds_wave_base, bool active) {
+    if (active) {
+        uint32_t* dst = lds_wave_base + 4 * lane_id();
+        for (int i = 0; i < 4; ++i) dst[i] = gsrc[i];
+    }
+}
+inline void wait_async_copies() { lds_fence(); }
+
 // every mad64 is one v_mad_u64_u32 lane-operation on the device: counted here so that tools/count_executed_mads.py can
 // state EXACTLY how many multiply-adds a kernel issues per element (bench.py's roofline.executed), not a hand model
 inline uint64_t& mad_counter() {

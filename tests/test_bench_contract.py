@@ -81,7 +81,7 @@ def _check_two_rank_line(out):
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 2 and out["warmup"] == 1
     assert out["scaling"] == "weak" and out["higher_is_better"] is True and out["vs_baseline"] is None
     assert out["bit_exact"] == {"roundtrip_full_batch": True, "strided_sample_vs_gmp_oracle": True, "strided_sample_rows": 6}
-    assert set(out["ops"]) == {"raw_add", "raw_mul_float56", "raw_mul_int64", "raw_mul_float56_neg10pct", "obfuscate"}
+    assert set(out["ops"]) >= {"raw_add", "raw_mul_float56", "raw_mul_int64", "raw_mul_float56_neg10pct", "obfuscate"}
     assert all(rec["bit_exact_strided_sample_vs_gmp_oracle"] is True and rec["value"] > 0 for rec in out["ops"].values())
     cfg4 = out["config4"]
     assert cfg4["total"] == 9 and cfg4["rows_per_gpu"] == 5 and cfg4["bit_exact_boundaries_and_sample_vs_gmp_oracle"] is True

@@ -283,3 +283,99 @@ def test_argument_errors_come_back_as_status_codes(native):
     # zero-length batches are fine everywhere
     assert ctx.multiexp(np.zeros((0, 64), np.uint32), np.zeros((0, 1), np.uint32)).tolist() == one.tolist()
     assert ctx.to_decimal(np.zeros((0, 64), np.uint32)).shape[0] == 0
+
+
+# ---- element-wise products: staged operand traffic, one-product form, Montgomery debt (csrc/mul_io.h) -----------------
+@pytest.mark.parametrize("key_bits,batch", [(256, 70), (1024, 1000), (2048, 5000), (2048, 3), (3072, 300)])
+def test_one_product_entry_and_debt_constants(native, key_bits, batch, group):
+    """phe_hip_montmul_dev = a*b/R mod n^2 with R = 2^phe_hip_mont_radix_bits; a row-constant R^(d+1) settles d missing
+    factors of R.  Against Python integers (canonical residues, so any correct engine agrees bit for bit)."""
+    from phe._device import DeviceArray
+    g = load_golden(key_bits)
+    ctx = make_ctx(native, g, private=False)
+    n = H(g["n"])
+    N, s2 = n * n, key_bits // 16
+    rng = random.Random(key_bits + batch)
+    a = [rng.randrange(N) for _ in range(batch)]
+    b = [rng.randrange(N) for _ in range(batch)]
+    a[0], b[0] = N - 1, N - 1
+    a[-1], b[-1] = 0, 1
+    R = 1 << ctx.mont_radix_bits()
+    assert R >= 16 * N
+    Rinv = pow(R, -1, N)
+    da, db = (DeviceArray.from_host(ctx, native.ints_to_limbs(v, s2)) for v in (a, b))
+    out = DeviceArray(ctx, batch, s2)
+    ctx.montmul_dev(da.ptr, db.ptr, False, out.ptr, batch)
+    ctx.sync()
+    assert native.limbs_to_ints(out.to_host()) == [x * y * Rinv % N for x, y in zip(a, b)]
+    for d in (0, 1, 5):
+        debt = DeviceArray.from_host(ctx, native.ints_to_limbs([x * pow(Rinv, d, N) % N for x in a], s2))
+        const = DeviceArray.from_host(ctx, native.ints_to_limbs([pow(R, d + 1, N)], s2))
+        ctx.montmul_dev(debt.ptr, const.ptr, True, out.ptr, batch)
+        ctx.sync()
+        assert native.limbs_to_ints(out.to_host()) == a
+    # the two-product entry on the same operands (the staged kernel where the geometry offers it)
+    ctx.mulmod_dev(da.ptr, db.ptr, out.ptr, batch)
+    ctx.sync()
+    assert native.limbs_to_ints(out.to_host()) == [x * y % N for x, y in zip(a, b)]
+
+
+def test_products_on_rows_that_are_not_16_byte_aligned(native, c_oracle):
+    """rows that start 4 bytes off a 16-byte boundary take the plain body (no 16-byte chunks): same results"""
+    from phe._device import DeviceArray
+    g = load_golden(2048)
+    ctx = make_ctx(native, g, private=False)
+    n = H(g["n"])
+    N, s2, batch = n * n, 128, 600
+    rng = random.Random(5)
+    a = [rng.randrange(N) for _ in range(batch)]
+    b = [rng.randrange(N) for _ in range(batch)]
+    flat = lambda v: np.concatenate([np.zeros(1, np.uint32), native.ints_to_limbs(v, s2).reshape(-1)])
+    da = DeviceArray.from_host(ctx, flat(a).reshape(-1, 1))
+    db = DeviceArray.from_host(ctx, flat(b).reshape(-1, 1))
+    out = DeviceArray(ctx, batch * s2 + 1, 1)
+    R = 1 << ctx.mont_radix_bits()
+    Rinv = pow(R, -1, N)
+    ctx.mulmod_dev(da.ptr + 4, db.ptr + 4, out.ptr + 4, batch)
+    ctx.sync()
+    assert native.limbs_to_ints(out.to_host().reshape(-1)[1:].reshape(batch, s2)) == [x * y % N for x, y in zip(a, b)]
+    ctx.montmul_dev(da.ptr + 4, db.ptr + 4, False, out.ptr + 4, batch)
+    ctx.sync()
+    assert native.limbs_to_ints(out.to_host().reshape(-1)[1:].reshape(batch, s2)) == [x * y * Rinv % N for x, y in zip(a, b)]
+
+
+@pytest.mark.parametrize("count", [1, 2, 7, 1000, 4099])
+def test_resident_vectors_add_lazily_and_settle_to_the_reference_bits(native, count):
+    """EncryptedVector on the device: `+` is one Montgomery product and leaves a debt, sum() is a tree of them; every way
+    of looking at the result (ciphertexts, host copy, decrypt, a further scalar multiplication) gives the bits that the
+    chain of _raw_add (phe/paillier.py:705-719) gives on integers"""
+    from phe import paillier
+    g = load_golden(1024)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    N = pub.nsquare
+    rng = random.Random(count)
+    xs = [rng.randrange(-10 ** 6, 10 ** 6) for _ in range(count)]
+    ys = [rng.randrange(-10 ** 6, 10 ** 6) for _ in range(count)]
+    rs = [rng.randrange(1, pub.n) for _ in range(2 * count)]
+    va = pub.encrypt_batch(xs, r_values=rs[:count], device=True)
+    vb = pub.encrypt_batch(ys, r_values=rs[count:], device=True)
+    ca, cb = va.ciphertexts(False), vb.ciphertexts(False)
+    s1 = va + vb
+    assert s1._debt == 1
+    s3 = (s1 + va) + (vb + vb)                       # debts 1 + 0 + 1 = 2, (0 + 0 + 1) = 1 -> 2 + 1 + 1 = 4
+    assert s3._debt == 4
+    want3 = [a * b % N * a % N * (b * b % N) % N for a, b in zip(ca, cb)]
+    total = s3.sum()                                 # the tree runs on the indebted rows
+    assert s3._debt == 4
+    acc = 1
+    for w in want3:
+        acc = acc * w % N
+    assert total.ciphertext(False) == acc
+    assert priv.decrypt(total) == sum(2 * x + 3 * y for x, y in zip(xs, ys))
+    assert s3.ciphertexts(False) == want3 and s3._debt == 0
+    assert s1.to_host().ciphertexts(False) == [a * b % N for a, b in zip(ca, cb)]
+    assert priv.decrypt_batch(va + vb + va) == [2 * x + y for x, y in zip(xs, ys)]
+    scaled = (va + vb) * 3                           # a scalar multiplication settles first
+    assert scaled.ciphertexts(False) == [pow(a * b % N, 3, N) for a, b in zip(ca, cb)]
+    assert va.sum().ciphertext(False) == __import__("functools").reduce(lambda p, c: p * c % N, ca, 1)
