@@ -194,6 +194,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--config4-key-bits", type=int, default=3072, choices=[256, 1024, 2048, 3072])
     ap.add_argument("--config4-total", type=int, default=0, help="plaintexts of the whole configs[3] job (0 = 2^20 per GPU)")
+    ap.add_argument("--lib-allgather", action="store_true",
+                    help="configs[3] leg: repeat the all-gather through the library's own RCCL communicator (phe_hip_allgather_dev)")
     ap.add_argument("--oracle-sample", type=int, default=4096, help="strided rows of the timed batch checked against libgmp")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--selftest-emu", action="store_true", help="CPU contract test: gloo + wave emulator, not a measurement")
@@ -631,6 +633,29 @@ def main():
         barrier()
         t_gather = time.perf_counter() - t0
         t_enc, t_gather = max_over_ranks([t_enc, t_gather])
+        lib_gather = None
+        if args.lib_allgather and be.name == "hip" and total % world == 0:
+            # the same exchange issued by the library's own RCCL communicator (include/phe_hip.h phe_hip_allgather_dev):
+            # the path of a host without a process group; the id travels over the torch group here
+            from phe.sharding import library_communicator
+            def exchange(uid):
+                box = [uid]
+                if use_dist:
+                    dist.broadcast_object_list(box, src=0)
+                return box[0]
+            comm = library_communicator(ctx4, rank, world, exchange)
+            full2 = be.empty(total, t2)
+            comm.allgather_dev(c4.data_ptr(), full2.data_ptr(), rows, t2, be.stream)      # first call: connection set-up
+            barrier()
+            t0 = time.perf_counter()
+            comm.allgather_dev(c4.data_ptr(), full2.data_ptr(), rows, t2, be.stream)
+            barrier()
+            t_lib = max_over_ranks([time.perf_counter() - t0])[0]
+            lib_gather = {"seconds": t_lib, "GBps_per_gpu": total * t2 * 4 / t_lib / 1e9,
+                          "same_bits_as_torch_all_gather": be.equal(full2, full)}
+            cfg4_ok = cfg4_ok and lib_gather["same_bits_as_torch_all_gather"]
+            comm.close()
+            del full2
         if rank == 0:
             bounds = [shard_bounds(total, world, k) for k in range(world)]
             idx = sorted(set([0, total - 1] + [b[0] for b in bounds if b[0] < total] + [max(0, b[1] - 1) for b in bounds] +
@@ -638,7 +663,7 @@ def main():
             ms, rs = zip(*[operands(i, 1) for i in idx])
             want = orc.encrypt(native.int_to_limbs(k4["n"], t1), be.np(be.cat(list(ms))), be.np(be.cat(list(rs))), nthreads=cores)
             got = full[idx].cpu().numpy().view(np.uint32)
-            cfg4_ok = bool(np.array_equal(got, want))
+            cfg4_ok = cfg4_ok and bool(np.array_equal(got, want))
             cfg4 = {"workload": "configs[3]: %d-bit key, %d plaintexts sharded over %d GPU(s) (%d per GPU), ONE all-gather "
                                 "of the ciphertext shards (phe.sharding.all_gather_rows, backend %s)"
                                 % (args.config4_key_bits, total, world, rows, be.dist_backend if use_dist else "none: 1 rank"),
@@ -646,6 +671,7 @@ def main():
                     "encrypt": {"seconds": t_enc, "value": total / t_enc, "unit": "encrypts/s"},
                     "all_gather": {"seconds": t_gather, "bytes_received_per_gpu": total * t2 * 4,
                                    "GBps_per_gpu": total * t2 * 4 / t_gather / 1e9 if use_dist else None},
+                    "all_gather_by_library_rccl": lib_gather,
                     "end_to_end_encrypts_per_s": total / (t_enc + t_gather),
                     "bit_exact_boundaries_and_sample_vs_gmp_oracle": cfg4_ok, "rows_checked": len(idx),
                     "geometry": ctx4.info()}

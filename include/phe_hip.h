@@ -217,6 +217,22 @@ int phe_hip_stream_sync(phe_hip_ctx* ctx, void* stream);
 int phe_hip_stream_create(phe_hip_ctx* ctx, void** stream);
 int phe_hip_stream_destroy(phe_hip_ctx* ctx, void* stream);
 
+/* ---- multi-GPU: the one exchange step of the path -------------------------------------------------
+ * Batches shard by contiguous row ranges, one process per GPU, and nothing crosses GPUs while encrypting / decrypting /
+ * adding (the reference has no multi-device code to cite).  Only when every device must hold the whole
+ * ciphertext vector are the shards concatenated: ONE all-gather over RCCL (xGMI inside a node).  A host framework that
+ * already owns a process group can do it itself (python-paillier_amd/phe/sharding.py uses torch.distributed); hosts
+ * without one use these: rank 0 makes an id, the host hands its 128 bytes to the other ranks by whatever channel it has,
+ * every rank creates its communicator on its context's device, then gathers device rows.  RCCL (librccl.so.1) is
+ * loaded on first use; PHE_HIP_EHIP with a message if it is missing.
+ * phe_hip_allgather_dev: local = (rows, limbs) words on this rank's device, all = (world * rows, limbs): rank r's rows at
+ * [r * rows, (r + 1) * rows) on every rank; equal `rows` on all ranks (pad the last shard).  Asynchronous on `stream`. */
+typedef struct phe_hip_comm phe_hip_comm;
+int phe_hip_comm_unique_id(uint8_t id[128]);
+int phe_hip_comm_create(phe_hip_ctx* ctx, const uint8_t id[128], int rank, int world, phe_hip_comm** out);
+int phe_hip_allgather_dev(phe_hip_comm* comm, const uint32_t* local, uint32_t* all, size_t rows, int limbs, void* stream);
+void phe_hip_comm_destroy(phe_hip_comm* comm);
+
 /* ---- diagnostics ----------------------------------------------------------------------------- */
 /* Runs the three DPP row primitives and the ballot on lane ids: out is (4, 64) uint32:
  * row 0 = row_down1(lane), row 1 = row_up1(lane), row 2 = row_bcast0(lane), row 3 = lane parity

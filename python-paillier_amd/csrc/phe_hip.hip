@@ -34,7 +34,13 @@
 #include "primality.h"
 // clang-format on
 
+#include <dlfcn.h>
+
 using namespace phe;
+
+struct phe_rccl_id {  // ncclUniqueId: 128 opaque bytes, passed by value (rccl.h NCCL_UNIQUE_ID_BYTES)
+    char internal[128];
+};
 using host::Big;
 
 // ------------------------------------------------------------------------------------------------
@@ -309,6 +315,16 @@ struct phe_hip_ctx {
     // staging for the host-pointer entry points
     uint32_t* stage[3] = {nullptr, nullptr, nullptr};
     size_t stage_words[3] = {0, 0, 0};
+    // large host batches: chunks double-buffered through pinned memory, uploads / kernels / downloads on three streams
+    struct HostPipe {
+        hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
+        hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
+        uint32_t* pin[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // pinned host: in0 | in1 | out
+        size_t pin_words[2][3] = {{0, 0, 0}, {0, 0, 0}};
+        uint32_t* dev[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};   // device:      in0 | in1 | out
+        size_t dev_words[2][3] = {{0, 0, 0}, {0, 0, 0}};
+        bool ready = false;
+    } pipe;
 };
 
 static int upload_modulus(const host::ModulusPack& m, DevModulus& d) {
@@ -751,6 +767,18 @@ void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
                         ctx->stage[1], ctx->stage[2]};
     for (uint32_t* b : bufs)
         if (b) (void)hipFree(b);
+    for (int k = 0; k < 2; ++k) {
+        for (int j = 0; j < 3; ++j) {
+            if (ctx->pipe.pin[k][j]) (void)hipHostFree(ctx->pipe.pin[k][j]);
+            if (ctx->pipe.dev[k][j]) (void)hipFree(ctx->pipe.dev[k][j]);
+        }
+        hipEvent_t evs[3] = {ctx->pipe.ev_in[k], ctx->pipe.ev_comp[k], ctx->pipe.ev_out[k]};
+        for (hipEvent_t e : evs)
+            if (e) (void)hipEventDestroy(e);
+    }
+    hipStream_t pipes[3] = {ctx->pipe.s_in, ctx->pipe.s_comp, ctx->pipe.s_out};
+    for (hipStream_t st : pipes)
+        if (st) (void)hipStreamDestroy(st);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
@@ -1101,12 +1129,100 @@ static int stage_in(phe_hip_ctx* ctx, int slot, const uint32_t* host_ptr, size_t
     return PHE_HIP_OK;
 }
 
+// ---- the same entry points for LARGE host batches: a chunked pipeline inside the library ----------------------------
+// The caller's buffers are ordinary (pageable) memory: a blocking hipMemcpy of the whole batch before and after the
+// kernel leaves the GPU idle during both copies.  From two chunks on, a batch instead moves in chunks of one full
+// residency of limb groups through PINNED staging buffers, two slots, three streams:
+//     host copy in (CPU) -> H2D (s_in) -> kernel (s_comp) -> D2H (s_out) -> host copy out (CPU)
+// so that the uploads of chunk k+1 and the downloads of chunk k-1 run under the kernel of chunk k.  A maintainer who
+// binds only the plain host-pointer functions gets the overlap without writing a pipeline.
+static const size_t kPipeChunkRows = 65536;  // a multiple of every kernel's resident limb groups (32768 / 65536)
+
+static int pipe_setup(phe_hip_ctx* ctx) {
+    auto& P = ctx->pipe;
+    if (P.ready) return PHE_HIP_OK;
+    HIP_TRY(hipStreamCreateWithFlags(&P.s_in, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&P.s_comp, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&P.s_out, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        HIP_TRY(hipEventCreateWithFlags(&P.ev_in[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&P.ev_comp[k], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&P.ev_out[k], hipEventDisableTiming));
+    }
+    P.ready = true;
+    return PHE_HIP_OK;
+}
+static int pipe_buffers(phe_hip_ctx* ctx, int slot, int j, size_t words) {
+    auto& P = ctx->pipe;
+    if (P.pin_words[slot][j] < words) {
+        if (P.pin[slot][j]) HIP_TRY(hipHostFree(P.pin[slot][j]));
+        P.pin[slot][j] = nullptr;
+        P.pin_words[slot][j] = 0;
+        HIP_TRY(hipHostMalloc((void**)&P.pin[slot][j], words * 4, hipHostMallocDefault));
+        P.pin_words[slot][j] = words;
+    }
+    return ensure_words(&P.dev[slot][j], &P.dev_words[slot][j], words);
+}
+
+// in0/in1: host rows of w0/w1 words (in1 may be null), out: host rows of wo words; launch(d_in0, d_in1, d_out, rows, stream)
+extern "C++" {
+template <class Launch>
+static int run_pipelined(phe_hip_ctx* ctx, const uint32_t* in0, size_t w0, const uint32_t* in1, size_t w1, uint32_t* out,
+                         size_t wo, size_t batch, Launch launch) {
+    if (int rc = pipe_setup(ctx)) return rc;
+    auto& P = ctx->pipe;
+    const size_t chunk = kPipeChunkRows;
+    const size_t n_chunks = (batch + chunk - 1) / chunk;
+    for (int slot = 0; slot < 2; ++slot) {
+        int rc = pipe_buffers(ctx, slot, 0, chunk * w0);
+        if (!rc && in1) rc = pipe_buffers(ctx, slot, 1, chunk * w1);
+        if (!rc) rc = pipe_buffers(ctx, slot, 2, chunk * wo);
+        if (rc) return rc;
+    }
+    auto rows_of = [&](size_t k) { return std::min(chunk, batch - k * chunk); };
+    auto drain = [&](size_t k) -> int {  // chunk k's results: wait for its download, then hand them to the caller
+        const int slot = (int)(k & 1);
+        HIP_TRY(hipEventSynchronize(P.ev_out[slot]));
+        memcpy(out + k * chunk * wo, P.pin[slot][2], rows_of(k) * wo * 4);
+        return PHE_HIP_OK;
+    };
+    for (size_t k = 0; k < n_chunks; ++k) {
+        const int slot = (int)(k & 1);
+        const size_t rows = rows_of(k);
+        if (k >= 2)
+            if (int rc = drain(k - 2)) return rc;  // frees this slot's buffers (its kernel and copies are complete)
+        memcpy(P.pin[slot][0], in0 + k * chunk * w0, rows * w0 * 4);
+        HIP_TRY(hipMemcpyAsync(P.dev[slot][0], P.pin[slot][0], rows * w0 * 4, hipMemcpyHostToDevice, P.s_in));
+        if (in1) {
+            memcpy(P.pin[slot][1], in1 + k * chunk * w1, rows * w1 * 4);
+            HIP_TRY(hipMemcpyAsync(P.dev[slot][1], P.pin[slot][1], rows * w1 * 4, hipMemcpyHostToDevice, P.s_in));
+        }
+        HIP_TRY(hipEventRecord(P.ev_in[slot], P.s_in));
+        HIP_TRY(hipStreamWaitEvent(P.s_comp, P.ev_in[slot], 0));
+        if (int rc = launch(P.dev[slot][0], in1 ? P.dev[slot][1] : nullptr, P.dev[slot][2], rows, P.s_comp)) return rc;
+        HIP_TRY(hipEventRecord(P.ev_comp[slot], P.s_comp));
+        HIP_TRY(hipStreamWaitEvent(P.s_out, P.ev_comp[slot], 0));
+        HIP_TRY(hipMemcpyAsync(P.pin[slot][2], P.dev[slot][2], rows * wo * 4, hipMemcpyDeviceToHost, P.s_out));
+        HIP_TRY(hipEventRecord(P.ev_out[slot], P.s_out));
+    }
+    for (size_t k = (n_chunks >= 2 ? n_chunks - 2 : 0); k < n_chunks; ++k)
+        if (int rc = drain(k)) return rc;
+    return PHE_HIP_OK;
+}
+}  // extern "C++"
+static bool pipelined_batch(size_t batch) { return batch >= 2 * kPipeChunkRows && !getenv("PHE_HIP_NO_PIPELINE"); }
+
 int phe_hip_encrypt(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch) {
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
     if (batch == 0) return PHE_HIP_OK;
     if (!m || !r || !c) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
     const size_t s1 = (size_t)ctx->pub.s1, s2 = (size_t)ctx->pub.s2;
+    if (pipelined_batch(batch))
+        return run_pipelined(ctx, m, s1, r, s1, c, s2, batch,
+                             [&](uint32_t* d0, uint32_t* d1, uint32_t* d2, size_t rows, hipStream_t st) {
+                                 return phe_hip_encrypt_dev(ctx, d0, d1, d2, rows, st);
+                             });
     int rc = stage_in(ctx, 0, m, batch * s1);
     if (!rc) rc = stage_in(ctx, 1, r, batch * s1);
     if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
@@ -1122,6 +1238,11 @@ int phe_hip_obfuscate(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t* r,
     if (!c_in || !r || !c_out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
     const size_t s1 = (size_t)ctx->pub.s1, s2 = (size_t)ctx->pub.s2;
+    if (pipelined_batch(batch))
+        return run_pipelined(ctx, c_in, s2, r, s1, c_out, s2, batch,
+                             [&](uint32_t* d0, uint32_t* d1, uint32_t* d2, size_t rows, hipStream_t st) {
+                                 return phe_hip_obfuscate_dev(ctx, d0, d1, d2, rows, st);
+                             });
     int rc = stage_in(ctx, 0, c_in, batch * s2);
     if (!rc) rc = stage_in(ctx, 1, r, batch * s1);
     if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
@@ -1137,6 +1258,11 @@ int phe_hip_decrypt(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t bat
     if (!c || !m) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
     const size_t s1 = (size_t)ctx->pub.s1, s2 = (size_t)ctx->pub.s2;
+    if (pipelined_batch(batch))
+        return run_pipelined(ctx, c, s2, nullptr, 0, m, s1, batch,
+                             [&](uint32_t* d0, uint32_t*, uint32_t* d2, size_t rows, hipStream_t st) {
+                                 return phe_hip_decrypt_dev(ctx, d0, d2, rows, st);
+                             });
     int rc = stage_in(ctx, 0, c, batch * s2);
     if (!rc) rc = stage_in(ctx, 1, nullptr, batch * s1);
     if (!rc) rc = phe_hip_decrypt_dev(ctx, ctx->stage[0], ctx->stage[1], batch, nullptr);
@@ -1151,6 +1277,8 @@ int phe_hip_mulmod(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, uint3
     if (!a || !b || !out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
     const size_t s2 = (size_t)ctx->pub.s2;
+    // (no chunked pipeline here: one product per 1.5 KB moved is PCIe-bound, and the runtime's own pageable-memory copy
+    //  (24 GB/s) beats a single-threaded copy into pinned staging (19 GB/s measured, profiles/r02c_host_abi.json))
     int rc = stage_in(ctx, 0, a, batch * s2);
     if (!rc) rc = stage_in(ctx, 1, b, batch * s2);
     if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
@@ -1554,6 +1682,94 @@ int phe_hip_stream_sync(phe_hip_ctx* ctx, void* stream) {
     if (int rc = bind_device(ctx)) return rc;
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return PHE_HIP_OK;
+}
+
+// ---- RCCL all-gather of ciphertext shards (include/phe_hip.h "multi-GPU") ---------------------------------------------
+// RCCL is resolved with dlopen on first use: the library has no link-time dependency on it, single-GPU hosts never load it,
+// and inside a torch process the already loaded librccl.so.1 (same SONAME) is the one that answers.
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, phe_rccl_id, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+int rccl_load() {
+    if (g_rccl.handle) return PHE_HIP_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* nm : names)
+        if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) return fail(PHE_HIP_EHIP, std::string("RCCL not available: ") + dlerror());
+    RcclApi a;
+    a.handle = h;
+    a.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+    a.CommInitRank = (int (*)(void**, int, phe_rccl_id, int))dlsym(h, "ncclCommInitRank");
+    a.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(h, "ncclAllGather");
+    a.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+    a.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy) return fail(PHE_HIP_EHIP, "RCCL symbols missing");
+    g_rccl = a;
+    return PHE_HIP_OK;
+}
+int rccl_fail(const char* what, int code) {
+    return fail(PHE_HIP_EHIP, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(code) : "rccl error"));
+}
+}  // namespace
+
+struct phe_hip_comm {
+    void* comm = nullptr;
+    int device = 0, rank = 0, world = 1;
+};
+
+int phe_hip_comm_unique_id(uint8_t id[128]) {
+    if (!id) return fail(PHE_HIP_EINVAL, "null id");
+    if (int rc = rccl_load()) return rc;
+    phe_rccl_id uid;
+    if (int e = g_rccl.GetUniqueId(&uid)) return rccl_fail("ncclGetUniqueId", e);
+    memcpy(id, uid.internal, 128);
+    return PHE_HIP_OK;
+}
+
+int phe_hip_comm_create(phe_hip_ctx* ctx, const uint8_t id[128], int rank, int world, phe_hip_comm** out) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (!id || !out || world < 1 || rank < 0 || rank >= world) return fail(PHE_HIP_EINVAL, "bad id / rank / world");
+    if (int rc = rccl_load()) return rc;
+    if (int rc = bind_device(ctx)) return rc;
+    phe_rccl_id uid;
+    memcpy(uid.internal, id, 128);
+    phe_hip_comm* c = new phe_hip_comm();
+    c->device = ctx->device;
+    c->rank = rank;
+    c->world = world;
+    if (int e = g_rccl.CommInitRank(&c->comm, world, uid, rank)) {
+        delete c;
+        return rccl_fail("ncclCommInitRank", e);
+    }
+    *out = c;
+    return PHE_HIP_OK;
+}
+
+int phe_hip_allgather_dev(phe_hip_comm* comm, const uint32_t* local, uint32_t* all, size_t rows, int limbs, void* stream) {
+    if (!comm || !comm->comm) return fail(PHE_HIP_EINVAL, "null communicator");
+    if (rows == 0) return PHE_HIP_OK;
+    if (!local || !all || limbs < 1) return fail(PHE_HIP_EINVAL, "null buffer / limbs");
+    HIP_TRY(hipSetDevice(comm->device));
+    if (int e = g_rccl.AllGather(local, all, rows * (size_t)limbs, 3 /* ncclUint32 */, comm->comm, (hipStream_t)stream))
+        return rccl_fail("ncclAllGather", e);
+    return PHE_HIP_OK;
+}
+
+void phe_hip_comm_destroy(phe_hip_comm* comm) {
+    if (!comm) return;
+    if (comm->comm && g_rccl.CommDestroy) {
+        (void)hipSetDevice(comm->device);
+        (void)g_rccl.CommDestroy(comm->comm);
+    }
+    delete comm;
 }
 
 int phe_hip_selftest_prims(int device, uint32_t* out) {

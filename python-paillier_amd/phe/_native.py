@@ -80,6 +80,11 @@ def lib():
         L.phe_hip_invert_dev.argtypes = [vp, vp, vp, sz, ctypes.POINTER(sz), vp]
         L.phe_hip_select_rows_dev.argtypes = [vp, vp, vp, vp, vp, ci, sz, vp]
         L.phe_hip_selftest_prims.argtypes = [ci, vp]
+        L.phe_hip_comm_unique_id.argtypes = [vp]
+        L.phe_hip_comm_create.argtypes = [vp, vp, ci, ci, ctypes.POINTER(vp)]
+        L.phe_hip_allgather_dev.argtypes = [vp, vp, vp, sz, ci, vp]
+        L.phe_hip_comm_destroy.argtypes = [vp]
+        L.phe_hip_comm_destroy.restype = None
         _lib = L
     return _lib
 
@@ -95,6 +100,7 @@ EXPORTED_SYMBOLS = [
     "phe_hip_multiexp", "phe_hip_multiexp_dev", "phe_hip_multiexp_rows_dev", "phe_hip_multiexp_csr_dev", "phe_hip_decimal_width", "phe_hip_to_decimal",
     "phe_hip_from_decimal", "phe_hip_to_decimal_dev", "phe_hip_from_decimal_dev", "phe_hip_stream_create",
     "phe_hip_stream_destroy", "phe_hip_miller_rabin", "phe_hip_montmul_dev", "phe_hip_mont_radix_bits",
+    "phe_hip_comm_unique_id", "phe_hip_comm_create", "phe_hip_allgather_dev", "phe_hip_comm_destroy",
 ]
 
 
@@ -526,6 +532,37 @@ class Context:
 
     def d2d(self, dst_ptr, src_ptr, nbytes, stream=0):
         _check(lib().phe_hip_memcpy_d2d(self._h, dst_ptr, src_ptr, nbytes, stream))
+
+
+def comm_unique_id():
+    """128 opaque bytes made by rank 0; every rank of the job passes the same bytes to Communicator"""
+    buf = (ctypes.c_uint8 * 128)()
+    _check(lib().phe_hip_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Communicator:
+    """RCCL communicator inside the library (include/phe_hip.h "multi-GPU"): one per rank, on the context's device"""
+
+    def __init__(self, ctx, unique_id, rank, world):
+        self._h = ctypes.c_void_p(None)
+        self.rank, self.world = rank, world
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
+        _check(lib().phe_hip_comm_create(ctx._h, buf, rank, world, ctypes.byref(self._h)))
+
+    def allgather_dev(self, local_ptr, all_ptr, rows, limbs, stream=0):
+        _check(lib().phe_hip_allgather_dev(self._h, local_ptr, all_ptr, rows, limbs, stream))
+
+    def close(self):
+        if self._h and self._h.value:
+            lib().phe_hip_comm_destroy(self._h)
+            self._h = ctypes.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def miller_rabin(n, base, device=0):

@@ -50,3 +50,19 @@ def gather_ciphertexts(local_limbs, total_rows, group=None):
     import torch
     t = torch.from_numpy(np.ascontiguousarray(local_limbs).view(np.int32))
     return all_gather_rows(t, total_rows, group).numpy().view(np.uint32)
+
+
+def library_communicator(ctx, rank, world_size, exchange):
+    """An RCCL communicator owned by the native library (include/phe_hip.h phe_hip_comm_create) for hosts that have no
+    process group of their own.  `exchange(id_bytes_or_None) -> id_bytes` is the host's channel for the 128-byte id:
+    called with the id on rank 0 and with None elsewhere, it must return rank 0's bytes on every rank (a file, a
+    socket, an MPI broadcast ...; with torch.distributed: dist.broadcast_object_list)."""
+    from . import _native
+    uid = exchange(_native.comm_unique_id() if rank == 0 else None)
+    return _native.Communicator(ctx, uid, rank, world_size)
+
+
+def all_gather_rows_library(comm, local_ptr, all_ptr, rows, limbs, stream=0):
+    """ONE ncclAllGather issued by the library: local (rows, limbs) device words -> all (world * rows, limbs) on every
+    rank, rank r at rows [r * rows, (r + 1) * rows).  Equal `rows` on every rank (pad the last shard)."""
+    comm.allgather_dev(local_ptr, all_ptr, rows, limbs, stream)

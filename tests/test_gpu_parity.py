@@ -379,3 +379,50 @@ def test_resident_vectors_add_lazily_and_settle_to_the_reference_bits(native, co
     scaled = (va + vb) * 3                           # a scalar multiplication settles first
     assert scaled.ciphertexts(False) == [pow(a * b % N, 3, N) for a, b in zip(ca, cb)]
     assert va.sum().ciphertext(False) == __import__("functools").reduce(lambda p, c: p * c % N, ca, 1)
+
+
+def test_large_host_batches_are_pipelined_and_equal_the_blocking_path(native, c_oracle, monkeypatch):
+    """host-pointer entry points from two chunks of 65536 rows on: chunks through pinned staging on three streams
+    (csrc/phe_hip.hip run_pipelined).  Ragged last chunk; same bits as the blocking path and as the oracle."""
+    g = load_golden(1024)
+    n = H(g["n"])
+    batch, s1 = 2 * 65536 + 4097, 32
+    rng = np.random.Generator(np.random.PCG64(11))
+    m = rng.integers(0, 2 ** 32, (batch, s1), dtype=np.uint64).astype(np.uint32)
+    r = rng.integers(0, 2 ** 32, (batch, s1), dtype=np.uint64).astype(np.uint32)
+    m[:, -1] = 0
+    r[:, -1] &= 0x3fffffff
+    r[:, 0] |= 1
+    ctx = make_ctx(native, g)
+    c = ctx.encrypt(m, r)                                        # pipelined
+    assert np.array_equal(ctx.decrypt(c), m)                      # pipelined decrypt
+    idx = np.r_[0, 65535, 65536, 131071, 131072, batch - 1, np.arange(7, batch, 9973)]
+    assert np.array_equal(c[idx], c_oracle.encrypt(native.int_to_limbs(n, s1), m[idx], r[idx], nthreads=4))
+    c2 = np.ascontiguousarray(c[::-1])
+    prod = ctx.mulmod(c, c2)
+    assert np.array_equal(prod[idx], c_oracle.add(native.int_to_limbs(n, s1), c[idx], c2[idx], nthreads=4))
+    plain = ctx.add_plain(c, m)
+    obf = ctx.obfuscate(c, r)
+    monkeypatch.setenv("PHE_HIP_NO_PIPELINE", "1")
+    ctx2 = make_ctx(native, g)
+    assert np.array_equal(ctx2.encrypt(m, r), c)
+    assert np.array_equal(ctx2.mulmod(c, c2), prod)
+    assert np.array_equal(ctx2.add_plain(c, m), plain)
+    assert np.array_equal(ctx2.obfuscate(c, r), obf)
+
+
+def test_library_rccl_allgather_single_rank(native):
+    """phe_hip_comm_* / phe_hip_allgather_dev with a world of one (all a 1-GPU box offers): RCCL loads, the communicator
+    comes up on the context's device and the gather is the identity.  N > 1 runs under bench.py --lib-allgather."""
+    from phe._device import DeviceArray
+    g = load_golden(1024)
+    ctx = make_ctx(native, g, private=False)
+    comm = native.Communicator(ctx, native.comm_unique_id(), 0, 1)
+    rows, limbs = 1000, 64
+    data = np.random.Generator(np.random.PCG64(2)).integers(0, 2 ** 32, (rows, limbs), dtype=np.uint64).astype(np.uint32)
+    src = DeviceArray.from_host(ctx, data)
+    dst = DeviceArray(ctx, rows, limbs)
+    comm.allgather_dev(src.ptr, dst.ptr, rows, limbs)
+    ctx.sync()
+    assert np.array_equal(dst.to_host(), data)
+    comm.close()
