@@ -500,8 +500,15 @@ inline PublicPlan build_public(const uint32_t* n, int n_limbs, int prefer_group 
     if (big_bits(P.n) < 2) throw std::invalid_argument("n too small");
     Big nsq = big_mul(P.n, P.n);
     P.nsq32 = big_resize(nsq, P.s2);
-    P.nsq = build_modulus(nsq, &P.n, 32 * P.s2, prefer_group);
     P.nsplit = build_split(P.n, 32 * P.s2, prefer_group);
+    try {
+        P.nsq = build_modulus(nsq, &P.n, 32 * P.s2, prefer_group);
+    } catch (const std::invalid_argument&) {
+        // n^2 is wider than the widest full-width geometry (keys above ~4170 bits, e.g. the 8192-bit keys of the
+        // reference's examples/benchmarks.py:88-90): every job modulo n^2 then runs on the pair form, if that exists
+        if (P.nsplit.G == 0) throw;
+        P.nsq = ModulusPack();
+    }
     P.exp_n = build_schedule(P.n);
     return P;
 }

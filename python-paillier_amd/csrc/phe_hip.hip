@@ -80,6 +80,7 @@ PHE_DECLARE_PART(g16b)
     int launch_multi_split(int L, int blocks, hipStream_t st, const SplitMultiArgs& A);           \
     int launch_multi_tables(int L, int blocks, hipStream_t st, const SplitTableArgs& A);          \
     int launch_multi_lookup(int L, int blocks, hipStream_t st, const SplitLookupArgs& A);         \
+    int launch_mul_split(int L, int blocks, hipStream_t st, const SplitMulArgs& A);               \
     }
 PHE_DECLARE_SPLIT_PART(s2a)
 PHE_DECLARE_SPLIT_PART(s2b)
@@ -143,44 +144,45 @@ struct SplitPart {
     int (*launch_multi_split)(int, int, hipStream_t, const SplitMultiArgs&);
     int (*launch_multi_tables)(int, int, hipStream_t, const SplitTableArgs&);
     int (*launch_multi_lookup)(int, int, hipStream_t, const SplitLookupArgs&);
+    int (*launch_mul_split)(int, int, hipStream_t, const SplitMulArgs&);
 };
 static const SplitPart kSplitParts[] = {
     {2, phe::s2a::occ_split, phe::s2a::launch_split, phe::s2a::occ_var_split, phe::s2a::launch_var_split,
      phe::s2a::occ_multi_split, phe::s2a::launch_multi_split, phe::s2a::launch_multi_tables,
-     phe::s2a::launch_multi_lookup},
+     phe::s2a::launch_multi_lookup, phe::s2a::launch_mul_split},
     {2, phe::s2b::occ_split, phe::s2b::launch_split, phe::s2b::occ_var_split, phe::s2b::launch_var_split,
      phe::s2b::occ_multi_split, phe::s2b::launch_multi_split, phe::s2b::launch_multi_tables,
-     phe::s2b::launch_multi_lookup},
+     phe::s2b::launch_multi_lookup, phe::s2b::launch_mul_split},
     {2, phe::s2c::occ_split, phe::s2c::launch_split, phe::s2c::occ_var_split, phe::s2c::launch_var_split,
      phe::s2c::occ_multi_split, phe::s2c::launch_multi_split, phe::s2c::launch_multi_tables,
-     phe::s2c::launch_multi_lookup},
+     phe::s2c::launch_multi_lookup, phe::s2c::launch_mul_split},
     {4, phe::s4a::occ_split, phe::s4a::launch_split, phe::s4a::occ_var_split, phe::s4a::launch_var_split,
      phe::s4a::occ_multi_split, phe::s4a::launch_multi_split, phe::s4a::launch_multi_tables,
-     phe::s4a::launch_multi_lookup},
+     phe::s4a::launch_multi_lookup, phe::s4a::launch_mul_split},
     {4, phe::s4b::occ_split, phe::s4b::launch_split, phe::s4b::occ_var_split, phe::s4b::launch_var_split,
      phe::s4b::occ_multi_split, phe::s4b::launch_multi_split, phe::s4b::launch_multi_tables,
-     phe::s4b::launch_multi_lookup},
+     phe::s4b::launch_multi_lookup, phe::s4b::launch_mul_split},
     {4, phe::s4c::occ_split, phe::s4c::launch_split, phe::s4c::occ_var_split, phe::s4c::launch_var_split,
      phe::s4c::occ_multi_split, phe::s4c::launch_multi_split, phe::s4c::launch_multi_tables,
-     phe::s4c::launch_multi_lookup},
+     phe::s4c::launch_multi_lookup, phe::s4c::launch_mul_split},
     {8, phe::s8a::occ_split, phe::s8a::launch_split, phe::s8a::occ_var_split, phe::s8a::launch_var_split,
      phe::s8a::occ_multi_split, phe::s8a::launch_multi_split, phe::s8a::launch_multi_tables,
-     phe::s8a::launch_multi_lookup},
+     phe::s8a::launch_multi_lookup, phe::s8a::launch_mul_split},
     {8, phe::s8b::occ_split, phe::s8b::launch_split, phe::s8b::occ_var_split, phe::s8b::launch_var_split,
      phe::s8b::occ_multi_split, phe::s8b::launch_multi_split, phe::s8b::launch_multi_tables,
-     phe::s8b::launch_multi_lookup},
+     phe::s8b::launch_multi_lookup, phe::s8b::launch_mul_split},
     {8, phe::s8c::occ_split, phe::s8c::launch_split, phe::s8c::occ_var_split, phe::s8c::launch_var_split,
      phe::s8c::occ_multi_split, phe::s8c::launch_multi_split, phe::s8c::launch_multi_tables,
-     phe::s8c::launch_multi_lookup},
+     phe::s8c::launch_multi_lookup, phe::s8c::launch_mul_split},
     {16, phe::s16a::occ_split, phe::s16a::launch_split, phe::s16a::occ_var_split, phe::s16a::launch_var_split,
      phe::s16a::occ_multi_split, phe::s16a::launch_multi_split, phe::s16a::launch_multi_tables,
-     phe::s16a::launch_multi_lookup},
+     phe::s16a::launch_multi_lookup, phe::s16a::launch_mul_split},
     {16, phe::s16b::occ_split, phe::s16b::launch_split, phe::s16b::occ_var_split, phe::s16b::launch_var_split,
      phe::s16b::occ_multi_split, phe::s16b::launch_multi_split, phe::s16b::launch_multi_tables,
-     phe::s16b::launch_multi_lookup},
+     phe::s16b::launch_multi_lookup, phe::s16b::launch_mul_split},
     {16, phe::s16c::occ_split, phe::s16c::launch_split, phe::s16c::occ_var_split, phe::s16c::launch_var_split,
      phe::s16c::occ_multi_split, phe::s16c::launch_multi_split, phe::s16c::launch_multi_tables,
-     phe::s16c::launch_multi_lookup},
+     phe::s16c::launch_multi_lookup, phe::s16c::launch_mul_split},
 };
 #define PHE_SPLIT_BY_GROUP(G_, CALL2)                 \
     [&]() -> int {                                    \
@@ -204,11 +206,14 @@ static const SplitPart kSplitParts[] = {
     }()
 
 constexpr int kTailBlock = 64;
+// threads per workgroup of the CRT tail: one wavefront, or half of one where p, q are so wide (4096 bits: 8192-bit keys)
+// that 64 per-thread workspaces exceed the LDS of a CU
+static int tail_block(int h) { return ((size_t)tail_ws_words(h) * kTailBlock * 4 > 150 * 1024) ? kTailBlock / 2 : kTailBlock; }
 __global__ void __launch_bounds__(kTailBlock) k_decrypt_tail(TailArgs A) {
     extern __shared__ __attribute__((aligned(16))) uint32_t tail_ws[];
-    const uint64_t item = (uint64_t)blockIdx.x * kTailBlock + threadIdx.x;
+    const uint64_t item = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (item >= A.batch) return;
-    const TailWs ws{tail_ws + threadIdx.x, kTailBlock};
+    const TailWs ws{tail_ws + threadIdx.x, (int)blockDim.x};
     decrypt_tail_one(A, ws, item);
 }
 
@@ -331,6 +336,7 @@ static int upload_modulus(const host::ModulusPack& m, DevModulus& d) {
     d.G = m.G;
     d.L = m.L;
     d.S = m.S;
+    if (m.G == 0) return PHE_HIP_OK;  // no full-width geometry for this modulus (wide keys: the pair form serves it)
     const size_t words = (size_t)5 * m.S;
     HIP_TRY(hipMalloc((void**)&d.blob, words * 4));
     std::vector<uint32_t> h(words);
@@ -614,6 +620,28 @@ static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, 
     A.out_stride = out_stride;
     A.limbs = limbs;
     A.batch = batch;
+    if (M.G == 0) {
+        // n^2 is wider than the widest full-width geometry (keys above ~4170 bits): the product runs on the pair form
+        const DevSplit& SP = ctx->d_nsplit;
+        if (!SP.G || one_product) return fail(PHE_HIP_EINVAL, "no product kernel for this key width");
+        SplitMulArgs B;
+        B.mod = SP.c;
+        B.a = a;
+        B.b = b;
+        B.out = out;
+        B.a_stride = a_stride;
+        B.b_stride = b_stride;
+        B.out_stride = out_stride;
+        B.limbs = limbs;
+        B.chunks = chunks_for(limbs, SP.H);
+        B.b_plain_limbs = b_plain_limbs;
+        B.batch = batch;
+        const int blocks = grid_blocks(ctx, batch, SP.G, 2);
+        if (PHE_SPLIT_BY_GROUP(SP.G, launch_mul_split(SP.L, blocks, stream, B)) < 0)
+            return fail(PHE_HIP_EINVAL, "unsupported split geometry for the product");
+        HIP_TRY(hipGetLastError());
+        return PHE_HIP_OK;
+    }
     // no table scratch here: let every CU hold as many groups as the batch offers (cap 8 blocks/CU)
     int G, L;
     light_geometry(M, G, L);
@@ -673,10 +701,11 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
     } catch (const std::exception& ex) {
         return fail(PHE_HIP_EINVAL, ex.what());
     }
+    if (ctx->pub.nsq.G == 0) ctx->use_split = true;  // wide keys have the pair form only
     int rc = upload_modulus(ctx->pub.nsq, ctx->d_nsq);
     if (!rc) rc = upload_split(ctx->pub.nsplit, ctx->d_nsplit);
     if (!rc) rc = upload_schedule(ctx->pub.exp_n, ctx->d_exp_n);
-    if (!rc && ctx->pub.nsq.G < 16 && !getenv("PHE_HIP_GROUP")) {
+    if (!rc && ctx->pub.nsq.G && ctx->pub.nsq.G < 16 && !getenv("PHE_HIP_GROUP")) {
         try {
             ctx->pub_lat = host::build_public(n, n_limbs, 16);
             rc = upload_modulus(ctx->pub_lat.nsq, ctx->d_nsq_lat);
@@ -740,7 +769,7 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
     if (!rc) rc = upload_schedule(ctx->priv.exp_q, ctx->d_exp_q);
     if (!rc) rc = upload_tail(ctx->priv.tail, ctx->d_tail);
     if (!rc) {
-        const size_t lds = (size_t)tail_ws_words(ctx->priv.tail.h) * kTailBlock * 4;
+        const size_t lds = (size_t)tail_ws_words(ctx->priv.tail.h) * tail_block(ctx->priv.tail.h) * 4;
         if (lds > 160 * 1024) rc = fail(PHE_HIP_EINVAL, "p/q too wide for the CRT tail kernel");
         else if (lds > 48 * 1024) {
             hipError_t e = hipFuncSetAttribute((const void*)k_decrypt_tail, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -797,7 +826,8 @@ int phe_hip_ctx_info(const phe_hip_ctx* ctx, int* n_limbs, int* ct_limbs, int* l
     if (lane_limbs_priv)
         *lane_limbs_priv = !ctx->has_private ? 0 : sp_priv ? ctx->priv.psplit.G * 100 + ctx->priv.psplit.L
                                                            : ctx->priv.psq.G * 100 + ctx->priv.psq.L;
-    if (rows_in_flight) *rows_in_flight = ctx->n_cus * std::max(1, ctx->blocks_per_cu ? ctx->blocks_per_cu : 2) * (kBlock / ctx->pub.nsq.G);
+    const int g_pub = sp_pub ? ctx->pub.nsplit.G : std::max(1, ctx->pub.nsq.G);
+    if (rows_in_flight) *rows_in_flight = ctx->n_cus * std::max(1, ctx->blocks_per_cu ? ctx->blocks_per_cu : 2) * (kBlock / g_pub);
     if (has_private) *has_private = ctx->has_private ? 1 : 0;
     return PHE_HIP_OK;
 }
@@ -908,9 +938,10 @@ int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t
     T.m_out = m;
     T.out_limbs = ctx->pub.s1;
     T.batch = batch;
-    const size_t lds = (size_t)tail_ws_words(T.k.h) * kTailBlock * 4;
-    const int blocks = (int)((batch + kTailBlock - 1) / kTailBlock);
-    k_decrypt_tail<<<dim3(blocks), dim3(kTailBlock), lds, st>>>(T);
+    const int tb = tail_block(T.k.h);
+    const size_t lds = (size_t)tail_ws_words(T.k.h) * tb * 4;
+    const int blocks = (int)((batch + tb - 1) / tb);
+    k_decrypt_tail<<<dim3(blocks), dim3(tb), lds, st>>>(T);
     HIP_TRY(hipGetLastError());
     return PHE_HIP_OK;
 }
@@ -931,6 +962,7 @@ int phe_hip_montmul_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, 
     if (!a || !b || !out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
     const size_t s2 = (size_t)ctx->pub.s2;
+    if (ctx->d_nsq.G == 0) return fail(PHE_HIP_EINVAL, "one-product form not available for this key width");
     // always the throughput geometry: R must not depend on the batch size
     return launch_mul(ctx, ctx->d_nsq, a, s2, b, b_is_row ? 0 : s2, out, s2, ctx->pub.s2, batch, (hipStream_t)stream, 0, 1);
 }
@@ -938,6 +970,7 @@ int phe_hip_montmul_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, 
 int phe_hip_mont_radix_bits(phe_hip_ctx* ctx, int* bits) {
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
     if (!bits) return fail(PHE_HIP_EINVAL, "null pointer");
+    if (ctx->d_nsq.G == 0) return fail(PHE_HIP_EINVAL, "one-product form not available for this key width");
     *bits = phe::kRadixBits * ctx->d_nsq.S;
     return PHE_HIP_OK;
 }

@@ -575,6 +575,51 @@ PHE_DEV void modexp_split_body(const SplitArgs& A, uint32_t* lds_row, uint32_t s
     }
 }
 
+// Element-wise product modulo n^2 on the pair representation, for key widths whose n^2 has no full-width geometry
+// (mont_core.h stops at 16 x 18 = 288 limbs ~ 8344 bits, i.e. keys up to ~4170 bits; examples/benchmarks.py:88-90 of the
+// reference times 8192-bit keys): both factors enter the pair form, one pair product, the canonical residue leaves
+// (same MulArgs as mulmod_body; b_plain_limbs > 0: a * (1 + n*m), the plaintext folded into split_exit as in encrypt).
+struct SplitMulArgs {
+    SplitConsts mod;
+    const uint32_t* a;
+    const uint32_t* b;
+    uint32_t* out;
+    size_t a_stride, b_stride, out_stride;
+    int limbs;          // 32-bit words of a ciphertext row
+    int chunks;         // ceil(32*limbs / (29 H))
+    int b_plain_limbs;  // 0: b is a residue mod n^2; > 0: b is a plaintext of that many words
+    uint64_t batch;
+};
+
+template <int G, int L>
+PHE_DEV void mulmod_split_body(const SplitMulArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots, uint32_t lane) {
+    constexpr int H = G * L;
+    const Lanes<G> ln(lane);
+    const uint32_t g = ln.g;
+    SplitLane<G, L> K;
+    load_row<L>(K.n, A.mod.n, g);
+    K.n0inv = A.mod.n0inv;
+    K.row_a = lds_row;
+    K.row_c = lds_row + H;
+    const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
+    for (uint64_t it = 0; it < n_iter; ++it) {
+        uint64_t item = slot + it * (uint64_t)total_slots;
+        const bool live = item < A.batch;
+        if (!live) item = A.batch - 1;
+        uint32_t X0[L], X1[L];
+        split_conv<G, L>(X0, X1, A.a + item * A.a_stride, A.limbs, A.chunks, A.mod, K, ln);
+        const uint32_t* mp = nullptr;
+        if (A.b_plain_limbs > 0) {
+            mp = A.b + item * A.b_stride;
+        } else {
+            uint32_t Y0[L], Y1[L];
+            split_conv<G, L>(Y0, Y1, A.b + item * A.b_stride, A.limbs, A.chunks, A.mod, K, ln);
+            split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
+        }
+        split_exit<G, L>(A.out + item * A.out_stride, A.limbs, X0, X1, mp, A.b_plain_limbs, A.mod, K, ln, live);
+    }
+}
+
 // Per-element exponents (phe/paillier.py:751 powmod(c, scalar, n^2); :749 with the inverted base) on the pair
 // representation: fixed 2^w-ary windows over the batch-wide maximum bit length, as modexp_var_body (mont_core.h).
 struct SplitVarArgs {

@@ -632,7 +632,16 @@ class Engine:
     # additions costs k + 1 products instead of 2k; what leaves the vector is the same canonical residue as before.
     def lazy_products(self):
         """True when the backend offers the one-product entry (include/phe_hip.h phe_hip_montmul_dev)"""
-        return hasattr(self.ctx, "montmul_dev") and hasattr(self.ctx, "malloc")
+        ok = self.__dict__.get("_lazy_ok")
+        if ok is None:
+            ok = hasattr(self.ctx, "montmul_dev") and hasattr(self.ctx, "malloc")
+            if ok:
+                try:
+                    self._mont_radix()
+                except ValueError:                    # no full-width geometry for n^2 (keys above ~4170 bits)
+                    ok = False
+            self._lazy_ok = ok
+        return ok
 
     def _mont_radix(self):
         R = self.__dict__.get("_mont_R")

@@ -266,6 +266,22 @@ static void run_miller_rabin(MillerRabinArgs A) {
 static int g_prefer_group = 0;
 static int g_engine = 1;  // 1: split-modulus kernels where a geometry exists (the product default), 0: full-width only
 
+// out = a*b mod n^2 (b_plain == 0) or a*(1 + n*m) mod n^2 (b = plaintexts of n_limbs words) on the PAIR form
+// (split_core.h:mulmod_split_body): the product kernel of key widths without a full-width geometry.  rc 2: no split geometry
+template <int G, int L>
+static void run_mul_split(SplitMulArgs A) {
+    constexpr int S2 = 2 * G * L, kPer = 64 / G;
+    const int n_waves = waves_for(A.batch, G);
+    const uint32_t total = (uint32_t)(kPer * n_waves);
+    for (int w = 0; w < n_waves; ++w) {
+        std::vector<uint32_t> lds(kPer * (S2 + kLdsPad));
+        wave::run_wave([&](uint32_t lane) {
+            const uint32_t grp = lane / G;
+            mulmod_split_body<G, L>(A, lds.data() + grp * (S2 + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
+        });
+    }
+}
+
 extern "C" {
 
 void emu_set_engine(int e) { g_engine = e ? 1 : 0; }
@@ -399,6 +415,25 @@ int emu_mulmod(const uint32_t* N, int limbs, const uint32_t* a, const uint32_t* 
         A.mod = consts_of(M); A.a = a; A.b = b; A.limbs = limbs; A.out = out; A.batch = B;
         A.a_stride = A.b_stride = A.out_stride = (size_t)limbs;
         DISPATCH_GL(M.G, M.L, (run_mul<GG, LL>(A)));
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+int emu_mulmod_n2_split(const uint32_t* n, int n_limbs, const uint32_t* a, const uint32_t* b, int b_plain, uint32_t* out,
+                        uint64_t B) {
+    try {
+        if (B == 0) return 0;
+        host::SplitPack M = host::build_split(host::big_from(n, n_limbs, n_limbs), 64 * n_limbs, g_prefer_group);
+        if (M.G == 0) return 2;
+        SplitMulArgs A;
+        memset(&A, 0, sizeof A);
+        A.mod = split_consts_of(M);
+        A.a = a; A.b = b; A.out = out; A.limbs = 2 * n_limbs; A.chunks = chunks_for(2 * n_limbs, M.H);
+        A.a_stride = A.out_stride = (size_t)(2 * n_limbs);
+        A.b_stride = b_plain ? (size_t)n_limbs : (size_t)(2 * n_limbs);
+        A.b_plain_limbs = b_plain ? n_limbs : 0;
+        A.batch = B;
+        DISPATCH_SPLIT(M.G, M.L, (run_mul_split<GG, LL>(A)));
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }

@@ -59,14 +59,22 @@ class EmuContext:
             return np.zeros((0, self.n_limbs), np.uint32)
         return emu().decrypt(*self._key, self.n_limbs, np.ascontiguousarray(c))
 
+    def _wide(self):
+        """n^2 beyond the widest full-width geometry (keys above ~4170 bits): products run on the pair form, as in the library"""
+        return 2 * self.n.bit_length() + 4 > 16 * 18 * 29
+
     def mulmod(self, a, b):
         if a.shape[0] == 0:
             return a.copy()
+        if self._wide():
+            return emu().mulmod_n2_split(self._n_arr, np.ascontiguousarray(a), np.ascontiguousarray(b))
         return emu().mulmod(self._nsq_arr, np.ascontiguousarray(a), np.ascontiguousarray(b))
 
     def add_plain(self, c, m):
         if c.shape[0] == 0:
             return c.copy()
+        if self._wide():
+            return emu().mulmod_n2_split(self._n_arr, np.ascontiguousarray(c), np.ascontiguousarray(m), b_plain=True)
         return emu().add_plain(self._n_arr, np.ascontiguousarray(c), np.ascontiguousarray(m))
 
     def powmod(self, base, exps):

@@ -71,6 +71,16 @@ class Emu:
         self._ck(self.L.emu_add_plain(P(n), n.shape[0], P(c), P(m), P(out), ctypes.c_uint64(c.shape[0])))
         return out
 
+    def mulmod_n2_split(self, n, a, b, b_plain=False):
+        """a*b mod n^2 (or a*(1 + n*m) for plaintext rows b) on the pair form — the product kernel of wide keys; None
+        without a split geometry"""
+        out = np.zeros_like(a)
+        rc = self.L.emu_mulmod_n2_split(P(n), n.shape[0], P(a), P(b), 1 if b_plain else 0, P(out), ctypes.c_uint64(a.shape[0]))
+        if rc == 2:
+            return None
+        self._ck(rc)
+        return out
+
     def powmod_var(self, N, base, exps):
         out = np.zeros_like(base)
         self._ck(self.L.emu_powmod_var(P(N), N.shape[0], P(base), P(exps), exps.shape[1], P(out),

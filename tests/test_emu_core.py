@@ -203,3 +203,65 @@ def test_powmod_var_mixed_lengths(emu):
     exps = [0, 1, 2, 16 ** 7, rng.getrandbits(56), rng.getrandbits(200), (1 << 64) - 1]
     got = emu.powmod_var(N, ints_to_limbs(bases, S), ints_to_limbs(exps, 8))
     assert limbs_to_ints(got) == [pow(b, e, N_int) for b, e in zip(bases, exps)]
+
+
+@pytest.mark.parametrize("key_bits,group", [(256, 0), (1024, 8), (2048, 8), (2048, 16), (3072, 16)])
+def test_staged_products_equal_the_plain_body(emu, key_bits, group):
+    """csrc/mul_io.h (rows copied global -> LDS as 16-byte chunks, limbs re-sliced from LDS, one- and two-product forms,
+    row-constant operand) against mont_core.h:mulmod_body and Python integers"""
+    import ctypes
+    from emu_lib import P
+    g = load_golden(key_bits)
+    n = H(g["n"])
+    N, s2 = n * n, key_bits // 16
+    rng = random.Random(key_bits)
+    B = 11
+    a = [rng.randrange(N) for _ in range(B)]
+    b = [rng.randrange(N) for _ in range(B)]
+    a[0], b[0] = N - 1, N - 1
+    A, Bm, Narr = ints_to_limbs(a, s2), ints_to_limbs(b, s2), int_to_limbs(N, s2)
+    emu.set_group(group)
+    try:
+        emu.L.emu_set_mul_io(1)
+        got = limbs_to_ints(emu.mulmod(Narr, A, Bm))
+        assert emu.L.emu_last_mul_staged() == 1
+        assert got == [x * y % N for x, y in zip(a, b)]
+        emu.L.emu_set_mul_io(0)
+        assert limbs_to_ints(emu.mulmod(Narr, A, Bm)) == got and emu.L.emu_last_mul_staged() == 0
+        emu.L.emu_set_mul_io(1)
+        out, rb = np.zeros_like(A), ctypes.c_int(0)
+        assert emu.L.emu_montmul_rows(P(Narr), s2, P(A), P(Bm), 0, P(out), ctypes.c_uint64(B), ctypes.byref(rb)) == 0
+        R = 1 << rb.value
+        Rinv = pow(R, -1, N)
+        assert limbs_to_ints(out) == [x * y * Rinv % N for x, y in zip(a, b)]
+        for d in (0, 2):                                        # a debt of d factors of R, settled by the constant R^(d+1)
+            debt = ints_to_limbs([x * pow(Rinv, d, N) % N for x in a], s2)
+            const = ints_to_limbs([pow(R, d + 1, N)], s2)
+            assert emu.L.emu_montmul_rows(P(Narr), s2, P(debt), P(const), 1, P(out), ctypes.c_uint64(B), None) == 0
+            assert limbs_to_ints(out) == a
+        m = [rng.randrange(n) for _ in range(B)]
+        plain = emu.add_plain(int_to_limbs(n, s2 // 2), A, ints_to_limbs(m, s2 // 2))
+        assert limbs_to_ints(plain) == [x * (1 + n * y) % N for x, y in zip(a, m)]
+    finally:
+        emu.set_group(0)
+        emu.L.emu_set_mul_io(1)
+
+
+def test_wide_key_products_on_the_pair_form(emu):
+    """keys whose n^2 has no full-width geometry (above ~4170 bits; 8192 here, as in examples/benchmarks.py:88-90 of the
+    reference): a*b mod n^2 and a*(1 + n*m) mod n^2 through split_core.h:mulmod_split_body"""
+    g = load_golden(8192)
+    n = H(g["n"])
+    N = n * n
+    rng = random.Random(1)
+    a = [rng.randrange(N) for _ in range(3)] + [N - 1]
+    b = [rng.randrange(N) for _ in range(3)] + [N - 1]
+    n_arr = int_to_limbs(n, 256)
+    got = emu.mulmod_n2_split(n_arr, ints_to_limbs(a, 512), ints_to_limbs(b, 512))
+    assert limbs_to_ints(got) == [x * y % N for x, y in zip(a, b)]
+    for e in g["raw_add"]:
+        out = emu.mulmod_n2_split(n_arr, ints_to_limbs([H(e["a"])], 512), ints_to_limbs([H(e["b"])], 512))
+        assert limbs_to_ints(out) == [H(e["out"])]
+    m = [rng.randrange(n) for _ in range(4)]
+    got = emu.mulmod_n2_split(n_arr, ints_to_limbs(a, 512), ints_to_limbs(m, 256), b_plain=True)
+    assert limbs_to_ints(got) == [x * (1 + n * y) % N for x, y in zip(a, m)]

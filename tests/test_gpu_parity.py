@@ -426,3 +426,52 @@ def test_library_rccl_allgather_single_rank(native):
     ctx.sync()
     assert np.array_equal(dst.to_host(), data)
     comm.close()
+
+
+def test_wide_keys_8192_bits(native, c_oracle):
+    """8192-bit keys — what the reference's own benchmark goes up to (examples/benchmarks.py:88-90): n^2 has no full-width
+    geometry, so the products (add, add a plaintext, the inversion tree) run on the pair form (k_mulmod_split) next to
+    the split-modulus exponentiations.  Golden vectors of the real reference, then a random batch against libgmp."""
+    ctx = check_golden(native, 8192)
+    info = ctx.info()
+    assert info["engine_pub"] == "split" and info["lane_limbs_pub"] // 100 == 16
+    g = load_golden(8192)
+    n_int, s1, s2 = H(g["n"]), 256, 512
+    rng = random.Random(8)
+    batch = 48
+    m = native.ints_to_limbs([rng.randrange(0, n_int) for _ in range(batch)], s1)
+    r = native.ints_to_limbs([rng.randrange(1, n_int) for _ in range(batch)], s1)
+    n_arr = native.int_to_limbs(n_int, s1)
+    c = ctx.encrypt(m, r)
+    assert np.array_equal(c, c_oracle.encrypt(n_arr, m, r, nthreads=8))
+    assert np.array_equal(ctx.decrypt(c), m)
+    c2 = np.ascontiguousarray(c[::-1])
+    assert np.array_equal(ctx.mulmod(c, c2), c_oracle.add(n_arr, c, c2, nthreads=8))
+    ones = np.zeros_like(m)
+    ones[:, 0] = 1
+    assert np.array_equal(ctx.add_plain(c, m), c_oracle.add(n_arr, c, c_oracle.encrypt(n_arr, m, ones, nthreads=8), nthreads=8))
+    inv = ctx.invert(c)
+    assert np.array_equal(ctx.mulmod(inv, c)[:, 0], np.ones(batch, np.uint32)) and not ctx.mulmod(inv, c)[:, 1:].any()
+    with pytest.raises(ValueError):
+        ctx.mont_radix_bits()                                    # the one-product form needs the full-width geometry
+
+
+def test_wide_keys_through_the_drop_in_api():
+    """the reference's benchmark loop (examples/benchmarks.py:38-71: encrypt, decrypt, add, multiply by a scalar) on an
+    8192-bit key through the drop-in classes, scalar and batched"""
+    from phe import paillier
+    g = load_golden(8192)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    for e in g["encrypt_api"]:
+        value = eval(e["value"])
+        en = pub.encrypt(value, r_value=H(e["r"]))
+        assert en.ciphertext(False) == H(e["c"]) and en.exponent == e["exponent"]
+        assert repr(priv.decrypt(en)) == e["decrypted"]
+    xs = [0.5, -3.25, 1e6, 7.0]
+    vec = pub.encrypt_batch(np.array(xs), device=True)
+    assert priv.decrypt_batch(vec + vec) == [2 * x for x in xs]
+    assert priv.decrypt_batch(vec * np.array([2.0, -1.0, 0.5, 3.0])) == [1.0, 3.25, 5e5, 21.0]
+    assert priv.decrypt(vec.sum()) == sum(xs)
+    nums = [pub.encrypt(x) for x in xs]
+    assert priv.decrypt(nums[0] + nums[1] * -2) == 0.5 + 6.5

@@ -73,7 +73,7 @@ def test_golden_python(key_bits):
         assert pub.raw_mul(H(e["c"]), H(e["s"])) == H(e["out"])
 
 
-@pytest.mark.parametrize("key_bits", KEYS)
+@pytest.mark.parametrize("key_bits", KEYS + [8192])
 def test_golden_c(c_oracle, key_bits):
     g = load_golden(key_bits)
     s1 = key_bits // 32
