@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""The reference's benchmark (examples/benchmarks.py:38-92: encrypt, decrypt, add a float, add a ciphertext, add 1.0,
+multiply by a float — per key size from 128 to 8192 bits) on this package, in the two forms a user can write:
+
+  scalar   the reference's own idiom, one Python object per number: `[pub.encrypt(x) for x in xs]`,
+           `[priv.decrypt(e) for e in encs]`, `[a + b for a, b in ...]` — every call a batch of one on the GPU
+           (encryptions draw their obfuscators r^n from a pool that is refilled by the launch);
+  batched  the same work through `encrypt_batch` / `EncryptedVector` operators / `decrypt_batch` on resident vectors.
+
+Prints the reference's table per key size and one JSON object at the end.  Needs an MI355X.
+
+    python examples/benchmarks_batched.py [--scalar-ops 300] [--batch 16384] [--key-sizes 128 256 ... 8192]
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "python-paillier_amd"))
+import phe as paillier  # noqa: E402
+
+OPS = ["encrypt", "decrypt", "add unencrypted and encrypted", "add encrypted and encrypted", "add encrypted and 1",
+       "multiply encrypted and unencrypted"]
+
+
+def timed(fn):
+    t0 = time.perf_counter()
+    out = fn()
+    return time.perf_counter() - t0, out
+
+
+def bench_key(key_size, scalar_ops, batch, rng):
+    t_key, (pub, priv) = timed(lambda: paillier.generate_paillier_keypair(n_length=key_size))
+    xs = [rng.random() for _ in range(scalar_ops)]
+    ys = [rng.random() for _ in range(scalar_ops)]
+    pub.encrypt(0.5)                                           # context creation and first launches stay outside
+    res = {"key_bits": key_size, "keygen_s": t_key, "scalar": {}, "batched": {}}
+    # ---- the reference's idiom --------------------------------------------------------------------------------
+    t, enc1 = timed(lambda: [pub.encrypt(x) for x in xs])
+    res["scalar"][OPS[0]] = t / scalar_ops
+    enc2 = [pub.encrypt(y) for y in ys]
+    t, dec = timed(lambda: [priv.decrypt(e) for e in enc1])
+    assert dec == xs
+    res["scalar"][OPS[1]] = t / scalar_ops
+    t, s1 = timed(lambda: [e + y for e, y in zip(enc1, ys)])
+    res["scalar"][OPS[2]] = t / scalar_ops
+    t, s2 = timed(lambda: [a + b for a, b in zip(enc1, enc2)])
+    res["scalar"][OPS[3]] = t / scalar_ops
+    t, s3 = timed(lambda: [e + 1.0 for e in enc1])
+    res["scalar"][OPS[4]] = t / scalar_ops
+    t, s4 = timed(lambda: [e * y for e, y in zip(enc1, ys)])
+    res["scalar"][OPS[5]] = t / scalar_ops
+    k = min(16, scalar_ops)
+    assert all(abs(priv.decrypt(a) - (x + y)) < 1e-9 for a, x, y in zip(s2[:k], xs, ys))
+    assert all(abs(priv.decrypt(a) - x * y) < 1e-9 for a, x, y in zip(s4[:k], xs, ys))
+    # ---- the batched API on resident vectors -------------------------------------------------------------------
+    X, Y = np.array([rng.random() for _ in range(batch)]), np.array([rng.random() for _ in range(batch)])
+    t, v1 = timed(lambda: pub.encrypt_batch(X, device=True))
+    res["batched"][OPS[0]] = t / batch
+    v2 = pub.encrypt_batch(Y, device=True)
+    t, back = timed(lambda: priv.decrypt_batch(v1))
+    assert back == X.tolist()
+    res["batched"][OPS[1]] = t / batch
+    t, a1 = timed(lambda: (v1 + Y).limbs(False))
+    res["batched"][OPS[2]] = t / batch
+    t, a2 = timed(lambda: (v1 + v2).limbs(False))
+    res["batched"][OPS[3]] = t / batch
+    t, a3 = timed(lambda: (v1 + 1.0).limbs(False))
+    res["batched"][OPS[4]] = t / batch
+    t, a4 = timed(lambda: (v1 * Y).limbs(False))
+    res["batched"][OPS[5]] = t / batch
+    got = priv.decrypt_batch((v1 + v2)[:64])
+    assert all(abs(g - (x + y)) < 1e-9 for g, x, y in zip(got, X[:64], Y[:64]))
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scalar-ops", type=int, default=300)
+    ap.add_argument("--batch", type=int, default=1 << 14)
+    ap.add_argument("--key-sizes", type=int, nargs="+", default=[128, 256, 512, 1024, 2048, 4096, 8192])
+    args = ap.parse_args()
+    rng = random.Random(1)
+    out = []
+    for ks in args.key_sizes:
+        batch = args.batch if ks <= 4096 else max(1024, args.batch // 8)
+        r = bench_key(ks, args.scalar_ops, batch, rng)
+        out.append(r)
+        print("Paillier Benchmarks with key size of %d bits (key pair in %.2f s)" % (ks, r["keygen_s"]))
+        print("%-38s %26s %30s" % ("operation", "scalar idiom: s (ops/s)", "batched x%d: s (ops/s)" % batch))
+        for op in OPS:
+            a, b = r["scalar"][op], r["batched"][op]
+            print("%-38s %14.6f (%9d) %16.9f (%11d)" % (op, a, int(1 / a), b, int(1 / b)))
+        sys.stdout.flush()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

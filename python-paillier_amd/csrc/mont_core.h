@@ -211,6 +211,7 @@ PHE_DEV void montmul(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[
 // 29-bit limbs [first_limb + g*L, +L) of the little-endian 32-bit-word number at p (limbs32 words)
 template <int L>
 PHE_DEV void load_u32_as_r29(uint32_t (&x)[L], const uint32_t* p, int limbs32, int first_limb, uint32_t g) {
+    g = wave::reread(g);  // offsets recomputed here instead of hoisted out of the element loop (wave_gfx950.h:reread)
 #pragma unroll
     for (int k = 0; k < L; ++k) {
         const int bit = kRadixBits * (first_limb + (int)g * L + k);
@@ -245,6 +246,7 @@ template <int G, int L>
 PHE_DEV void store_r29_as_u32(uint32_t* p, int limbs32, const uint32_t (&t)[L], uint32_t* row, uint32_t g,
                               bool live) {
     constexpr int S = G * L;
+    g = wave::reread(g);
     lds_put<L>(row, t, g);
     if (live) {
         for (int j = (int)g; j < limbs32; j += G) {

@@ -109,16 +109,6 @@ PHE_DEV void store_words(uint32_t* p, int limbs32, const uint32_t (&t)[L], uint3
     wave::lds_fence();
 }
 
-// a pointer the optimiser must re-read: keeps loop-invariant constant rows (R^2, n*R) from being hoisted into registers
-// that would then be live across every product
-template <typename T>
-PHE_DEV const T* opaque(const T* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+s"(p));
-#endif
-    return p;
-}
-
 // out = a*b mod N (two products), or a*b*R^-1 mod N (ONE = A.one_product), canonical.  b_stride == 0: one row b for the
 // whole batch (a constant such as R^(d+1) mod N).  Needs A.vec_ok (16-byte aligned rows, limbs a multiple of 4): the
 // launcher takes mont_core.h:mulmod_body otherwise.
@@ -157,14 +147,18 @@ PHE_DEV void mul_io_body(const MulArgs& A, uint32_t* row, uint32_t* stage, uint3
         if (!live) item = A.batch - 1;
         uint32_t x[L], y[L];
         wave::wait_async_copies();
-        limbs_from_stage<G, L>(y, stage_b, gw, g);
-        digits_from_stage<G, L>(row, stage_a, gw, g);
+        {
+            const uint32_t gi = wave::reread(g), gwi = wave::reread(gw);
+            limbs_from_stage<G, L>(y, stage_b, gwi, gi);
+            digits_from_stage<G, L>(row, stage_a, gwi, gi);
+        }
         wave::lds_fence();
         if (it + 1 < n_iter) {  // the next element's rows: copied while this one is multiplied
             uint64_t nxt = slot + (it + 1) * (uint64_t)total_slots;
             if (nxt >= A.batch) nxt = A.batch - 1;
-            stage_row_async<G, L>(stage_a, A.a + nxt * A.a_stride, A.limbs, g);
-            stage_row_async<G, L>(stage_b, A.b + nxt * A.b_stride, b_limbs, g);
+            const uint32_t gi = wave::reread(g);
+            stage_row_async<G, L>(stage_a, A.a + nxt * A.a_stride, A.limbs, gi);
+            stage_row_async<G, L>(stage_b, A.b + nxt * A.b_stride, b_limbs, gi);
         }
         if (A.b_plain_limbs > 0) {
             // nude ciphertext of the plaintext: 1 + n*m (mod n^2), value < 2N; the plaintext is the multiplier
@@ -172,7 +166,7 @@ PHE_DEV void mul_io_body(const MulArgs& A, uint32_t* row, uint32_t* stage, uint3
             uint32_t am[L];
             load_row<L>(am, row, g);                // a's digits back from the row (rare path: add a plaintext)
             lds_put<L>(row, y, g);
-            load_row<L>(y, opaque(A.mod.aux), g);
+            load_row<L>(y, wave::reread_ptr(A.mod.aux), g);
             montmul<G, L>(y, row, y, n, n0inv, ln);
             if (g == 0u) y[0] += 1u;
             lds_put<L>(row, am, g);
@@ -184,7 +178,7 @@ PHE_DEV void mul_io_body(const MulArgs& A, uint32_t* row, uint32_t* stage, uint3
             montmul<G, L>(x, row, y, n, n0inv, ln);  // a*b
         }
         canonicalize<G, L>(x, n, ln);
-        store_words<G, L>(A.out + item * A.out_stride, A.limbs, x, row, g, live);
+        store_words<G, L>(A.out + item * A.out_stride, A.limbs, x, row, wave::reread(g), live);
     }
 }
 

@@ -376,8 +376,8 @@ PHE_DEV void split_conv(uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t* sr
     for (int j = 0; j < chunks; ++j) {
         load_u32_as_r29<L>(tmp, src, limbs32, j * H, ln.g);
         lds_put<L>(K.row_a, tmp, ln.g);
-        load_row<L>(d0, C.conv + (size_t)(2 * j) * H, ln.g);
-        load_row<L>(d1, C.conv + (size_t)(2 * j + 1) * H, ln.g);
+        load_row<L>(d0, wave::reread_ptr(C.conv) + (size_t)(2 * j) * H, ln.g);
+        load_row<L>(d1, wave::reread_ptr(C.conv) + (size_t)(2 * j + 1) * H, ln.g);
         if (j == 0) {
             pair_mul_plain<G, L>(X0, X1, d0, d1, K, ln);
         } else {
@@ -387,8 +387,8 @@ PHE_DEV void split_conv(uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t* sr
         }
     }
     if (chunks > 1) {  // the sums exceed the lazy bounds: one product with the pair of 1 restores them
-        load_row<L>(d0, C.e, ln.g);
-        load_row<L>(d1, C.e + H, ln.g);
+        load_row<L>(d0, wave::reread_ptr(C.e), ln.g);
+        load_row<L>(d1, wave::reread_ptr(C.e) + H, ln.g);
         split_mul<G, L>(X0, X1, d0, d1, K, ln);
     }
 }
@@ -443,6 +443,7 @@ template <int G, int L>
 PHE_DEV void store_pair_as_u32(uint32_t* p, int limbs32, const uint32_t (&lo)[L], const uint32_t (&hi)[L],
                                uint32_t* row, uint32_t g, bool live) {
     constexpr int H = G * L, S2 = 2 * H;
+    g = wave::reread(g);
     wave::lds_fence();
 #pragma unroll
     for (int k = 0; k < L; ++k) {
@@ -496,7 +497,7 @@ PHE_DEV void split_exit(uint32_t* out, int out_limbs, uint32_t (&X0)[L], uint32_
     }
     // t mod n, canonical
     lds_put<L>(K.row_a, t, g);
-    load_row<L>(cst, C.r1, g);
+    load_row<L>(cst, wave::reread_ptr(C.r1), g);
     montmul<G, L>(t, K.row_a, cst, K.n, K.n0inv, ln);
     canonicalize<G, L>(t, K.n, ln);
     // v = u + n*t  (< n^2 + 2n), then the canonical residue
@@ -506,8 +507,8 @@ PHE_DEV void split_exit(uint32_t* out, int out_limbs, uint32_t (&X0)[L], uint32_
     wave::lds_fence();
     load_row<L>(lo, K.row_c, g);
     normalize_full<G, L>(hi, ln);
-    load_row<L>(cst, C.nsq, g);
-    load_row<L>(t, C.nsq + H, g);
+    load_row<L>(cst, wave::reread_ptr(C.nsq), g);
+    load_row<L>(t, wave::reread_ptr(C.nsq) + H, g);
     cond_sub_pair<G, L>(lo, hi, cst, t, ln);
     store_pair_as_u32<G, L>(out, out_limbs, lo, hi, K.row_a, g, live);
 }
@@ -658,8 +659,8 @@ PHE_DEV void modexp_var_split_body(const SplitVarArgs& A, uint32_t* lds_row, uin
         uint32_t X0[L], X1[L], Y0[L], Y1[L];
         split_conv<G, L>(Y0, Y1, A.base + item * (uint64_t)A.base_limbs, A.base_limbs, A.base_chunks, A.mod, K, ln);
         // table: base^0 (the pair of 1) .. base^(2^w - 1)
-        load_row<L>(X0, A.mod.e, g);
-        load_row<L>(X1, A.mod.e + H, g);
+        load_row<L>(X0, wave::reread_ptr(A.mod.e), g);
+        load_row<L>(X1, wave::reread_ptr(A.mod.e) + H, g);
         store_row<L>(tbl, X0, g);
         store_row<L>(tbl + H, X1, g);
         store_row<L>(tbl + S2, Y0, g);
@@ -905,8 +906,8 @@ PHE_DEV void multiexp_lookup_body(const SplitLookupArgs& A, uint32_t* lds_row, u
         const uint64_t first = A.row_ptr ? A.row_ptr[r] : r * A.batch;
         const uint64_t count = A.row_ptr ? A.row_ptr[r + 1] - first : A.batch;
         uint32_t X0[L], X1[L], Y0[L], Y1[L];
-        load_row<L>(X0, A.mod.e, g);
-        load_row<L>(X1, A.mod.e + H, g);
+        load_row<L>(X0, wave::reread_ptr(A.mod.e), g);
+        load_row<L>(X1, wave::reread_ptr(A.mod.e) + H, g);
         for (int wi = A.n_windows - 1; wi >= 0; --wi) {
             if (wi != A.n_windows - 1)
                 for (int s = 0; s < A.window; ++s) split_square<G, L>(X0, X1, K, ln);

@@ -112,6 +112,23 @@ PHE_DEV void wait_async_copies() {
     lds_fence();
 }
 
+// A value the optimiser must treat as freshly produced.  Every memory / LDS offset of the operand movement code is a
+// function of the lane's position in its group, i.e. invariant across the element loop of a kernel: left alone, the
+// compiler hoists hundreds of precomputed offsets out of that loop, runs out of registers and spills them (round 2:
+// k_mulmod 340 VGPRs = one wave per SIMD, the staged variant 90 spilled VGPRs).  Re-reading the position where such code
+// starts makes it recompute its offsets — a few hundred full-rate instructions next to tens of thousands of multiply-adds.
+PHE_DEV uint32_t reread(uint32_t x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// The same for a (wave-uniform) pointer to per-key constants: a load through it is not hoisted out of the element loop
+// into registers that would stay live — and be spilled — across every product.
+PHE_DEV const uint32_t* reread_ptr(const uint32_t* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // 32x32+64 -> 64 multiply-accumulate: v_mad_u64_u32 with a full 64-bit addend.  The radix-2^29 core
 // keeps every accumulator below 2^64 by construction, so the carry-out is never needed.
 PHE_DEV uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }
