@@ -483,6 +483,10 @@ class Engine:
         self.__dict__.setdefault("_obf_pool", []).append([block, 0])
         return self.obfuscators_available()
 
+    def clear_obfuscator_pool(self):
+        """drop the obfuscators made ahead of time (nothing was handed out twice; the unused ones are simply forgotten)"""
+        self.__dict__["_obf_pool"] = []
+
     def obfuscators_available(self):
         return sum(b.rows - used for b, used in self.__dict__.get("_obf_pool", []))
 

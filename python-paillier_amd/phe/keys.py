@@ -146,6 +146,10 @@ class PaillierPublicKey(object):
     def obfuscators_available(self):
         return self._get_engine().obfuscators_available()
 
+    def discard_obfuscators(self):
+        """forget the obfuscators made ahead of time: the next encryptions draw and exponentiate on the spot again"""
+        self._get_engine().clear_obfuscator_pool()
+
     # ---- batched API ------------------------------------------------------------------------------
     def raw_encrypt_batch(self, plaintexts, r_values=None):
         """List of ints -> list of int ciphertexts; r_values=None draws fresh obfuscators."""
