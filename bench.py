@@ -410,6 +410,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args)
 
+    # stdout carries exactly ONE line (rank 0's JSON): libraries that print on their own (RCCL's version banner when a
+    # communicator comes up) are sent to stderr for the whole run; the line itself is written to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch.distributed as dist
     from phe import _native as native
@@ -801,7 +807,8 @@ def main():
         if cpu:
             out["speedup_vs_cpu_all_cores"] = {"encrypt": value / cpu["value"],
                                                "decrypt": out["decrypt"]["value"] / cpu["decrypts_per_s"]}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         flag = max_over_ranks([0.0 if ok else 1.0])[0]
         ok = flag == 0.0
