@@ -228,6 +228,33 @@ PHE_DEV void shift_row(uint64_t (&acc)[L], int j, uint32_t dmask) {
     }
 }
 
+// The quotient digit of the first accumulator set and its entry into the second one.  Two measurement-only variants
+// (never in the shipped library, built by tools/exp/build_variants.sh):
+//   PHE_VARIANT_QMAD    the digit enters by one more multiply-add (m * [lane 0 ? 1 : 0]) instead of v_and + 64-bit add
+//   PHE_VARIANT_UNITINV the digit is the accumulator's low word itself (what a modulus with n = -1 mod 2^29 would allow):
+//                       WRONG RESULTS, timing only
+#if defined(PHE_VARIANT_UNITINV)
+#define PHE_SECOND_QUOTIENT(x) ((uint32_t)(x))
+#else
+#define PHE_SECOND_QUOTIENT(x) ((uint32_t)(x) * n0inv)
+#endif
+#if defined(PHE_VARIANT_QMAD)
+#define PHE_QUOTIENT_STEP()                                                                  \
+    const uint32_t mraw = (uint32_t)p[j] * n0inv;                                            \
+    const uint32_t m = wave::grp_bcast0<G>(mraw, ln) & vmask;                                \
+    q[j] = wave::mad64(m, wave::reread(lane0 ? 1u : 0u), q[j]);
+#elif defined(PHE_VARIANT_UNITINV)
+#define PHE_QUOTIENT_STEP()                                                                  \
+    const uint32_t mraw = (uint32_t)p[j];                                                    \
+    const uint32_t m = wave::grp_bcast0<G>(mraw, ln) & vmask;                                \
+    q[j] += (uint64_t)(mraw & lane0);
+#else
+#define PHE_QUOTIENT_STEP()                                                                  \
+    const uint32_t mraw = (uint32_t)p[j] * n0inv;                                            \
+    const uint32_t m = wave::grp_bcast0<G>(mraw, ln) & vmask;                                \
+    q[j] += (uint64_t)(mraw & lane0); /* quotient digit i of the first sum = digit i of the addend m */
+#endif
+
 // z0 = (a*b0 + m*n) / R,   z1 = (m + a*b1 + m2*n) / R.     a: H digits in LDS.
 // Squaring: b0 = X0, b1 = 2*X1.  Conversion of a plain chunk a: (b0, b1) = pair(R^(j+2)).
 template <int G, int L>
@@ -251,12 +278,10 @@ PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
             for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(ai, b0[k], p[(k + j) % L]);
 #pragma unroll
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(ai, b1[k], q[(k + j) % L]);
-            const uint32_t mraw = (uint32_t)p[j] * n0inv;
-            const uint32_t m = wave::grp_bcast0<G>(mraw, ln) & vmask;
-            q[j] += (uint64_t)(mraw & lane0);  // quotient digit i of the first sum = digit i of the addend m
+            PHE_QUOTIENT_STEP()
 #pragma unroll
             for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(m, n[k], p[(k + j) % L]);
-            const uint32_t m2 = wave::grp_bcast0<G>((uint32_t)q[j] * n0inv, ln) & vmask;
+            const uint32_t m2 = wave::grp_bcast0<G>(PHE_SECOND_QUOTIENT(q[j]), ln) & vmask;
 #pragma unroll
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(m2, n[k], q[(k + j) % L]);
             shift_row<G, L>(p, j, dmask);
@@ -292,12 +317,10 @@ PHE_DEV void pair_pass3(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(ai, b1[k], q[(k + j) % L]);
 #pragma unroll
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(ci, b0[k], q[(k + j) % L]);
-            const uint32_t mraw = (uint32_t)p[j] * n0inv;
-            const uint32_t m = wave::grp_bcast0<G>(mraw, ln) & vmask;
-            q[j] += (uint64_t)(mraw & lane0);
+            PHE_QUOTIENT_STEP()
 #pragma unroll
             for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(m, n[k], p[(k + j) % L]);
-            const uint32_t m2 = wave::grp_bcast0<G>((uint32_t)q[j] * n0inv, ln) & vmask;
+            const uint32_t m2 = wave::grp_bcast0<G>(PHE_SECOND_QUOTIENT(q[j]), ln) & vmask;
 #pragma unroll
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(m2, n[k], q[(k + j) % L]);
             shift_row<G, L>(p, j, dmask);

@@ -14,7 +14,8 @@ import threading
 import numpy as np
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libphe_hip.so")
+# PHE_HIP_LIB: another build of the same library (measurement variants of tools/exp/build_variants.sh); default lib/libphe_hip.so
+LIB_PATH = os.environ.get("PHE_HIP_LIB") or os.path.join(_PKG_ROOT, "lib", "libphe_hip.so")
 
 OK, EINVAL, EHIP, ENOINVERSE = 0, 1, 2, 3
 
