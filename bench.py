@@ -297,6 +297,9 @@ class HipBackend:
     def montmul(self, ctx, a, b, b_is_row, out, rows):
         ctx.montmul_dev(a.data_ptr(), b.data_ptr(), b_is_row, out.data_ptr(), rows, self.stream)
 
+    def encrypt_owner(self, ctx, m, r, c, rows):
+        ctx.encrypt_owner_dev(m.data_ptr(), r.data_ptr(), c.data_ptr(), rows, self.stream)
+
     def upload(self, arr):
         import numpy as np
         return self.torch.from_numpy(np.ascontiguousarray(arr).view(np.int32)).to(self.dev)
@@ -568,6 +571,12 @@ def main():
                              "per pass: 8 additions at one Montgomery product each + 1 settling product; `value` counts passes")
             ops["raw_add_resident_chain"]["additions_per_s"] = ops["raw_add_resident_chain"]["value"] * chain
             del tmp
+        if hasattr(be, "encrypt_owner") and getattr(ctx, "owner_encrypt_offered", lambda: False)():
+            # raw_encrypt by the holder of the private key: r^n from its CRT halves (half-width numbers), lifted to n^2 —
+            # NOT the headline (that is the public-key path above); the whole batch must equal the public path's ciphertexts
+            ops_ok &= run_op("raw_encrypt_key_owner", lambda k: be.encrypt_owner(ctx, m, r, out, k), 2,
+                             lambda: be.equal(out, c),
+                             "same (m, r) as the headline batch; check = every ciphertext equals the public-key path's")
         scal = {}
         for name, bits, seed in (("raw_mul_float56", 56, 77), ("raw_mul_int64", 63, 78)):
             e = be.rand(B, 2, seed + 10 * rank)
@@ -766,7 +775,8 @@ def main():
         if ops:
             canon = mac32_ops(args.key_bits)
             exec_key = {"raw_add": "raw_add", "raw_mul_float56": "raw_mul_56bit", "raw_mul_int64": "raw_mul_63bit",
-                        "obfuscate": "obfuscate"}
+                        "obfuscate": "obfuscate", "raw_encrypt_key_owner": "encrypt_key_owner"}
+            canon["raw_encrypt_key_owner"] = enc_mac
             for name, rec in ops.items():
                 per_gpu = rec["value"] / world
                 if name == "raw_add_resident_chain":

@@ -87,6 +87,7 @@ int phe_hip_encrypt(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint
 
 /* c_out[i] = c_in[i] * r[i]^n mod n^2       — EncryptedNumber.obfuscate(), phe/paillier.py:603-624
  * (with the obfuscator r an explicit input; the reference draws it at :621). */
+int phe_hip_encrypt_owner(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch);
 int phe_hip_obfuscate(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t* r, uint32_t* c_out, size_t batch);
 
 /* m[i] = PaillierPrivateKey.raw_decrypt(c[i]) — phe/paillier.py:328-354 incl. l_function :362-364
@@ -149,6 +150,13 @@ int phe_hip_miller_rabin(int device, const uint32_t* n, const uint32_t* base, in
 
 /* ---- the hot path, device buffers (resident operands; asynchronous on `stream`) -------------- */
 int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch, void* stream);
+/* raw_encrypt for the HOLDER of the private key (private context): the same value (1 + n*m) * r^n mod n^2, bit for bit, but
+ * r^n is taken modulo p^2 and modulo q^2 (half-width numbers: about half the multiply-adds in all) and lifted to n^2 by
+ * the Chinese remainder theorem.  The reference has no such function (its raw_encrypt, phe/paillier.py:102-139, only knows
+ * the public key); the drop-in uses it when the key object it is asked to encrypt under shares an engine with its private
+ * key.  EINVAL on public contexts and for key widths without the needed geometries (use phe_hip_encrypt_dev then). */
+int phe_hip_ctx_owner_encrypt(const phe_hip_ctx* ctx, int* offered); /* 1 if the two entry points below will work */
+int phe_hip_encrypt_owner_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch, void* stream);
 int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t* r, uint32_t* c_out, size_t batch, void* stream);
 int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t batch, void* stream);
 int phe_hip_mulmod_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t batch, void* stream);

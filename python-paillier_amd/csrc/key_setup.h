@@ -549,5 +549,75 @@ inline PrivatePlan build_private(const uint32_t* p, const uint32_t* q, const uin
     return P;
 }
 
+// scalar inverse of a residue modulo an odd N (binary extended Euclid); false if gcd != 1
+inline bool big_invert_odd(const Big& a_in, const Big& N, Big& out) {
+    const size_t w = N.size();
+    Big u = a_in, v = N, x1(w, 0u), x2(w, 0u);
+    x1[0] = 1;
+    auto is_one = [](const Big& x) {
+        if (x[0] != 1) return false;
+        for (size_t i = 1; i < x.size(); ++i)
+            if (x[i]) return false;
+        return true;
+    };
+    auto halve_mod = [&](Big& x) {  // x <- x/2 mod N
+        uint32_t carry = 0;
+        if (x[0] & 1u) carry = big_add_inplace(x, N);
+        for (size_t i = 0; i + 1 < w; ++i) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+        x[w - 1] = (x[w - 1] >> 1) | (carry << 31);
+    };
+    auto shr1 = [&](Big& x) {
+        for (size_t i = 0; i + 1 < w; ++i) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
+        x[w - 1] >>= 1;
+    };
+    if (big_is_zero(u)) return false;
+    while (!is_one(u) && !is_one(v)) {
+        while ((u[0] & 1u) == 0u) { shr1(u); halve_mod(x1); }
+        while ((v[0] & 1u) == 0u) { shr1(v); halve_mod(x2); }
+        if (big_cmp(u, v) >= 0) {
+            big_sub_inplace(u, v);
+            if (big_sub_inplace(x1, x2)) big_add_inplace(x1, N);
+            if (big_is_zero(u)) return false;  // gcd = v != 1
+        } else {
+            big_sub_inplace(v, u);
+            if (big_sub_inplace(x2, x1)) big_add_inplace(x2, N);
+        }
+    }
+    out = is_one(u) ? x1 : x2;
+    return true;
+}
+
+
+// which (G, L) the split translation units instantiate (kernels_s*.hip): the CRT lift runs there on the full-width
+// geometry of q^2
+inline bool split_part_holds(int G, int L) {
+    const int* list = G == 16 ? kS16 : G == 8 ? kS8 : G == 4 ? kS4 : G == 2 ? kS2 : nullptr;
+    const int count = G == 16 ? 8 : G == 8 ? 4 : G == 4 ? 4 : G == 2 ? 3 : 0;
+    for (int i = 0; i < count; ++i)
+        if (list[i] == L) return true;
+    return false;
+}
+
+// Encryption by the key owner (split_core.h:crt_lift_body): K = (p^2)^-1 mod q^2 as K*R and (q^2 - K)*R mod q^2 (R =
+// 2^(29 S), S the limbs of q^2's full-width geometry), and p^2, as rows of S limbs.  false: no inverse (p^2, q^2 not coprime)
+struct OwnerLift {
+    std::vector<uint32_t> kr, nkr, psq;
+};
+inline bool build_owner_lift(const Big& bp, const Big& bq, int S, OwnerLift& W) {
+    const Big qsq = big_mul(bq, bq), psq = big_mul(bp, bp);
+    const int w32 = (big_bits(qsq) + 31) / 32;
+    const Big N = big_resize(qsq, w32);
+    const Big P2 = big_resize(psq, w32);  // p < q: p^2 < q^2
+    Big K;
+    if (!big_invert_odd(P2, N, K)) return false;
+    Big NK = N;
+    big_sub_inplace(NK, K);
+    const int rbits = kRadixBits * S;
+    W.kr = to_r29(big_shift_mod(K, rbits, N), S);
+    W.nkr = to_r29(big_shift_mod(NK, rbits, N), S);
+    W.psq = to_r29(P2, S);
+    return true;
+}
+
 }  // namespace host
 }  // namespace phe

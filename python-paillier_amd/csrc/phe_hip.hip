@@ -81,6 +81,7 @@ PHE_DECLARE_PART(g16b)
     int launch_multi_tables(int L, int blocks, hipStream_t st, const SplitTableArgs& A);          \
     int launch_multi_lookup(int L, int blocks, hipStream_t st, const SplitLookupArgs& A);         \
     int launch_mul_split(int L, int blocks, hipStream_t st, const SplitMulArgs& A);               \
+    int launch_crt_lift(int L, int blocks, hipStream_t st, const CrtLiftArgs& A);                 \
     }
 PHE_DECLARE_SPLIT_PART(s2a)
 PHE_DECLARE_SPLIT_PART(s2b)
@@ -145,44 +146,45 @@ struct SplitPart {
     int (*launch_multi_tables)(int, int, hipStream_t, const SplitTableArgs&);
     int (*launch_multi_lookup)(int, int, hipStream_t, const SplitLookupArgs&);
     int (*launch_mul_split)(int, int, hipStream_t, const SplitMulArgs&);
+    int (*launch_crt_lift)(int, int, hipStream_t, const CrtLiftArgs&);
 };
 static const SplitPart kSplitParts[] = {
     {2, phe::s2a::occ_split, phe::s2a::launch_split, phe::s2a::occ_var_split, phe::s2a::launch_var_split,
      phe::s2a::occ_multi_split, phe::s2a::launch_multi_split, phe::s2a::launch_multi_tables,
-     phe::s2a::launch_multi_lookup, phe::s2a::launch_mul_split},
+     phe::s2a::launch_multi_lookup, phe::s2a::launch_mul_split, phe::s2a::launch_crt_lift},
     {2, phe::s2b::occ_split, phe::s2b::launch_split, phe::s2b::occ_var_split, phe::s2b::launch_var_split,
      phe::s2b::occ_multi_split, phe::s2b::launch_multi_split, phe::s2b::launch_multi_tables,
-     phe::s2b::launch_multi_lookup, phe::s2b::launch_mul_split},
+     phe::s2b::launch_multi_lookup, phe::s2b::launch_mul_split, phe::s2b::launch_crt_lift},
     {2, phe::s2c::occ_split, phe::s2c::launch_split, phe::s2c::occ_var_split, phe::s2c::launch_var_split,
      phe::s2c::occ_multi_split, phe::s2c::launch_multi_split, phe::s2c::launch_multi_tables,
-     phe::s2c::launch_multi_lookup, phe::s2c::launch_mul_split},
+     phe::s2c::launch_multi_lookup, phe::s2c::launch_mul_split, phe::s2c::launch_crt_lift},
     {4, phe::s4a::occ_split, phe::s4a::launch_split, phe::s4a::occ_var_split, phe::s4a::launch_var_split,
      phe::s4a::occ_multi_split, phe::s4a::launch_multi_split, phe::s4a::launch_multi_tables,
-     phe::s4a::launch_multi_lookup, phe::s4a::launch_mul_split},
+     phe::s4a::launch_multi_lookup, phe::s4a::launch_mul_split, phe::s4a::launch_crt_lift},
     {4, phe::s4b::occ_split, phe::s4b::launch_split, phe::s4b::occ_var_split, phe::s4b::launch_var_split,
      phe::s4b::occ_multi_split, phe::s4b::launch_multi_split, phe::s4b::launch_multi_tables,
-     phe::s4b::launch_multi_lookup, phe::s4b::launch_mul_split},
+     phe::s4b::launch_multi_lookup, phe::s4b::launch_mul_split, phe::s4b::launch_crt_lift},
     {4, phe::s4c::occ_split, phe::s4c::launch_split, phe::s4c::occ_var_split, phe::s4c::launch_var_split,
      phe::s4c::occ_multi_split, phe::s4c::launch_multi_split, phe::s4c::launch_multi_tables,
-     phe::s4c::launch_multi_lookup, phe::s4c::launch_mul_split},
+     phe::s4c::launch_multi_lookup, phe::s4c::launch_mul_split, phe::s4c::launch_crt_lift},
     {8, phe::s8a::occ_split, phe::s8a::launch_split, phe::s8a::occ_var_split, phe::s8a::launch_var_split,
      phe::s8a::occ_multi_split, phe::s8a::launch_multi_split, phe::s8a::launch_multi_tables,
-     phe::s8a::launch_multi_lookup, phe::s8a::launch_mul_split},
+     phe::s8a::launch_multi_lookup, phe::s8a::launch_mul_split, phe::s8a::launch_crt_lift},
     {8, phe::s8b::occ_split, phe::s8b::launch_split, phe::s8b::occ_var_split, phe::s8b::launch_var_split,
      phe::s8b::occ_multi_split, phe::s8b::launch_multi_split, phe::s8b::launch_multi_tables,
-     phe::s8b::launch_multi_lookup, phe::s8b::launch_mul_split},
+     phe::s8b::launch_multi_lookup, phe::s8b::launch_mul_split, phe::s8b::launch_crt_lift},
     {8, phe::s8c::occ_split, phe::s8c::launch_split, phe::s8c::occ_var_split, phe::s8c::launch_var_split,
      phe::s8c::occ_multi_split, phe::s8c::launch_multi_split, phe::s8c::launch_multi_tables,
-     phe::s8c::launch_multi_lookup, phe::s8c::launch_mul_split},
+     phe::s8c::launch_multi_lookup, phe::s8c::launch_mul_split, phe::s8c::launch_crt_lift},
     {16, phe::s16a::occ_split, phe::s16a::launch_split, phe::s16a::occ_var_split, phe::s16a::launch_var_split,
      phe::s16a::occ_multi_split, phe::s16a::launch_multi_split, phe::s16a::launch_multi_tables,
-     phe::s16a::launch_multi_lookup, phe::s16a::launch_mul_split},
+     phe::s16a::launch_multi_lookup, phe::s16a::launch_mul_split, phe::s16a::launch_crt_lift},
     {16, phe::s16b::occ_split, phe::s16b::launch_split, phe::s16b::occ_var_split, phe::s16b::launch_var_split,
      phe::s16b::occ_multi_split, phe::s16b::launch_multi_split, phe::s16b::launch_multi_tables,
-     phe::s16b::launch_multi_lookup, phe::s16b::launch_mul_split},
+     phe::s16b::launch_multi_lookup, phe::s16b::launch_mul_split, phe::s16b::launch_crt_lift},
     {16, phe::s16c::occ_split, phe::s16c::launch_split, phe::s16c::occ_var_split, phe::s16c::launch_var_split,
      phe::s16c::occ_multi_split, phe::s16c::launch_multi_split, phe::s16c::launch_multi_tables,
-     phe::s16c::launch_multi_lookup, phe::s16c::launch_mul_split},
+     phe::s16c::launch_multi_lookup, phe::s16c::launch_mul_split, phe::s16c::launch_crt_lift},
 };
 #define PHE_SPLIT_BY_GROUP(G_, CALL2)                 \
     [&]() -> int {                                    \
@@ -317,6 +319,9 @@ struct phe_hip_ctx {
     size_t lookup_words = 0;
     uint32_t* partial = nullptr;  // multi-exponentiation: one product per chunk, joined in place by a k_mulmod tree
     size_t partial_words = 0;
+    // encryption by the key owner (CRT lift): K*R, (q^2 - K)*R mod q^2 and p^2 as rows of d_qsq.S limbs; null = not offered
+    uint32_t* owner_blob = nullptr;
+    int owner_G = 0, owner_L = 0;
     // staging for the host-pointer entry points
     uint32_t* stage[3] = {nullptr, nullptr, nullptr};
     size_t stage_words[3] = {0, 0, 0};
@@ -730,6 +735,34 @@ int phe_hip_ctx_create_public(const uint32_t* n, int n_limbs, int device, phe_hi
     return PHE_HIP_OK;
 }
 
+// Constants of the key owner's encryption (split_core.h:crt_lift_body; key_setup.h:build_owner_lift).  Not offered
+// (owner_blob stays null, the public path serves) when the half-exponentiations have no pair form or no split part
+// holds the full-width geometry of q^2.
+static int setup_owner_encrypt(phe_hip_ctx* ctx) {
+    const host::ModulusPack& Q = ctx->priv.qsq;
+    if (!ctx->use_split || !ctx->priv.psplit.G || !ctx->priv.qsplit.G || !ctx->pub.nsq.G || Q.G == 0) return PHE_HIP_OK;
+    DevModulus shape;
+    shape.G = Q.G;
+    shape.L = Q.L;
+    int G, L;
+    light_geometry(shape, G, L);
+    if (!host::split_part_holds(G, L)) return PHE_HIP_OK;
+    try {
+        host::OwnerLift W;
+        if (!host::build_owner_lift(ctx->priv.tail.p, ctx->priv.tail.q, Q.S, W)) return PHE_HIP_OK;
+        std::vector<uint32_t> blob(W.kr);
+        blob.insert(blob.end(), W.nkr.begin(), W.nkr.end());
+        blob.insert(blob.end(), W.psq.begin(), W.psq.end());
+        HIP_TRY(hipMalloc((void**)&ctx->owner_blob, blob.size() * 4));
+        HIP_TRY(hipMemcpy(ctx->owner_blob, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+        ctx->owner_G = G;
+        ctx->owner_L = L;
+    } catch (const std::exception& ex) {
+        return fail(PHE_HIP_EINVAL, ex.what());
+    }
+    return PHE_HIP_OK;
+}
+
 int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p, const uint32_t* q,
                                const uint32_t* hp, const uint32_t* hq, const uint32_t* p_inverse, int pq_limbs,
                                int device, phe_hip_ctx** out) {
@@ -776,6 +809,7 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
             if (e != hipSuccess) rc = fail(PHE_HIP_EHIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
         }
     }
+    if (!rc) rc = setup_owner_encrypt(ctx);
     if (rc) {
         phe_hip_ctx_destroy(ctx);
         return rc;
@@ -793,7 +827,7 @@ void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
                         ctx->d_nsq_lat.blob, ctx->d_psq_lat.blob, ctx->d_qsq_lat.blob,
                         ctx->d_nsq.blob, ctx->d_psq.blob, ctx->d_qsq.blob, ctx->d_exp_n.ops, ctx->d_exp_p.ops,
                         ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->table2, ctx->scratch, ctx->partial, ctx->lookup, (uint32_t*)ctx->flags, ctx->stage[0],
-                        ctx->stage[1], ctx->stage[2]};
+                        ctx->stage[1], ctx->stage[2], ctx->owner_blob};
     for (uint32_t* b : bufs)
         if (b) (void)hipFree(b);
     for (int k = 0; k < 2; ++k) {
@@ -857,6 +891,54 @@ int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, 
                                           (hipStream_t)stream);
     return launch_uniform<kModeEncrypt>(ctx, pick_nsq(ctx, batch), ctx->d_exp_n, r, ctx->pub.s1, m, ctx->pub.s1, c, ctx->pub.s2,
                                         batch, (hipStream_t)stream);
+}
+
+// raw_encrypt by the holder of the private key: r^n mod n^2 from r^n mod p^2 and r^n mod q^2 (the half-exponentiation
+// kernels with the exponent n), lifted by k_crt_lift, times 1 + n*m by the product kernel.  Same bits as phe_hip_encrypt_dev.
+int phe_hip_encrypt_owner_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (!ctx->has_private) return fail(PHE_HIP_EINVAL, "owner encryption needs a private-key context");
+    if (!ctx->owner_blob) return fail(PHE_HIP_EINVAL, "owner encryption is not offered for this key width");
+    if (batch == 0) return PHE_HIP_OK;
+    if (!m || !r || !c) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int S = (std::max(ctx->priv.psq.bits, ctx->priv.qsq.bits) + 31) / 32;
+    int rc = ensure_words(&ctx->scratch, &ctx->scratch_words, (size_t)2 * batch * S);
+    if (rc) return rc;
+    uint32_t* yp = ctx->scratch;
+    uint32_t* yq = ctx->scratch + batch * (size_t)S;
+    // always the throughput geometry of the halves: the lift's constants belong to it
+    rc = launch_split<kModeHalfDecrypt>(ctx, ctx->d_psplit, ctx->d_exp_n, r, ctx->pub.s1, nullptr, 0, yp, S, batch, st);
+    if (!rc) rc = launch_split<kModeHalfDecrypt>(ctx, ctx->d_qsplit, ctx->d_exp_n, r, ctx->pub.s1, nullptr, 0, yq, S, batch, st);
+    if (rc) return rc;
+    const int QS = ctx->d_qsq.S;
+    CrtLiftArgs A;
+    A.mod = ctx->d_qsq.c;
+    A.kr = ctx->owner_blob;
+    A.nkr = ctx->owner_blob + QS;
+    A.psq = ctx->owner_blob + 2 * QS;
+    A.yp = yp;
+    A.yq = yq;
+    A.x_stride = (size_t)S;
+    A.x_limbs = S;
+    A.out = c;
+    A.out_limbs = ctx->pub.s2;
+    A.batch = batch;
+    const int blocks = grid_blocks(ctx, batch, ctx->owner_G, 2);
+    if (PHE_SPLIT_BY_GROUP(ctx->owner_G, launch_crt_lift(ctx->owner_L, blocks, st, A)) < 0)
+        return fail(PHE_HIP_EINVAL, "unsupported geometry for the CRT lift");
+    HIP_TRY(hipGetLastError());
+    // c <- r^n * (1 + n*m) mod n^2, in place (every limb group reads its row before it writes it)
+    const size_t s1 = (size_t)ctx->pub.s1, s2 = (size_t)ctx->pub.s2;
+    return launch_mul(ctx, ctx->d_nsq, c, s2, m, s1, c, s2, ctx->pub.s2, batch, st, ctx->pub.s1);
+}
+
+int phe_hip_ctx_owner_encrypt(const phe_hip_ctx* ctx, int* offered) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (!offered) return fail(PHE_HIP_EINVAL, "null pointer");
+    *offered = (ctx->has_private && ctx->owner_blob) ? 1 : 0;
+    return PHE_HIP_OK;
 }
 
 int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t* r, uint32_t* c_out, size_t batch,
@@ -1265,6 +1347,26 @@ int phe_hip_encrypt(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint
     return PHE_HIP_OK;
 }
 
+int phe_hip_encrypt_owner(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!m || !r || !c) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    const size_t s1 = (size_t)ctx->pub.s1, s2 = (size_t)ctx->pub.s2;
+    if (pipelined_batch(batch))
+        return run_pipelined(ctx, m, s1, r, s1, c, s2, batch,
+                             [&](uint32_t* d0, uint32_t* d1, uint32_t* d2, size_t rows, hipStream_t st) {
+                                 return phe_hip_encrypt_owner_dev(ctx, d0, d1, d2, rows, st);
+                             });
+    int rc = stage_in(ctx, 0, m, batch * s1);
+    if (!rc) rc = stage_in(ctx, 1, r, batch * s1);
+    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
+    if (!rc) rc = phe_hip_encrypt_owner_dev(ctx, ctx->stage[0], ctx->stage[1], ctx->stage[2], batch, nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(c, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));
+    return PHE_HIP_OK;
+}
+
 int phe_hip_obfuscate(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t* r, uint32_t* c_out, size_t batch) {
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
     if (batch == 0) return PHE_HIP_OK;
@@ -1392,43 +1494,7 @@ int phe_hip_multiexp(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, 
 }
 
 // ---- batched inversion (Montgomery's trick over a product tree) ------------------------------------
-// host scalar inverse of an odd-modulus residue (binary extended Euclid); false if gcd != 1
-static bool host_invert(const Big& a_in, const Big& N, Big& out) {
-    const size_t w = N.size();
-    Big u = a_in, v = N, x1(w, 0u), x2(w, 0u);
-    x1[0] = 1;
-    auto is_one = [](const Big& x) {
-        if (x[0] != 1) return false;
-        for (size_t i = 1; i < x.size(); ++i)
-            if (x[i]) return false;
-        return true;
-    };
-    auto halve_mod = [&](Big& x) {  // x <- x/2 mod N
-        uint32_t carry = 0;
-        if (x[0] & 1u) carry = host::big_add_inplace(x, N);
-        for (size_t i = 0; i + 1 < w; ++i) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
-        x[w - 1] = (x[w - 1] >> 1) | (carry << 31);
-    };
-    auto shr1 = [&](Big& x) {
-        for (size_t i = 0; i + 1 < w; ++i) x[i] = (x[i] >> 1) | (x[i + 1] << 31);
-        x[w - 1] >>= 1;
-    };
-    if (host::big_is_zero(u)) return false;
-    while (!is_one(u) && !is_one(v)) {
-        while ((u[0] & 1u) == 0u) { shr1(u); halve_mod(x1); }
-        while ((v[0] & 1u) == 0u) { shr1(v); halve_mod(x2); }
-        if (host::big_cmp(u, v) >= 0) {
-            host::big_sub_inplace(u, v);
-            if (host::big_sub_inplace(x1, x2)) host::big_add_inplace(x1, N);
-            if (host::big_is_zero(u)) return false;  // gcd = v != 1
-        } else {
-            host::big_sub_inplace(v, u);
-            if (host::big_sub_inplace(x2, x1)) host::big_add_inplace(x2, N);
-        }
-    }
-    out = is_one(u) ? x1 : x2;
-    return true;
-}
+static bool host_invert(const Big& a_in, const Big& N, Big& out) { return host::big_invert_odd(a_in, N, out); }
 
 // a_is_device/out_is_device pick the copy kinds; the trees live in stage[0] (products) and stage[1] (inverses).
 static int invert_impl(phe_hip_ctx* ctx, const uint32_t* a, bool a_is_device, uint32_t* out, bool out_is_device,

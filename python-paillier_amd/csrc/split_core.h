@@ -644,6 +644,67 @@ PHE_DEV void mulmod_split_body(const SplitMulArgs& A, uint32_t* lds_row, uint32_
     }
 }
 
+// Encryption by the key owner: r^n mod n^2 from its two CRT halves (phe/paillier.py:137 obfuscator = powmod(r, n, nsquare)
+// is one exponentiation modulo n^2; whoever holds p and q can take it modulo p^2 and modulo q^2 — half-width numbers, a
+// quarter of the multiply-adds each — and lift).  With y_p = r^n mod p^2, y_q = r^n mod q^2 (canonical, from the
+// half-exponentiation kernels run with the exponent n) and K = (p^2)^-1 mod q^2:
+//     u = (y_q - y_p) * K mod q^2 = y_q*K + y_p*(q^2 - K)   (mod q^2: additions only),      y = y_p + p^2 * u  <  n^2
+// which IS the canonical residue r^n mod n^2: the same bits the one big exponentiation returns.  Full-width geometry of
+// q^2: S = G*L limbs, R = 2^(29 S) >= 16 q^2.
+struct CrtLiftArgs {
+    ModConsts mod;        // modulus q^2 (n, r1 used)
+    const uint32_t* kr;   // K * R mod q^2
+    const uint32_t* nkr;  // (q^2 - K) * R mod q^2
+    const uint32_t* psq;  // p^2
+    const uint32_t* yp;   // (batch, x_stride) words
+    const uint32_t* yq;
+    size_t x_stride;
+    int x_limbs;          // words of a row that hold the value
+    uint32_t* out;        // (batch, out_limbs) words: r^n mod n^2
+    int out_limbs;
+    uint64_t batch;
+};
+
+template <int G, int L>
+PHE_DEV void crt_lift_body(const CrtLiftArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots, uint32_t lane) {
+    constexpr int S = G * L;
+    const Lanes<G> ln(lane);
+    const uint32_t g = ln.g;
+    const uint32_t n0inv = A.mod.n0inv;
+    uint32_t* row = lds_row;       // S digits: the multiplier of the current product
+    uint32_t* row2 = lds_row + S;  // S digits: the low half of the final product
+    uint32_t n[L];
+    load_row<L>(n, A.mod.n, g);
+    const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
+    for (uint64_t it = 0; it < n_iter; ++it) {
+        uint64_t item = slot + it * (uint64_t)total_slots;
+        const bool live = item < A.batch;
+        if (!live) item = A.batch - 1;
+        uint32_t a[L], m1[L], m2[L], cst[L];
+        load_u32_as_r29<L>(a, A.yq + item * A.x_stride, A.x_limbs, 0, g);
+        lds_put<L>(row, a, g);
+        load_row<L>(cst, wave::reread_ptr(A.kr), g);
+        montmul<G, L>(m1, row, cst, n, n0inv, ln);  // y_q * K
+        load_u32_as_r29<L>(a, A.yp + item * A.x_stride, A.x_limbs, 0, g);
+        lds_put<L>(row, a, g);
+        load_row<L>(cst, wave::reread_ptr(A.nkr), g);
+        montmul<G, L>(m2, row, cst, n, n0inv, ln);  // y_p * (q^2 - K)
+        add_normalize<G, L>(m1, m2, ln);            // < 4 q^2
+        lds_put<L>(row, m1, g);
+        load_row<L>(cst, wave::reread_ptr(A.mod.r1), g);
+        montmul<G, L>(m1, row, cst, n, n0inv, ln);  // the same value, below 2 q^2 again
+        canonicalize<G, L>(m1, n, ln);              // u in [0, q^2)
+        lds_put<L>(row, m1, g);
+        load_row<L>(cst, wave::reread_ptr(A.psq), g);
+        uint32_t hi[L], lo[L];
+        mul_wide<G, L>(hi, row, cst, a, row2, ln);  // u * p^2 + y_p = hi * R + lo
+        wave::lds_fence();
+        load_row<L>(lo, row2, g);
+        normalize_full<G, L>(hi, ln);
+        store_pair_as_u32<G, L>(A.out + item * (uint64_t)A.out_limbs, A.out_limbs, lo, hi, row, g, live);
+    }
+}
+
 // Per-element exponents (phe/paillier.py:751 powmod(c, scalar, n^2); :749 with the inverted base) on the pair
 // representation: fixed 2^w-ary windows over the batch-wide maximum bit length, as modexp_var_body (mont_core.h).
 struct SplitVarArgs {

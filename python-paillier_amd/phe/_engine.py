@@ -147,11 +147,27 @@ class Engine:
         return x if isinstance(x, np.ndarray) else self.cipher_limbs([v % self.nsquare for v in x])
 
     # ---- the five hot functions (limb arrays in, limb arrays out) ------------------------------
+    def owner_encrypt(self):
+        """True when this engine holds the private key and the library offers the CRT form of raw_encrypt for the key
+        width (include/phe_hip.h phe_hip_encrypt_owner_dev): r^n mod n^2 from r^n mod p^2 and r^n mod q^2 — about half
+        the multiply-adds, the same bits.  Every encryption path of the engine takes it then."""
+        ok = self.__dict__.get("_owner_ok")
+        if ok is None:
+            probe = getattr(self.ctx, "owner_encrypt_offered", None)
+            ok = self._owner_ok = bool(probe()) if probe and os.environ.get("PHE_HIP_OWNER_ENCRYPT", "1") != "0" else False
+        return ok
+
+    def _encrypt_dev(self, m_ptr, r_ptr, c_ptr, rows, stream=0):
+        fn = self.ctx.encrypt_owner_dev if self.owner_encrypt() else self.ctx.encrypt_dev
+        fn(m_ptr, r_ptr, c_ptr, rows, stream)
+
     def raw_encrypt(self, m, r):
         """(1 + n*m) * r^n mod n^2 per row.  m is reduced mod n on the way in (value-identical to the
         reference's `% nsquare`, which lets m = n, n+1 wrap to 0, 1: phe/tests/paillier_test.py:114-126)."""
         if not isinstance(m, np.ndarray):
             m = self.plain_limbs([v % self.n for v in m])
+        if self.owner_encrypt():
+            return self.ctx.encrypt_owner(m, self._as_plain(r))
         return self.ctx.encrypt(m, self._as_plain(r))
 
     def obfuscate(self, c, r):
@@ -426,7 +442,7 @@ class Engine:
         m = self.upload_plain([v % self.n for v in m] if not isinstance(m, np.ndarray) else m)
         r = self.upload_plain(r)
         out = DeviceArray(self.ctx, m.rows, self.ct_limbs)
-        self.ctx.encrypt_dev(m.ptr, r.ptr, out.ptr, m.rows)
+        self._encrypt_dev(m.ptr, r.ptr, out.ptr, m.rows)
         self.ctx.sync()
         return out
 
@@ -457,7 +473,7 @@ class Engine:
             keep += [m_d, r_d]
             if host is not None and st:
                 self.ctx.sync(st)                         # the previous chunk is complete (its successor starts right away)
-            self.ctx.encrypt_dev(m_d.ptr, r_d.ptr, out.rows_view(lo, hi).ptr, hi - lo, st)
+            self._encrypt_dev(m_d.ptr, r_d.ptr, out.rows_view(lo, hi).ptr, hi - lo, st)
             if host is not None and st and prev is not None:
                 self.ctx.d2h(host[prev[0]:prev[1]], out.rows_view(*prev).ptr)     # download under this chunk's kernel
             prev = (lo, hi)

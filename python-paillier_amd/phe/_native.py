@@ -46,6 +46,9 @@ def lib():
         L.phe_hip_ctx_engine.argtypes = [vp] + [ctypes.POINTER(ci)] * 2
         L.phe_hip_ctx_set_blocks_per_cu.argtypes = [vp, ci]
         L.phe_hip_encrypt.argtypes = [vp, vp, vp, vp, sz]
+        L.phe_hip_encrypt_owner.argtypes = [vp, vp, vp, vp, sz]
+        L.phe_hip_encrypt_owner_dev.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.phe_hip_ctx_owner_encrypt.argtypes = [vp, ctypes.POINTER(ci)]
         L.phe_hip_obfuscate.argtypes = [vp, vp, vp, vp, sz]
         L.phe_hip_decrypt.argtypes = [vp, vp, vp, sz]
         L.phe_hip_mulmod.argtypes = [vp, vp, vp, vp, sz]
@@ -102,6 +105,7 @@ EXPORTED_SYMBOLS = [
     "phe_hip_from_decimal", "phe_hip_to_decimal_dev", "phe_hip_from_decimal_dev", "phe_hip_stream_create",
     "phe_hip_stream_destroy", "phe_hip_miller_rabin", "phe_hip_montmul_dev", "phe_hip_mont_radix_bits",
     "phe_hip_comm_unique_id", "phe_hip_comm_create", "phe_hip_allgather_dev", "phe_hip_comm_destroy",
+    "phe_hip_encrypt_owner", "phe_hip_encrypt_owner_dev", "phe_hip_ctx_owner_encrypt",
 ]
 
 
@@ -257,6 +261,25 @@ class Context:
         c = np.empty((m.shape[0], self.ct_limbs), np.uint32)
         _check(lib().phe_hip_encrypt(self._h, _ptr(m), _ptr(r), _ptr(c), m.shape[0]))
         return c
+
+    def owner_encrypt_offered(self):
+        """True on a private-key context whose key width has the geometries of the CRT form of raw_encrypt"""
+        flag = ctypes.c_int(0)
+        _check(lib().phe_hip_ctx_owner_encrypt(self._h, ctypes.byref(flag)))
+        return bool(flag.value)
+
+    def encrypt_owner(self, m, r):
+        """raw_encrypt by the key owner (r^n from its CRT halves): the same bits as encrypt()"""
+        m = _rows(m, self.n_limbs, "m")
+        r = _rows(r, self.n_limbs, "r")
+        if m.shape[0] != r.shape[0]:
+            raise ValueError("m and r batch sizes differ")
+        c = np.empty((m.shape[0], self.ct_limbs), np.uint32)
+        _check(lib().phe_hip_encrypt_owner(self._h, _ptr(m), _ptr(r), _ptr(c), m.shape[0]))
+        return c
+
+    def encrypt_owner_dev(self, m_ptr, r_ptr, c_ptr, batch, stream=0):
+        _check(lib().phe_hip_encrypt_owner_dev(self._h, m_ptr, r_ptr, c_ptr, batch, stream))
 
     def obfuscate(self, c_in, r):
         c_in = _rows(c_in, self.ct_limbs, "c_in")

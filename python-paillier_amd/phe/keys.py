@@ -230,8 +230,14 @@ class PaillierPrivateKey(object):
     def _get_engine(self):
         if self._engine is None:
             self._engine = Engine(self.public_key.n, self.p, self.q, self.hp, self.hq, self.p_inverse)
-            if self.public_key._engine is None:
-                self.public_key._engine = self._engine
+            # the public key of a key pair works through the private key's engine from here on: one GPU context per key
+            # pair, and encryptions under it take the key owner's CRT form (Engine.owner_encrypt: same ciphertext bits,
+            # about half the work).  Obfuscators made ahead of time move over (device pointers are valid across contexts).
+            old = self.public_key._engine
+            if old is not None and old is not self._engine:
+                self._engine.__dict__.setdefault("_obf_pool", []).extend(old.__dict__.get("_obf_pool", []))
+                old.__dict__["_obf_pool"] = []
+            self.public_key._engine = self._engine
         return self._engine
 
     def __repr__(self):

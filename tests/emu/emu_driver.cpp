@@ -282,6 +282,27 @@ static void run_mul_split(SplitMulArgs A) {
     }
 }
 
+template <int G, int L>
+static void run_crt_lift(CrtLiftArgs A) {
+    constexpr int S2 = 2 * G * L, kPer = 64 / G;
+    const int n_waves = waves_for(A.batch, G);
+    const uint32_t total = (uint32_t)(kPer * n_waves);
+    for (int w = 0; w < n_waves; ++w) {
+        std::vector<uint32_t> lds(kPer * (S2 + kLdsPad));
+        wave::run_wave([&](uint32_t lane) {
+            const uint32_t grp = lane / G;
+            crt_lift_body<G, L>(A, lds.data() + grp * (S2 + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
+        });
+    }
+}
+
+// the full-width geometry the products / the CRT lift use for a modulus pack (phe_hip.hip:light_geometry)
+static void light_geometry_of(const host::ModulusPack& M, int& G, int& L) {
+    G = M.G; L = M.L;
+    if (G == 4 && L == 36) { G = 8; L = 18; }
+    else if (G == 2 && L == 36) { G = 4; L = 18; }
+}
+
 extern "C" {
 
 void emu_set_engine(int e) { g_engine = e ? 1 : 0; }
@@ -353,6 +374,51 @@ int emu_encrypt(const uint32_t* n, int n_limbs, const uint32_t* m, const uint32_
         A.out = c_out; A.out_limbs = P.s2; A.batch = B;
         if (c_in) { DISPATCH_GL(P.nsq.G, P.nsq.L, (run_uniform<GG, LL, kModeObfuscate>(A))); }
         else { DISPATCH_GL(P.nsq.G, P.nsq.L, (run_uniform<GG, LL, kModeEncrypt>(A))); }
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// raw_encrypt by the key owner (phe_hip_encrypt_owner_dev): r^n mod p^2 and mod q^2 by the half-exponentiation kernels
+// with the exponent n, the CRT lift, then the product with 1 + n*m.  rc 2: not offered for this key (no geometry)
+int emu_encrypt_owner(const uint32_t* n, const uint32_t* p, const uint32_t* q, const uint32_t* hp, const uint32_t* hq,
+                      const uint32_t* p_inverse, int pq_limbs, int n_limbs, const uint32_t* m, const uint32_t* r,
+                      uint32_t* c_out, uint64_t B) {
+    try {
+        if (B == 0) return 0;
+        host::PublicPlan PUB = host::build_public(n, n_limbs, g_prefer_group);
+        host::PrivatePlan P = host::build_private(p, q, hp, hq, p_inverse, pq_limbs, n_limbs, g_prefer_group);
+        int G, L;
+        light_geometry_of(P.qsq, G, L);
+        if (!P.psplit.G || !P.qsplit.G || !PUB.nsq.G || !host::split_part_holds(G, L)) return 2;
+        host::OwnerLift W;
+        if (!host::build_owner_lift(P.tail.p, P.tail.q, P.qsq.S, W)) return 2;
+        const int S = (std::max(P.psq.bits, P.qsq.bits) + 31) / 32;
+        std::vector<uint32_t> yp((size_t)B * S), yq((size_t)B * S);
+        for (int half = 0; half < 2; ++half) {
+            const host::SplitPack& SP = half ? P.qsplit : P.psplit;
+            SplitArgs A;
+            memset(&A, 0, sizeof A);
+            A.mod = split_consts_of(SP);
+            A.sched = PUB.exp_n.ops.data(); A.n_ops = (int)PUB.exp_n.ops.size();
+            A.first_idx = PUB.exp_n.first_idx; A.tbl_entries = PUB.exp_n.tbl_entries;
+            A.base = r; A.base_limbs = P.s1; A.base_chunks = chunks_for(P.s1, SP.H);
+            A.out = half ? yq.data() : yp.data(); A.out_limbs = S; A.batch = B;
+            DISPATCH_SPLIT(SP.G, SP.L, (run_split<GG, LL, kModeHalfDecrypt>(A)));
+        }
+        CrtLiftArgs A;
+        memset(&A, 0, sizeof A);
+        A.mod = consts_of(P.qsq);
+        A.kr = W.kr.data(); A.nkr = W.nkr.data(); A.psq = W.psq.data();
+        A.yp = yp.data(); A.yq = yq.data(); A.x_stride = (size_t)S; A.x_limbs = S;
+        A.out = c_out; A.out_limbs = P.s2; A.batch = B;
+        DISPATCH_SPLIT(G, L, (run_crt_lift<GG, LL>(A)));
+        MulArgs Mu;
+        memset(&Mu, 0, sizeof Mu);
+        Mu.mod = consts_of(PUB.nsq); Mu.a = c_out; Mu.b = m; Mu.out = c_out; Mu.limbs = PUB.s2; Mu.batch = B;
+        Mu.a_stride = Mu.out_stride = (size_t)PUB.s2; Mu.b_stride = (size_t)PUB.s1; Mu.b_plain_limbs = PUB.s1;
+        int MG, ML;
+        light_geometry_of(PUB.nsq, MG, ML);
+        DISPATCH_GL(MG, ML, (run_mul<GG, LL>(Mu)));
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }

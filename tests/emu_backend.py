@@ -47,6 +47,17 @@ class EmuContext:
             return np.zeros((0, self.ct_limbs), np.uint32)
         return emu().encrypt(self._n_arr, np.ascontiguousarray(m), np.ascontiguousarray(r))
 
+    def owner_encrypt_offered(self):
+        return self.has_private and not self._wide() and self.n_limbs >= 2
+
+    def encrypt_owner(self, m, r):
+        if m.shape[0] == 0:
+            return np.zeros((0, self.ct_limbs), np.uint32)
+        out = emu().encrypt_owner(self._n_arr, *self._key, np.ascontiguousarray(m), np.ascontiguousarray(r))
+        if out is None:
+            raise ValueError("owner encryption is not offered for this key width")
+        return out
+
     def obfuscate(self, c_in, r):
         if c_in.shape[0] == 0:
             return c_in.copy()

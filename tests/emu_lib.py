@@ -55,6 +55,16 @@ class Emu:
         self._ck(self.L.emu_encrypt(P(n), s1, None, P(r), P(c_in), P(out), ctypes.c_uint64(c_in.shape[0])))
         return out
 
+    def encrypt_owner(self, n, p, q, hp, hq, pinv, m, r):
+        """raw_encrypt by the key owner (CRT halves + lift + plaintext factor); None where the library would not offer it"""
+        out = np.zeros((m.shape[0], 2 * n.shape[0]), np.uint32)
+        rc = self.L.emu_encrypt_owner(P(n), P(p), P(q), P(hp), P(hq), P(pinv), p.shape[0], n.shape[0], P(m), P(r), P(out),
+                                      ctypes.c_uint64(m.shape[0]))
+        if rc == 2:
+            return None
+        self._ck(rc)
+        return out
+
     def decrypt(self, p, q, hp, hq, pinv, n_limbs, c):
         out = np.zeros((c.shape[0], n_limbs), np.uint32)
         self._ck(self.L.emu_decrypt(P(p), P(q), P(hp), P(hq), P(pinv), p.shape[0], n_limbs, P(c), P(out),

@@ -493,6 +493,8 @@ def test_obfuscator_pool_offline_online_split():
     assert pub.obfuscators_available() == 0 and all(un._obfuscated)
     assert all(a != b for a, b in zip(nude, un.ciphertexts(False))) and priv.decrypt_batch(un) == vals[:1500].tolist()
     pub.precompute_obfuscators(3)
+    eng = pub._get_engine()                # the key pair's engine by now (the private key's; the pool moved over with it)
+    assert eng is priv._get_engine()
     peek = _native.limbs_to_ints(eng._obf_pool[0][0].rows_view(0, 1).to_host())[0]
     one = pub.encrypt(2.5)                                                 # scalar API: obfuscate() takes from the pool too
     nude = pub.encrypt(2.5, r_value=1)
@@ -618,3 +620,25 @@ def test_obfuscator_pool_is_handed_out_once_across_threads():
     [t.join() for t in threads]
     flat = sorted(x for part in taken for x in part)
     assert flat == list(range(20000))
+
+
+def test_public_key_of_a_key_pair_encrypts_through_the_owner_path(backend):
+    """once the private key's engine exists, the public key of the pair works through it and its encryptions take the
+    key owner's CRT form (Engine.owner_encrypt) — the ciphertext bits are those of the golden fixture either way"""
+    g = load_golden(1024)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    before = [pub.raw_encrypt(H(e["m"]), H(e["r"])) for e in g["raw_encrypt"][:4]]          # public path
+    assert not pub._get_engine().owner_encrypt()
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    assert priv.raw_decrypt(before[0]) == H(g["raw_encrypt"][0]["m"]) % pub.n
+    eng = pub._get_engine()
+    assert eng is priv._get_engine() and eng.owner_encrypt()
+    enc = g["raw_encrypt"]
+    assert pub.raw_encrypt_batch([H(e["m"]) for e in enc], [H(e["r"]) for e in enc]) == [H(e["c"]) for e in enc]
+    assert before == [H(e["c"]) for e in enc[:4]]
+    for e in g["encrypt_api"]:
+        value = eval(e["value"])
+        en = pub.encrypt(value, r_value=H(e["r"]))
+        assert en.ciphertext(False) == H(e["c"]) and en.exponent == e["exponent"]
+    xs = np.array([1.5, -2.25, 1e-3, 7.0])
+    assert priv.decrypt_batch(pub.encrypt_batch(xs)) == xs.tolist()                         # fresh obfuscators

@@ -265,3 +265,19 @@ def test_wide_key_products_on_the_pair_form(emu):
     m = [rng.randrange(n) for _ in range(4)]
     got = emu.mulmod_n2_split(n_arr, ints_to_limbs(a, 512), ints_to_limbs(m, 256), b_plain=True)
     assert limbs_to_ints(got) == [x * (1 + n * y) % N for x, y in zip(a, m)]
+
+
+@pytest.mark.parametrize("key_bits,count", [(256, 20), (1024, 8), (2048, 4), (3072, 2)])
+def test_key_owner_encryption_equals_the_golden_vectors(emu, key_bits, count):
+    """raw_encrypt by the key owner (r^n from its CRT halves modulo p^2 and q^2, split_core.h:crt_lift_body) returns the
+    ciphertexts the real reference returned, incl. m in {0, 1, max_int, ...} and r in {1, n-1}"""
+    g = load_golden(key_bits)
+    n = H(g["n"])
+    s1 = key_bits // 32
+    pq = max(1, s1 // 2)
+    key = [int_to_limbs(H(g[k]), pq) for k in ("p", "q", "hp", "hq", "p_inverse")]
+    enc = g["raw_encrypt"][:count]
+    m = ints_to_limbs([H(e["m"]) % n for e in enc], s1)
+    r = ints_to_limbs([H(e["r"]) for e in enc], s1)
+    out = emu.encrypt_owner(int_to_limbs(n, s1), *key, m, r)
+    assert out is not None and limbs_to_ints(out) == [H(e["c"]) for e in enc]

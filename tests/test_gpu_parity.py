@@ -475,3 +475,43 @@ def test_wide_keys_through_the_drop_in_api():
     assert priv.decrypt(vec.sum()) == sum(xs)
     nums = [pub.encrypt(x) for x in xs]
     assert priv.decrypt(nums[0] + nums[1] * -2) == 0.5 + 6.5
+
+
+@pytest.mark.parametrize("key_bits,batch", [(256, 100), (1024, 3000), (2048, 40000), (3072, 300), (4096, 40)])
+def test_key_owner_encryption_gives_the_public_path_bits(native, c_oracle, key_bits, batch):
+    """phe_hip_encrypt_owner(_dev): r^n mod n^2 from r^n mod p^2 and r^n mod q^2 (half-exponentiation kernels with the
+    exponent n), CRT lift, plaintext factor.  The same ciphertexts as phe_hip_encrypt and as the libgmp oracle."""
+    rng = random.Random(key_bits)
+    if key_bits == 4096:
+        def prime(bits):
+            while True:
+                cand = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+                if pow(2, cand - 1, cand) == 1 and pow(3, cand - 1, cand) == 1:
+                    return cand
+        while True:
+            p, q = prime(2048), prime(2048)
+            if p != q and (p * q).bit_length() == 4096:
+                break
+        n_int, s1 = p * q, 128
+        p, q, hp, hq, pinv = c_oracle.private_constants(n_int, p, q, s1, 64)
+        ctx = native.Context(n_int, p, q, hp, hq, pinv, n_limbs=s1)
+    else:
+        g = load_golden(key_bits)
+        n_int, s1 = H(g["n"]), key_bits // 32
+        ctx = make_ctx(native, g)
+        enc = g["raw_encrypt"]
+        got = ctx.encrypt_owner(native.ints_to_limbs([H(e["m"]) % n_int for e in enc], s1),
+                                native.ints_to_limbs([H(e["r"]) for e in enc], s1))
+        assert native.limbs_to_ints(got) == [H(e["c"]) for e in enc]
+    assert ctx.owner_encrypt_offered()
+    m = native.ints_to_limbs([rng.randrange(0, n_int) for _ in range(batch)], s1)
+    r = native.ints_to_limbs([rng.randrange(1, n_int) for _ in range(batch)], s1)
+    c_owner = ctx.encrypt_owner(m, r)
+    assert np.array_equal(c_owner, ctx.encrypt(m, r))
+    idx = np.arange(0, batch, max(1, batch // 40))
+    assert np.array_equal(c_owner[idx], c_oracle.encrypt(native.int_to_limbs(n_int, s1), m[idx], r[idx], nthreads=8))
+    assert np.array_equal(ctx.decrypt(c_owner), m)
+    pub_only = native.Context(n_int, n_limbs=s1)
+    assert not pub_only.owner_encrypt_offered()
+    with pytest.raises(ValueError):
+        pub_only.encrypt_owner(m[:2], r[:2])

@@ -58,6 +58,13 @@ def main():
             native.limbs_to_ints(r[:1])[0], n, n * n) % (n * n)
         emu.obfuscate(n_arr, c, r)
         res["obfuscate"] = count() / B
+        key_o = [native.int_to_limbs(v, sh) for v in (p, q, H("hp"), H("hq"), H("p_inverse"))]
+        co = emu.encrypt_owner(n_arr, *key_o, m, r)
+        if co is not None:
+            assert np.array_equal(co, c)
+            res["encrypt_key_owner"] = count() / B
+        else:
+            count()
         key = [native.int_to_limbs(v, sh) for v in (p, q, H("hp"), H("hq"), H("p_inverse"))]
         back = emu.decrypt(*key, s1, c)
         res["decrypt"] = count() / B
