@@ -7,6 +7,10 @@ multiply by a float — per key size from 128 to 8192 bits) on this package, in 
            (encryptions draw their obfuscators r^n from a pool that is refilled by the launch);
   batched  the same work through `encrypt_batch` / `EncryptedVector` operators / `decrypt_batch` on resident vectors.
 
+Both keys of the pair live in the process (as in the reference's script), so once the private key has been used the
+encryptions take the key owner's CRT form (same ciphertexts, about half the work); the first scalar
+column entry ("encrypt") is measured before that, on the public path with pooled obfuscators.
+
 Prints the reference's table per key size and one JSON object at the end.  Needs an MI355X.
 
     python examples/benchmarks_batched.py [--scalar-ops 300] [--batch 16384] [--key-sizes 128 256 ... 8192]

@@ -171,7 +171,24 @@ class Engine:
         return self.ctx.encrypt(m, self._as_plain(r))
 
     def obfuscate(self, c, r):
-        return self.ctx.obfuscate(self._as_cipher(c), self._as_plain(r))
+        c, r = self._as_cipher(c), self._as_plain(r)
+        if self.owner_encrypt():
+            # r^n through the key owner's CRT halves (raw_encrypt of the plaintext 0), then one product: same bits
+            rn = self.ctx.encrypt_owner(np.zeros((r.shape[0], self.n_limbs), dtype=np.uint32), r)
+            return self.ctx.mulmod(c, rn)
+        return self.ctx.obfuscate(c, r)
+
+    def _obfuscate_dev(self, c_ptr, r_ptr, out_ptr, rows, stream=0):
+        """c * r^n on resident rows: the fused / composed public kernels, or — for a key owner — r^n from the CRT halves
+        into `out`, then the product with c in place"""
+        if not self.owner_encrypt():
+            self.ctx.obfuscate_dev(c_ptr, r_ptr, out_ptr, rows, stream)
+            return
+        zeros = self.__dict__.get("_zero_plain")
+        if zeros is None or zeros.rows < rows:
+            zeros = self._zero_plain = DeviceArray.from_host(self.ctx, np.zeros((max(rows, 1 << 16), self.n_limbs), dtype=np.uint32))
+        self.ctx.encrypt_owner_dev(zeros.ptr, r_ptr, out_ptr, rows, stream)
+        self.ctx.mulmod_dev(c_ptr, out_ptr, out_ptr, rows, stream)
 
     def raw_decrypt(self, c):
         return self.ctx.decrypt(self._as_cipher(c))
@@ -557,7 +574,7 @@ class Engine:
                     r[sel] = random_lt_n_limbs(self.n, len(sel), self.n_limbs)
             r_d = DeviceArray.from_host(self.ctx, r)
             keep.append(r_d)
-            self.ctx.obfuscate_dev(c.rows_view(lo, hi).ptr, r_d.ptr, out.rows_view(lo, hi).ptr, hi - lo, st)
+            self._obfuscate_dev(c.rows_view(lo, hi).ptr, r_d.ptr, out.rows_view(lo, hi).ptr, hi - lo, st)
             lo, chunk = hi, 1 << 16
         self.ctx.sync(st)
         return out
@@ -565,7 +582,7 @@ class Engine:
     def obfuscate_dev(self, c, r):
         r = self.upload_plain(r)
         out = DeviceArray(self.ctx, c.rows, self.ct_limbs)
-        self.ctx.obfuscate_dev(c.ptr, r.ptr, out.ptr, c.rows)
+        self._obfuscate_dev(c.ptr, r.ptr, out.ptr, c.rows)
         self.ctx.sync()
         return out
 

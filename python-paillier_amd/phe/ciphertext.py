@@ -303,7 +303,7 @@ class EncryptedVector(object):
             else:
                 from ._engine import random_lt_n_limbs
                 r = random_lt_n_limbs(pk.n, len(rows), eng.n_limbs)
-                self._limbs[rows] = eng.ctx.obfuscate(np.ascontiguousarray(self._limbs[rows]), r)
+                self._limbs[rows] = eng.obfuscate(np.ascontiguousarray(self._limbs[rows]), r)
             self._obfuscated[rows] = True
             return self
         r = list(r_values) if r_values is not None else random_lt_n(pk.n, len(rows))

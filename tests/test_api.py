@@ -642,3 +642,22 @@ def test_public_key_of_a_key_pair_encrypts_through_the_owner_path(backend):
         assert en.ciphertext(False) == H(e["c"]) and en.exponent == e["exponent"]
     xs = np.array([1.5, -2.25, 1e-3, 7.0])
     assert priv.decrypt_batch(pub.encrypt_batch(xs)) == xs.tolist()                         # fresh obfuscators
+
+
+def test_obfuscation_under_a_key_pair_takes_the_owner_path_and_keeps_the_reference_bits(backend):
+    """EncryptedNumber.obfuscate (phe/paillier.py:603-624: c * r^n mod n^2) through an engine that holds the private key:
+    r^n comes from the CRT halves; the golden `obfuscate` vectors of the real reference must still come out"""
+    g = load_golden(1024)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    eng = priv._get_engine()
+    assert pub._get_engine() is eng and eng.owner_encrypt()
+    obf = g["obfuscate"]
+    got = eng.to_ints(eng.obfuscate([H(e["c_in"]) for e in obf], [H(e["r"]) for e in obf]))
+    assert got == [H(e["c_out"]) for e in obf]
+    vec = pub.encrypt_batch([1.5, -2.0, 3.25], r_values=[1, 1, 1])
+    before = vec.ciphertexts(False)
+    vec.obfuscate(r_values=[5, 7, 11])
+    n2 = pub.nsquare
+    assert vec.ciphertexts(False) == [c * pow(r, pub.n, n2) % n2 for c, r in zip(before, (5, 7, 11))]
+    assert priv.decrypt_batch(vec) == [1.5, -2.0, 3.25]
