@@ -1251,7 +1251,10 @@ static int stage_in(phe_hip_ctx* ctx, int slot, const uint32_t* host_ptr, size_t
 //     host copy in (CPU) -> H2D (s_in) -> kernel (s_comp) -> D2H (s_out) -> host copy out (CPU)
 // so that the uploads of chunk k+1 and the downloads of chunk k-1 run under the kernel of chunk k.  A maintainer who
 // binds only the plain host-pointer functions gets the overlap without writing a pipeline.
-static const size_t kPipeChunkRows = 65536;  // a multiple of every kernel's resident limb groups (32768 / 65536)
+// Chunks are multiples of every kernel's resident limb groups (32768 / 65536): a short first chunk (little to upload
+// before the first kernel starts), long middle chunks (each launch ends with a drain bubble: fewer launches), a short last
+// one (little to download after the last kernel ends).
+static const size_t kPipeEdgeRows = 65536, kPipeChunkRows = 131072;  // (decrypt keeps 65536 groups resident: an edge of 32768 rows would run at half occupancy)
 
 static int pipe_setup(phe_hip_ctx* ctx) {
     auto& P = ctx->pipe;
@@ -1286,19 +1289,31 @@ static int run_pipelined(phe_hip_ctx* ctx, const uint32_t* in0, size_t w0, const
                          size_t wo, size_t batch, Launch launch) {
     if (int rc = pipe_setup(ctx)) return rc;
     auto& P = ctx->pipe;
-    const size_t chunk = kPipeChunkRows;
-    const size_t n_chunks = (batch + chunk - 1) / chunk;
+    // chunk boundaries: edge | full chunks ... | edge
+    std::vector<size_t> lo;
+    {
+        size_t at = 0;
+        lo.push_back(0);
+        at = std::min(batch, kPipeEdgeRows);
+        while (at < batch) {
+            lo.push_back(at);
+            const size_t left = batch - at;
+            at += (left > kPipeChunkRows + kPipeEdgeRows) ? kPipeChunkRows : (left > kPipeEdgeRows ? left - kPipeEdgeRows : left);
+        }
+        lo.push_back(batch);
+    }
+    const size_t n_chunks = lo.size() - 1;
     for (int slot = 0; slot < 2; ++slot) {
-        int rc = pipe_buffers(ctx, slot, 0, chunk * w0);
-        if (!rc && in1) rc = pipe_buffers(ctx, slot, 1, chunk * w1);
-        if (!rc) rc = pipe_buffers(ctx, slot, 2, chunk * wo);
+        int rc = pipe_buffers(ctx, slot, 0, kPipeChunkRows * w0);
+        if (!rc && in1) rc = pipe_buffers(ctx, slot, 1, kPipeChunkRows * w1);
+        if (!rc) rc = pipe_buffers(ctx, slot, 2, kPipeChunkRows * wo);
         if (rc) return rc;
     }
-    auto rows_of = [&](size_t k) { return std::min(chunk, batch - k * chunk); };
+    auto rows_of = [&](size_t k) { return lo[k + 1] - lo[k]; };
     auto drain = [&](size_t k) -> int {  // chunk k's results: wait for its download, then hand them to the caller
         const int slot = (int)(k & 1);
         HIP_TRY(hipEventSynchronize(P.ev_out[slot]));
-        memcpy(out + k * chunk * wo, P.pin[slot][2], rows_of(k) * wo * 4);
+        memcpy(out + lo[k] * wo, P.pin[slot][2], rows_of(k) * wo * 4);
         return PHE_HIP_OK;
     };
     for (size_t k = 0; k < n_chunks; ++k) {
@@ -1306,10 +1321,10 @@ static int run_pipelined(phe_hip_ctx* ctx, const uint32_t* in0, size_t w0, const
         const size_t rows = rows_of(k);
         if (k >= 2)
             if (int rc = drain(k - 2)) return rc;  // frees this slot's buffers (its kernel and copies are complete)
-        memcpy(P.pin[slot][0], in0 + k * chunk * w0, rows * w0 * 4);
+        memcpy(P.pin[slot][0], in0 + lo[k] * w0, rows * w0 * 4);
         HIP_TRY(hipMemcpyAsync(P.dev[slot][0], P.pin[slot][0], rows * w0 * 4, hipMemcpyHostToDevice, P.s_in));
         if (in1) {
-            memcpy(P.pin[slot][1], in1 + k * chunk * w1, rows * w1 * 4);
+            memcpy(P.pin[slot][1], in1 + lo[k] * w1, rows * w1 * 4);
             HIP_TRY(hipMemcpyAsync(P.dev[slot][1], P.pin[slot][1], rows * w1 * 4, hipMemcpyHostToDevice, P.s_in));
         }
         HIP_TRY(hipEventRecord(P.ev_in[slot], P.s_in));
@@ -1325,7 +1340,7 @@ static int run_pipelined(phe_hip_ctx* ctx, const uint32_t* in0, size_t w0, const
     return PHE_HIP_OK;
 }
 }  // extern "C++"
-static bool pipelined_batch(size_t batch) { return batch >= 2 * kPipeChunkRows && !getenv("PHE_HIP_NO_PIPELINE"); }
+static bool pipelined_batch(size_t batch) { return batch >= 2 * kPipeEdgeRows && !getenv("PHE_HIP_NO_PIPELINE"); }
 
 int phe_hip_encrypt(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch) {
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
