@@ -281,3 +281,19 @@ def test_key_owner_encryption_equals_the_golden_vectors(emu, key_bits, count):
     r = ints_to_limbs([H(e["r"]) for e in enc], s1)
     out = emu.encrypt_owner(int_to_limbs(n, s1), *key, m, r)
     assert out is not None and limbs_to_ints(out) == [H(e["c"]) for e in enc]
+
+
+def test_key_owner_encryption_with_obfuscators_that_share_a_factor_with_n(emu):
+    """r = p, q, multiples of them, 1, n - 1: r^n mod p^2 is 0 when p | r, the lift must still give pow(r, n, n^2)
+    (the reference does not restrict r: phe/paillier.py:136-139)"""
+    g = load_golden(256)
+    n, p, q = H(g["n"]), H(g["p"]), H(g["q"])
+    N = n * n
+    key = [int_to_limbs(H(g[k]), 4) for k in ("p", "q", "hp", "hq", "p_inverse")]
+    rng = random.Random(3)
+    rs = [p, q, p * 3 % n, q * 5 % n, 1, n - 1, 2, p - 1, q + 1] + [rng.randrange(1, n) for _ in range(7)]
+    ms = [0, n - 1, 1] + [rng.randrange(n) for _ in range(13)]
+    out = emu.encrypt_owner(int_to_limbs(n, 8), *key, ints_to_limbs(ms, 8), ints_to_limbs(rs, 8))
+    want = [(1 + n * m) * pow(r, n, N) % N for m, r in zip(ms, rs)]
+    assert limbs_to_ints(out) == want
+    assert limbs_to_ints(emu.encrypt(int_to_limbs(n, 8), ints_to_limbs(ms, 8), ints_to_limbs(rs, 8))) == want
