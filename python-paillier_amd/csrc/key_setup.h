@@ -489,6 +489,11 @@ struct PublicPlan {
     Big nsq32;           // n^2, s2 limbs (32-bit) — host-side scalar work of batched inversion
     ModulusPack nsq;
     SplitPack nsplit;    // pair arithmetic modulo n for encrypt / obfuscate (G == 0: not available)
+    // the same for the SCALED modulus n' = k*n, k = -n^-1 mod 2^29 (n' = -1 mod 2^29: quotient digits need no multiply,
+    // split_core.h PHE_QUOTIENT_STEP), offered when n' still fits the geometry of n (29 spare bits) and the full-width
+    // geometry of n^2 can take the result modulo n'^2 in (G == 0: not offered).  unit_words: 32-bit words of such a row.
+    SplitPack nunit;
+    int unit_words = 0;
     Schedule exp_n;
 };
 
@@ -510,6 +515,18 @@ inline PublicPlan build_public(const uint32_t* n, int n_limbs, int prefer_group 
         P.nsq = ModulusPack();
     }
     P.exp_n = build_schedule(P.n);
+    if (P.nsplit.G && P.nsq.G) {
+        Big k(1, P.nsplit.n0inv);                       // -n^-1 mod 2^29
+        Big nk = big_mul(P.n, k);                       // n' = k*n = -1 (mod 2^29)
+        const int bits = big_bits(nk);
+        if (bits + 4 <= kRadixBits * P.nsplit.H && 2 * bits <= kRadixBits * P.nsq.S) {
+            SplitPack U = build_split(big_resize(nk, (bits + 31) / 32), 32 * P.s2, prefer_group);
+            if (U.G == P.nsplit.G && U.L == P.nsplit.L && U.n0inv == 1u) {
+                P.nunit = U;
+                P.unit_words = ((2 * bits + 31) / 32 + 3) & ~3;  // rows of a multiple of 4 words (16-byte chunks)
+            }
+        }
+    }
     return P;
 }
 

@@ -472,6 +472,8 @@ struct MulArgs {
                                             // the product is taken with 1 + n*m — E(a) * g^m, the "add a plaintext" of
                                             // EncryptedNumber._add_encoded (phe/paillier.py:673-675); needs mod.aux
     uint64_t batch;
+    int a_limbs;                            // 0: rows of a hold `limbs` words; > 0: that many (a value up to R, e.g. a residue
+                                            // modulo the scaled modulus n'^2 that is brought to n^2 by this product)
     int one_product;                        // mul_io.h: 1 = a*b*R^-1 mod N (one Montgomery product) instead of a*b mod N
     int vec_ok;                             // mul_io.h: every row pointer and stride is 16-byte aligned
 };
@@ -490,7 +492,7 @@ PHE_DEV void mulmod_body(const MulArgs& A, uint32_t* lds_row, uint32_t slot, uin
         const bool live = item < A.batch;
         if (!live) item = A.batch - 1;
         uint32_t x[L], y[L];
-        load_u32_as_r29<L>(x, A.a + item * A.a_stride, A.limbs, 0, g);
+        load_u32_as_r29<L>(x, A.a + item * A.a_stride, A.a_limbs > 0 ? A.a_limbs : A.limbs, 0, g);
         if (A.b_plain_limbs > 0) {
             // nude ciphertext of the plaintext: 1 + n*m (mod n^2), value < 2N
             load_u32_as_r29<L>(y, A.b + item * A.b_stride, A.b_plain_limbs, 0, g);

@@ -125,6 +125,7 @@ PHE_DEV void mul_io_body(const MulArgs& A, uint32_t* row, uint32_t* stage, uint3
     uint32_t* stage_a = stage;
     uint32_t* stage_b = stage + IO::kStageWave;
     const int b_limbs = A.b_plain_limbs > 0 ? A.b_plain_limbs : A.limbs;
+    const int a_limbs = A.a_limbs > 0 ? A.a_limbs : A.limbs;
     uint32_t n[L];
     load_row<L>(n, A.mod.n, g);
     // chunks at or beyond the row length are never copied: they must read as zero
@@ -138,7 +139,7 @@ PHE_DEV void mul_io_body(const MulArgs& A, uint32_t* row, uint32_t* stage, uint3
     const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
     {
         const uint64_t first = (slot < A.batch) ? slot : A.batch - 1;
-        stage_row_async<G, L>(stage_a, A.a + first * A.a_stride, A.limbs, g);
+        stage_row_async<G, L>(stage_a, A.a + first * A.a_stride, a_limbs, g);
         stage_row_async<G, L>(stage_b, A.b + first * A.b_stride, b_limbs, g);
     }
     for (uint64_t it = 0; it < n_iter; ++it) {
@@ -157,7 +158,7 @@ PHE_DEV void mul_io_body(const MulArgs& A, uint32_t* row, uint32_t* stage, uint3
             uint64_t nxt = slot + (it + 1) * (uint64_t)total_slots;
             if (nxt >= A.batch) nxt = A.batch - 1;
             const uint32_t gi = wave::reread(g);
-            stage_row_async<G, L>(stage_a, A.a + nxt * A.a_stride, A.limbs, gi);
+            stage_row_async<G, L>(stage_a, A.a + nxt * A.a_stride, a_limbs, gi);
             stage_row_async<G, L>(stage_b, A.b + nxt * A.b_stride, b_limbs, gi);
         }
         if (A.b_plain_limbs > 0) {

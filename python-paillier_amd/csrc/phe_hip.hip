@@ -82,6 +82,8 @@ PHE_DECLARE_PART(g16b)
     int launch_multi_lookup(int L, int blocks, hipStream_t st, const SplitLookupArgs& A);         \
     int launch_mul_split(int L, int blocks, hipStream_t st, const SplitMulArgs& A);               \
     int launch_crt_lift(int L, int blocks, hipStream_t st, const CrtLiftArgs& A);                 \
+    int occ_split_unit(int L);                                                                    \
+    int launch_split_unit(int L, int blocks, hipStream_t st, const SplitArgs& A);                 \
     }
 PHE_DECLARE_SPLIT_PART(s2a)
 PHE_DECLARE_SPLIT_PART(s2b)
@@ -147,44 +149,46 @@ struct SplitPart {
     int (*launch_multi_lookup)(int, int, hipStream_t, const SplitLookupArgs&);
     int (*launch_mul_split)(int, int, hipStream_t, const SplitMulArgs&);
     int (*launch_crt_lift)(int, int, hipStream_t, const CrtLiftArgs&);
+    int (*occ_split_unit)(int);
+    int (*launch_split_unit)(int, int, hipStream_t, const SplitArgs&);
 };
 static const SplitPart kSplitParts[] = {
     {2, phe::s2a::occ_split, phe::s2a::launch_split, phe::s2a::occ_var_split, phe::s2a::launch_var_split,
      phe::s2a::occ_multi_split, phe::s2a::launch_multi_split, phe::s2a::launch_multi_tables,
-     phe::s2a::launch_multi_lookup, phe::s2a::launch_mul_split, phe::s2a::launch_crt_lift},
+     phe::s2a::launch_multi_lookup, phe::s2a::launch_mul_split, phe::s2a::launch_crt_lift, phe::s2a::occ_split_unit, phe::s2a::launch_split_unit},
     {2, phe::s2b::occ_split, phe::s2b::launch_split, phe::s2b::occ_var_split, phe::s2b::launch_var_split,
      phe::s2b::occ_multi_split, phe::s2b::launch_multi_split, phe::s2b::launch_multi_tables,
-     phe::s2b::launch_multi_lookup, phe::s2b::launch_mul_split, phe::s2b::launch_crt_lift},
+     phe::s2b::launch_multi_lookup, phe::s2b::launch_mul_split, phe::s2b::launch_crt_lift, phe::s2b::occ_split_unit, phe::s2b::launch_split_unit},
     {2, phe::s2c::occ_split, phe::s2c::launch_split, phe::s2c::occ_var_split, phe::s2c::launch_var_split,
      phe::s2c::occ_multi_split, phe::s2c::launch_multi_split, phe::s2c::launch_multi_tables,
-     phe::s2c::launch_multi_lookup, phe::s2c::launch_mul_split, phe::s2c::launch_crt_lift},
+     phe::s2c::launch_multi_lookup, phe::s2c::launch_mul_split, phe::s2c::launch_crt_lift, phe::s2c::occ_split_unit, phe::s2c::launch_split_unit},
     {4, phe::s4a::occ_split, phe::s4a::launch_split, phe::s4a::occ_var_split, phe::s4a::launch_var_split,
      phe::s4a::occ_multi_split, phe::s4a::launch_multi_split, phe::s4a::launch_multi_tables,
-     phe::s4a::launch_multi_lookup, phe::s4a::launch_mul_split, phe::s4a::launch_crt_lift},
+     phe::s4a::launch_multi_lookup, phe::s4a::launch_mul_split, phe::s4a::launch_crt_lift, phe::s4a::occ_split_unit, phe::s4a::launch_split_unit},
     {4, phe::s4b::occ_split, phe::s4b::launch_split, phe::s4b::occ_var_split, phe::s4b::launch_var_split,
      phe::s4b::occ_multi_split, phe::s4b::launch_multi_split, phe::s4b::launch_multi_tables,
-     phe::s4b::launch_multi_lookup, phe::s4b::launch_mul_split, phe::s4b::launch_crt_lift},
+     phe::s4b::launch_multi_lookup, phe::s4b::launch_mul_split, phe::s4b::launch_crt_lift, phe::s4b::occ_split_unit, phe::s4b::launch_split_unit},
     {4, phe::s4c::occ_split, phe::s4c::launch_split, phe::s4c::occ_var_split, phe::s4c::launch_var_split,
      phe::s4c::occ_multi_split, phe::s4c::launch_multi_split, phe::s4c::launch_multi_tables,
-     phe::s4c::launch_multi_lookup, phe::s4c::launch_mul_split, phe::s4c::launch_crt_lift},
+     phe::s4c::launch_multi_lookup, phe::s4c::launch_mul_split, phe::s4c::launch_crt_lift, phe::s4c::occ_split_unit, phe::s4c::launch_split_unit},
     {8, phe::s8a::occ_split, phe::s8a::launch_split, phe::s8a::occ_var_split, phe::s8a::launch_var_split,
      phe::s8a::occ_multi_split, phe::s8a::launch_multi_split, phe::s8a::launch_multi_tables,
-     phe::s8a::launch_multi_lookup, phe::s8a::launch_mul_split, phe::s8a::launch_crt_lift},
+     phe::s8a::launch_multi_lookup, phe::s8a::launch_mul_split, phe::s8a::launch_crt_lift, phe::s8a::occ_split_unit, phe::s8a::launch_split_unit},
     {8, phe::s8b::occ_split, phe::s8b::launch_split, phe::s8b::occ_var_split, phe::s8b::launch_var_split,
      phe::s8b::occ_multi_split, phe::s8b::launch_multi_split, phe::s8b::launch_multi_tables,
-     phe::s8b::launch_multi_lookup, phe::s8b::launch_mul_split, phe::s8b::launch_crt_lift},
+     phe::s8b::launch_multi_lookup, phe::s8b::launch_mul_split, phe::s8b::launch_crt_lift, phe::s8b::occ_split_unit, phe::s8b::launch_split_unit},
     {8, phe::s8c::occ_split, phe::s8c::launch_split, phe::s8c::occ_var_split, phe::s8c::launch_var_split,
      phe::s8c::occ_multi_split, phe::s8c::launch_multi_split, phe::s8c::launch_multi_tables,
-     phe::s8c::launch_multi_lookup, phe::s8c::launch_mul_split, phe::s8c::launch_crt_lift},
+     phe::s8c::launch_multi_lookup, phe::s8c::launch_mul_split, phe::s8c::launch_crt_lift, phe::s8c::occ_split_unit, phe::s8c::launch_split_unit},
     {16, phe::s16a::occ_split, phe::s16a::launch_split, phe::s16a::occ_var_split, phe::s16a::launch_var_split,
      phe::s16a::occ_multi_split, phe::s16a::launch_multi_split, phe::s16a::launch_multi_tables,
-     phe::s16a::launch_multi_lookup, phe::s16a::launch_mul_split, phe::s16a::launch_crt_lift},
+     phe::s16a::launch_multi_lookup, phe::s16a::launch_mul_split, phe::s16a::launch_crt_lift, phe::s16a::occ_split_unit, phe::s16a::launch_split_unit},
     {16, phe::s16b::occ_split, phe::s16b::launch_split, phe::s16b::occ_var_split, phe::s16b::launch_var_split,
      phe::s16b::occ_multi_split, phe::s16b::launch_multi_split, phe::s16b::launch_multi_tables,
-     phe::s16b::launch_multi_lookup, phe::s16b::launch_mul_split, phe::s16b::launch_crt_lift},
+     phe::s16b::launch_multi_lookup, phe::s16b::launch_mul_split, phe::s16b::launch_crt_lift, phe::s16b::occ_split_unit, phe::s16b::launch_split_unit},
     {16, phe::s16c::occ_split, phe::s16c::launch_split, phe::s16c::occ_var_split, phe::s16c::launch_var_split,
      phe::s16c::occ_multi_split, phe::s16c::launch_multi_split, phe::s16c::launch_multi_tables,
-     phe::s16c::launch_multi_lookup, phe::s16c::launch_mul_split, phe::s16c::launch_crt_lift},
+     phe::s16c::launch_multi_lookup, phe::s16c::launch_mul_split, phe::s16c::launch_crt_lift, phe::s16c::occ_split_unit, phe::s16c::launch_split_unit},
 };
 #define PHE_SPLIT_BY_GROUP(G_, CALL2)                 \
     [&]() -> int {                                    \
@@ -297,6 +301,9 @@ struct phe_hip_ctx {
     DevModulus d_nsq, d_psq, d_qsq;
     bool use_split = true;  // PHE_HIP_ENGINE=full: keep the uniform-exponent jobs on the full-width kernels
     DevSplit d_nsplit, d_psplit, d_qsplit, d_nsplit_lat, d_psplit_lat, d_qsplit_lat;
+    DevSplit d_nunit;                 // the scaled modulus n' = k*n (key_setup.h PublicPlan::nunit); G == 0: not offered
+    uint32_t* unit_tmp = nullptr;     // r^n mod n'^2, rows of pub.unit_words words
+    size_t unit_tmp_words = 0;
     // latency geometry: small batches cannot fill the GPU, so they use 16-lane groups (half the limbs per
     // lane => about half the time per product) when the key size offers both
     bool has_lat_pub = false, has_lat_priv = false;
@@ -480,9 +487,9 @@ static int chunks_for(int limbs32, int H) { return std::max(1, (32 * limbs32 + 2
 template <int MODE>
 static int launch_split(phe_hip_ctx* ctx, const DevSplit& M, const DevSchedule& E, const uint32_t* base, int base_limbs,
                         const uint32_t* post, int post_limbs, uint32_t* out, int out_limbs, size_t batch,
-                        hipStream_t stream, bool second_table = false) {
+                        hipStream_t stream, bool second_table = false, bool unit = false) {
     int per_cu = ctx->blocks_per_cu;
-    if (per_cu == 0) per_cu = PHE_SPLIT_BY_GROUP(M.G, occ_split(M.L, MODE));
+    if (per_cu == 0) per_cu = unit ? PHE_SPLIT_BY_GROUP(M.G, occ_split_unit(M.L)) : PHE_SPLIT_BY_GROUP(M.G, occ_split(M.L, MODE));
     if (per_cu < 0) return fail(PHE_HIP_EINVAL, "unsupported split geometry");
     const int blocks = grid_blocks(ctx, batch, M.G, per_cu);
     const size_t rows = (size_t)blocks * (size_t)(kBlock / M.G);
@@ -505,7 +512,8 @@ static int launch_split(phe_hip_ctx* ctx, const DevSplit& M, const DevSchedule& 
     A.out_limbs = out_limbs;
     A.table = *tbl;
     A.batch = batch;
-    if (PHE_SPLIT_BY_GROUP(M.G, launch_split(M.L, MODE, blocks, stream, A)) < 0)
+    if ((unit ? PHE_SPLIT_BY_GROUP(M.G, launch_split_unit(M.L, blocks, stream, A))
+              : PHE_SPLIT_BY_GROUP(M.G, launch_split(M.L, MODE, blocks, stream, A))) < 0)
         return fail(PHE_HIP_EINVAL, "unsupported split geometry");
     HIP_TRY(hipGetLastError());
     return PHE_HIP_OK;
@@ -609,13 +617,14 @@ static int launch_var(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* bas
 
 static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, size_t a_stride, const uint32_t* b,
                       size_t b_stride, uint32_t* out, size_t out_stride, int limbs, size_t batch,
-                      hipStream_t stream, int b_plain_limbs = 0, int one_product = 0) {
+                      hipStream_t stream, int b_plain_limbs = 0, int one_product = 0, int a_limbs = 0) {
     MulArgs A;
     A.b_plain_limbs = b_plain_limbs;
     A.one_product = one_product;
+    A.a_limbs = a_limbs;
     // 16-byte chunks (mul_io.h) when every row starts on a 16-byte boundary; otherwise word by word
     A.vec_ok = ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15u) == 0 && a_stride % 4 == 0 && b_stride % 4 == 0 &&
-                out_stride % 4 == 0 && limbs % 4 == 0 && b_plain_limbs % 4 == 0) ? 1 : 0;
+                out_stride % 4 == 0 && limbs % 4 == 0 && b_plain_limbs % 4 == 0 && a_limbs % 4 == 0) ? 1 : 0;
     A.mod = M.c;
     A.a = a;
     A.b = b;
@@ -709,6 +718,7 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
     if (ctx->pub.nsq.G == 0) ctx->use_split = true;  // wide keys have the pair form only
     int rc = upload_modulus(ctx->pub.nsq, ctx->d_nsq);
     if (!rc) rc = upload_split(ctx->pub.nsplit, ctx->d_nsplit);
+    if (!rc && !getenv("PHE_HIP_NO_UNIT")) rc = upload_split(ctx->pub.nunit, ctx->d_nunit);
     if (!rc) rc = upload_schedule(ctx->pub.exp_n, ctx->d_exp_n);
     if (!rc && ctx->pub.nsq.G && ctx->pub.nsq.G < 16 && !getenv("PHE_HIP_GROUP")) {
         try {
@@ -827,7 +837,7 @@ void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
                         ctx->d_nsq_lat.blob, ctx->d_psq_lat.blob, ctx->d_qsq_lat.blob,
                         ctx->d_nsq.blob, ctx->d_psq.blob, ctx->d_qsq.blob, ctx->d_exp_n.ops, ctx->d_exp_p.ops,
                         ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->table2, ctx->scratch, ctx->partial, ctx->lookup, (uint32_t*)ctx->flags, ctx->stage[0],
-                        ctx->stage[1], ctx->stage[2], ctx->owner_blob};
+                        ctx->stage[1], ctx->stage[2], ctx->owner_blob, ctx->d_nunit.blob, ctx->unit_tmp};
     for (uint32_t* b : bufs)
         if (b) (void)hipFree(b);
     for (int k = 0; k < 2; ++k) {
@@ -881,11 +891,32 @@ int phe_hip_ctx_set_blocks_per_cu(phe_hip_ctx* ctx, int blocks_per_cu) {
 }
 
 // ---- device-pointer entry points -----------------------------------------------------------------
+// the bare power r^n through the scaled modulus (key_setup.h PublicPlan::nunit): throughput geometry only
+static bool unit_power_offered(const phe_hip_ctx* ctx, size_t batch) {
+    return ctx->use_split && ctx->d_nunit.G && ctx->d_nsq.G && !(ctx->has_lat_pub && small_batch(ctx, batch));
+}
+static int unit_power(phe_hip_ctx* ctx, const uint32_t* r, size_t batch, hipStream_t st) {
+    const size_t w = (size_t)ctx->pub.unit_words;
+    int rc = ensure_words(&ctx->unit_tmp, &ctx->unit_tmp_words, batch * w);
+    if (rc) return rc;
+    return launch_split<kModeEncrypt>(ctx, ctx->d_nunit, ctx->d_exp_n, r, ctx->pub.s1, nullptr, ctx->pub.s1, ctx->unit_tmp,
+                                      ctx->pub.unit_words, batch, st, false, true);
+}
+
 int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch, void* stream) {
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
     if (batch == 0) return PHE_HIP_OK;
     if (!m || !r || !c) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
+    if (unit_power_offered(ctx, batch)) {
+        // r^n modulo the scaled modulus n'^2 (no multiply per quotient digit), then ONE pass of the product kernel takes
+        // the residue modulo n'^2 to (1 + n*m) * r^n mod n^2 (it accepts any a < R): the same canonical ciphertext
+        int rc = unit_power(ctx, r, batch, (hipStream_t)stream);
+        if (rc) return rc;
+        const size_t s1 = (size_t)ctx->pub.s1, s2 = (size_t)ctx->pub.s2, w = (size_t)ctx->pub.unit_words;
+        return launch_mul(ctx, ctx->d_nsq, ctx->unit_tmp, w, m, s1, c, s2, ctx->pub.s2, batch, (hipStream_t)stream, ctx->pub.s1, 0,
+                          ctx->pub.unit_words);
+    }
     if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G)
         return launch_split<kModeEncrypt>(ctx, sp, ctx->d_exp_n, r, ctx->pub.s1, m, ctx->pub.s1, c, ctx->pub.s2, batch,
                                           (hipStream_t)stream);
@@ -947,6 +978,15 @@ int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t
     if (batch == 0) return PHE_HIP_OK;
     if (!c_in || !r || !c_out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
+    if (unit_power_offered(ctx, batch) && !getenv("PHE_HIP_FUSED_OBFUSCATE")) {
+        // r^n modulo the scaled modulus, then the product with the ciphertext brings it to n^2 (in-place calls included:
+        // the power sits in its own buffer)
+        int rc = unit_power(ctx, r, batch, (hipStream_t)stream);
+        if (rc) return rc;
+        const size_t s2 = (size_t)ctx->pub.s2, w = (size_t)ctx->pub.unit_words;
+        return launch_mul(ctx, ctx->d_nsq, ctx->unit_tmp, w, c_in, s2, c_out, s2, ctx->pub.s2, batch, (hipStream_t)stream, 0, 0,
+                          ctx->pub.unit_words);
+    }
     if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G) {
         if (c_in != c_out && !getenv("PHE_HIP_FUSED_OBFUSCATE")) {
             // r^n with the encrypt instantiation (no plaintext factor), then one k_mulmod by the ciphertext: the fused

@@ -73,7 +73,7 @@ struct SplitArgs {
 
 // ---- single-word passes (used by the conversions out of the pair form) -----------------------------------------
 // out = (a*b + m*n) / R with the quotient digits m_i stored to m_row (LDS, H words); a: H digits in LDS.
-template <int G, int L>
+template <int G, int L, bool U = false>
 PHE_DEV void montmul_q(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[L], uint32_t* m_row,
                        const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln) {
     constexpr int H = G * L;
@@ -88,7 +88,7 @@ PHE_DEV void montmul_q(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b
             const uint32_t ai = a[i + j];
 #pragma unroll
             for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(ai, b[k], acc[(k + j) % L]);
-            const uint32_t m = wave::grp_bcast0<G>(((uint32_t)acc[j] * n0inv) & kLimbMask, ln);
+            const uint32_t m = wave::grp_bcast0<G>((U ? (uint32_t)acc[j] : (uint32_t)acc[j] * n0inv) & kLimbMask, ln);
             mq[j] = m;
 #pragma unroll
             for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(m, n[k], acc[(k + j) % L]);
@@ -145,7 +145,7 @@ PHE_DEV void montmac2(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)
 
 // out = (addend + a*b + m2*n) / R;  a and the addend: H digits each in LDS (the addend is the quotient of a previous
 // montmul_q: the second word of a pair product when the sweeps are not fused)
-template <int G, int L>
+template <int G, int L, bool U = false>
 PHE_DEV void montmul_addend(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[L], const uint32_t* addend_row,
                             const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln) {
     constexpr int H = G * L;
@@ -161,7 +161,7 @@ PHE_DEV void montmul_addend(uint32_t (&out)[L], const uint32_t* a, const uint32_
             const uint32_t ai = a[i + j];
 #pragma unroll
             for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(ai, b[k], acc[(k + j) % L]);
-            const uint32_t m2 = wave::grp_bcast0<G>((uint32_t)acc[j] * n0inv, ln) & vmask;
+            const uint32_t m2 = wave::grp_bcast0<G>(U ? (uint32_t)acc[j] : (uint32_t)acc[j] * n0inv, ln) & vmask;
 #pragma unroll
             for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(m2, n[k], acc[(k + j) % L]);
             const uint64_t low = acc[j];
@@ -228,36 +228,27 @@ PHE_DEV void shift_row(uint64_t (&acc)[L], int j, uint32_t dmask) {
     }
 }
 
-// The quotient digit of the first accumulator set and its entry into the second one.  Two measurement-only variants
-// (never in the shipped library, built by tools/exp/build_variants.sh):
-//   PHE_VARIANT_QMAD    the digit enters by one more multiply-add (m * [lane 0 ? 1 : 0]) instead of v_and + 64-bit add
-//   PHE_VARIANT_UNITINV the digit is the accumulator's low word itself (what a modulus with n = -1 mod 2^29 would allow):
-//                       WRONG RESULTS, timing only
-#if defined(PHE_VARIANT_UNITINV)
-#define PHE_SECOND_QUOTIENT(x) ((uint32_t)(x))
-#else
-#define PHE_SECOND_QUOTIENT(x) ((uint32_t)(x) * n0inv)
-#endif
+// The quotient digit of the first accumulator set and its entry into the second one.  UNIT (template flag U of the sweeps):
+// the modulus is the SCALED one, n' = k*n with k = -n^-1 mod 2^29, so that n' = -1 (mod 2^29) and the quotient digit is
+// the accumulator's low 29 bits themselves — no v_mul_lo (key_setup.h:build_public; same-box A/B of exactly this change:
+// +2.7 % encrypts/s, -2.2 % VALU instructions, profiles/r02h_ab_sweep_variants.txt).  PHE_VARIANT_QMAD: measurement-only
+// variant of DESIGN 6.1 (the digit enters by one more multiply-add), built by tools/exp/build_variants.sh, never shipped.
+#define PHE_SECOND_QUOTIENT(x) (U ? (uint32_t)(x) : (uint32_t)(x) * n0inv)
 #if defined(PHE_VARIANT_QMAD)
 #define PHE_QUOTIENT_STEP()                                                                  \
-    const uint32_t mraw = (uint32_t)p[j] * n0inv;                                            \
+    const uint32_t mraw = U ? (uint32_t)p[j] : (uint32_t)p[j] * n0inv;                       \
     const uint32_t m = wave::grp_bcast0<G>(mraw, ln) & vmask;                                \
     q[j] = wave::mad64(m, wave::reread(lane0 ? 1u : 0u), q[j]);
-#elif defined(PHE_VARIANT_UNITINV)
-#define PHE_QUOTIENT_STEP()                                                                  \
-    const uint32_t mraw = (uint32_t)p[j];                                                    \
-    const uint32_t m = wave::grp_bcast0<G>(mraw, ln) & vmask;                                \
-    q[j] += (uint64_t)(mraw & lane0);
 #else
 #define PHE_QUOTIENT_STEP()                                                                  \
-    const uint32_t mraw = (uint32_t)p[j] * n0inv;                                            \
+    const uint32_t mraw = U ? (uint32_t)p[j] : (uint32_t)p[j] * n0inv;                       \
     const uint32_t m = wave::grp_bcast0<G>(mraw, ln) & vmask;                                \
     q[j] += (uint64_t)(mraw & lane0); /* quotient digit i of the first sum = digit i of the addend m */
 #endif
 
 // z0 = (a*b0 + m*n) / R,   z1 = (m + a*b1 + m2*n) / R.     a: H digits in LDS.
 // Squaring: b0 = X0, b1 = 2*X1.  Conversion of a plain chunk a: (b0, b1) = pair(R^(j+2)).
-template <int G, int L>
+template <int G, int L, bool U = false>
 PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a, const uint32_t (&b0)[L],
                         const uint32_t (&b1)[L], const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln) {
     constexpr int H = G * L;
@@ -294,7 +285,7 @@ PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
 
 // z0 = (a*b0 + m*n) / R,   z1 = (m + a*b1 + c*b0 + m2*n) / R.     a, c: H digits each in LDS.
 // Product (X0, X1) * (Y0, Y1): a = X0, c = X1, b = (Y0, Y1).
-template <int G, int L>
+template <int G, int L, bool U = false>
 PHE_DEV void pair_pass3(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a, const uint32_t* c,
                         const uint32_t (&b0)[L], const uint32_t (&b1)[L], const uint32_t (&n)[L], uint32_t n0inv,
                         const Lanes<G>& ln) {
@@ -331,8 +322,8 @@ PHE_DEV void pair_pass3(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
     normalize_partial<G, L>(z1, q, ln);
 }
 
-template <int G, int L>
-struct SplitLane {  // what every pass needs, loaded once per kernel
+template <int G, int L, bool U = false>
+struct SplitLane {  // what every pass needs, loaded once per kernel (U: the modulus is the scaled one, see PHE_QUOTIENT_STEP)
     uint32_t n[L];
     uint32_t n0inv;
     uint32_t* row_a;  // H words: digits of X0 (or of a plain multiplier)
@@ -341,23 +332,23 @@ struct SplitLane {  // what every pass needs, loaded once per kernel
 
 // (z0, z1) = (a*b0 + m*n, m + a*b1 + m2*n) / R with a already in row_a: one fused sweep, or two single sweeps with the
 // quotient digits handed over through row_c when the lanes are too wide for the fused one
-template <int G, int L>
+template <int G, int L, bool U>
 PHE_DEV void pair_mul_plain(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t (&b0)[L], const uint32_t (&b1)[L],
-                            const SplitLane<G, L>& K, const Lanes<G>& ln) {
+                            const SplitLane<G, L, U>& K, const Lanes<G>& ln) {
     if constexpr (L <= kMaxFusedL) {
-        pair_pass2<G, L>(z0, z1, K.row_a, b0, b1, K.n, K.n0inv, ln);
+        pair_pass2<G, L, U>(z0, z1, K.row_a, b0, b1, K.n, K.n0inv, ln);
     } else {
         uint32_t u[L];
-        montmul_q<G, L>(u, K.row_a, b0, K.row_c, K.n, K.n0inv, ln);
+        montmul_q<G, L, U>(u, K.row_a, b0, K.row_c, K.n, K.n0inv, ln);
         wave::lds_fence();
-        montmul_addend<G, L>(z1, K.row_a, b1, K.row_c, K.n, K.n0inv, ln);
+        montmul_addend<G, L, U>(z1, K.row_a, b1, K.row_c, K.n, K.n0inv, ln);
 #pragma unroll
         for (int k = 0; k < L; ++k) z0[k] = u[k];
     }
 }
 
-template <int G, int L>
-PHE_DEV void split_square(uint32_t (&X0)[L], uint32_t (&X1)[L], const SplitLane<G, L>& K, const Lanes<G>& ln) {
+template <int G, int L, bool U>
+PHE_DEV void split_square(uint32_t (&X0)[L], uint32_t (&X1)[L], const SplitLane<G, L, U>& K, const Lanes<G>& ln) {
     uint32_t d[L];
     lds_put<L>(K.row_a, X0, ln.g);
 #pragma unroll
@@ -366,9 +357,9 @@ PHE_DEV void split_square(uint32_t (&X0)[L], uint32_t (&X1)[L], const SplitLane<
     pair_mul_plain<G, L>(X0, X1, X0, d, K, ln);
 }
 
-template <int G, int L>
+template <int G, int L, bool U>
 PHE_DEV void split_mul(uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t (&Y0)[L], const uint32_t (&Y1)[L],
-                       const SplitLane<G, L>& K, const Lanes<G>& ln) {
+                       const SplitLane<G, L, U>& K, const Lanes<G>& ln) {
     if constexpr (L <= kMaxFusedL) {
         wave::lds_fence();
 #pragma unroll
@@ -377,7 +368,7 @@ PHE_DEV void split_mul(uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t (&Y0
             K.row_c[ln.g * L + k] = X1[k];
         }
         wave::lds_fence();
-        pair_pass3<G, L>(X0, X1, K.row_a, K.row_c, Y0, Y1, K.n, K.n0inv, ln);
+        pair_pass3<G, L, U>(X0, X1, K.row_a, K.row_c, Y0, Y1, K.n, K.n0inv, ln);
     } else {
         // three single sweeps: X1*Y0, then (X0*Y0 with its quotient) and (quotient + X0*Y1); the second word stays
         // below 3n instead of 2n, which every operation accepts
@@ -391,9 +382,9 @@ PHE_DEV void split_mul(uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t (&Y0
 }
 
 // the number in the 32-bit-word row src -> pair representation
-template <int G, int L>
+template <int G, int L, bool U>
 PHE_DEV void split_conv(uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t* src, int limbs32, int chunks,
-                        const SplitConsts& C, const SplitLane<G, L>& K, const Lanes<G>& ln) {
+                        const SplitConsts& C, const SplitLane<G, L, U>& K, const Lanes<G>& ln) {
     constexpr int H = G * L;
     uint32_t tmp[L], d0[L], d1[L], u[L], t[L];
     for (int j = 0; j < chunks; ++j) {
@@ -488,9 +479,9 @@ PHE_DEV void store_pair_as_u32(uint32_t* p, int limbs32, const uint32_t (&lo)[L]
 }
 
 // pair -> canonical residue of x * (1 + n*mp) mod n^2 (mp == nullptr: of x), written as 32-bit words
-template <int G, int L>
+template <int G, int L, bool U>
 PHE_DEV void split_exit(uint32_t* out, int out_limbs, uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t* mp,
-                        int mp_limbs, const SplitConsts& C, const SplitLane<G, L>& K, const Lanes<G>& ln, bool live) {
+                        int mp_limbs, const SplitConsts& C, const SplitLane<G, L, U>& K, const Lanes<G>& ln, bool live) {
     constexpr int H = G * L;
     const uint32_t g = ln.g;
     uint32_t u[L], t[L], cst[L];
@@ -537,13 +528,13 @@ PHE_DEV void split_exit(uint32_t* out, int out_limbs, uint32_t (&X0)[L], uint32_
 }
 
 // ---- the batched exponentiation -------------------------------------------------------------------------------
-template <int G, int L, int MODE>
+template <int G, int L, int MODE, bool U = false>
 PHE_DEV void modexp_split_body(const SplitArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots,
                                uint32_t lane) {
     constexpr int H = G * L, S2 = 2 * H;
     const Lanes<G> ln(lane);
     const uint32_t g = ln.g;
-    SplitLane<G, L> K;
+    SplitLane<G, L, U> K;
     load_row<L>(K.n, A.mod.n, g);
     K.n0inv = A.mod.n0inv;
     K.row_a = lds_row;

@@ -99,7 +99,7 @@ static int g_mul_io = 1;  // 1: mul_io.h (the kernels' body), 0: mont_core.h:mul
 static bool rows_vec_ok(const MulArgs& A) {
     auto al = [](const void* p) { return ((uintptr_t)p & 15u) == 0; };
     return al(A.a) && al(A.b) && al(A.out) && A.a_stride % 4 == 0 && A.b_stride % 4 == 0 && A.out_stride % 4 == 0 &&
-           A.limbs % 4 == 0 && A.b_plain_limbs % 4 == 0;
+           A.limbs % 4 == 0 && A.b_plain_limbs % 4 == 0 && A.a_limbs % 4 == 0;
 }
 
 // the element-wise product the way k_mulmod runs it: the staged body (mul_io.h) where the geometry offers it and the rows
@@ -175,7 +175,7 @@ static SplitConsts split_consts_of(const host::SplitPack& m) {
 }
 static int chunks_for(int limbs32, int H) { return std::max(1, (32 * limbs32 + 29 * H - 1) / (29 * H)); }
 
-template <int G, int L, int MODE>
+template <int G, int L, int MODE, bool U = false>
 static void run_split(SplitArgs A) {
     constexpr int S2 = 2 * G * L, kPer = 64 / G;
     const int n_waves = waves_for(A.batch, G);
@@ -186,7 +186,7 @@ static void run_split(SplitArgs A) {
         std::vector<uint32_t> lds(kPer * (S2 + kLdsPad));
         wave::run_wave([&](uint32_t lane) {
             const uint32_t grp = lane / G;
-            modexp_split_body<G, L, MODE>(A, lds.data() + grp * (S2 + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
+            modexp_split_body<G, L, MODE, U>(A, lds.data() + grp * (S2 + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
         });
     }
 }
@@ -264,6 +264,7 @@ static void run_miller_rabin(MillerRabinArgs A) {
     }
 }
 static int g_prefer_group = 0;
+static int g_unit = 1;    // 1: the scaled-modulus path for r^n where the key offers it (the library's large-batch form)
 static int g_engine = 1;  // 1: split-modulus kernels where a geometry exists (the product default), 0: full-width only
 
 // out = a*b mod n^2 (b_plain == 0) or a*(1 + n*m) mod n^2 (b = plaintexts of n_limbs words) on the PAIR form
@@ -307,6 +308,10 @@ extern "C" {
 
 void emu_set_engine(int e) { g_engine = e ? 1 : 0; }
 void emu_set_mul_io(int e) { g_mul_io = e ? 1 : 0; }
+void emu_set_unit(int e) { g_unit = e ? 1 : 0; }
+int emu_unit_offered(const uint32_t* n, int n_limbs) {
+    try { return host::build_public(n, n_limbs, g_prefer_group).nunit.G ? 1 : 0; } catch (...) { return 0; }
+}
 int emu_last_mul_staged() { return g_last_mul_staged; }
 
 // multiply-add lane-operations (wave::mad64 calls) since the last reset, over all 64 lanes of every emulated wave
@@ -350,6 +355,32 @@ int emu_encrypt(const uint32_t* n, int n_limbs, const uint32_t* m, const uint32_
     try {
         if (B == 0) return 0;
         host::PublicPlan P = host::build_public(n, n_limbs, g_prefer_group);
+        if (g_engine && g_unit && P.nunit.G) {
+            // the library's large-batch path: r^n modulo the scaled modulus n'^2 (quotient digits without a multiply), then
+            // one pass of the product kernel takes that residue to (1 + n*m) * r^n mod n^2 (or c_in * r^n)
+            const host::SplitPack& M = P.nunit;
+            const int W = P.unit_words;
+            std::vector<uint32_t> tmp((size_t)B * W + 4);
+            uint32_t* t16 = tmp.data() + ((16 - ((uintptr_t)tmp.data() & 15u)) & 15u) / 4;   // 16-byte aligned rows
+            SplitArgs A;
+            memset(&A, 0, sizeof A);
+            A.mod = split_consts_of(M);
+            A.sched = P.exp_n.ops.data(); A.n_ops = (int)P.exp_n.ops.size();
+            A.first_idx = P.exp_n.first_idx; A.tbl_entries = P.exp_n.tbl_entries;
+            A.base = r; A.base_limbs = P.s1; A.base_chunks = chunks_for(P.s1, M.H);
+            A.post = nullptr; A.post_limbs = P.s1; A.post_chunks = 1;
+            A.out = t16; A.out_limbs = W; A.batch = B;
+            DISPATCH_SPLIT(M.G, M.L, (run_split<GG, LL, kModeEncrypt, true>(A)));
+            MulArgs Mu;
+            memset(&Mu, 0, sizeof Mu);
+            Mu.mod = consts_of(P.nsq); Mu.a = t16; Mu.a_limbs = W; Mu.a_stride = (size_t)W;
+            Mu.b = c_in ? c_in : m; Mu.b_stride = c_in ? (size_t)P.s2 : (size_t)P.s1; Mu.b_plain_limbs = c_in ? 0 : P.s1;
+            Mu.out = c_out; Mu.out_stride = (size_t)P.s2; Mu.limbs = P.s2; Mu.batch = B;
+            int MG, ML;
+            light_geometry_of(P.nsq, MG, ML);
+            DISPATCH_GL(MG, ML, (run_mul<GG, LL>(Mu)));
+            return 0;
+        }
         if (g_engine && P.nsplit.G) {
             const host::SplitPack& M = P.nsplit;
             SplitArgs A;

@@ -515,3 +515,42 @@ def test_key_owner_encryption_gives_the_public_path_bits(native, c_oracle, key_b
     assert not pub_only.owner_encrypt_offered()
     with pytest.raises(ValueError):
         pub_only.encrypt_owner(m[:2], r[:2])
+
+
+@pytest.mark.parametrize("key_bits,batch", [(2048, 40000), (3072, 9000), (4096, 1200)])
+def test_scaled_modulus_path_gives_the_plain_path_bits(native, c_oracle, key_bits, batch, monkeypatch):
+    """large batches take r^n modulo the scaled modulus n' = k*n (n' = -1 mod 2^29: quotient digits without a multiply)
+    and one product pass back to n^2; PHE_HIP_NO_UNIT keeps the plain kernels: identical ciphertexts, and the oracle's"""
+    rng = random.Random(key_bits + 1)
+    if key_bits == 4096:
+        def prime(bits):
+            while True:
+                cand = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+                if pow(2, cand - 1, cand) == 1 and pow(3, cand - 1, cand) == 1:
+                    return cand
+        while True:
+            p, q = prime(2048), prime(2048)
+            if p != q and (p * q).bit_length() == 4096:
+                break
+        n_int, s1 = p * q, 128
+        make = lambda: native.Context(n_int, n_limbs=s1)
+    else:
+        g = load_golden(key_bits)
+        n_int, s1 = H(g["n"]), key_bits // 32
+        make = lambda: make_ctx(native, g, private=False)
+    m = native.ints_to_limbs([rng.randrange(0, n_int) for _ in range(batch)], s1)
+    r = native.ints_to_limbs([rng.randrange(1, n_int) for _ in range(batch)], s1)
+    m[0], r[0] = 0, 0
+    r[0, 0] = 1                                                   # r = 1
+    r[1] = native.int_to_limbs(n_int - 1, s1)
+    ctx = make()
+    c = ctx.encrypt(m, r)
+    idx = np.r_[0, 1, np.arange(2, batch, max(1, batch // 30))]
+    n_arr = native.int_to_limbs(n_int, s1)
+    assert np.array_equal(c[idx], c_oracle.encrypt(n_arr, m[idx], r[idx], nthreads=8))
+    ob = ctx.obfuscate(c, r)
+    assert np.array_equal(ob[idx], c_oracle.obfuscate(n_arr, c[idx], r[idx], nthreads=8))
+    monkeypatch.setenv("PHE_HIP_NO_UNIT", "1")
+    plain = make()
+    assert np.array_equal(plain.encrypt(m, r), c)
+    assert np.array_equal(plain.obfuscate(c, r), ob)
