@@ -5,11 +5,13 @@
 // stores are a visible share of the time.  Round 1's mulmod_body read every 29-bit limb with its own pair of 4-byte
 // global loads (lane g of a group starts at bit 29*g*L: 64 different cache lines per wave instruction, 72 such
 // instructions per element) and waited for them before the first multiply.  Here
-//   * rows travel as 16-byte chunks, consecutive lanes of a limb group on consecutive chunks (coalesced
-//     global_load_dwordx4 / global_store_dwordx4), staged through LDS where the 32-bit words are re-sliced into
-//     29-bit limbs (and back);
-//   * the chunks of element i+1 are fetched into registers before the products of element i start, so their latency
-//     is covered by ~2 x 20 k multiply-adds instead of being waited for;
+//   * rows travel as 16-byte chunks, consecutive lanes of a limb group on consecutive chunks: in by LDS-DMA
+//     (global_load_lds_dwordx4: global -> LDS without a register round trip; the destination is lane-linear, so the
+//     staging area is laid out [chunk][lane][4 words] per wave), out by global_store_dwordx4; the 32-bit words are
+//     re-sliced into 29-bit limbs (and back) from LDS;
+//   * the copies of element i+1 are issued right after the limbs of element i have been sliced out, so they land under
+//     the ~20-40 k multiply-adds of element i instead of being waited for (a register prefetch was tried first: the
+//     allocator spilled the prefetched words, which made the kernel wait for the loads before the products after all);
 //   * `one_product` gives a*b*R^-1 mod N (canonical) — ONE Montgomery product.  Resident ciphertext vectors use it for
 //     chains of homomorphic additions: the missing powers of R are tracked per vector and settled by a single
 //     product with R^(d+1) mod N when the plain residues are needed (phe/ciphertext.py, "Montgomery debt").
