@@ -17,7 +17,9 @@
  *     phe_hip_last_error() (thread-local).  Nothing throws across the boundary.  Argument/range
  *     validation that the reference does in Python (TypeError/ValueError) stays in the host
  *     language; the kernels compute on whatever limbs they are given, modulo the stated ranges.
- *   - Plain functions take HOST pointers and are synchronous (upload, compute, download).
+ *   - Plain functions take HOST pointers (ordinary pageable memory) and are synchronous.  From 131072 rows on,
+ *     phe_hip_encrypt / _encrypt_owner / _obfuscate / _decrypt move the batch in chunks through pinned staging buffers
+ *     on three internal streams (uploads and downloads under the kernels); smaller batches upload, compute, download.
  *     *_dev functions take DEVICE pointers (hipMalloc'd / torch CUDA tensors) and enqueue on
  *     `stream` (a hipStream_t passed as void*, NULL = default stream) without synchronising.
  *   - A context is bound to one device and is not thread-safe; use one per host thread / rank.
