@@ -700,7 +700,7 @@ def main():
 
         def cpu_timed(fn, target_s):
             """Time fn(count) on a bounded sample: a short probe sizes the sample for ~target_s seconds."""
-            probe = min(B, max(cores, 2 * cores))
+            probe = min(B, 32 * cores)                     # large enough that thread start-up does not dominate the estimate
             t0 = time.perf_counter()
             fn(probe)
             rate = probe / max(time.perf_counter() - t0, 1e-6)
@@ -750,6 +750,9 @@ def main():
             "achieved": rate(enc_exec, enc_kernel_s) / 1e12 if enc_exec else None, "peak": peak / 1e12, "unit": "Tmad/s (v_mad_u64_u32 lane-operations = MAC32)",
             "frac": frac(enc_exec, enc_kernel_s),
             "frac_note": "multiply-adds the kernel EXECUTES per second / nominal integer-VALU peak (<= 1 by construction)",
+            "kernel_note": "where the key width offers it (>= 2048 bits) r^n runs modulo the scaled modulus n' = k*n = -1 mod 2^29 "
+                           "(template flag `unit`: no v_mul_lo per quotient digit) and ONE k_mulmod_staged pass brings the residue to "
+                           "(1 + n*m) * r^n mod n^2; launch_ms_avg and the executed count cover both kernels",
             "executed_mad_per_encrypt": enc_exec, "executed_source": exec_src,
             "frac_of_sustained_mad_rate": (rate(enc_exec, enc_kernel_s) / sustained) if (sustained and enc_exec) else None,
             "canonical_mac32_per_encrypt": enc_mac, "canonical_achieved": enc_mac * B / enc_kernel_s / 1e12,
