@@ -661,3 +661,39 @@ def test_obfuscation_under_a_key_pair_takes_the_owner_path_and_keeps_the_referen
     n2 = pub.nsquare
     assert vec.ciphertexts(False) == [c * pow(r, pub.n, n2) % n2 for c, r in zip(before, (5, 7, 11))]
     assert priv.decrypt_batch(vec) == [1.5, -2.0, 3.25]
+
+
+@pytest.mark.gpu
+def test_scalar_encryption_from_several_threads_never_shares_an_obfuscator():
+    """pub.encrypt() from several threads on one key.  ctypes drops the GIL inside the native
+    calls and the pool refills by the launch; the per-key lock must keep every r^n single-use: all obfuscators distinct,
+    every value decrypts."""
+    import threading
+    g = load_golden(1024)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    per, threads = 300, 6
+    out = [[None] * per for _ in range(threads)]
+    errors = []
+
+    def worker(t):
+        try:
+            for i in range(per):
+                out[t][i] = pub.encrypt(1000 * t + i)
+        except Exception as exc:                                   # surfaced below
+            errors.append(exc)
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(threads)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors
+    n, n2 = pub.n, pub.nsquare
+    seen = set()
+    for t in range(threads):
+        vals = priv.decrypt_batch(out[t])
+        assert vals == [1000 * t + i for i in range(per)]
+        for i, e in enumerate(out[t]):
+            m = 1000 * t + i
+            obf = e.ciphertext(False) * pow(1 + n * m, -1, n2) % n2      # = r^n of this ciphertext
+            assert obf not in seen and obf != 1
+            seen.add(obf)
+    assert len(seen) == per * threads
