@@ -18,8 +18,9 @@ The same JSON line also carries
   ops          — configs[2]: _raw_add, _raw_mul by float-like 56-bit / int64 scalars and with 10 % negative scalars
                  (the inverse branch of phe/paillier.py:745-749), obfuscate — each over the whole batch, with its own
                  roofline entry and a strided sample checked against the libgmp oracle;
-  config4      — configs[3] (N > 1, or --config4): a 3072-bit key, one shard of 2^20 plaintexts per GPU (8M on 8 GPUs),
-                 the ciphertext shards concatenated on every GPU by ONE RCCL all-gather (phe.sharding.all_gather_rows);
+  config4      — configs[3]: a 3072-bit key, one shard of 2^20 plaintexts per GPU (8M on 8 GPUs; at N = 1 one shard of 2^18
+                 rows), the ciphertext shards concatenated on every GPU by ONE RCCL all-gather (phe.sharding.all_gather_rows)
+                 and, for N > 1, once more by the library's own RCCL communicator (phe_hip_allgather_dev), bits compared;
                  shard-boundary rows + a strided sample against the oracle;
   roofline     — dominant kernel (k_modexp_split<4,18,encrypt>): `frac` = multiply-adds the kernel EXECUTES
                  (v_mad_u64_u32 lane-operations, exact count from profiles/executed_mads_r*.json, cross-checked with the
@@ -190,12 +191,14 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=0, help="elements for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ops", action="store_true", help="skip the configs[2] leg")
-    ap.add_argument("--config4", action="store_true", help="run the configs[3] leg at N=1 too (always on for N>1)")
+    ap.add_argument("--config4", action="store_true", help="(kept for old command lines: the configs[3] leg now always runs)")
     ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--config4-key-bits", type=int, default=3072, choices=[256, 1024, 2048, 3072])
-    ap.add_argument("--config4-total", type=int, default=0, help="plaintexts of the whole configs[3] job (0 = 2^20 per GPU)")
+    ap.add_argument("--config4-total", type=int, default=0,
+                    help="plaintexts of the whole configs[3] job (0 = 2^20 per GPU for N > 1; at N = 1 one shard of 2^18)")
     ap.add_argument("--lib-allgather", action="store_true",
-                    help="configs[3] leg: repeat the all-gather through the library's own RCCL communicator (phe_hip_allgather_dev)")
+                    help="N = 1: repeat the configs[3] gather through the library's own RCCL communicator (always on for N > 1)")
+    ap.add_argument("--no-lib-allgather", action="store_true")
     ap.add_argument("--oracle-sample", type=int, default=4096, help="strided rows of the timed batch checked against libgmp")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--selftest-emu", action="store_true", help="CPU contract test: gloo + wave emulator, not a measurement")
@@ -613,11 +616,13 @@ def main():
 
     # ---- configs[3]: a shard per GPU under a 3072-bit key + ONE all-gather of the ciphertext shards ---------------
     cfg4, cfg4_ok = None, True
-    if (world > 1 or args.config4) and not args.no_config4:
+    if not args.no_config4:
         k4 = golden(args.config4_key_bits)
         t1, t2 = args.config4_key_bits // 32, args.config4_key_bits // 16
         ctx4 = be.context(k4["n"], n_limbs=t1)
-        total = args.config4_total or world * (1 << 20)
+        # N > 1: the job of BASELINE configs[3] scaled to the ranks present (2^20 per GPU: 8M on 8 GPUs).  N = 1: ONE SHARD
+        # of 2^18 rows of that job (~1.6 s), so that the driver's default line carries a 3072-bit number at all
+        total = args.config4_total or (world * (1 << 20) if world > 1 else (1 << 18))
         lo, hi = shard_bounds(total, world, rank)
         rows = hi - lo
         blk = 1 << 16
@@ -649,7 +654,7 @@ def main():
         t_gather = time.perf_counter() - t0
         t_enc, t_gather = max_over_ranks([t_enc, t_gather])
         lib_gather = None
-        if args.lib_allgather and be.name == "hip" and total % world == 0:
+        if (args.lib_allgather or world > 1) and not args.no_lib_allgather and be.name == "hip" and total % world == 0:
             # the same exchange issued by the library's own RCCL communicator (include/phe_hip.h phe_hip_allgather_dev):
             # the path of a host without a process group; the id travels over the torch group here
             from phe.sharding import library_communicator
@@ -679,9 +684,11 @@ def main():
             want = orc.encrypt(native.int_to_limbs(k4["n"], t1), be.np(be.cat(list(ms))), be.np(be.cat(list(rs))), nthreads=cores)
             got = full[idx].cpu().numpy().view(np.uint32)
             cfg4_ok = cfg4_ok and bool(np.array_equal(got, want))
-            cfg4 = {"workload": "configs[3]: %d-bit key, %d plaintexts sharded over %d GPU(s) (%d per GPU), ONE all-gather "
+            cfg4 = {"workload": "configs[3]: %d-bit key, %d plaintexts sharded over %d GPU(s) (%d per GPU%s), ONE all-gather "
                                 "of the ciphertext shards (phe.sharding.all_gather_rows, backend %s)"
-                                % (args.config4_key_bits, total, world, rows, be.dist_backend if use_dist else "none: 1 rank"),
+                                % (args.config4_key_bits, total, world, rows,
+                                   "" if world > 1 or args.config4_total else ": one shard of 2^18 rows of the 8M job",
+                                   be.dist_backend if use_dist else "none: 1 rank"),
                     "total": total, "rows_per_gpu": rows,
                     "encrypt": {"seconds": t_enc, "value": total / t_enc, "unit": "encrypts/s"},
                     "all_gather": {"seconds": t_gather, "bytes_received_per_gpu": total * t2 * 4,

@@ -22,7 +22,11 @@
  *     on three internal streams (uploads and downloads under the kernels); smaller batches upload, compute, download.
  *     *_dev functions take DEVICE pointers (hipMalloc'd / torch CUDA tensors) and enqueue on
  *     `stream` (a hipStream_t passed as void*, NULL = default stream) without synchronising.
- *   - A context is bound to one device and is not thread-safe; use one per host thread / rank.
+ *   - A context is bound to one device and is not thread-safe: calls on one context must not overlap in HOST time (one
+ *     per host thread / rank, or a lock around the calls).  On the DEVICE there is one stream order per context: the
+ *     window tables and intermediates of a call belong to the context, so a *_dev call issued on another stream than
+ *     the previous one first makes its stream wait for that call's work (an event, no host synchronisation).  Work on
+ *     different contexts runs concurrently.
  *   - All results are canonical residues, bit-identical to the reference's gmpy2/CPython values.
  */
 #ifndef PHE_HIP_H
@@ -80,6 +84,25 @@ int phe_hip_ctx_engine(const phe_hip_ctx* ctx, int* split_pub, int* split_priv);
  * per kernel (the default). */
 int phe_hip_ctx_set_blocks_per_cu(phe_hip_ctx* ctx, int blocks_per_cu);
 
+/* The geometry ladder.  A number is owned by a limb group of G lanes; rung 0 is the narrowest group the key width offers
+ * (most limbs per lane: the best throughput once every SIMD of the GPU has a wave).  A batch too small to fill the GPU
+ * that way runs on a wider rung — fewer limbs per lane, a shorter dependent chain per product, more lanes per number —
+ * chosen per call from the batch size.  Results are identical on every rung.
+ * phe_hip_ctx_ladder: the rungs as G*100 + L, narrowest first, for the n-side and the p/q-side kernels (up to `capacity`
+ * entries each are written; *n_pub / *n_priv = how many exist).  phe_hip_ctx_set_group: 0 = choose by batch size (default),
+ * G = always the rung of G-lane groups (the next wider one if there is none) — for tests and measurements.
+ * phe_hip_ctx_last_launch: what the last encrypt / obfuscate / decrypt / pair call took: *path = bit set of
+ * 1 (r^n modulo the scaled modulus k*n), 2 (key owner's CRT form), 4 (decrypt halves side by side on two streams),
+ * 8 (host batch pipelined through pinned chunks), 16 (fused obfuscate kernel); *geom_pub / *geom_priv = G*100 + L of the
+ * exponentiation kernels used.  Any pointer may be NULL. */
+int phe_hip_ctx_ladder(const phe_hip_ctx* ctx, int* pub_geoms, int* priv_geoms, int capacity, int* n_pub, int* n_priv);
+int phe_hip_ctx_set_group(phe_hip_ctx* ctx, int group);
+int phe_hip_ctx_last_launch(const phe_hip_ctx* ctx, int* path, int* geom_pub, int* geom_priv);
+
+/* Frees the grow-only device and pinned buffers of the context (window tables, intermediates, staging of the host-pointer
+ * entry points and of their chunk pipeline); the next call allocates what it needs.  Synchronises the device. */
+int phe_hip_ctx_release_scratch(phe_hip_ctx* ctx);
+
 /* ---- the hot path, host buffers ------------------------------------------------------------ */
 
 /* c[i] = (1 + n*m[i]) * r[i]^n mod n^2      — PaillierPublicKey.raw_encrypt(m, r_value=r),
@@ -87,9 +110,13 @@ int phe_hip_ctx_set_blocks_per_cu(phe_hip_ctx* ctx, int blocks_per_cu);
  * reference's `% nsquare`, :134);  r: (batch, n_limbs), 0 < r < n;  c: (batch, ct_limbs). */
 int phe_hip_encrypt(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch);
 
+/* The same value, bit for bit, for a caller that holds the private key (private context): r^n from its CRT halves modulo
+ * p^2 and q^2 — see phe_hip_encrypt_owner_dev below.  EINVAL on public contexts and for key widths without the needed
+ * geometries (phe_hip_ctx_owner_encrypt tells).  Pipelined from 131072 rows on like phe_hip_encrypt. */
+int phe_hip_encrypt_owner(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch);
+
 /* c_out[i] = c_in[i] * r[i]^n mod n^2       — EncryptedNumber.obfuscate(), phe/paillier.py:603-624
  * (with the obfuscator r an explicit input; the reference draws it at :621). */
-int phe_hip_encrypt_owner(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch);
 int phe_hip_obfuscate(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t* r, uint32_t* c_out, size_t batch);
 
 /* m[i] = PaillierPrivateKey.raw_decrypt(c[i]) — phe/paillier.py:328-354 incl. l_function :362-364
@@ -171,6 +198,30 @@ int phe_hip_add_plain_dev(phe_hip_ctx* ctx, const uint32_t* c, const uint32_t* m
 int phe_hip_montmul_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, int b_is_row, uint32_t* out, size_t batch,
                         void* stream);
 int phe_hip_mont_radix_bits(phe_hip_ctx* ctx, int* bits);
+
+/* Resident ciphertext rows in the engine's own form ("pair form", csrc/split_core.h).  A vector that is only multiplied —
+ * chains of EncryptedNumber.__add__ (= _raw_add, phe/paillier.py:705-719), sum() trees, obfuscators r^n made ahead of time —
+ * can stay in the representation the exponentiation kernels compute in: x*R mod n^2 = X0 - n*X1 with X0, X1 half-width
+ * numbers, stored as rows of phe_hip_pair_words() words (2 * ceil((bits(n)+4)/29) rounded to the limb-group size: 144
+ * for a 2048-bit key's 128-word ciphertext) of 29-bit limbs.  A homomorphic addition on such rows is ONE pair product
+ * (5 half-width limb products against 16 for mulmod, 8 for phe_hip_montmul_dev), nothing is left to settle, and the rows
+ * never pass through 32-bit words in between.
+ *   phe_hip_to_pair_dev   : c (batch, ct_limbs), any value < 2^(32*ct_limbs)  ->  pair rows
+ *   phe_hip_pair_mul_dev  : out[i] = a[i] * b[i] (pair rows; b_is_row != 0: the single row b for every i)
+ *   phe_hip_from_pair_dev : pair rows -> the canonical residue mod n^2, bit-identical to what the chain of _raw_add returns;
+ *                           with m != NULL (plaintexts, (batch, n_limbs)) the residue of x * (1 + n*m): raw_encrypt(m, r)
+ *                           from r^n kept in the pair form (phe/paillier.py:134-139), or adding a plaintext (:673-675).
+ * The contents of a pair row are NOT canonical (lazy reduction): compare ciphertexts only after from_pair.
+ * EINVAL without the split-modulus engine (PHE_HIP_ENGINE=full or a key width it has no kernel for). */
+int phe_hip_pair_words(const phe_hip_ctx* ctx, int* words);
+int phe_hip_to_pair_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* pair, size_t batch, void* stream);
+int phe_hip_pair_mul_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, int b_is_row, uint32_t* out, size_t batch,
+                         void* stream);
+int phe_hip_from_pair_dev(phe_hip_ctx* ctx, const uint32_t* pair, const uint32_t* m, uint32_t* c, size_t batch, void* stream);
+/* out (ONE pair row) = the product of all `batch` pair rows: the homomorphic sum of a resident vector — sum(enc_list) in
+ * the reference is a chain of _raw_add (phe/paillier.py:705-719); the product of residues is independent of the order —
+ * as a pairwise tree of log2(batch) launches queued back to back on `stream`, no host round trip between the levels. */
+int phe_hip_pair_reduce_dev(phe_hip_ctx* ctx, const uint32_t* pair, size_t batch, uint32_t* out, void* stream);
 /* max_exp_bits: upper bound on the bit length of every e[i] (0 = 32*exp_limbs) */
 int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, int max_exp_bits,
                        uint32_t* out, size_t batch, void* stream);

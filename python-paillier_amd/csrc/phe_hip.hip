@@ -84,6 +84,7 @@ PHE_DECLARE_PART(g16b)
     int launch_crt_lift(int L, int blocks, hipStream_t st, const CrtLiftArgs& A);                 \
     int occ_split_unit(int L);                                                                    \
     int launch_split_unit(int L, int blocks, hipStream_t st, const SplitArgs& A);                 \
+    int launch_pair(int L, int op, int blocks, hipStream_t st, const PairArgs& A);                \
     }
 PHE_DECLARE_SPLIT_PART(s2a)
 PHE_DECLARE_SPLIT_PART(s2b)
@@ -151,44 +152,45 @@ struct SplitPart {
     int (*launch_crt_lift)(int, int, hipStream_t, const CrtLiftArgs&);
     int (*occ_split_unit)(int);
     int (*launch_split_unit)(int, int, hipStream_t, const SplitArgs&);
+    int (*launch_pair)(int, int, int, hipStream_t, const PairArgs&);
 };
 static const SplitPart kSplitParts[] = {
     {2, phe::s2a::occ_split, phe::s2a::launch_split, phe::s2a::occ_var_split, phe::s2a::launch_var_split,
      phe::s2a::occ_multi_split, phe::s2a::launch_multi_split, phe::s2a::launch_multi_tables,
-     phe::s2a::launch_multi_lookup, phe::s2a::launch_mul_split, phe::s2a::launch_crt_lift, phe::s2a::occ_split_unit, phe::s2a::launch_split_unit},
+     phe::s2a::launch_multi_lookup, phe::s2a::launch_mul_split, phe::s2a::launch_crt_lift, phe::s2a::occ_split_unit, phe::s2a::launch_split_unit, phe::s2a::launch_pair},
     {2, phe::s2b::occ_split, phe::s2b::launch_split, phe::s2b::occ_var_split, phe::s2b::launch_var_split,
      phe::s2b::occ_multi_split, phe::s2b::launch_multi_split, phe::s2b::launch_multi_tables,
-     phe::s2b::launch_multi_lookup, phe::s2b::launch_mul_split, phe::s2b::launch_crt_lift, phe::s2b::occ_split_unit, phe::s2b::launch_split_unit},
+     phe::s2b::launch_multi_lookup, phe::s2b::launch_mul_split, phe::s2b::launch_crt_lift, phe::s2b::occ_split_unit, phe::s2b::launch_split_unit, phe::s2b::launch_pair},
     {2, phe::s2c::occ_split, phe::s2c::launch_split, phe::s2c::occ_var_split, phe::s2c::launch_var_split,
      phe::s2c::occ_multi_split, phe::s2c::launch_multi_split, phe::s2c::launch_multi_tables,
-     phe::s2c::launch_multi_lookup, phe::s2c::launch_mul_split, phe::s2c::launch_crt_lift, phe::s2c::occ_split_unit, phe::s2c::launch_split_unit},
+     phe::s2c::launch_multi_lookup, phe::s2c::launch_mul_split, phe::s2c::launch_crt_lift, phe::s2c::occ_split_unit, phe::s2c::launch_split_unit, phe::s2c::launch_pair},
     {4, phe::s4a::occ_split, phe::s4a::launch_split, phe::s4a::occ_var_split, phe::s4a::launch_var_split,
      phe::s4a::occ_multi_split, phe::s4a::launch_multi_split, phe::s4a::launch_multi_tables,
-     phe::s4a::launch_multi_lookup, phe::s4a::launch_mul_split, phe::s4a::launch_crt_lift, phe::s4a::occ_split_unit, phe::s4a::launch_split_unit},
+     phe::s4a::launch_multi_lookup, phe::s4a::launch_mul_split, phe::s4a::launch_crt_lift, phe::s4a::occ_split_unit, phe::s4a::launch_split_unit, phe::s4a::launch_pair},
     {4, phe::s4b::occ_split, phe::s4b::launch_split, phe::s4b::occ_var_split, phe::s4b::launch_var_split,
      phe::s4b::occ_multi_split, phe::s4b::launch_multi_split, phe::s4b::launch_multi_tables,
-     phe::s4b::launch_multi_lookup, phe::s4b::launch_mul_split, phe::s4b::launch_crt_lift, phe::s4b::occ_split_unit, phe::s4b::launch_split_unit},
+     phe::s4b::launch_multi_lookup, phe::s4b::launch_mul_split, phe::s4b::launch_crt_lift, phe::s4b::occ_split_unit, phe::s4b::launch_split_unit, phe::s4b::launch_pair},
     {4, phe::s4c::occ_split, phe::s4c::launch_split, phe::s4c::occ_var_split, phe::s4c::launch_var_split,
      phe::s4c::occ_multi_split, phe::s4c::launch_multi_split, phe::s4c::launch_multi_tables,
-     phe::s4c::launch_multi_lookup, phe::s4c::launch_mul_split, phe::s4c::launch_crt_lift, phe::s4c::occ_split_unit, phe::s4c::launch_split_unit},
+     phe::s4c::launch_multi_lookup, phe::s4c::launch_mul_split, phe::s4c::launch_crt_lift, phe::s4c::occ_split_unit, phe::s4c::launch_split_unit, phe::s4c::launch_pair},
     {8, phe::s8a::occ_split, phe::s8a::launch_split, phe::s8a::occ_var_split, phe::s8a::launch_var_split,
      phe::s8a::occ_multi_split, phe::s8a::launch_multi_split, phe::s8a::launch_multi_tables,
-     phe::s8a::launch_multi_lookup, phe::s8a::launch_mul_split, phe::s8a::launch_crt_lift, phe::s8a::occ_split_unit, phe::s8a::launch_split_unit},
+     phe::s8a::launch_multi_lookup, phe::s8a::launch_mul_split, phe::s8a::launch_crt_lift, phe::s8a::occ_split_unit, phe::s8a::launch_split_unit, phe::s8a::launch_pair},
     {8, phe::s8b::occ_split, phe::s8b::launch_split, phe::s8b::occ_var_split, phe::s8b::launch_var_split,
      phe::s8b::occ_multi_split, phe::s8b::launch_multi_split, phe::s8b::launch_multi_tables,
-     phe::s8b::launch_multi_lookup, phe::s8b::launch_mul_split, phe::s8b::launch_crt_lift, phe::s8b::occ_split_unit, phe::s8b::launch_split_unit},
+     phe::s8b::launch_multi_lookup, phe::s8b::launch_mul_split, phe::s8b::launch_crt_lift, phe::s8b::occ_split_unit, phe::s8b::launch_split_unit, phe::s8b::launch_pair},
     {8, phe::s8c::occ_split, phe::s8c::launch_split, phe::s8c::occ_var_split, phe::s8c::launch_var_split,
      phe::s8c::occ_multi_split, phe::s8c::launch_multi_split, phe::s8c::launch_multi_tables,
-     phe::s8c::launch_multi_lookup, phe::s8c::launch_mul_split, phe::s8c::launch_crt_lift, phe::s8c::occ_split_unit, phe::s8c::launch_split_unit},
+     phe::s8c::launch_multi_lookup, phe::s8c::launch_mul_split, phe::s8c::launch_crt_lift, phe::s8c::occ_split_unit, phe::s8c::launch_split_unit, phe::s8c::launch_pair},
     {16, phe::s16a::occ_split, phe::s16a::launch_split, phe::s16a::occ_var_split, phe::s16a::launch_var_split,
      phe::s16a::occ_multi_split, phe::s16a::launch_multi_split, phe::s16a::launch_multi_tables,
-     phe::s16a::launch_multi_lookup, phe::s16a::launch_mul_split, phe::s16a::launch_crt_lift, phe::s16a::occ_split_unit, phe::s16a::launch_split_unit},
+     phe::s16a::launch_multi_lookup, phe::s16a::launch_mul_split, phe::s16a::launch_crt_lift, phe::s16a::occ_split_unit, phe::s16a::launch_split_unit, phe::s16a::launch_pair},
     {16, phe::s16b::occ_split, phe::s16b::launch_split, phe::s16b::occ_var_split, phe::s16b::launch_var_split,
      phe::s16b::occ_multi_split, phe::s16b::launch_multi_split, phe::s16b::launch_multi_tables,
-     phe::s16b::launch_multi_lookup, phe::s16b::launch_mul_split, phe::s16b::launch_crt_lift, phe::s16b::occ_split_unit, phe::s16b::launch_split_unit},
+     phe::s16b::launch_multi_lookup, phe::s16b::launch_mul_split, phe::s16b::launch_crt_lift, phe::s16b::occ_split_unit, phe::s16b::launch_split_unit, phe::s16b::launch_pair},
     {16, phe::s16c::occ_split, phe::s16c::launch_split, phe::s16c::occ_var_split, phe::s16c::launch_var_split,
      phe::s16c::occ_multi_split, phe::s16c::launch_multi_split, phe::s16c::launch_multi_tables,
-     phe::s16c::launch_multi_lookup, phe::s16c::launch_mul_split, phe::s16c::launch_crt_lift, phe::s16c::occ_split_unit, phe::s16c::launch_split_unit},
+     phe::s16c::launch_multi_lookup, phe::s16c::launch_mul_split, phe::s16c::launch_crt_lift, phe::s16c::occ_split_unit, phe::s16c::launch_split_unit, phe::s16c::launch_pair},
 };
 #define PHE_SPLIT_BY_GROUP(G_, CALL2)                 \
     [&]() -> int {                                    \
@@ -300,16 +302,37 @@ struct phe_hip_ctx {
     host::PrivatePlan priv;
     DevModulus d_nsq, d_psq, d_qsq;
     bool use_split = true;  // PHE_HIP_ENGINE=full: keep the uniform-exponent jobs on the full-width kernels
-    DevSplit d_nsplit, d_psplit, d_qsplit, d_nsplit_lat, d_psplit_lat, d_qsplit_lat;
+    DevSplit d_nsplit, d_psplit, d_qsplit;
     DevSplit d_nunit;                 // the scaled modulus n' = k*n (key_setup.h PublicPlan::nunit); G == 0: not offered
     uint32_t* unit_tmp = nullptr;     // r^n mod n'^2, rows of pub.unit_words words
     size_t unit_tmp_words = 0;
-    // latency geometry: small batches cannot fill the GPU, so they use 16-lane groups (half the limbs per
-    // lane => about half the time per product) when the key size offers both
-    bool has_lat_pub = false, has_lat_priv = false;
-    host::PublicPlan pub_lat;
-    host::PrivatePlan priv_lat;
-    DevModulus d_nsq_lat, d_psq_lat, d_qsq_lat;
+    // Geometry ladder.  The members above (pub / d_nsq / d_nsplit, priv / d_psq ...) are rung 0: the narrowest limb groups,
+    // i.e. the most limbs per lane = the fewest instructions per multiply-add = the best throughput once every SIMD has a
+    // wave.  A batch too small for that (batch * G lanes < the chip's lanes) climbs to wider groups — fewer limbs per lane,
+    // shorter dependent chains per product, more lanes per number — until the chip is filled or the groups are 16 wide
+    // (pick_rung).  The constants of a modulus are rows of G*L limbs in global limb order, so every rung has its own copies.
+    struct PubRung {
+        host::PublicPlan plan;
+        DevModulus nsq;
+        DevSplit nsplit;
+    };
+    struct PrivRung {
+        host::PrivatePlan plan;
+        DevModulus psq, qsq;
+        DevSplit psplit, qsplit;
+    };
+    std::vector<PubRung> pub_rungs;    // rungs 1.. of the public side, by increasing group width
+    std::vector<PrivRung> priv_rungs;  // rungs 1.. of the private side
+    bool force_unit = false;           // PHE_HIP_FORCE_UNIT=1: r^n through the scaled modulus whatever the batch size (tests)
+    int force_group = 0;               // phe_hip_ctx_set_group: 0 = pick by batch size; G = the rung whose groups are G lanes wide
+    int fill_pct = 85;                 // a rung is taken when the batch gives every SIMD at least this % of a wave (PHE_HIP_FILL_PCT)
+    // what the last launch on this context took (phe_hip_ctx_last_launch): tests assert the path they meant to exercise
+    int last_path = 0, last_geom_pub = 0, last_geom_priv = 0;
+    // one stream order per context: every *_dev call waits for the previous call's work when it is issued on another
+    // stream (the window tables and intermediates are the context's, not the call's)
+    hipEvent_t ev_busy = nullptr;
+    hipStream_t busy_stream = nullptr;
+    bool busy_valid = false;
     DevSchedule d_exp_n, d_exp_p, d_exp_q;
     DevTail d_tail;
     // grow-only device scratch
@@ -665,15 +688,46 @@ static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, 
     return PHE_HIP_OK;
 }
 
-// batches at or below this many elements run on the latency geometry (one 16-lane group per SIMD wave slot)
-static bool small_batch(const phe_hip_ctx* ctx, size_t batch) { return batch <= (size_t)ctx->n_cus * 16; }
+// ---- the geometry ladder --------------------------------------------------------------------------------------------
+// A launch of `batch` numbers on groups of G lanes occupies batch*G lanes; the chip has n_cus * 4 SIMDs * 64 lanes per wave
+// slot.  One wave per SIMD already runs these kernels at ~95 % of their two-wave rate, a SIMD without a wave
+// runs nothing: so the narrowest rung (fewest lanes per number, most limbs per lane, fewest instructions per multiply-add)
+// that still gives every SIMD fill_pct % of a wave wins, and below that the groups widen — each step halves the limbs per
+// lane and with them the length of the dependent chain of a product (at ~0.88x the multiply-adds per instruction).
+static bool fills_chip(const phe_hip_ctx* ctx, size_t batch, int G, int concurrent = 1) {
+    return batch * (size_t)G * (size_t)concurrent * 100 >= (size_t)ctx->n_cus * 256 * (size_t)ctx->fill_pct;
+}
+static int light_group(const DevModulus& M) {
+    int G, L;
+    light_geometry(M, G, L);
+    return G;
+}
+// rung index (0 = the members of the context, k >= 1 = pub_rungs[k-1]) whose width(rung) fills the chip, else the widest
+template <class Width>
+static int pick_rung(const phe_hip_ctx* ctx, size_t batch, int n_rungs, Width width, int concurrent = 1) {
+    if (ctx->force_group) {
+        for (int k = 0; k < n_rungs; ++k)
+            if (width(k) >= ctx->force_group) return k;
+        return n_rungs - 1;
+    }
+    for (int k = 0; k < n_rungs; ++k)
+        if (width(k) && fills_chip(ctx, batch, width(k), concurrent)) return k;
+    return n_rungs - 1;
+}
+static const DevModulus& nsq_rung(const phe_hip_ctx* ctx, int k) { return k == 0 ? ctx->d_nsq : ctx->pub_rungs[(size_t)k - 1].nsq; }
+static const DevSplit& nsplit_rung(const phe_hip_ctx* ctx, int k) { return k == 0 ? ctx->d_nsplit : ctx->pub_rungs[(size_t)k - 1].nsplit; }
+// the full-width kernels modulo n^2 (products; the second engine)
 static const DevModulus& pick_nsq(const phe_hip_ctx* ctx, size_t batch) {
-    return (ctx->has_lat_pub && small_batch(ctx, batch)) ? ctx->d_nsq_lat : ctx->d_nsq;
+    const int k = pick_rung(ctx, batch, 1 + (int)ctx->pub_rungs.size(), [&](int r) { return nsq_rung(ctx, r).G ? light_group(nsq_rung(ctx, r)) : 0; });
+    return nsq_rung(ctx, k);
 }
-
-static const DevSplit& pick_nsplit(const phe_hip_ctx* ctx, size_t batch) {
-    return (ctx->has_lat_pub && small_batch(ctx, batch)) ? ctx->d_nsplit_lat : ctx->d_nsplit;
+// the pair-form kernels modulo n
+static int pick_nsplit_rung(const phe_hip_ctx* ctx, size_t batch) {
+    return pick_rung(ctx, batch, 1 + (int)ctx->pub_rungs.size(), [&](int r) { return nsplit_rung(ctx, r).G; });
 }
+static const DevSplit& pick_nsplit(const phe_hip_ctx* ctx, size_t batch) { return nsplit_rung(ctx, pick_nsplit_rung(ctx, batch)); }
+static int geom_code(int G, int L) { return G * 100 + L; }
+enum : int { kPathUnit = 1, kPathOwner = 2, kPathSideBySide = 4, kPathPipelined = 8, kPathFusedObfuscate = 16 };
 
 static int check_ctx(const phe_hip_ctx* ctx) {
     if (!ctx) return fail(PHE_HIP_EINVAL, "null context");
@@ -683,6 +737,35 @@ static int bind_device(const phe_hip_ctx* ctx) {
     HIP_TRY(hipSetDevice(ctx->device));
     return PHE_HIP_OK;
 }
+
+// One stream order per context.  The window tables, the decrypt intermediates and the staging blocks belong to the context,
+// not to a call: two calls issued on different streams would otherwise run concurrently on the same scratch.  Every entry
+// point that launches on the context's scratch therefore makes its stream wait for the previous call's work (an event; no
+// host synchronisation) and leaves its own event behind.  Calls from several HOST threads still need the caller's lock.
+struct CtxOrder {
+    phe_hip_ctx* ctx;
+    hipStream_t st;
+    int rc = PHE_HIP_OK;
+    CtxOrder(phe_hip_ctx* c, void* stream) : ctx(c), st((hipStream_t)stream) {
+        if (ctx->busy_valid && ctx->busy_stream != st) {
+            const hipError_t e = hipStreamWaitEvent(st, ctx->ev_busy, 0);
+            if (e != hipSuccess) rc = fail(PHE_HIP_EHIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
+        }
+    }
+    ~CtxOrder() {
+        if (!ctx->ev_busy && hipEventCreateWithFlags(&ctx->ev_busy, hipEventDisableTiming) != hipSuccess) ctx->ev_busy = nullptr;
+        if (ctx->ev_busy && hipEventRecord(ctx->ev_busy, st) == hipSuccess) {
+            ctx->busy_stream = st;
+            ctx->busy_valid = true;
+        } else {
+            (void)hipDeviceSynchronize();  // no event to order the next call by: drain instead
+            ctx->busy_valid = false;
+        }
+    }
+};
+#define PHE_CTX_ORDER(ctx, stream)   \
+    CtxOrder order_(ctx, stream);    \
+    if (order_.rc) return order_.rc
 
 extern "C" {
 
@@ -720,14 +803,37 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
     if (!rc) rc = upload_split(ctx->pub.nsplit, ctx->d_nsplit);
     if (!rc && !getenv("PHE_HIP_NO_UNIT")) rc = upload_split(ctx->pub.nunit, ctx->d_nunit);
     if (!rc) rc = upload_schedule(ctx->pub.exp_n, ctx->d_exp_n);
-    if (!rc && ctx->pub.nsq.G && ctx->pub.nsq.G < 16 && !getenv("PHE_HIP_GROUP")) {
-        try {
-            ctx->pub_lat = host::build_public(n, n_limbs, 16);
-            rc = upload_modulus(ctx->pub_lat.nsq, ctx->d_nsq_lat);
-            if (!rc) rc = upload_split(ctx->pub_lat.nsplit, ctx->d_nsplit_lat);
-            ctx->has_lat_pub = (rc == PHE_HIP_OK);
-        } catch (const std::exception& ex) {
-            rc = fail(PHE_HIP_EINVAL, ex.what());
+    ctx->force_unit = getenv("PHE_HIP_FORCE_UNIT") != nullptr;
+    if (const char* e = getenv("PHE_HIP_FILL_PCT")) {
+        const int v = atoi(e);
+        if (v >= 10 && v <= 400) ctx->fill_pct = v;
+    }
+    if (!rc && !getenv("PHE_HIP_GROUP")) {
+        // the wider rungs of the ladder: 8- and 16-lane groups where they differ from what is already there
+        for (int prefer : {8, 16}) {
+            try {
+                phe_hip_ctx::PubRung R;
+                R.plan = host::build_public(n, n_limbs, prefer);
+                const auto same = [&](const host::PublicPlan& o) {
+                    return o.nsq.G == R.plan.nsq.G && o.nsq.L == R.plan.nsq.L && o.nsplit.G == R.plan.nsplit.G && o.nsplit.L == R.plan.nsplit.L;
+                };
+                bool have = same(ctx->pub);
+                for (const auto& o : ctx->pub_rungs) have = have || same(o.plan);
+                if (have) continue;
+                // a wider rung is worth having only if it shortens the product: rows x multiply-adds per row (H * L) must
+                // drop by a fifth at least (padding to the compiled limb counts can eat the whole gain)
+                const host::PublicPlan& prev = ctx->pub_rungs.empty() ? ctx->pub : ctx->pub_rungs.back().plan;
+                const auto chain = [&](const host::PublicPlan& o) {
+                    return (ctx->use_split && o.nsplit.G) ? o.nsplit.H * o.nsplit.L : o.nsq.S * o.nsq.L;
+                };
+                if (chain(R.plan) * 5 > chain(prev) * 4) continue;
+                rc = upload_modulus(R.plan.nsq, R.nsq);
+                if (!rc) rc = upload_split(R.plan.nsplit, R.nsplit);
+                if (rc) break;
+                ctx->pub_rungs.push_back(R);
+            } catch (const std::exception&) {
+                // no compiled kernel of that width covers this key: the ladder simply has no such rung
+            }
         }
     }
     return rc;
@@ -796,16 +902,31 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
     if (!rc) rc = upload_modulus(ctx->priv.qsq, ctx->d_qsq);
     if (!rc) rc = upload_split(ctx->priv.psplit, ctx->d_psplit);
     if (!rc) rc = upload_split(ctx->priv.qsplit, ctx->d_qsplit);
-    if (!rc && ctx->priv.psq.G < 16 && !getenv("PHE_HIP_GROUP")) {
-        try {
-            ctx->priv_lat = host::build_private(p, q, hp, hq, p_inverse, pq_limbs, n_limbs, 16);
-            rc = upload_modulus(ctx->priv_lat.psq, ctx->d_psq_lat);
-            if (!rc) rc = upload_modulus(ctx->priv_lat.qsq, ctx->d_qsq_lat);
-            if (!rc) rc = upload_split(ctx->priv_lat.psplit, ctx->d_psplit_lat);
-            if (!rc) rc = upload_split(ctx->priv_lat.qsplit, ctx->d_qsplit_lat);
-            ctx->has_lat_priv = (rc == PHE_HIP_OK);
-        } catch (const std::exception& ex) {
-            rc = fail(PHE_HIP_EINVAL, ex.what());
+    if (!rc && !getenv("PHE_HIP_GROUP")) {
+        for (int prefer : {4, 8, 16}) {
+            try {
+                phe_hip_ctx::PrivRung R;
+                R.plan = host::build_private(p, q, hp, hq, p_inverse, pq_limbs, n_limbs, prefer);
+                const auto same = [&](const host::PrivatePlan& o) {
+                    return o.psq.G == R.plan.psq.G && o.psq.L == R.plan.psq.L && o.psplit.G == R.plan.psplit.G &&
+                           o.psplit.L == R.plan.psplit.L && o.qsplit.G == R.plan.qsplit.G && o.qsplit.L == R.plan.qsplit.L;
+                };
+                bool have = same(ctx->priv);
+                for (const auto& o : ctx->priv_rungs) have = have || same(o.plan);
+                if (have) continue;
+                const host::PrivatePlan& prev = ctx->priv_rungs.empty() ? ctx->priv : ctx->priv_rungs.back().plan;
+                const auto chain = [&](const host::PrivatePlan& o) {
+                    return (ctx->use_split && o.qsplit.G) ? o.qsplit.H * o.qsplit.L : o.qsq.S * o.qsq.L;
+                };
+                if (chain(R.plan) * 5 > chain(prev) * 4) continue;  // see the public rungs
+                rc = upload_modulus(R.plan.psq, R.psq);
+                if (!rc) rc = upload_modulus(R.plan.qsq, R.qsq);
+                if (!rc) rc = upload_split(R.plan.psplit, R.psplit);
+                if (!rc) rc = upload_split(R.plan.qsplit, R.qsplit);
+                if (rc) break;
+                ctx->priv_rungs.push_back(R);
+            } catch (const std::exception&) {
+            }
         }
     }
     if (!rc) rc = upload_schedule(ctx->priv.exp_p, ctx->d_exp_p);
@@ -832,12 +953,12 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
 void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    uint32_t* bufs[] = {ctx->d_nsplit.blob, ctx->d_psplit.blob, ctx->d_qsplit.blob, ctx->d_nsplit_lat.blob,
-                        ctx->d_psplit_lat.blob, ctx->d_qsplit_lat.blob,
-                        ctx->d_nsq_lat.blob, ctx->d_psq_lat.blob, ctx->d_qsq_lat.blob,
+    std::vector<uint32_t*> bufs = {ctx->d_nsplit.blob, ctx->d_psplit.blob, ctx->d_qsplit.blob,
                         ctx->d_nsq.blob, ctx->d_psq.blob, ctx->d_qsq.blob, ctx->d_exp_n.ops, ctx->d_exp_p.ops,
                         ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->table2, ctx->scratch, ctx->partial, ctx->lookup, (uint32_t*)ctx->flags, ctx->stage[0],
                         ctx->stage[1], ctx->stage[2], ctx->owner_blob, ctx->d_nunit.blob, ctx->unit_tmp};
+    for (const auto& R : ctx->pub_rungs) { bufs.push_back(R.nsq.blob); bufs.push_back(R.nsplit.blob); }
+    for (const auto& R : ctx->priv_rungs) { bufs.push_back(R.psq.blob); bufs.push_back(R.qsq.blob); bufs.push_back(R.psplit.blob); bufs.push_back(R.qsplit.blob); }
     for (uint32_t* b : bufs)
         if (b) (void)hipFree(b);
     for (int k = 0; k < 2; ++k) {
@@ -852,6 +973,7 @@ void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
     hipStream_t pipes[3] = {ctx->pipe.s_in, ctx->pipe.s_comp, ctx->pipe.s_out};
     for (hipStream_t st : pipes)
         if (st) (void)hipStreamDestroy(st);
+    if (ctx->ev_busy) (void)hipEventDestroy(ctx->ev_busy);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
@@ -890,10 +1012,43 @@ int phe_hip_ctx_set_blocks_per_cu(phe_hip_ctx* ctx, int blocks_per_cu) {
     return PHE_HIP_OK;
 }
 
+int phe_hip_ctx_set_group(phe_hip_ctx* ctx, int group) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (group != 0 && group != 2 && group != 4 && group != 8 && group != 16) return fail(PHE_HIP_EINVAL, "group must be 0 (by batch size), 2, 4, 8 or 16");
+    ctx->force_group = group;
+    return PHE_HIP_OK;
+}
+
+int phe_hip_ctx_ladder(const phe_hip_ctx* ctx, int* pub_geoms, int* priv_geoms, int capacity, int* n_pub, int* n_priv) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    const bool sp_pub = ctx->use_split && ctx->pub.nsplit.G, sp_priv = ctx->use_split && ctx->priv.psplit.G;
+    int k = 0;
+    const auto put = [&](int* dst, int code) { if (dst && k < capacity) dst[k] = code; ++k; };
+    put(pub_geoms, sp_pub ? geom_code(ctx->pub.nsplit.G, ctx->pub.nsplit.L) : geom_code(ctx->pub.nsq.G, ctx->pub.nsq.L));
+    for (const auto& R : ctx->pub_rungs) put(pub_geoms, sp_pub ? geom_code(R.plan.nsplit.G, R.plan.nsplit.L) : geom_code(R.plan.nsq.G, R.plan.nsq.L));
+    if (n_pub) *n_pub = k;
+    k = 0;
+    if (ctx->has_private) {
+        put(priv_geoms, sp_priv ? geom_code(ctx->priv.psplit.G, ctx->priv.psplit.L) : geom_code(ctx->priv.psq.G, ctx->priv.psq.L));
+        for (const auto& R : ctx->priv_rungs) put(priv_geoms, sp_priv ? geom_code(R.plan.psplit.G, R.plan.psplit.L) : geom_code(R.plan.psq.G, R.plan.psq.L));
+    }
+    if (n_priv) *n_priv = k;
+    return PHE_HIP_OK;
+}
+
+int phe_hip_ctx_last_launch(const phe_hip_ctx* ctx, int* path, int* geom_pub, int* geom_priv) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (path) *path = ctx->last_path;
+    if (geom_pub) *geom_pub = ctx->last_geom_pub;
+    if (geom_priv) *geom_priv = ctx->last_geom_priv;
+    return PHE_HIP_OK;
+}
+
 // ---- device-pointer entry points -----------------------------------------------------------------
 // the bare power r^n through the scaled modulus (key_setup.h PublicPlan::nunit): throughput geometry only
 static bool unit_power_offered(const phe_hip_ctx* ctx, size_t batch) {
-    return ctx->use_split && ctx->d_nunit.G && ctx->d_nsq.G && !(ctx->has_lat_pub && small_batch(ctx, batch));
+    if (!(ctx->use_split && ctx->d_nunit.G && ctx->d_nsq.G)) return false;
+    return ctx->force_unit || pick_nsplit_rung(ctx, batch) == 0;
 }
 static int unit_power(phe_hip_ctx* ctx, const uint32_t* r, size_t batch, hipStream_t st) {
     const size_t w = (size_t)ctx->pub.unit_words;
@@ -908,7 +1063,11 @@ int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, 
     if (batch == 0) return PHE_HIP_OK;
     if (!m || !r || !c) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
+    ctx->last_path = 0;
     if (unit_power_offered(ctx, batch)) {
+        ctx->last_path = kPathUnit;
+        ctx->last_geom_pub = geom_code(ctx->d_nunit.G, ctx->d_nunit.L);
         // r^n modulo the scaled modulus n'^2 (no multiply per quotient digit), then ONE pass of the product kernel takes
         // the residue modulo n'^2 to (1 + n*m) * r^n mod n^2 (it accepts any a < R): the same canonical ciphertext
         int rc = unit_power(ctx, r, batch, (hipStream_t)stream);
@@ -917,11 +1076,15 @@ int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, 
         return launch_mul(ctx, ctx->d_nsq, ctx->unit_tmp, w, m, s1, c, s2, ctx->pub.s2, batch, (hipStream_t)stream, ctx->pub.s1, 0,
                           ctx->pub.unit_words);
     }
-    if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G)
+    if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G) {
+        ctx->last_geom_pub = geom_code(sp.G, sp.L);
         return launch_split<kModeEncrypt>(ctx, sp, ctx->d_exp_n, r, ctx->pub.s1, m, ctx->pub.s1, c, ctx->pub.s2, batch,
                                           (hipStream_t)stream);
-    return launch_uniform<kModeEncrypt>(ctx, pick_nsq(ctx, batch), ctx->d_exp_n, r, ctx->pub.s1, m, ctx->pub.s1, c, ctx->pub.s2,
-                                        batch, (hipStream_t)stream);
+    }
+    const DevModulus& fw = pick_nsq(ctx, batch);
+    ctx->last_geom_pub = geom_code(fw.G, fw.L);
+    return launch_uniform<kModeEncrypt>(ctx, fw, ctx->d_exp_n, r, ctx->pub.s1, m, ctx->pub.s1, c, ctx->pub.s2, batch,
+                                        (hipStream_t)stream);
 }
 
 // raw_encrypt by the holder of the private key: r^n mod n^2 from r^n mod p^2 and r^n mod q^2 (the half-exponentiation
@@ -933,7 +1096,10 @@ int phe_hip_encrypt_owner_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_
     if (batch == 0) return PHE_HIP_OK;
     if (!m || !r || !c) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
     hipStream_t st = (hipStream_t)stream;
+    ctx->last_path = kPathOwner;
+    ctx->last_geom_priv = geom_code(ctx->d_psplit.G, ctx->d_psplit.L);
     const int S = (std::max(ctx->priv.psq.bits, ctx->priv.qsq.bits) + 31) / 32;
     int rc = ensure_words(&ctx->scratch, &ctx->scratch_words, (size_t)2 * batch * S);
     if (rc) return rc;
@@ -978,7 +1144,11 @@ int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t
     if (batch == 0) return PHE_HIP_OK;
     if (!c_in || !r || !c_out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
+    ctx->last_path = 0;
     if (unit_power_offered(ctx, batch) && !getenv("PHE_HIP_FUSED_OBFUSCATE")) {
+        ctx->last_path = kPathUnit;
+        ctx->last_geom_pub = geom_code(ctx->d_nunit.G, ctx->d_nunit.L);
         // r^n modulo the scaled modulus, then the product with the ciphertext brings it to n^2 (in-place calls included:
         // the power sits in its own buffer)
         int rc = unit_power(ctx, r, batch, (hipStream_t)stream);
@@ -988,6 +1158,7 @@ int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t
                           ctx->pub.unit_words);
     }
     if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G) {
+        ctx->last_geom_pub = geom_code(sp.G, sp.L);
         if (c_in != c_out && !getenv("PHE_HIP_FUSED_OBFUSCATE")) {
             // r^n with the encrypt instantiation (no plaintext factor), then one k_mulmod by the ciphertext: the fused
             // kModeObfuscate instantiation spills more (PMC: 94 KB written per element against 20 KB,
@@ -998,6 +1169,7 @@ int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t
             const size_t s2 = (size_t)ctx->pub.s2;
             return launch_mul(ctx, pick_nsq(ctx, batch), c_out, s2, c_in, s2, c_out, s2, ctx->pub.s2, batch, (hipStream_t)stream);
         }
+        ctx->last_path = kPathFusedObfuscate;
         return launch_split<kModeObfuscate>(ctx, sp, ctx->d_exp_n, r, ctx->pub.s1, c_in, ctx->pub.s2, c_out, ctx->pub.s2,
                                             batch, (hipStream_t)stream);
     }
@@ -1011,6 +1183,7 @@ int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t
     if (batch == 0) return PHE_HIP_OK;
     if (!c || !m) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
     // x_p, x_q rows in 32-bit words; only their low h words are read by the tail
     const int S = (std::max(ctx->priv.psq.bits, ctx->priv.qsq.bits) + 31) / 32;
     int rc = ensure_words(&ctx->scratch, &ctx->scratch_words, (size_t)2 * batch * S);
@@ -1018,12 +1191,24 @@ int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t
     uint32_t* xp = ctx->scratch;
     uint32_t* xq = ctx->scratch + batch * (size_t)S;
     hipStream_t st = (hipStream_t)stream;
-    const bool lat = ctx->has_lat_priv && small_batch(ctx, batch);
-    const DevSplit& sp_p = lat ? ctx->d_psplit_lat : ctx->d_psplit;
-    const DevSplit& sp_q = lat ? ctx->d_qsplit_lat : ctx->d_qsplit;
-    if (lat && ctx->use_split && sp_p.G && sp_q.G) {
-        // a small batch cannot fill the GPU and each half is a chain of ~key_bits/2 dependent squarings: run the two
-        // halves side by side (the q half on an internal stream with its own window tables), join before the tail
+    // the rung of the halves: the two exponentiations are independent, so a batch that cannot fill the chip with one of them
+    // runs both side by side (the q half on an internal stream with its own window tables) and needs only half the lanes
+    const int n_rungs = 1 + (int)ctx->priv_rungs.size();
+    const auto psplit_of = [&](int k) -> const DevSplit& { return k == 0 ? ctx->d_psplit : ctx->priv_rungs[(size_t)k - 1].psplit; };
+    const auto qsplit_of = [&](int k) -> const DevSplit& { return k == 0 ? ctx->d_qsplit : ctx->priv_rungs[(size_t)k - 1].qsplit; };
+    const auto psq_of = [&](int k) -> const DevModulus& { return k == 0 ? ctx->d_psq : ctx->priv_rungs[(size_t)k - 1].psq; };
+    const auto qsq_of = [&](int k) -> const DevModulus& { return k == 0 ? ctx->d_qsq : ctx->priv_rungs[(size_t)k - 1].qsq; };
+    const bool split_ok = ctx->use_split && ctx->d_psplit.G && ctx->d_qsplit.G;
+    const auto width = [&](int k) { return split_ok ? psplit_of(k).G : psq_of(k).G; };
+    int rung = pick_rung(ctx, batch, n_rungs, width, split_ok ? 2 : 1);
+    if (split_ok && !(psplit_of(rung).G && qsplit_of(rung).G)) rung = 0;
+    const DevSplit& sp_p = psplit_of(rung);
+    const DevSplit& sp_q = qsplit_of(rung);
+    // side by side unless one half alone already gives every SIMD two waves
+    const bool side_by_side = split_ok && !fills_chip(ctx, batch, sp_p.G / 2 > 0 ? sp_p.G / 2 : 1);
+    ctx->last_geom_priv = split_ok ? geom_code(sp_p.G, sp_p.L) : geom_code(psq_of(rung).G, psq_of(rung).L);
+    ctx->last_path = side_by_side ? kPathSideBySide : 0;
+    if (side_by_side) {
         if (!ctx->aux_stream) {
             HIP_TRY(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
             HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -1039,17 +1224,15 @@ int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t
         if (rc) return rc;
         HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
     } else {
-        if (ctx->use_split && sp_p.G)
+        if (split_ok)
             rc = launch_split<kModeHalfDecrypt>(ctx, sp_p, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0, xp, S, batch, st);
         else
-            rc = launch_uniform<kModeHalfDecrypt>(ctx, lat ? ctx->d_psq_lat : ctx->d_psq, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0,
-                                                  xp, S, batch, st);
+            rc = launch_uniform<kModeHalfDecrypt>(ctx, psq_of(rung), ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0, xp, S, batch, st);
         if (rc) return rc;
-        if (ctx->use_split && sp_q.G)
+        if (split_ok)
             rc = launch_split<kModeHalfDecrypt>(ctx, sp_q, ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0, xq, S, batch, st);
         else
-            rc = launch_uniform<kModeHalfDecrypt>(ctx, lat ? ctx->d_qsq_lat : ctx->d_qsq, ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0,
-                                                  xq, S, batch, st);
+            rc = launch_uniform<kModeHalfDecrypt>(ctx, qsq_of(rung), ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0, xq, S, batch, st);
         if (rc) return rc;
     }
     TailArgs T;
@@ -1073,6 +1256,7 @@ int phe_hip_mulmod_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, u
     if (batch == 0) return PHE_HIP_OK;
     if (!a || !b || !out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
     const size_t s2 = (size_t)ctx->pub.s2;
     return launch_mul(ctx, pick_nsq(ctx, batch), a, s2, b, s2, out, s2, ctx->pub.s2, batch, (hipStream_t)stream);
 }
@@ -1083,6 +1267,7 @@ int phe_hip_montmul_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, 
     if (batch == 0) return PHE_HIP_OK;
     if (!a || !b || !out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
     const size_t s2 = (size_t)ctx->pub.s2;
     if (ctx->d_nsq.G == 0) return fail(PHE_HIP_EINVAL, "one-product form not available for this key width");
     // always the throughput geometry: R must not depend on the batch size
@@ -1102,8 +1287,115 @@ int phe_hip_add_plain_dev(phe_hip_ctx* ctx, const uint32_t* c, const uint32_t* m
     if (batch == 0) return PHE_HIP_OK;
     if (!c || !m || !out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
     const size_t s1 = (size_t)ctx->pub.s1, s2 = (size_t)ctx->pub.s2;
     return launch_mul(ctx, pick_nsq(ctx, batch), c, s2, m, s1, out, s2, ctx->pub.s2, batch, (hipStream_t)stream, ctx->pub.s1);
+}
+
+// ---- resident rows in the pair form (split_core.h "resident ciphertext rows") ----------------------------------------------
+// The rows are H | H limbs of rung 0's pair geometry; a wider rung with the same H can serve a small batch of them.
+static const DevSplit& pick_pair_split(const phe_hip_ctx* ctx, size_t batch) {
+    const int n_rungs = 1 + (int)ctx->pub_rungs.size();
+    const int k = pick_rung(ctx, batch, n_rungs, [&](int r) { return nsplit_rung(ctx, r).H == ctx->d_nsplit.H ? nsplit_rung(ctx, r).G : 0; });
+    const DevSplit& sp = nsplit_rung(ctx, k);
+    return sp.H == ctx->d_nsplit.H ? sp : ctx->d_nsplit;
+}
+static int pair_launch(phe_hip_ctx* ctx, int op, const uint32_t* a, const uint32_t* b, size_t b_stride, int b_limbs, uint32_t* out,
+                       size_t batch, hipStream_t st) {
+    if (!(ctx->use_split && ctx->d_nsplit.G)) return fail(PHE_HIP_EINVAL, "the pair form needs the split-modulus engine");
+    const DevSplit& sp = pick_pair_split(ctx, batch);
+    PairArgs A;
+    A.mod = sp.c;
+    A.a = a;
+    A.b = b;
+    A.out = out;
+    A.b_stride = b_stride;
+    A.limbs = ctx->pub.s2;
+    A.chunks = chunks_for(ctx->pub.s2, sp.H);
+    A.b_limbs = b_limbs;
+    A.batch = batch;
+    ctx->last_geom_pub = geom_code(sp.G, sp.L);
+    const int blocks = grid_blocks(ctx, batch, sp.G, 2);
+    if (PHE_SPLIT_BY_GROUP(sp.G, launch_pair(sp.L, op, blocks, st, A)) < 0) return fail(PHE_HIP_EINVAL, "unsupported split geometry");
+    HIP_TRY(hipGetLastError());
+    return PHE_HIP_OK;
+}
+
+int phe_hip_pair_words(const phe_hip_ctx* ctx, int* words) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (!words) return fail(PHE_HIP_EINVAL, "null pointer");
+    if (!(ctx->use_split && ctx->d_nsplit.G)) return fail(PHE_HIP_EINVAL, "the pair form needs the split-modulus engine");
+    *words = 2 * ctx->d_nsplit.H;
+    return PHE_HIP_OK;
+}
+
+int phe_hip_to_pair_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* pair, size_t batch, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!c || !pair) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
+    return pair_launch(ctx, 0, c, nullptr, 0, 0, pair, batch, (hipStream_t)stream);
+}
+
+int phe_hip_from_pair_dev(phe_hip_ctx* ctx, const uint32_t* pair, const uint32_t* m, uint32_t* c, size_t batch, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!c || !pair) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
+    return pair_launch(ctx, 1, pair, m, 0, ctx->pub.s1, c, batch, (hipStream_t)stream);
+}
+
+int phe_hip_pair_mul_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, int b_is_row, uint32_t* out, size_t batch,
+                         void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!a || !b || !out) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
+    return pair_launch(ctx, 2, a, b, b_is_row ? 0 : (size_t)2 * ctx->d_nsplit.H, 0, out, batch, (hipStream_t)stream);
+}
+
+// out = the product of all `batch` pair rows (one pair row): the pairwise tree of EncryptedVector.sum() — sum(enc_list) in the
+// reference is a left-to-right chain of _raw_add (phe/paillier.py:705-719); the product of residues does not depend on the
+// order — as log2(batch) launches queued back to back, no host round trip between the levels.
+int phe_hip_pair_reduce_dev(phe_hip_ctx* ctx, const uint32_t* pair, size_t batch, uint32_t* out, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (!pair || !out || batch == 0) return fail(PHE_HIP_EINVAL, "null buffer / empty vector");
+    if (int rc = bind_device(ctx)) return rc;
+    if (!(ctx->use_split && ctx->d_nsplit.G)) return fail(PHE_HIP_EINVAL, "the pair form needs the split-modulus engine");
+    PHE_CTX_ORDER(ctx, stream);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t w = (size_t)2 * ctx->d_nsplit.H;
+    if (batch == 1) {
+        HIP_TRY(hipMemcpyAsync(out, pair, w * 4, hipMemcpyDeviceToDevice, st));
+        return PHE_HIP_OK;
+    }
+    size_t cur = batch / 2;  // rows after the first level (+ the unpaired row, if any)
+    int rc = ensure_words(&ctx->partial, &ctx->partial_words, (cur + 1) * w);
+    if (rc) return rc;
+    uint32_t* P = ctx->partial;
+    rc = pair_launch(ctx, 2, pair, pair + cur * w, w, 0, P, cur, st);
+    if (rc) return rc;
+    if (batch & 1) {
+        HIP_TRY(hipMemcpyAsync(P + cur * w, pair + (batch - 1) * w, w * 4, hipMemcpyDeviceToDevice, st));
+        ++cur;
+    }
+    while (cur > 1) {
+        const size_t half = cur / 2;
+        // in place: every limb group reads its two rows before it writes row i, and row i is nobody else's operand
+        rc = pair_launch(ctx, 2, P, P + half * w, w, 0, P, half, st);
+        if (rc) return rc;
+        if (cur & 1) {
+            HIP_TRY(hipMemcpyAsync(P + half * w, P + (cur - 1) * w, w * 4, hipMemcpyDeviceToDevice, st));
+            cur = half + 1;
+        } else {
+            cur = half;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(out, P, w * 4, hipMemcpyDeviceToDevice, st));
+    return PHE_HIP_OK;
 }
 
 int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, int max_exp_bits,
@@ -1113,6 +1405,7 @@ int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e
     if (!base || !e || !out || exp_limbs < 1) return fail(PHE_HIP_EINVAL, "null buffer / exp_limbs");
     if (max_exp_bits <= 0 || max_exp_bits > 32 * exp_limbs) max_exp_bits = 32 * exp_limbs;
     if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
     if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G)
         return launch_var_split(ctx, sp, base, ctx->pub.s2, e, exp_limbs, max_exp_bits, out, ctx->pub.s2, batch,
                                 (hipStream_t)stream);
@@ -1197,6 +1490,7 @@ int phe_hip_multiexp_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t*
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
     if (!out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
     return multiexp_rows_impl(ctx, base, nullptr, e, nullptr, exp_limbs, max_exp_bits, out, batch, 1, (hipStream_t)stream);
 }
 
@@ -1206,6 +1500,7 @@ int phe_hip_multiexp_rows_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
     if (!out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
     return multiexp_rows_impl(ctx, base, base_inv, e, neg, exp_limbs, max_exp_bits, out, batch, rows, (hipStream_t)stream);
 }
 
@@ -1223,6 +1518,7 @@ int phe_hip_multiexp_csr_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint3
     if (neg && !base_inv) return fail(PHE_HIP_EINVAL, "a sign mask needs the inverted bases");
     if (max_exp_bits <= 0 || max_exp_bits > 32 * exp_limbs) max_exp_bits = 32 * exp_limbs;
     if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
     if (!(ctx->use_split && ctx->d_nsplit.G))
         return fail(PHE_HIP_EINVAL, "the table form needs the split-modulus engine (call phe_hip_multiexp_dev row by row on this key)");
     hipStream_t st = (hipStream_t)stream;
@@ -1232,7 +1528,7 @@ int phe_hip_multiexp_csr_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint3
         // one geometry for both kernels (the table rows are H = G*L limbs of that geometry); the ladders are the bulk of
         // the work and their parallelism is `rows`: 16-lane groups (half the time per product) until the rows alone
         // fill the throughput geometry's resident groups halfway
-        const DevSplit& M = (ctx->has_lat_pub && rows <= (size_t)ctx->n_cus * 64) ? ctx->d_nsplit_lat : ctx->d_nsplit;
+        const DevSplit& M = pick_nsplit(ctx, rows);
         int rc = ensure_words(&ctx->lookup, &ctx->lookup_words, batch * signs * per * 2 * (size_t)M.H);
         if (rc) return rc;
         SplitTableArgs T;
@@ -1295,6 +1591,7 @@ static int stage_in(phe_hip_ctx* ctx, int slot, const uint32_t* host_ptr, size_t
 // before the first kernel starts), long middle chunks (each launch ends with a drain bubble: fewer launches), a short last
 // one (little to download after the last kernel ends).
 static const size_t kPipeEdgeRows = 65536, kPipeChunkRows = 131072;  // (decrypt keeps 65536 groups resident: an edge of 32768 rows would run at half occupancy)
+static const size_t kPipeChunkBytes = (size_t)64 << 20;  // cap of one staging buffer: wide keys take proportionally fewer rows per chunk
 
 static int pipe_setup(phe_hip_ctx* ctx) {
     auto& P = ctx->pipe;
@@ -1329,24 +1626,33 @@ static int run_pipelined(phe_hip_ctx* ctx, const uint32_t* in0, size_t w0, const
                          size_t wo, size_t batch, Launch launch) {
     if (int rc = pipe_setup(ctx)) return rc;
     auto& P = ctx->pipe;
+    // rows per chunk: the usual sizes, fewer when the rows are wide (a staging buffer stays below kPipeChunkBytes)
+    const size_t row_bytes = 4 * std::max(std::max(w0, w1), wo);
+    size_t chunk_rows = kPipeChunkRows, edge_rows = kPipeEdgeRows;
+    while (chunk_rows > 8192 && chunk_rows * row_bytes > kPipeChunkBytes) {
+        chunk_rows /= 2;
+        edge_rows = std::max<size_t>(edge_rows / 2, 4096);
+    }
     // chunk boundaries: edge | full chunks ... | edge
     std::vector<size_t> lo;
+    size_t widest = 0;
     {
         size_t at = 0;
         lo.push_back(0);
-        at = std::min(batch, kPipeEdgeRows);
+        at = std::min(batch, edge_rows);
         while (at < batch) {
             lo.push_back(at);
             const size_t left = batch - at;
-            at += (left > kPipeChunkRows + kPipeEdgeRows) ? kPipeChunkRows : (left > kPipeEdgeRows ? left - kPipeEdgeRows : left);
+            at += (left > chunk_rows + edge_rows) ? chunk_rows : (left > edge_rows ? left - edge_rows : left);
         }
         lo.push_back(batch);
+        for (size_t k = 0; k + 1 < lo.size(); ++k) widest = std::max(widest, lo[k + 1] - lo[k]);
     }
     const size_t n_chunks = lo.size() - 1;
     for (int slot = 0; slot < 2; ++slot) {
-        int rc = pipe_buffers(ctx, slot, 0, kPipeChunkRows * w0);
-        if (!rc && in1) rc = pipe_buffers(ctx, slot, 1, kPipeChunkRows * w1);
-        if (!rc) rc = pipe_buffers(ctx, slot, 2, kPipeChunkRows * wo);
+        int rc = pipe_buffers(ctx, slot, 0, widest * w0);
+        if (!rc && in1) rc = pipe_buffers(ctx, slot, 1, widest * w1);
+        if (!rc) rc = pipe_buffers(ctx, slot, 2, widest * wo);
         if (rc) return rc;
     }
     auto rows_of = [&](size_t k) { return lo[k + 1] - lo[k]; };
@@ -1356,7 +1662,9 @@ static int run_pipelined(phe_hip_ctx* ctx, const uint32_t* in0, size_t w0, const
         memcpy(out + lo[k] * wo, P.pin[slot][2], rows_of(k) * wo * 4);
         return PHE_HIP_OK;
     };
-    for (size_t k = 0; k < n_chunks; ++k) {
+    // one chunk through the three streams; a failure leaves copies / kernels of earlier chunks in flight on the pinned and
+    // device slots, so the streams are drained below before the error is reported
+    auto step = [&](size_t k) -> int {
         const int slot = (int)(k & 1);
         const size_t rows = rows_of(k);
         if (k >= 2)
@@ -1374,13 +1682,51 @@ static int run_pipelined(phe_hip_ctx* ctx, const uint32_t* in0, size_t w0, const
         HIP_TRY(hipStreamWaitEvent(P.s_out, P.ev_comp[slot], 0));
         HIP_TRY(hipMemcpyAsync(P.pin[slot][2], P.dev[slot][2], rows * wo * 4, hipMemcpyDeviceToHost, P.s_out));
         HIP_TRY(hipEventRecord(P.ev_out[slot], P.s_out));
+        return PHE_HIP_OK;
+    };
+    int rc = PHE_HIP_OK;
+    for (size_t k = 0; k < n_chunks && !rc; ++k) rc = step(k);
+    for (size_t k = (n_chunks >= 2 ? n_chunks - 2 : 0); k < n_chunks && !rc; ++k) rc = drain(k);
+    if (rc) {
+        const std::string msg = g_err;  // the first error is the one to report
+        (void)hipStreamSynchronize(P.s_in);
+        (void)hipStreamSynchronize(P.s_comp);
+        (void)hipStreamSynchronize(P.s_out);
+        g_err = msg;
+        return rc;
     }
-    for (size_t k = (n_chunks >= 2 ? n_chunks - 2 : 0); k < n_chunks; ++k)
-        if (int rc = drain(k)) return rc;
+    ctx->last_path |= kPathPipelined;
     return PHE_HIP_OK;
 }
 }  // extern "C++"
 static bool pipelined_batch(size_t batch) { return batch >= 2 * kPipeEdgeRows && !getenv("PHE_HIP_NO_PIPELINE"); }
+
+// Give the grow-only buffers of a context back (window tables, intermediates, the staging of the host-pointer entry points
+// and the pinned chunk buffers of their pipeline): after a one-off large batch a long-lived context need not keep GiBs.
+// Synchronises the device; the next call allocates what it needs again.
+int phe_hip_ctx_release_scratch(phe_hip_ctx* ctx) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (int rc = bind_device(ctx)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    uint32_t** bufs[] = {&ctx->table, &ctx->table2, &ctx->scratch, &ctx->partial, &ctx->lookup, &ctx->unit_tmp,
+                         &ctx->stage[0], &ctx->stage[1], &ctx->stage[2]};
+    size_t* sizes[] = {&ctx->table_words, &ctx->table2_words, &ctx->scratch_words, &ctx->partial_words, &ctx->lookup_words,
+                       &ctx->unit_tmp_words, &ctx->stage_words[0], &ctx->stage_words[1], &ctx->stage_words[2]};
+    for (int i = 0; i < 9; ++i) {
+        if (*bufs[i]) HIP_TRY(hipFree(*bufs[i]));
+        *bufs[i] = nullptr;
+        *sizes[i] = 0;
+    }
+    for (int k = 0; k < 2; ++k)
+        for (int j = 0; j < 3; ++j) {
+            if (ctx->pipe.pin[k][j]) HIP_TRY(hipHostFree(ctx->pipe.pin[k][j]));
+            if (ctx->pipe.dev[k][j]) HIP_TRY(hipFree(ctx->pipe.dev[k][j]));
+            ctx->pipe.pin[k][j] = ctx->pipe.dev[k][j] = nullptr;
+            ctx->pipe.pin_words[k][j] = ctx->pipe.dev_words[k][j] = 0;
+        }
+    return PHE_HIP_OK;
+}
+
 
 int phe_hip_encrypt(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch) {
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
@@ -1630,6 +1976,7 @@ int phe_hip_invert_dev(phe_hip_ctx* ctx, const uint32_t* a, uint32_t* out, size_
     if (batch == 0) return PHE_HIP_OK;
     if (!a || !out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
     return invert_impl(ctx, a, true, out, true, batch, bad_index, (hipStream_t)stream);
 }
 
@@ -1664,6 +2011,7 @@ int phe_hip_to_decimal_dev(phe_hip_ctx* ctx, const uint32_t* limbs, int words, c
     if (!limbs || !digits || words < 1 || width < 1) return fail(PHE_HIP_EINVAL, "null buffer / words / width");
     if (phe::radix::tile_bytes(words) > kMaxRadixTile) return fail(PHE_HIP_EINVAL, "number too wide for the conversion tile");
     if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
     hipStream_t st = (hipStream_t)stream;
     if (int rc = radix_flags(ctx, st)) return rc;
     if (phe::radix::launch_to_decimal(limbs, words, digits, width, batch, ctx->flags, ctx->n_cus * 8, st) < 0)
@@ -1683,6 +2031,7 @@ int phe_hip_from_decimal_dev(phe_hip_ctx* ctx, const char* digits, int width, ui
     if (!limbs || !digits || words < 1 || width < 1) return fail(PHE_HIP_EINVAL, "null buffer / words / width");
     if (phe::radix::tile_bytes(words) > kMaxRadixTile) return fail(PHE_HIP_EINVAL, "number too wide for the conversion tile");
     if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
     hipStream_t st = (hipStream_t)stream;
     if (int rc = radix_flags(ctx, st)) return rc;
     if (phe::radix::launch_from_decimal(digits, width, limbs, words, batch, ctx->flags, ctx->flags + 1, ctx->n_cus * 8, st) < 0)

@@ -635,6 +635,103 @@ PHE_DEV void mulmod_split_body(const SplitMulArgs& A, uint32_t* lds_row, uint32_
     }
 }
 
+// ---- resident ciphertext rows in the pair form ("the engine's own format") ---------------------------------------------
+// A device-resident ciphertext vector that is only multiplied (chains of EncryptedNumber.__add__ = _raw_add,
+// phe/paillier.py:705-719; sum() trees; the obfuscators r^n made ahead of time) need not go through 32-bit words between
+// two steps: a row is kept as (X0 | X1), 2H almost-normalised 29-bit limbs in global limb order — 144 words for a 2048-bit
+// key's 128-word ciphertext.  A homomorphic addition on such rows is ONE pair product (5*H^2 multiply-adds; the full-width
+// form costs two Montgomery products = 16*H^2, its one-product "debt" form 8*H^2) with no slicing of words into limbs, no
+// carry look-ahead and no conditional subtraction, and the pair form of a product IS the product's pair form: nothing to
+// settle.  to_pair_body / from_pair_body convert at the boundary (split_conv / split_exit, the very routines every
+// exponentiation enters and leaves by), so what reaches the caller is the same canonical residue as ever.
+struct PairArgs {
+    SplitConsts mod;
+    const uint32_t* a;    // to_pair: (batch, limbs) 32-bit-word rows;  from_pair / pair_mul: (batch, 2H) pair rows
+    const uint32_t* b;    // pair_mul: pair rows, b_stride words apart (0: one row for the whole batch);
+                          // from_pair: plaintexts (batch, b_limbs) to fold in as 1 + n*m, or nullptr
+    uint32_t* out;        // to_pair / pair_mul: (batch, 2H) pair rows;  from_pair: (batch, limbs) 32-bit-word rows
+    size_t b_stride;
+    int limbs;            // 32-bit words of a ciphertext row
+    int chunks;           // ceil(32*limbs / (29 H))
+    int b_limbs;
+    uint64_t batch;
+};
+
+template <int G, int L>
+PHE_DEV void to_pair_body(const PairArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots, uint32_t lane) {
+    constexpr int H = G * L, S2 = 2 * H;
+    const Lanes<G> ln(lane);
+    const uint32_t g = ln.g;
+    SplitLane<G, L> K;
+    load_row<L>(K.n, A.mod.n, g);
+    K.n0inv = A.mod.n0inv;
+    K.row_a = lds_row;
+    K.row_c = lds_row + H;
+    const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
+    for (uint64_t it = 0; it < n_iter; ++it) {
+        uint64_t item = slot + it * (uint64_t)total_slots;
+        const bool live = item < A.batch;
+        if (!live) item = A.batch - 1;
+        uint32_t X0[L], X1[L];
+        split_conv<G, L>(X0, X1, A.a + item * (uint64_t)A.limbs, A.limbs, A.chunks, A.mod, K, ln);
+        if (live) {
+            store_row<L>(A.out + item * (uint64_t)S2, X0, g);
+            store_row<L>(A.out + item * (uint64_t)S2 + H, X1, g);
+        }
+    }
+}
+
+template <int G, int L>
+PHE_DEV void from_pair_body(const PairArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots, uint32_t lane) {
+    constexpr int H = G * L, S2 = 2 * H;
+    const Lanes<G> ln(lane);
+    const uint32_t g = ln.g;
+    SplitLane<G, L> K;
+    load_row<L>(K.n, A.mod.n, g);
+    K.n0inv = A.mod.n0inv;
+    K.row_a = lds_row;
+    K.row_c = lds_row + H;
+    const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
+    for (uint64_t it = 0; it < n_iter; ++it) {
+        uint64_t item = slot + it * (uint64_t)total_slots;
+        const bool live = item < A.batch;
+        if (!live) item = A.batch - 1;
+        uint32_t X0[L], X1[L];
+        load_row<L>(X0, A.a + item * (uint64_t)S2, g);
+        load_row<L>(X1, A.a + item * (uint64_t)S2 + H, g);
+        const uint32_t* mp = A.b ? A.b + item * (uint64_t)A.b_limbs : nullptr;
+        split_exit<G, L>(A.out + item * (uint64_t)A.limbs, A.limbs, X0, X1, mp, A.b_limbs, A.mod, K, ln, live);
+    }
+}
+
+template <int G, int L>
+PHE_DEV void pair_mul_body(const PairArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots, uint32_t lane) {
+    constexpr int H = G * L, S2 = 2 * H;
+    const Lanes<G> ln(lane);
+    const uint32_t g = ln.g;
+    SplitLane<G, L> K;
+    load_row<L>(K.n, A.mod.n, g);
+    K.n0inv = A.mod.n0inv;
+    K.row_a = lds_row;
+    K.row_c = lds_row + H;
+    const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
+    for (uint64_t it = 0; it < n_iter; ++it) {
+        uint64_t item = slot + it * (uint64_t)total_slots;
+        const bool live = item < A.batch;
+        if (!live) item = A.batch - 1;
+        uint32_t X0[L], X1[L], Y0[L], Y1[L];
+        load_row<L>(X0, A.a + item * (uint64_t)S2, g);
+        load_row<L>(X1, A.a + item * (uint64_t)S2 + H, g);
+        load_row<L>(Y0, A.b + item * A.b_stride, g);
+        load_row<L>(Y1, A.b + item * A.b_stride + H, g);
+        split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
+        if (live) {
+            store_row<L>(A.out + item * (uint64_t)S2, X0, g);
+            store_row<L>(A.out + item * (uint64_t)S2 + H, X1, g);
+        }
+    }
+}
+
 // Encryption by the key owner: r^n mod n^2 from its two CRT halves (phe/paillier.py:137 obfuscator = powmod(r, n, nsquare)
 // is one exponentiation modulo n^2; whoever holds p and q can take it modulo p^2 and modulo q^2 — half-width numbers, a
 // quarter of the multiply-adds each — and lift).  With y_p = r^n mod p^2, y_q = r^n mod q^2 (canonical, from the

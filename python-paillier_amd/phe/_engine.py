@@ -99,6 +99,46 @@ def random_lt_n_limbs(n, count, limbs, out=None):
         out[rows] = fresh
 
 
+class ObfuscatorPool:
+    """Obfuscators r^n mod n^2 made ahead of time, each handed out ONCE (two ciphertexts sharing one reveal m1 - m2).
+    The pool is an object of its own with its own lock because it outlives the engine it was filled through: when a key
+    pair's private engine takes over from the public one (keys.PaillierPrivateKey._get_engine) both engines hold the SAME
+    pool, so a thread still inside the old engine and a thread inside the new one cannot be handed the same rows.
+    blocks: [DeviceArray, rows already used]; form: "pair" (rows in the engine's pair form) or "u32"."""
+
+    def __init__(self):
+        self.lock = threading.RLock()
+        self.blocks = []
+
+    def available(self):
+        with self.lock:
+            return sum(b.rows - used for b, used in self.blocks)
+
+    def add(self, block):
+        with self.lock:
+            self.blocks.append([block, 0])
+
+    def clear(self):
+        with self.lock:
+            self.blocks = []
+
+    def take(self, count):
+        """views of `count` unused rows (a list of DeviceArray views), or None if the pool is short; consumed"""
+        with self.lock:
+            if count <= 0 or sum(b.rows - used for b, used in self.blocks) < count:
+                return None
+            parts, need = [], count
+            while need:
+                block, used = self.blocks[0]
+                k = min(need, block.rows - used)
+                parts.append(block.rows_view(used, used + k))
+                self.blocks[0][1] = used + k
+                need -= k
+                if self.blocks[0][1] == block.rows:
+                    self.blocks.pop(0)
+            return parts
+
+
 # Every public Engine method runs under the engine's re-entrant lock (see _native.serialised).  A key's engine owns
 # shared state: the obfuscator pool, whose entries must never be handed out twice (two ciphertexts sharing r^n reveal
 # m1 - m2), the host staging buffers, the native context's window tables and launch stream.
@@ -113,6 +153,7 @@ class Engine:
         self.ctx = _native.Context(n, p, q, hp, hq, p_inverse, device=self.device)
         self.n_limbs = self.ctx.n_limbs
         self.ct_limbs = self.ctx.ct_limbs
+        self._obf = ObfuscatorPool()
 
     # ---- reusable host staging (a fresh 32 MB numpy buffer costs more in page faults than the kernel it feeds) ---
     def scratch(self, name, rows, cols):
@@ -508,43 +549,110 @@ class Engine:
     # and exponentiates at encryption time).  A pool of them, each used ONCE, turns the online part of encrypt_batch /
     # obfuscate into one product per element: c = (1 + n m) * r^n — the same value raw_encrypt(m, r) returns for that r.
     def fill_obfuscator_pool(self, count):
-        """draw `count` fresh r in [1, n) and keep r^n mod n^2 in HBM (raw_encrypt of the plaintext 0: 1 + n*0 = 1)"""
+        """draw `count` fresh r in [1, n) and keep r^n mod n^2 in HBM (raw_encrypt of the plaintext 0: 1 + n*0 = 1) — as
+        rows of the engine's pair form where it has one: the online part of an encryption is then one exit from that form
+        with the plaintext folded in (Engine.encrypt_from_obfuscators)"""
         if count <= 0:
             return self.obfuscators_available()
         zeros = np.zeros((count, self.n_limbs), dtype=np.uint32)
         block = self.raw_encrypt_fresh(zeros, device=True)
-        self.__dict__.setdefault("_obf_pool", []).append([block, 0])
+        if self.pair_form():
+            block = self.to_pair_dev(block)
+        self._obf.add(block)
         return self.obfuscators_available()
 
     def clear_obfuscator_pool(self):
         """drop the obfuscators made ahead of time (nothing was handed out twice; the unused ones are simply forgotten)"""
-        self.__dict__["_obf_pool"] = []
+        self._obf.clear()
 
     def obfuscators_available(self):
-        return sum(b.rows - used for b, used in self.__dict__.get("_obf_pool", []))
+        return self._obf.available()
 
-    def take_obfuscators(self, count):
-        """`count` unused obfuscators as one DeviceArray (views where possible), or None if the pool is short;
-        they are consumed: nothing is handed out twice"""
-        pool = self.__dict__.get("_obf_pool", [])
-        if count <= 0 or self.obfuscators_available() < count:
+    def _take_pool_rows(self, count):
+        """`count` unused pool rows as ONE DeviceArray in the pool's form (a view where possible), or None; consumed"""
+        parts = self._obf.take(count)
+        if parts is None:
             return None
-        parts, need = [], count
-        while need:
-            block, used = pool[0]
-            k = min(need, block.rows - used)
-            parts.append(block.rows_view(used, used + k))
-            pool[0][1] = used + k
-            need -= k
-            if pool[0][1] == block.rows:
-                pool.pop(0)
         if len(parts) == 1:
             return parts[0]
-        out = DeviceArray(self.ctx, count, self.ct_limbs)
+        out = DeviceArray(self.ctx, count, parts[0].cols)
         lo = 0
         for part in parts:
-            self.ctx.d2d(out.ptr + lo * self.ct_limbs * 4, part.ptr, part.nbytes)
+            self.ctx.d2d(out.ptr + lo * part.cols * 4, part.ptr, part.nbytes)
             lo += part.rows
+        self.ctx.sync()
+        return out
+
+    def take_obfuscators(self, count):
+        """`count` unused obfuscators r^n mod n^2 as plain ciphertext rows (DeviceArray of ct_limbs words), or None if
+        the pool is short; they are consumed: nothing is handed out twice"""
+        rows = self._take_pool_rows(count)
+        if rows is None or rows.cols == self.ct_limbs:
+            return rows
+        return self.from_pair_dev(rows)
+
+    def encrypt_from_obfuscators(self, plaintexts):
+        """raw_encrypt(m_i, r_i) for pooled r_i (each used once): (1 + n*m_i) * r_i^n mod n^2 as a DeviceArray, or None
+        if the pool is short.  plaintexts: (count, n_limbs) limb rows or Python ints."""
+        if not isinstance(plaintexts, np.ndarray):
+            plaintexts = self.plain_limbs([v % self.n for v in plaintexts])
+        rows = self._take_pool_rows(plaintexts.shape[0])
+        if rows is None:
+            return None
+        if rows.cols == self.ct_limbs:
+            return self.add_plain_dev(rows, plaintexts)
+        return self.from_pair_dev(rows, plaintexts)
+
+    def peek_obfuscators(self, count):
+        """the next `count` unused obfuscators r^n mod n^2 as Python ints, WITHOUT consuming them (tests, diagnostics)"""
+        out = []
+        with self._obf.lock:
+            for block, used in self._obf.blocks:
+                k = min(count - len(out), block.rows - used)
+                if k <= 0:
+                    break
+                view = block.rows_view(used, used + k)
+                if view.cols != self.ct_limbs:
+                    view = self.from_pair_dev(view)
+                out += self.to_ints(view.to_host())
+        return out
+
+    # ---- resident rows in the pair form (include/phe_hip.h "pair form") ---------------------------------------------------
+    def pair_form(self):
+        """words of a pair-form row (0: not offered — no split-modulus engine, an emulated backend, PHE_HIP_PAIR_FORM=0)"""
+        w = self.__dict__.get("_pair_words")
+        if w is None:
+            probe = getattr(self.ctx, "pair_words", None)
+            w = self._pair_words = int(probe()) if probe and os.environ.get("PHE_HIP_PAIR_FORM", "1") != "0" else 0
+        return w
+
+    def to_pair_dev(self, c):
+        out = DeviceArray(self.ctx, c.rows, self.pair_form())
+        self.ctx.to_pair_dev(c.ptr, out.ptr, c.rows)
+        self.ctx.sync()
+        return out
+
+    def from_pair_dev(self, pair, plaintexts=None):
+        """pair rows -> canonical ciphertext rows; with plaintexts (limb rows / DeviceArray) the residue of x * (1 + n*m)"""
+        m = None
+        if plaintexts is not None:
+            m = plaintexts if isinstance(plaintexts, DeviceArray) else self.upload_plain(plaintexts)
+        out = DeviceArray(self.ctx, pair.rows, self.ct_limbs)
+        self.ctx.from_pair_dev(pair.ptr, m.ptr if m is not None else None, out.ptr, pair.rows)
+        self.ctx.sync()
+        return out
+
+    def pair_mul_dev(self, a, b):
+        """row-wise product of two pair-form vectors (b with one row: that row for every a): one homomorphic addition"""
+        out = DeviceArray(self.ctx, a.rows, a.cols)
+        self.ctx.pair_mul_dev(a.ptr, b.ptr, b.rows == 1 and a.rows != 1, out.ptr, a.rows)
+        self.ctx.sync()
+        return out
+
+    def pair_reduce_dev(self, pair):
+        """the product of all rows of a pair-form vector as one pair row (the tree of EncryptedVector.sum, one call)"""
+        out = DeviceArray(self.ctx, 1, pair.cols)
+        self.ctx.pair_reduce_dev(pair.ptr, pair.rows, out.ptr)
         self.ctx.sync()
         return out
 
@@ -595,25 +703,31 @@ class Engine:
     def raw_decrypt_dev_chunks(self, c, chunk=1 << 16):
         """raw_decrypt of a resident vector as a generator of (lo, hi, plaintext limbs on the host): while the caller
         works on one chunk (download + decoding), the kernels of the next one run — they are queued on the engine's
-        non-blocking stream right after the finished chunk is awaited, and the blocking download does not wait for them."""
-        st = self._launch_stream()
+        non-blocking stream right after the finished chunk is awaited, and the blocking download does not wait for them.
+        (A generator: the engine's lock is taken around each step, never across a yield — see _native.serialised.)"""
+        with self._lock:
+            st = self._launch_stream()
         rows = c.rows
         if rows <= chunk or not st:
             if rows:
                 yield 0, rows, self.raw_decrypt_dev(c)
             return
-        out = DeviceArray(self.ctx, rows, self.n_limbs)
+        with self._lock:
+            out = DeviceArray(self.ctx, rows, self.n_limbs)
 
         def launch(lo):
             hi = min(rows, lo + chunk)
             self.ctx.decrypt_dev(c.rows_view(lo, hi).ptr, out.rows_view(lo, hi).ptr, hi - lo, st)
             return hi
         try:
-            lo, hi = 0, launch(0)
+            with self._lock:
+                lo, hi = 0, launch(0)
             while lo < rows:
-                self.ctx.sync(st)                               # chunk [lo, hi) is complete
-                nxt = launch(hi) if hi < rows else hi
-                yield lo, hi, out.rows_view(lo, hi).to_host()
+                with self._lock:
+                    self.ctx.sync(st)                           # chunk [lo, hi) is complete
+                    nxt = launch(hi) if hi < rows else hi
+                    host = out.rows_view(lo, hi).to_host()      # blocking copy on the NULL stream, under the next kernels
+                yield lo, hi, host
                 lo, hi = hi, nxt
         finally:
             # a consumer that stops early (e.g. OverflowError while decoding a row) drops the generator with the next
@@ -624,7 +738,8 @@ class Engine:
         """raw_decrypt_dev_chunks for a HOST limb array: the upload of chunk k+1 and the download + decoding of chunk k
         both happen while kernels run (uploads and downloads are blocking copies on the NULL stream, the kernels are
         queued on the engine's non-blocking stream)."""
-        st = self._launch_stream()
+        with self._lock:
+            st = self._launch_stream()
         rows = c.shape[0]
         if rows <= chunk or not st:
             if rows:
@@ -642,16 +757,19 @@ class Engine:
             lo, hi = bounds[k]
             self.ctx.decrypt_dev(inputs[k].ptr, outputs[k].ptr, hi - lo, st)
         try:
-            stage(0)
-            launch(0)
+            with self._lock:
+                stage(0)
+                launch(0)
             for k, (lo, hi) in enumerate(bounds):
-                if k + 1 < len(bounds):
-                    stage(k + 1)                                 # upload under the kernels of chunk k
-                self.ctx.sync(st)                                # chunk k is complete
-                if k + 1 < len(bounds):
-                    launch(k + 1)
-                yield lo, hi, outputs.pop(k).to_host()           # download + the caller's decoding under chunk k+1
-                inputs.pop(k)
+                with self._lock:
+                    if k + 1 < len(bounds):
+                        stage(k + 1)                             # upload under the kernels of chunk k
+                    self.ctx.sync(st)                            # chunk k is complete
+                    if k + 1 < len(bounds):
+                        launch(k + 1)
+                    host = outputs.pop(k).to_host()              # download under chunk k+1
+                    inputs.pop(k)
+                yield lo, hi, host                               # the caller decodes under chunk k+1
         finally:
             self.ctx.sync(st)                                    # see raw_decrypt_dev_chunks: nothing in flight on release
 

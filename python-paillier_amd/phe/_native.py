@@ -89,6 +89,15 @@ def lib():
         L.phe_hip_allgather_dev.argtypes = [vp, vp, vp, sz, ci, vp]
         L.phe_hip_comm_destroy.argtypes = [vp]
         L.phe_hip_comm_destroy.restype = None
+        L.phe_hip_ctx_ladder.argtypes = [vp, vp, vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
+        L.phe_hip_ctx_set_group.argtypes = [vp, ci]
+        L.phe_hip_ctx_last_launch.argtypes = [vp] + [ctypes.POINTER(ci)] * 3
+        L.phe_hip_ctx_release_scratch.argtypes = [vp]
+        L.phe_hip_pair_words.argtypes = [vp, ctypes.POINTER(ci)]
+        L.phe_hip_to_pair_dev.argtypes = [vp, vp, vp, sz, vp]
+        L.phe_hip_pair_mul_dev.argtypes = [vp, vp, vp, ci, vp, sz, vp]
+        L.phe_hip_from_pair_dev.argtypes = [vp, vp, vp, vp, sz, vp]
+        L.phe_hip_pair_reduce_dev.argtypes = [vp, vp, sz, vp, vp]
         _lib = L
     return _lib
 
@@ -106,6 +115,8 @@ EXPORTED_SYMBOLS = [
     "phe_hip_stream_destroy", "phe_hip_miller_rabin", "phe_hip_montmul_dev", "phe_hip_mont_radix_bits",
     "phe_hip_comm_unique_id", "phe_hip_comm_create", "phe_hip_allgather_dev", "phe_hip_comm_destroy",
     "phe_hip_encrypt_owner", "phe_hip_encrypt_owner_dev", "phe_hip_ctx_owner_encrypt",
+    "phe_hip_ctx_ladder", "phe_hip_ctx_set_group", "phe_hip_ctx_last_launch", "phe_hip_ctx_release_scratch",
+    "phe_hip_pair_words", "phe_hip_to_pair_dev", "phe_hip_pair_mul_dev", "phe_hip_from_pair_dev", "phe_hip_pair_reduce_dev",
 ]
 
 
@@ -181,24 +192,23 @@ def serialised(cls):
     """Class decorator: every public method runs under the instance's re-entrant lock `self._lock`.  ctypes drops the
     GIL inside each native call and a native context (its window tables, launch streams, the size-keyed block pool)
     is not thread-safe, while the reference's functions are stateless and callable from any thread — so calls on one
-    key are serialised here instead of being left to the caller."""
+    key are serialised here instead of being left to the caller.
+
+    Generator methods are left alone: a lock held across `yield` would block every other thread on the key while the
+    consumer works on a chunk, and would be orphaned if the generator were finalised on another thread.  They take
+    `self._lock` around each of their own steps instead (every native call they make is locked by the Context anyway, and
+    the library keeps one stream order per context, so work another thread slips in between two steps cannot race on the
+    context's scratch)."""
     for name, fn in list(vars(cls).items()):
-        if name.startswith("_") or not inspect.isfunction(fn):
+        if name.startswith("_") or not inspect.isfunction(fn) or inspect.isgeneratorfunction(fn):
             continue
-        if inspect.isgeneratorfunction(fn):
-            def wrap(fn):
-                @functools.wraps(fn)
-                def locked_gen(self, *a, **kw):
-                    with self._lock:                      # held until the generator is exhausted, closed or collected
-                        yield from fn(self, *a, **kw)
-                return locked_gen
-        else:
-            def wrap(fn):
-                @functools.wraps(fn)
-                def locked(self, *a, **kw):
-                    with self._lock:
-                        return fn(self, *a, **kw)
-                return locked
+
+        def wrap(fn):
+            @functools.wraps(fn)
+            def locked(self, *a, **kw):
+                with self._lock:
+                    return fn(self, *a, **kw)
+            return locked
         setattr(cls, name, wrap(fn))
     return cls
 
@@ -251,6 +261,48 @@ class Context:
 
     def set_blocks_per_cu(self, k):
         _check(lib().phe_hip_ctx_set_blocks_per_cu(self._h, int(k)))
+
+    def ladder(self):
+        """the geometry ladder: ([G*100 + L, ...] of the n-side kernels, the same for the p/q side), narrowest groups first"""
+        cap = 8
+        pub, priv = (ctypes.c_int * cap)(), (ctypes.c_int * cap)()
+        n_pub, n_priv = ctypes.c_int(0), ctypes.c_int(0)
+        _check(lib().phe_hip_ctx_ladder(self._h, pub, priv, cap, ctypes.byref(n_pub), ctypes.byref(n_priv)))
+        return list(pub[:min(cap, n_pub.value)]), list(priv[:min(cap, n_priv.value)])
+
+    def set_group(self, group):
+        """0: the rung is picked from the batch size; G: always the rung of G-lane limb groups (tests, measurements)"""
+        _check(lib().phe_hip_ctx_set_group(self._h, int(group)))
+
+    PATH_UNIT, PATH_OWNER, PATH_SIDE_BY_SIDE, PATH_PIPELINED, PATH_FUSED_OBFUSCATE = 1, 2, 4, 8, 16
+
+    def last_launch(self):
+        """what the last encrypt / obfuscate / decrypt / pair call took: {"path": PATH_* bits, "geom_pub", "geom_priv"}"""
+        v = [ctypes.c_int(0) for _ in range(3)]
+        _check(lib().phe_hip_ctx_last_launch(self._h, *[ctypes.byref(x) for x in v]))
+        return {"path": v[0].value, "geom_pub": v[1].value, "geom_priv": v[2].value}
+
+    def release_scratch(self):
+        _check(lib().phe_hip_ctx_release_scratch(self._h))
+
+    # ---- resident rows in the pair form (include/phe_hip.h "pair form") ----
+    def pair_words(self):
+        """words of a pair-form row, or 0 when the context has no split-modulus engine"""
+        w = ctypes.c_int(0)
+        rc = lib().phe_hip_pair_words(self._h, ctypes.byref(w))
+        return w.value if rc == OK else 0
+
+    def to_pair_dev(self, c_ptr, pair_ptr, batch, stream=0):
+        _check(lib().phe_hip_to_pair_dev(self._h, c_ptr, pair_ptr, batch, stream))
+
+    def pair_mul_dev(self, a_ptr, b_ptr, b_is_row, out_ptr, batch, stream=0):
+        _check(lib().phe_hip_pair_mul_dev(self._h, a_ptr, b_ptr, 1 if b_is_row else 0, out_ptr, batch, stream))
+
+    def from_pair_dev(self, pair_ptr, m_ptr, c_ptr, batch, stream=0):
+        _check(lib().phe_hip_from_pair_dev(self._h, pair_ptr, m_ptr, c_ptr, batch, stream))
+
+    def pair_reduce_dev(self, pair_ptr, batch, out_ptr, stream=0):
+        _check(lib().phe_hip_pair_reduce_dev(self._h, pair_ptr, batch, out_ptr, stream))
 
     # ---- host-array entry points (numpy uint32, row-major (batch, limbs)) ----
     def encrypt(self, m, r):

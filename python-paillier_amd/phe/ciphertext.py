@@ -151,13 +151,19 @@ class EncryptedVector(object):
     host numpy array or a device-resident DeviceArray (`device=True` / `.to_device()`), in which case every
     operation below runs on HBM-resident operands and only plaintext-sized data crosses PCIe."""
 
-    def __init__(self, public_key, limbs, exponents, obfuscated=False, _debt=0):
+    def __init__(self, public_key, limbs, exponents, obfuscated=False, _debt=0, _pair=False):
         self.public_key = public_key
         self.on_device = isinstance(limbs, DeviceArray)
         self._store = limbs if self.on_device else np.ascontiguousarray(limbs, dtype=np.uint32)
-        # resident vectors only: the rows hold x * R^-debt mod n^2 (Engine "Montgomery debt": chains of additions at one
-        # Montgomery product each); anything that looks at `_limbs` settles the debt first, so the lazy form never leaves
+        # resident vectors only, two lazy forms of the rows; anything that looks at `_limbs` converts back first, so neither
+        # ever leaves the vector:
+        #   _debt: the rows hold x * R^-debt mod n^2 (Engine "Montgomery debt": a chain of additions on rows of 32-bit
+        #          words costs one full-width Montgomery product per addition, the powers of R are settled at the end);
+        #   _pair: the rows are in the engine's pair form (include/phe_hip.h "pair form": what the exponentiation kernels
+        #          compute in) — an addition is ONE half-width pair product, nothing to settle, no word/limb conversion
+        #          between two steps.  Entered by to_pair() and inherited by the results of `+` and sum().
         self._debt = int(_debt) if self.on_device else 0
+        self._pair = bool(_pair) and self.on_device
         self._exps = np.array(exponents if isinstance(exponents, np.ndarray) else list(exponents), dtype=np.int64).reshape(-1)
         shape = self._store.shape
         if len(shape) != 2 or shape[0] != len(self._exps):
@@ -167,14 +173,31 @@ class EncryptedVector(object):
 
     @property
     def _limbs(self):
-        if self._debt:
+        if self._pair:
+            self._store = self.public_key._get_engine().from_pair_dev(self._store)
+            self._pair = False
+        elif self._debt:
             self._store = self.public_key._get_engine().scale_dev(self._store, self._debt)
             self._debt = 0
         return self._store
 
     @_limbs.setter
     def _limbs(self, value):
-        self._store, self._debt = value, 0
+        self._store, self._debt, self._pair = value, 0, False
+
+    def to_pair(self):
+        """This vector, resident, with its rows in the engine's pair form (a no-op without the split-modulus engine): worth
+        it for rows that will be added to several times — `+` between two resident vectors then costs one pair product, and
+        sum() one call.  Everything else (download, decrypt, `*`, obfuscate, indexing) converts back by itself."""
+        vec = self if self.on_device else self.to_device()
+        eng = self.public_key._get_engine()
+        if vec._pair or not eng.pair_form():
+            return vec
+        return EncryptedVector(self.public_key, eng.to_pair_dev(vec._limbs), vec._exps, vec._obfuscated.copy(), _pair=True)
+
+    def _pair_store(self):
+        """the rows in pair form (converted if need be; the vector itself is left as it is)"""
+        return self._store if self._pair else self.public_key._get_engine().to_pair_dev(self._limbs)
 
     @property
     def exponents(self):
@@ -292,11 +315,14 @@ class EncryptedVector(object):
             pooled = None
             if self.on_device and len(rows) == len(self):
                 from . import keys
-                pooled = eng.take_obfuscators(len(self))
+                take = eng._take_pool_rows if (self._pair and eng.pair_form()) else eng.take_obfuscators
+                pooled = take(len(self))
                 if pooled is None and len(self) <= keys.SCALAR_POOL_REFILL // 4:
                     eng.fill_obfuscator_pool(keys.SCALAR_POOL_REFILL)
-                    pooled = eng.take_obfuscators(len(self))
-            if pooled is not None:
+                    pooled = take(len(self))
+            if pooled is not None and self._pair and pooled.cols == self._store.cols:
+                self._store = eng.pair_mul_dev(self._store, pooled)      # both in pair form: one pair product, stays there
+            elif pooled is not None:
                 self._limbs = eng.raw_add_dev(self._limbs, pooled)       # c * r^n with r^n made ahead of time, used once
             elif self.on_device:
                 self._limbs = eng.obfuscate_fresh_dev(self._limbs, None if len(rows) == len(self) else rows)
@@ -340,8 +366,8 @@ class EncryptedVector(object):
         rows = np.nonzero(new < old)[0]
         flags = self._obfuscated.copy()
         if len(rows) == 0:
-            if self.on_device:                                # same rows, same debt: nothing to settle
-                return EncryptedVector(self.public_key, self._store, new, flags, _debt=self._debt)
+            if self.on_device:                                # same rows, same lazy form: nothing to convert
+                return EncryptedVector(self.public_key, self._store, new, flags, _debt=self._debt, _pair=self._pair)
             return self._like(self._limbs.copy(), new, flags)
         pk = self.public_key
         delta = (old - new)[rows]
@@ -396,6 +422,9 @@ class EncryptedVector(object):
             a, target = self._aligned(other._exps)
             b = other.decrease_exponent_to(target)
             eng = pk._get_engine()
+            if self.on_device and (a._pair or b._pair) and eng.pair_form():
+                # one pair product (the operand that is not in pair form yet is converted: it pays once, the sum stays)
+                return EncryptedVector(pk, eng.pair_mul_dev(a._pair_store(), b._pair_store()), target, _pair=True)
             if self.on_device and eng.lazy_products():
                 # one Montgomery product; the missing powers of R are settled when the residues are looked at
                 return EncryptedVector(pk, eng.montmul_dev(a._store, b._store), target, _debt=a._debt + b._debt + 1)
@@ -489,6 +518,10 @@ class EncryptedVector(object):
         pk = self.public_key
         eng = pk._get_engine()
         cur = self.decrease_exponent_to(int(self._exps.min()))
+        if self.on_device and cur._pair and eng.pair_form():
+            # rows already in pair form: the whole pairwise tree is one call (log2 launches queued back to back), one exit
+            root = eng.from_pair_dev(eng.pair_reduce_dev(cur._store))
+            return EncryptedNumber(pk, eng.to_ints(root.to_host())[0], int(cur._exps[0]))
         if self.on_device and eng.lazy_products():
             # the pairwise tree at ONE Montgomery product per node: a level turns rows of debt d into rows of debt 2d + 1
             # (an odd row out is taken to the same debt by a product with a constant); settled once, at the root

@@ -7,6 +7,7 @@ Key generation and the once-per-key constants (p_inverse, hp, hq) are cold, host
 (out of the hot path); everything per-ciphertext runs on the GPU.
 """
 import random
+import threading
 
 try:
     from collections.abc import Mapping
@@ -70,12 +71,18 @@ class PaillierPublicKey(object):
         self.nsquare = n * n
         self.max_int = n // 3 - 1
         self._engine = None
+        self._engine_lock = threading.Lock()
 
-    # one GPU context per key, created on first use (a private key shares its context with its public key)
+    # one GPU context per key, created on first use (a private key shares its context with its public key); the creation
+    # is guarded so that two threads never build two contexts — and two obfuscator pools — for one key
     def _get_engine(self):
-        if self._engine is None:
-            self._engine = Engine(self.n)
-        return self._engine
+        eng = self._engine
+        if eng is None:
+            with self._engine_lock:
+                if self._engine is None:
+                    self._engine = Engine(self.n)
+                eng = self._engine
+        return eng
 
     def __repr__(self):
         return "<PaillierPublicKey {}>".format(hex(hash(self))[2:][:10])
@@ -112,22 +119,21 @@ class PaillierPublicKey(object):
             # fresh obfuscator: one fused launch (1 + n*m) * r^n, flagged obfuscated like
             # encrypt_encoded + obfuscate() in the reference (phe/paillier.py:189-193)
             eng = self._get_engine()
-            obf = None
             if hasattr(eng.ctx, "encrypt_dev"):
-                obf = eng.take_obfuscators(1)
-                if obf is None and SCALAR_POOL_REFILL:
-                    # one scalar encryption is one latency-bound exponentiation on an otherwise idle GPU: draw and
-                    # exponentiate a launch-full of obfuscators in the same ~time and keep the rest for the next calls
-                    eng.fill_obfuscator_pool(SCALAR_POOL_REFILL)
-                    obf = eng.take_obfuscators(1)
-            if obf is not None:
-                # an obfuscator made ahead of time (precompute_obfuscators), used once: r^n * (1 + n m), one small launch
+                # an obfuscator r^n made ahead of time (precompute_obfuscators), used once: r^n * (1 + n m), one small
+                # launch.  One scalar encryption is one latency-bound exponentiation on an otherwise idle GPU: when the
+                # pool is dry, draw and exponentiate a launch-full of obfuscators in the same ~time and keep the rest
                 if not isinstance(encoding.encoding, int):
                     raise TypeError('Expected int type plaintext but got: %s' % type(encoding.encoding))
-                limbs = eng.add_plain_dev(obf, eng.plain_limbs([encoding.encoding % self.n]))
-                number = EncryptedNumber(self, eng.to_ints(limbs.to_host())[0], encoding.exponent)
-                number._EncryptedNumber__is_obfuscated = True
-                return number
+                plain = eng.plain_limbs([encoding.encoding % self.n])
+                limbs = eng.encrypt_from_obfuscators(plain)
+                if limbs is None and SCALAR_POOL_REFILL:
+                    eng.fill_obfuscator_pool(SCALAR_POOL_REFILL)
+                    limbs = eng.encrypt_from_obfuscators(plain)
+                if limbs is not None:
+                    number = EncryptedNumber(self, eng.to_ints(limbs.to_host())[0], encoding.exponent)
+                    number._EncryptedNumber__is_obfuscated = True
+                    return number
             c = self.raw_encrypt(encoding.encoding, self.get_random_lt_n())
             number = EncryptedNumber(self, c, encoding.exponent)
             number._EncryptedNumber__is_obfuscated = True
@@ -176,15 +182,14 @@ class PaillierPublicKey(object):
         else:
             m, exps = EncodedNumber.encode_many(self, values, precision)
         count = len(exps)
-        obf = None
+        limbs = None
         if fresh and isinstance(m, np.ndarray) and hasattr(eng.ctx, "encrypt_dev"):
-            obf = eng.take_obfuscators(count)
-            if obf is None and 0 < count <= SCALAR_POOL_REFILL // 4:
-                eng.fill_obfuscator_pool(SCALAR_POOL_REFILL)       # a small batch is as latency-bound as a scalar call
-                obf = eng.take_obfuscators(count)
-        if obf is not None:
             # online part only: (1 + n m) * r^n with r^n from the pool made by precompute_obfuscators (each used once)
-            limbs = eng.add_plain_dev(obf, m)
+            limbs = eng.encrypt_from_obfuscators(m)
+            if limbs is None and 0 < count <= SCALAR_POOL_REFILL // 4:
+                eng.fill_obfuscator_pool(SCALAR_POOL_REFILL)       # a small batch is as latency-bound as a scalar call
+                limbs = eng.encrypt_from_obfuscators(m)
+        if limbs is not None:
             if not device:
                 limbs = limbs.to_host()
         elif fresh and isinstance(m, np.ndarray) and hasattr(eng.ctx, "encrypt_dev"):
@@ -216,6 +221,7 @@ class PaillierPrivateKey(object):
             self.hp = self.h_function(self.p, self.psquare)
             self.hq = self.h_function(self.q, self.qsquare)
         self._engine = None
+        self._engine_lock = threading.Lock()
 
     @staticmethod
     def from_totient(public_key, totient):
@@ -228,17 +234,25 @@ class PaillierPrivateKey(object):
         return PaillierPrivateKey(public_key, p, q)
 
     def _get_engine(self):
-        if self._engine is None:
-            self._engine = Engine(self.public_key.n, self.p, self.q, self.hp, self.hq, self.p_inverse)
-            # the public key of a key pair works through the private key's engine from here on: one GPU context per key
-            # pair, and encryptions under it take the key owner's CRT form (Engine.owner_encrypt: same ciphertext bits,
-            # about half the work).  Obfuscators made ahead of time move over (device pointers are valid across contexts).
-            old = self.public_key._engine
-            if old is not None and old is not self._engine:
-                self._engine.__dict__.setdefault("_obf_pool", []).extend(old.__dict__.get("_obf_pool", []))
-                old.__dict__["_obf_pool"] = []
-            self.public_key._engine = self._engine
-        return self._engine
+        eng = self._engine
+        if eng is not None:
+            return eng
+        with self._engine_lock:
+            if self._engine is None:
+                fresh = Engine(self.public_key.n, self.p, self.q, self.hp, self.hq, self.p_inverse)
+                # The public key of a key pair works through the private key's engine from here on: one GPU context per key
+                # pair, and encryptions under it take the key owner's CRT form (Engine.owner_encrypt: same ciphertext bits,
+                # about half the work).  Obfuscators made ahead of time stay where they are: the new engine adopts the old
+                # engine's pool OBJECT (device pointers are valid across contexts), so a thread that is still inside the old
+                # engine and a thread inside the new one take rows under the same lock — nothing is handed out twice.
+                pub = self.public_key
+                with pub._engine_lock:
+                    old = pub._engine
+                    if old is not None and old is not fresh:
+                        fresh._obf = old._obf
+                    pub._engine = fresh
+                self._engine = fresh
+            return self._engine
 
     def __repr__(self):
         return "<PaillierPrivateKey for {}>".format(repr(self.public_key))

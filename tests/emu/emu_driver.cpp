@@ -29,6 +29,7 @@ static thread_local std::string g_err;
         case 1601: { constexpr int GG = 16, LL = 1; CALL; break; }                    \
         case 1602: { constexpr int GG = 16, LL = 2; CALL; break; }                    \
         case 1603: { constexpr int GG = 16, LL = 3; CALL; break; }                    \
+        case 1604: { constexpr int GG = 16, LL = 4; CALL; break; }                    \
         case 1605: { constexpr int GG = 16, LL = 5; CALL; break; }                    \
         case 1607: { constexpr int GG = 16, LL = 7; CALL; break; }                    \
         case 1609: { constexpr int GG = 16, LL = 9; CALL; break; }                    \
@@ -148,6 +149,7 @@ static void run_mul(MulArgs A) {
         case 1601: { constexpr int GG = 16, LL = 1; CALL; break; }                    \
         case 1602: { constexpr int GG = 16, LL = 2; CALL; break; }                    \
         case 1603: { constexpr int GG = 16, LL = 3; CALL; break; }                    \
+        case 1604: { constexpr int GG = 16, LL = 4; CALL; break; }                    \
         case 1605: { constexpr int GG = 16, LL = 5; CALL; break; }                    \
         case 1607: { constexpr int GG = 16, LL = 7; CALL; break; }                    \
         case 1609: { constexpr int GG = 16, LL = 9; CALL; break; }                    \
@@ -160,6 +162,7 @@ static void run_mul(MulArgs A) {
         case 409: { constexpr int GG = 4, LL = 9; CALL; break; }                      \
         case 414: { constexpr int GG = 4, LL = 14; CALL; break; }                     \
         case 418: { constexpr int GG = 4, LL = 18; CALL; break; }                     \
+        case 805: { constexpr int GG = 8, LL = 5; CALL; break; }                      \
         case 807: { constexpr int GG = 8, LL = 7; CALL; break; }                      \
         case 809: { constexpr int GG = 8, LL = 9; CALL; break; }                      \
         case 814: { constexpr int GG = 8, LL = 14; CALL; break; }                     \
@@ -293,6 +296,24 @@ static void run_crt_lift(CrtLiftArgs A) {
         wave::run_wave([&](uint32_t lane) {
             const uint32_t grp = lane / G;
             crt_lift_body<G, L>(A, lds.data() + grp * (S2 + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
+        });
+    }
+}
+
+// resident rows in the pair form (split_core.h): op 0 words -> pair, 1 pair -> words (* (1 + n*m) when plaintexts are given), 2 pair * pair
+template <int G, int L>
+static void run_pair(int op, PairArgs A) {
+    constexpr int S2 = 2 * G * L, kPer = 64 / G;
+    const int n_waves = waves_for(A.batch, G);
+    const uint32_t total = (uint32_t)(kPer * n_waves);
+    for (int w = 0; w < n_waves; ++w) {
+        std::vector<uint32_t> lds(kPer * (S2 + kLdsPad));
+        wave::run_wave([&](uint32_t lane) {
+            const uint32_t grp = lane / G;
+            uint32_t* row = lds.data() + grp * (S2 + kLdsPad);
+            if (op == 0) to_pair_body<G, L>(A, row, (uint32_t)w * kPer + grp, total, lane);
+            else if (op == 1) from_pair_body<G, L>(A, row, (uint32_t)w * kPer + grp, total, lane);
+            else pair_mul_body<G, L>(A, row, (uint32_t)w * kPer + grp, total, lane);
         });
     }
 }
@@ -627,6 +648,34 @@ int emu_split_pair_op(int G, int L, const uint32_t* n, int n_limbs, int op, cons
                 }
             });
         }));
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// the pair-form entry points (phe_hip_to_pair_dev / from_pair_dev / pair_mul_dev).  The rows are those of the geometry that
+// build_public picks WITHOUT a group preference (rung 0 of the library); `group` > 0 runs them on a wider geometry with the
+// same H, as the library's ladder does for small batches.  *pair_words = 2H.  rc 2: no split geometry / no such rung.
+int emu_pair_op(const uint32_t* n, int n_limbs, int op, int group, const uint32_t* a, const uint32_t* b, int b_is_row,
+                uint32_t* out, uint64_t B, int* pair_words) {
+    try {
+        const host::PublicPlan P0 = host::build_public(n, n_limbs, 0);
+        if (!P0.nsplit.G) return 2;
+        if (pair_words) *pair_words = 2 * P0.nsplit.H;
+        if (B == 0) return 0;
+        host::SplitPack M = P0.nsplit;
+        if (group > 0) {
+            M = host::build_public(n, n_limbs, group).nsplit;
+            if (M.G == 0 || M.H != P0.nsplit.H) return 2;
+        }
+        PairArgs A;
+        memset(&A, 0, sizeof A);
+        A.mod = split_consts_of(M);
+        A.a = a; A.b = b; A.out = out;
+        A.limbs = P0.s2; A.chunks = chunks_for(P0.s2, M.H);
+        A.b_stride = (op == 2 && !b_is_row) ? (size_t)(2 * M.H) : 0;
+        A.b_limbs = (op == 1 && b) ? P0.s1 : 0;
+        A.batch = B;
+        DISPATCH_SPLIT(M.G, M.L, (run_pair<GG, LL>(op, A)));
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }

@@ -105,6 +105,31 @@ class Emu:
         self._ck(self.L.emu_split_pair_op(G, L, P(n), len(n), op, P(X), Yp, P(out), out_limbs))
         return out
 
+    def pair_words(self, n):
+        w = ctypes.c_int(0)
+        rc = self.L.emu_pair_op(P(n), n.shape[0], 0, 0, None, None, 0, None, ctypes.c_uint64(0), ctypes.byref(w))
+        return 0 if rc == 2 else w.value
+
+    def pair_op(self, n, op, a, b=None, b_is_row=False, group=0):
+        """the pair-form entry points: op 0 words -> pair, 1 pair -> words (b: plaintext rows or None), 2 pair * pair.
+        group > 0: on the wider rung of that group width (None if it does not share the rows' limb count)."""
+        w = ctypes.c_int(0)
+        rc = self.L.emu_pair_op(P(n), n.shape[0], 0, 0, None, None, 0, None, ctypes.c_uint64(0), ctypes.byref(w))
+        if rc == 2:
+            return None
+        self._ck(rc)
+        cols = 2 * n.shape[0] if op == 1 else w.value
+        a = np.ascontiguousarray(a, np.uint32)
+        out = np.zeros((a.shape[0], cols), np.uint32)
+        if b is not None:
+            b = np.ascontiguousarray(b, np.uint32)
+        rc = self.L.emu_pair_op(P(n), n.shape[0], op, group, P(a), P(b) if b is not None else None, 1 if b_is_row else 0,
+                                P(out), ctypes.c_uint64(a.shape[0]), None)
+        if rc == 2:
+            return None
+        self._ck(rc)
+        return out
+
     def powmod_n2(self, n, base, exps):
         """base^exp mod n^2 the way phe_hip_powmod runs it (split-modulus kernel when the engine is on)"""
         out = np.zeros_like(base)

@@ -475,7 +475,7 @@ def test_obfuscator_pool_offline_online_split():
     assert pub.obfuscators_available() == 0
     assert pub.precompute_obfuscators(3000) == 3000
     eng = pub._get_engine()
-    first = _native.limbs_to_ints(eng._obf_pool[0][0].rows_view(0, 4).to_host())
+    first = eng.peek_obfuscators(4)
     assert all(1 < f < nsq for f in first) and len(set(first)) == 4
     vec = pub.encrypt_batch(vals[:1000], device=True)
     assert pub.obfuscators_available() == 2000 and all(vec._obfuscated) and vec.on_device
@@ -495,7 +495,7 @@ def test_obfuscator_pool_offline_online_split():
     pub.precompute_obfuscators(3)
     eng = pub._get_engine()                # the key pair's engine by now (the private key's; the pool moved over with it)
     assert eng is priv._get_engine()
-    peek = _native.limbs_to_ints(eng._obf_pool[0][0].rows_view(0, 1).to_host())[0]
+    peek = eng.peek_obfuscators(1)[0]
     one = pub.encrypt(2.5)                                                 # scalar API: obfuscate() takes from the pool too
     nude = pub.encrypt(2.5, r_value=1)
     assert pub.obfuscators_available() == 2 and one.ciphertext(False) == nude.ciphertext(False) * peek % nsq
@@ -597,6 +597,8 @@ def test_obfuscator_pool_is_handed_out_once_across_threads():
     from phe import _engine
 
     class Block:
+        cols = 8
+
         def __init__(self, lo, hi):
             self.lo, self.hi, self.rows = lo, hi, hi - lo
 
@@ -605,7 +607,9 @@ def test_obfuscator_pool_is_handed_out_once_across_threads():
 
     eng = _engine.Engine.__new__(_engine.Engine)
     eng._lock = threading.RLock()
-    eng._obf_pool = [[Block(0, 20000), 0]]
+    eng.ct_limbs = Block.cols
+    eng._obf = _engine.ObfuscatorPool()
+    eng._obf.add(Block(0, 20000))
     taken, barrier = [[] for _ in range(8)], threading.Barrier(8)
 
     def worker(k):
@@ -620,6 +624,73 @@ def test_obfuscator_pool_is_handed_out_once_across_threads():
     [t.join() for t in threads]
     flat = sorted(x for part in taken for x in part)
     assert flat == list(range(20000))
+
+
+def test_pool_survives_the_private_engine_taking_over_under_concurrent_takers(monkeypatch):
+    """pub.encrypt() in some threads while another thread creates the key pair's private engine
+    for the first time.  The private engine adopts the public engine's pool OBJECT (one lock), and the creation of an
+    engine is guarded: every pooled row is handed out exactly once, each key builds exactly one engine.  Host logic only:
+    the engine's native context is a stand-in."""
+    import threading
+    import time
+    from phe import _engine, keys
+
+    class Block:
+        cols = 8
+
+        def __init__(self, lo, hi):
+            self.lo, self.hi, self.rows = lo, hi, hi - lo
+
+        def rows_view(self, lo, hi):
+            return Block(self.lo + lo, self.lo + hi)
+
+    built = []
+
+    class StubEngine(_engine.Engine):
+        def __init__(self, n, p=None, *rest, **kw):          # no native context: only what the pool logic touches
+            time.sleep(0.02)                                  # a slow context creation widens the window
+            self._lock = threading.RLock()
+            self.n, self.ct_limbs = n, Block.cols
+            self._obf = _engine.ObfuscatorPool()
+            built.append("priv" if p is not None else "pub")
+
+    monkeypatch.setattr(keys, "Engine", StubEngine)
+    g = load_golden(256)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    total = 40000
+    first = [None] * 4
+    gate = threading.Barrier(4)
+
+    def make(k):
+        gate.wait()
+        first[k] = pub._get_engine()
+    ts = [threading.Thread(target=make, args=(k,)) for k in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert built == ["pub"] and all(e is first[0] for e in first)          # one engine although four threads asked at once
+    first[0]._obf.add(Block(0, total))
+    taken, start = [[] for _ in range(6)], threading.Barrier(7)
+
+    def taker(k):
+        start.wait()
+        while True:
+            part = pub._get_engine().take_obfuscators(1)          # whichever engine the key points at right now
+            if part is None:
+                return
+            taken[k].append(part.lo)
+
+    def owner():
+        start.wait()
+        time.sleep(0.005)
+        priv._get_engine()
+    ts = [threading.Thread(target=taker, args=(k,)) for k in range(6)] + [threading.Thread(target=owner)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert built == ["pub", "priv"]
+    assert pub._get_engine() is priv._get_engine() and pub._get_engine()._obf is first[0]._obf
+    flat = sorted(x for part in taken for x in part)
+    assert flat == list(range(total))                                       # nothing lost, nothing handed out twice
 
 
 def test_public_key_of_a_key_pair_encrypts_through_the_owner_path(backend):

@@ -1,0 +1,390 @@
+"""GPU tests of round 3 (run with -m gpu on an MI355X), all through the C-ABI:
+  * the geometry ladder: every rung gives the golden bits, and the rung is picked from the batch size;
+  * the paths that only large batches / key owners take (scaled modulus, CRT form of raw_encrypt) on the golden edge
+    plaintexts m in {n-1, n, n+1, max_int +- 1} unreduced (phe/paillier.py:134, phe/tests/paillier_test.py:114-126),
+    with the path that ran asserted through phe_hip_ctx_last_launch;
+  * one stream order per context;
+  * resident rows in the pair form (phe_hip_to_pair_dev / pair_mul_dev / from_pair_dev / pair_reduce_dev);
+  * the ctypes stub of INTEGRATION.md section B, extracted from the document and executed.
+Nothing here reads /root/reference."""
+import os
+import random
+import re
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import PKG, ROOT, load_golden
+
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+pytestmark = pytest.mark.gpu
+
+
+def H(x):
+    return int(x, 16)
+
+
+@pytest.fixture(scope="module")
+def native():
+    from phe import _native
+    assert _native.device_count() >= 1
+    return _native
+
+
+def make_ctx(native, g, private=True):
+    if private:
+        return native.Context(H(g["n"]), H(g["p"]), H(g["q"]), H(g["hp"]), H(g["hq"]), H(g["p_inverse"]),
+                              n_limbs=g["key_bits"] // 32)
+    return native.Context(H(g["n"]), n_limbs=g["key_bits"] // 32)
+
+
+def golden_hot_path(native, ctx, g):
+    """encrypt / decrypt / obfuscate / powmod of the fixture through ctx; returns what last_launch said after each"""
+    key_bits = g["key_bits"]
+    s1, s2 = key_bits // 32, key_bits // 16
+    L = native.ints_to_limbs
+    seen = {}
+    enc = g["raw_encrypt"]
+    c = ctx.encrypt(L([H(e["m"]) for e in enc], s1), L([H(e["r"]) for e in enc], s1))
+    assert native.limbs_to_ints(c) == [H(e["c"]) for e in enc]
+    seen["encrypt"] = ctx.last_launch()
+    dec = g["raw_decrypt"]
+    if ctx.has_private:
+        m = ctx.decrypt(L([H(e["c"]) for e in dec], s2))
+        assert native.limbs_to_ints(m) == [H(e["m"]) for e in dec]
+        seen["decrypt"] = ctx.last_launch()
+    obf = g["obfuscate"]
+    c2 = ctx.obfuscate(L([H(e["c_in"]) for e in obf], s2), L([H(e["r"]) for e in obf], s1))
+    assert native.limbs_to_ints(c2) == [H(e["c_out"]) for e in obf]
+    seen["obfuscate"] = ctx.last_launch()
+    n_int, max_int = H(g["n"]), H(g["max_int"])
+    pos = [e for e in g["raw_mul"] if H(e["s"]) < n_int - max_int]
+    out = ctx.powmod(L([H(e["c"]) for e in pos], s2), L([H(e["s"]) for e in pos], s1))
+    assert native.limbs_to_ints(out) == [H(e["out"]) for e in pos]
+    add = g["raw_add"]
+    out = ctx.mulmod(L([H(e["a"]) for e in add], s2), L([H(e["b"]) for e in add], s2))
+    assert native.limbs_to_ints(out) == [H(e["out"]) for e in add]
+    return seen
+
+
+@pytest.mark.parametrize("key_bits", [1024, 2048, 3072])
+def test_every_rung_of_the_ladder_gives_the_golden_bits(native, key_bits):
+    g = load_golden(key_bits)
+    ctx = make_ctx(native, g)
+    pub, priv = ctx.ladder()
+    assert len(pub) >= 2 and len(priv) >= 2, (pub, priv)
+    assert pub == sorted(pub, key=lambda c: c // 100) and priv == sorted(priv, key=lambda c: c // 100)   # narrowest first
+    lanes = lambda code: (code // 100) * (code % 100)
+    assert all(lanes(c) * 29 >= key_bits + 4 for c in pub) and all(lanes(c) * 29 >= key_bits // 2 + 4 for c in priv)
+    for width in sorted({c // 100 for c in pub + priv}):
+        ctx.set_group(width)
+        seen = golden_hot_path(native, ctx, g)
+        want_pub = next((c for c in pub if c // 100 >= width), pub[-1])
+        want_priv = next((c for c in priv if c // 100 >= width), priv[-1])
+        path_unit = seen["encrypt"]["path"] & ctx.PATH_UNIT
+        assert seen["encrypt"]["geom_pub"] == (pub[0] if path_unit else want_pub), (width, seen)
+        assert bool(path_unit) == (want_pub == pub[0] and key_bits >= 2048)       # the scaled modulus rides on rung 0 only
+        assert seen["decrypt"]["geom_priv"] == want_priv, (width, seen)
+    ctx.set_group(0)
+
+
+def test_the_rung_follows_the_batch_size(native, c_oracle):
+    """2048-bit key: 100 rows -> 16-lane groups, a few thousand -> 8-lane groups, tens of thousands -> rung 0; the decrypt
+    halves run side by side until one of them fills the GPU alone; every size bit-exact (oracle sample + round trip)"""
+    g = load_golden(2048)
+    n_int = H(g["n"])
+    n = native.int_to_limbs(n_int, 64)
+    ctx = make_ctx(native, g)
+    pub, priv = ctx.ladder()
+    rs = np.random.Generator(np.random.PCG64(99))
+    widths_pub, widths_priv = [], []
+    for batch in (100, 3000, 9000, 20000, 70000):
+        m = rs.integers(0, 1 << 32, size=(batch, 64), dtype=np.uint32)
+        r = rs.integers(0, 1 << 32, size=(batch, 64), dtype=np.uint32)
+        m[:, 63] = 0
+        r[:, 63] &= 0x3fffffff
+        r[:, 0] |= 1
+        c = ctx.encrypt(m, r)
+        info = ctx.last_launch()
+        widths_pub.append(info["geom_pub"] // 100)
+        back = ctx.decrypt(c)
+        info = ctx.last_launch()
+        widths_priv.append((info["geom_priv"] // 100, bool(info["path"] & ctx.PATH_SIDE_BY_SIDE)))
+        assert np.array_equal(back, m), batch
+        idx = np.arange(0, batch, max(1, batch // 37))
+        assert np.array_equal(c[idx], c_oracle.encrypt(n, m[idx], r[idx], nthreads=8)), batch
+    assert widths_pub == sorted(widths_pub, reverse=True) and widths_pub[0] == 16 and widths_pub[-1] == pub[0] // 100
+    assert len(set(widths_pub)) >= 3, widths_pub                     # at least three rungs were exercised
+    assert [w for w, _ in widths_priv] == sorted([w for w, _ in widths_priv], reverse=True)
+    assert widths_priv[0][1] and not widths_priv[-1][1], widths_priv   # small: halves side by side; 70000 rows: one after the other
+    assert widths_priv[-1][0] == priv[0] // 100
+
+
+@pytest.mark.parametrize("key_bits", [2048, 3072])
+def test_scaled_modulus_path_on_the_golden_vectors(native, key_bits, monkeypatch):
+    """PHE_HIP_FORCE_UNIT: r^n modulo the scaled modulus k*n for small batches too — every golden raw_encrypt / obfuscate
+    vector (m = 0, 1, max_int +- 1, n-1, n, n+1 unreduced; r = 1, n-1) through it, and the path asserted"""
+    monkeypatch.setenv("PHE_HIP_FORCE_UNIT", "1")
+    g = load_golden(key_bits)
+    ctx = make_ctx(native, g, private=False)
+    seen = golden_hot_path(native, ctx, g)
+    assert seen["encrypt"]["path"] & ctx.PATH_UNIT and seen["obfuscate"]["path"] & ctx.PATH_UNIT
+    n_int = H(g["n"])
+    ms = [H(e["m"]) for e in g["raw_encrypt"]]
+    assert any(m == n_int for m in ms) and any(m == n_int + 1 for m in ms) and any(m == n_int - 1 for m in ms)
+    monkeypatch.delenv("PHE_HIP_FORCE_UNIT")
+    plain = make_ctx(native, g, private=False)
+    seen = golden_hot_path(native, plain, g)
+    assert not seen["encrypt"]["path"] & ctx.PATH_UNIT                    # a handful of rows: the latency rung, plain modulus
+
+
+def test_scaled_modulus_and_owner_paths_on_the_reference_trace(native, monkeypatch):
+    """every raw_encrypt / obfuscate call the reference's own suites made under a 2048-bit key
+    (tests/golden/reference_suite_trace.json.gz, recorded on the real reference) replayed (a) through the scaled-modulus
+    path and (b), where the trace holds the key's primes, through the key owner's CRT form with the plaintexts as the
+    suite passed them (m >= n included) — the path asserted each time"""
+    import gzip
+    import json
+    from conftest import GOLDEN
+    with gzip.open(os.path.join(GOLDEN, "reference_suite_trace.json.gz"), "rb") as f:
+        trace = json.loads(f.read().decode())
+    keys = [{k: (int(v, 16) if v is not None else None) for k, v in key.items()} for key in trace["keys"]]
+    monkeypatch.setenv("PHE_HIP_FORCE_UNIT", "1")
+    L = native.ints_to_limbs
+    unit_done = owner_done = 0
+    for k, key in enumerate(keys):
+        n_int = key["n"]
+        if n_int.bit_length() < 2048:
+            continue
+        s1 = (n_int.bit_length() + 31) // 32
+        wrap = 1 << (32 * s1)
+        enc = [[int(v, 16) for v in row[3:]] for row in trace["ops"] if row[1] == "enc" and row[2] == k]
+        obf = [[int(v, 16) for v in row[3:]] for row in trace["ops"] if row[1] == "obf" and row[2] == k]
+        if not enc and not obf:
+            continue
+        ctx = native.Context(n_int, n_limbs=s1)
+        if enc:
+            got = ctx.encrypt(L([v[0] % wrap for v in enc], s1), L([v[1] for v in enc], s1))
+            assert ctx.last_launch()["path"] & ctx.PATH_UNIT
+            assert native.limbs_to_ints(got) == [v[2] for v in enc]
+            unit_done += len(enc)
+        if obf:
+            got = ctx.obfuscate(L([v[0] % (n_int * n_int) for v in obf], 2 * s1), L([v[1] for v in obf], s1))
+            assert ctx.last_launch()["path"] & ctx.PATH_UNIT
+            assert native.limbs_to_ints(got) == [v[2] for v in obf]
+            unit_done += len(obf)
+        if key["p"] and enc:
+            import phe
+            priv = phe.PaillierPrivateKey(phe.PaillierPublicKey(n_int), key["p"], key["q"])
+            own = native.Context(n_int, priv.p, priv.q, priv.hp, priv.hq, priv.p_inverse, n_limbs=s1)
+            if own.owner_encrypt_offered():
+                got = own.encrypt_owner(L([v[0] % wrap for v in enc], s1), L([v[1] for v in enc], s1))
+                assert own.last_launch()["path"] & own.PATH_OWNER
+                assert native.limbs_to_ints(got) == [v[2] for v in enc]
+                owner_done += len(enc)
+    assert unit_done >= 100 and owner_done >= 20, (unit_done, owner_done)
+
+
+@pytest.mark.parametrize("key_bits", [1024, 2048, 3072])
+def test_key_owner_encryption_with_unreduced_plaintexts(native, key_bits):
+    """encrypt_owner on the golden raw_encrypt vectors AS GIVEN — m = n, n + 1 and n - 1 included, not reduced by the
+    caller (phe/paillier.py:134 `(n * plaintext + 1) % nsquare` wraps them; phe/tests/paillier_test.py:114-126) — and
+    the CRT path asserted"""
+    g = load_golden(key_bits)
+    ctx = make_ctx(native, g)
+    assert ctx.owner_encrypt_offered()
+    s1 = key_bits // 32
+    enc = g["raw_encrypt"]
+    n_int = H(g["n"])
+    assert sum(1 for e in enc if H(e["m"]) >= n_int) >= 2
+    c = ctx.encrypt_owner(native.ints_to_limbs([H(e["m"]) for e in enc], s1), native.ints_to_limbs([H(e["r"]) for e in enc], s1))
+    assert ctx.last_launch()["path"] & ctx.PATH_OWNER
+    assert native.limbs_to_ints(c) == [H(e["c"]) for e in enc]
+    edge = [n_int - 1, n_int, n_int + 1, (1 << (32 * s1)) - 1, 0, 1]
+    rng = random.Random(key_bits)
+    r = [rng.randrange(1, n_int) for _ in edge]
+    c = ctx.encrypt_owner(native.ints_to_limbs(edge, s1), native.ints_to_limbs(r, s1))
+    n2 = n_int * n_int
+    assert native.limbs_to_ints(c) == [(1 + n_int * m) % n2 * pow(rr, n_int, n2) % n2 for m, rr in zip(edge, r)]
+    assert native.limbs_to_ints(ctx.decrypt(c)) == [m % n_int for m in edge]
+
+
+def test_one_stream_order_per_context(native, c_oracle):
+    """Two decrypt_dev calls on ONE context issued back to back on two different non-blocking streams, no host
+    synchronisation in between: the second must wait for the first (they share the context's intermediates and window
+    tables).  Both results are checked; without the ordering the first call's x_p / x_q would be overwritten under it."""
+    from phe._device import DeviceArray
+    g = load_golden(2048)
+    n_int = H(g["n"])
+    ctx = make_ctx(native, g)
+    rng = np.random.Generator(np.random.PCG64(5))
+    B = 6000
+    plain = []
+    cts = []
+    for k in range(2):
+        m = rng.integers(0, 1 << 32, size=(B, 64), dtype=np.uint32)
+        r = rng.integers(0, 1 << 32, size=(B, 64), dtype=np.uint32)
+        m[:, 63] = 0
+        r[:, 63] &= 0x3fffffff
+        r[:, 0] |= 1
+        plain.append(m)
+        cts.append(DeviceArray.from_host(ctx, ctx.encrypt(m, r)))
+    s_a, s_b = ctx.stream_create(), ctx.stream_create()
+    outs = [DeviceArray(ctx, B, 64), DeviceArray(ctx, B, 64)]
+    for rep in range(3):
+        ctx.decrypt_dev(cts[0].ptr, outs[0].ptr, B, s_a)
+        ctx.decrypt_dev(cts[1].ptr, outs[1].ptr, B, s_b)
+        ctx.sync(s_b)
+        ctx.sync(s_a)
+        assert np.array_equal(outs[0].to_host(), plain[0]) and np.array_equal(outs[1].to_host(), plain[1]), rep
+    ctx.stream_destroy(s_a)
+    ctx.stream_destroy(s_b)
+
+
+# ---- resident rows in the pair form --------------------------------------------------------------------------------------
+@pytest.mark.parametrize("key_bits,batch", [(1024, 300), (2048, 40), (2048, 9000), (2048, 40000), (3072, 700)])
+def test_pair_form_entry_points(native, c_oracle, key_bits, batch):
+    from phe._device import DeviceArray
+    g = load_golden(key_bits)
+    n_int = H(g["n"])
+    n2, s1, s2 = n_int * n_int, key_bits // 32, key_bits // 16
+    n = native.int_to_limbs(n_int, s1)
+    ctx = make_ctx(native, g, private=False)
+    words = ctx.pair_words()
+    assert words and 29 * (words // 2) >= key_bits + 4
+    rs = np.random.Generator(np.random.PCG64(key_bits + batch))
+    a = rs.integers(0, 1 << 32, size=(batch, s2), dtype=np.uint32)
+    b = rs.integers(0, 1 << 32, size=(batch, s2), dtype=np.uint32)
+    a[:, s2 - 1] = 0
+    b[:, s2 - 1] = 0                                               # < n^2 (n^2 has 2*key_bits bits, the top word is not full)
+    a[0] = 0
+    a[0, 0] = 1
+    a[1] = native.int_to_limbs(n2 - 1, s2)
+    a[2] = 0xffffffff                                               # above n^2: to_pair takes any value of the width
+    da, db = DeviceArray.from_host(ctx, a), DeviceArray.from_host(ctx, b)
+    pa, pb = DeviceArray(ctx, batch, words), DeviceArray(ctx, batch, words)
+    ctx.to_pair_dev(da.ptr, pa.ptr, batch)
+    ctx.to_pair_dev(db.ptr, pb.ptr, batch)
+    out = DeviceArray(ctx, batch, s2)
+    ctx.from_pair_dev(pa.ptr, None, out.ptr, batch)
+    ctx.sync()
+    back = out.to_host()
+    idx = np.unique(np.concatenate([np.arange(0, min(batch, 4)), np.arange(0, batch, max(1, batch // 53))]))
+    assert native.limbs_to_ints(back[idx]) == [v % n2 for v in native.limbs_to_ints(a[idx])]
+    prod = DeviceArray(ctx, batch, words)
+    ctx.pair_mul_dev(pa.ptr, pb.ptr, False, prod.ptr, batch)
+    for _ in range(3):                                              # a chain of additions stays in the pair form
+        ctx.pair_mul_dev(prod.ptr, pb.ptr, False, prod.ptr, batch)
+    ctx.from_pair_dev(prod.ptr, None, out.ptr, batch)
+    ctx.sync()
+    got = out.to_host()
+    a_red = c_oracle.add(n, a, native.ints_to_limbs([1] * batch, s2), nthreads=8)      # a mod n^2
+    want = a_red
+    for _ in range(4):
+        want = c_oracle.add(n, want, b, nthreads=8)
+    assert np.array_equal(got, want)
+    # the single row b for every a, and the plaintext factor on the way out
+    ctx.pair_mul_dev(pa.ptr, pb.ptr, True, prod.ptr, batch)
+    m = rs.integers(0, 1 << 32, size=(batch, s1), dtype=np.uint32)
+    m[0] = native.int_to_limbs(n_int, s1)                           # m = n wraps to 0
+    dm = DeviceArray.from_host(ctx, m)
+    ctx.from_pair_dev(prod.ptr, dm.ptr, out.ptr, batch)
+    ctx.sync()
+    got = out.to_host()
+    b0 = native.limbs_to_ints(b[:1])[0]
+    for i in idx.tolist():
+        av, mv = native.limbs_to_ints(a[i:i + 1])[0], native.limbs_to_ints(m[i:i + 1])[0]
+        assert native.limbs_to_ints(got[i:i + 1])[0] == av * b0 % n2 * (1 + n_int * (mv % n_int)) % n2, i
+    # the tree: product of all rows
+    root = DeviceArray(ctx, 1, words)
+    ctx.pair_reduce_dev(pb.ptr, batch, root.ptr)
+    one = DeviceArray(ctx, 1, s2)
+    ctx.from_pair_dev(root.ptr, None, one.ptr, 1)
+    ctx.sync()
+    total = 1
+    for v in native.limbs_to_ints(b):
+        total = total * v % n2
+    assert native.limbs_to_ints(one.to_host())[0] == total
+
+
+def test_encrypted_vector_in_pair_form(native):
+    """EncryptedVector.to_pair(): `+` between resident vectors is one pair product and stays in pair form, sum() is one call,
+    obfuscate() multiplies by pooled r^n in pair form; what leaves the vector is what the plain path gives, bit for bit"""
+    import phe
+    g = load_golden(2048)
+    pub = phe.PaillierPublicKey(H(g["n"]))
+    priv = phe.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    xs = np.arange(5000, dtype=np.float64) / 8 - 300
+    ys = np.arange(5000, dtype=np.int64) * 3 - 7000
+    r = [3 + i for i in range(5000)]
+    a = pub.encrypt_batch(xs, r_values=r, device=True)
+    b = pub.encrypt_batch(ys, r_values=r, device=True)
+    plain_sum = (a + b) + b
+    pa = a.to_pair()
+    assert pa._pair and pa.on_device
+    s = (pa + b) + b.to_pair()
+    assert s._pair
+    assert s.ciphertexts(False) == plain_sum.ciphertexts(False)          # the same canonical residues
+    assert not s._pair                                                     # looking at the rows converted them back
+    assert priv.decrypt_batch(s) == (xs + 2 * ys).tolist()
+    tot_pair, tot_plain = (pa + b).sum(), (a + b).sum()
+    assert tot_pair.ciphertext(False) == tot_plain.ciphertext(False) and tot_pair.exponent == tot_plain.exponent
+    assert priv.decrypt(tot_pair) == float(np.sum(xs + ys))
+    eng = pub._get_engine()
+    assert eng.pair_form()
+    pub.precompute_obfuscators(6000)
+    peek = eng.peek_obfuscators(2)
+    v = a.to_pair()
+    before = a.ciphertexts(False)[:2]
+    v.obfuscate()
+    assert v._pair and all(v._obfuscated) and pub.obfuscators_available() == 1000
+    n2 = pub.nsquare
+    assert v.ciphertexts(False)[:2] == [c * f % n2 for c, f in zip(before, peek)]
+    assert priv.decrypt_batch(v) == xs.tolist()
+    fresh = pub.encrypt_batch(ys[:1000], device=True)                      # from the pool (pair form) with the plaintext folded in
+    assert pub.obfuscators_available() == 0 and priv.decrypt_batch(fresh) == ys[:1000].tolist()
+
+
+def test_integration_stub_of_section_b_runs(native, c_oracle):
+    """The code a python-paillier maintainer would paste is extracted from the document and
+    executed as it stands against plain key objects; encrypt / decrypt through it are checked against the libgmp oracle"""
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    section = text[text.index("## B."):]
+    block = re.search(r"```python\n(# phe/hip_backend\.py.*?)```", section, re.S).group(1)
+    lib_path = os.path.join(PKG, "lib", "libphe_hip.so")
+    assert 'ctypes.CDLL("libphe_hip.so")' in block
+    block = block.replace('ctypes.CDLL("libphe_hip.so")', "ctypes.CDLL(%r)" % lib_path)   # the document names the soname only
+    scope = {}
+    exec(compile(block, "INTEGRATION.md:B", "exec"), scope)
+    g = load_golden(2048)
+
+    class Pub:
+        n = H(g["n"])
+
+    class Priv:
+        p, q, hp, hq, p_inverse = (H(g[k]) for k in ("p", "q", "hp", "hq", "p_inverse"))
+    hip = scope["HipContext"](Pub, Priv)
+    enc = g["raw_encrypt"]
+    cts = hip.raw_encrypt_batch([H(e["m"]) % (1 << 2048) for e in enc], [H(e["r"]) for e in enc])
+    assert cts == [H(e["c"]) for e in enc]
+    rng = random.Random(11)
+    ms = [rng.randrange(Pub.n) for _ in range(33)]
+    rs = [rng.randrange(1, Pub.n) for _ in range(33)]
+    cts = hip.raw_encrypt_batch(ms, rs)
+    n = native.int_to_limbs(Pub.n, 64)
+    want = c_oracle.encrypt(n, native.ints_to_limbs(ms, 64), native.ints_to_limbs(rs, 64), nthreads=4)
+    assert cts == native.limbs_to_ints(want)
+    assert hip.raw_decrypt_batch(cts) == ms
+    pub_only = scope["HipContext"](Pub)
+    assert pub_only.raw_encrypt_batch(ms[:3], rs[:3]) == cts[:3]
+    with pytest.raises(ValueError):                                       # status code -> ValueError, as the stub maps it
+        pub_only.raw_decrypt_batch(cts[:1])
+    if "ciphertext_strings" in section:                                   # the second block (a method for the same class)
+        more = re.search(r"```python\n(    def ciphertext_strings.*?)```", section, re.S).group(1)
+        ns = dict(scope)
+        exec(compile("class _More(HipContext):\n" + more, "INTEGRATION.md:B2", "exec"), ns)
+        ext = ns["_More"](Pub)
+        assert ext.ciphertext_strings(cts[:5]) == [str(c) for c in cts[:5]]

@@ -34,6 +34,18 @@ def main():
                                   "group by name").fetchall()
                 for g in geo:
                     print("   geometry %s: grid=%s wg=%s lds=%s vgpr=%s agpr=%s sgpr=%s scratch=%s" % ((short(g[0]),) + g[1:]))
+                # the same kernel serves several legs (decrypt halves / key-owner halves, full batches / warm launches):
+                # one row per (kernel, grid size), so that a leg's average launch time can be read off on its own
+                try:
+                    cols = [c[1] for c in con.execute("pragma table_info(kernels)").fetchall()]
+                    dur = "duration" if "duration" in cols else "(end - start)"
+                    per = con.execute("select name, grid_x, count(*), avg(%s), sum(%s) from kernels where name like '%%phe%%' or "
+                                      "name like '%%k_decrypt%%' group by name, grid_x order by sum(%s) desc" % (dur, dur, dur)).fetchall()
+                    print("-- per (kernel, grid) launch times (ns -> us)")
+                    for r in per:
+                        print("   %-86s grid=%-9s calls=%-5d avg_us=%14.1f total_us=%14.1f" % (short(r[0]), r[1], r[2], r[3] / 1e3, r[4] / 1e3))
+                except sqlite3.OperationalError as exc:
+                    print("   (no per-grid breakdown: %s; columns of `kernels`: %s)" % (exc, cols if "cols" in dir() else "?"))
             try:
                 rows = con.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection "
                                    "group by kernel_name, counter_name").fetchall()
