@@ -89,10 +89,11 @@ int phe_hip_ctx_set_blocks_per_cu(phe_hip_ctx* ctx, int blocks_per_cu);
  * that way runs on a wider rung — fewer limbs per lane, a shorter dependent chain per product, more lanes per number —
  * chosen per call from the batch size.  Results are identical on every rung.
  * phe_hip_ctx_ladder: the rungs as G*100 + L, narrowest first, for the n-side and the p/q-side kernels (up to `capacity`
- * entries each are written; *n_pub / *n_priv = how many exist).  phe_hip_ctx_set_group: 0 = choose by batch size (default),
- * G = always the rung of G-lane groups (the next wider one if there is none) — for tests and measurements.
+ * entries each are written; *n_pub / *n_priv = how many exist; the widest rung is G = 64, one number per wavefront, for a
+ * handful of numbers).  phe_hip_ctx_set_group: 0 = choose by batch size (default), G in {2, 4, 8, 16, 64} = always the rung of
+ * G-lane groups (the next wider one if there is none) — for tests and measurements.
  * phe_hip_ctx_last_launch: what the last encrypt / obfuscate / decrypt / pair call took: *path = bit set of
- * 1 (r^n modulo the scaled modulus k*n), 2 (key owner's CRT form), 4 (decrypt halves side by side on two streams),
+ * 1 (r^n modulo the scaled modulus k*n), 2 (key owner's CRT form), 4 (decrypt halves side by side in one grid),
  * 8 (host batch pipelined through pinned chunks), 16 (fused obfuscate kernel); *geom_pub / *geom_priv = G*100 + L of the
  * exponentiation kernels used.  Any pointer may be NULL. */
 int phe_hip_ctx_ladder(const phe_hip_ctx* ctx, int* pub_geoms, int* priv_geoms, int capacity, int* n_pub, int* n_priv);
@@ -295,9 +296,9 @@ int phe_hip_allgather_dev(phe_hip_comm* comm, const uint32_t* local, uint32_t* a
 void phe_hip_comm_destroy(phe_hip_comm* comm);
 
 /* ---- diagnostics ----------------------------------------------------------------------------- */
-/* Runs the three DPP row primitives and the ballot on lane ids: out is (4, 64) uint32:
- * row 0 = row_down1(lane), row 1 = row_up1(lane), row 2 = row_bcast0(lane), row 3 = lane parity
- * ballot folded per lane.  Used by tests/test_gpu_parity.py::test_wave_primitives to pin the emulator's semantics. */
+/* Runs the cross-lane primitives of csrc/wave_gfx950.h on lane ids: out is 1026 uint32 — for 16-lane groups down1 / up1 /
+ * bcast0 (3 x 64), the ballot of (lane % 3 == 0) folded per lane (64) and as two words, then down1 / up1 / bcast0 for groups of
+ * 8, 4, 2 and 64 lanes (3 x 64 each).  Used by tests/test_gpu_parity.py::test_wave_primitives to pin the emulator's semantics. */
 int phe_hip_selftest_prims(int device, uint32_t* out);
 
 #ifdef __cplusplus

@@ -288,10 +288,22 @@ static const int kS8[] = {5, 7, 9, 14, 18};
 static const int kS4[] = {9, 14, 18, 27};
 static const int kS2[] = {9, 18, 27};
 constexpr int kMaxSplitL = 31;  // two products per digit per sweep: 2L * 2^58 < 2^64 (fused sweeps, three products: L <= 21)
+// G = 64: ONE number per wavefront (wave_gfx950.h: wave-wide DPP shifts, scalar broadcast) — the latency rung for a handful
+// of numbers.  Its numbers need not fill the 64*L limbs: SplitPack::rows (a multiple of L) is what a sweep runs over.
+static const int kS64[] = {1, 2, 3, 5};
 
 inline Geometry pick_geometry_split(int n_bits, int prefer_group) {
     const int need = (n_bits + 4 + kRadixBits - 1) / kRadixBits;
     Geometry best;
+    if (prefer_group == 64) {
+        for (int L : kS64)
+            if (64 * L >= need) {
+                best.G = 64;
+                best.L = L;
+                return best;
+            }
+        return best;  // wider than 64 x 5 limbs (keys above ~9200 bits): no whole-wave kernel
+    }
     auto consider = [&](int G, int L) {
         const int S = G * L;
         if (S < need) return;
@@ -316,6 +328,7 @@ inline Geometry pick_geometry_split(int n_bits, int prefer_group) {
 
 struct SplitPack {
     int G = 0, L = 0, H = 0;  // H = G*L limbs of 29 bits cover n (+4 bits)
+    int rows = 0;             // limbs a number really has, R = 2^(29 rows): H, except for G = 64 (the least multiple of L that covers n)
     int bits = 0;             // bits of n
     int chunks = 0;           // conv rows available: inputs of up to chunks*29*H bits
     std::vector<uint32_t> n, r1;  // H limbs each: n, R mod n
@@ -335,16 +348,31 @@ inline SplitPack build_split(const Big& n_any, int max_input_bits, int prefer_gr
     P.G = geo.G;
     P.L = geo.L;
     P.H = geo.S();
+    P.rows = P.H;
+    if (P.G == 64) {
+        // a multiple of the digits a whole-wave sweep takes per trip (split_core.h Trip<64, L>: 4, 4, 6, 10)
+        const int need = (P.bits + 4 + kRadixBits - 1) / kRadixBits;
+        const int trip = (P.L == 1 ? 4 : 2) * P.L;
+        P.rows = (need + trip - 1) / trip * trip;
+        if (P.rows > P.H) P.rows = P.H;  // (64*L is a multiple of every trip length)
+    }
     const Big n = big_resize(n_any, w);
     if ((n[0] & 1u) == 0u) throw std::invalid_argument("modulus must be odd");
-    const int rbits = kRadixBits * P.H;
+    const int rbits = kRadixBits * P.rows;
     P.chunks = std::max(1, (max_input_bits + rbits - 1) / rbits);
     const Big nsq = big_resize(big_mul(n, n), 2 * w);
     Big one((size_t)w, 0u);
     one[0] = 1;
     P.n = to_r29(n, P.H);
     P.r1 = to_r29(big_shift_mod(one, rbits, n), P.H);
-    P.nsq = to_r29(nsq, 2 * P.H);
+    {   // n^2 = lo + hi * R as two rows of H limbs (for rows == H simply its 2H limbs)
+        const std::vector<uint32_t> all = to_r29(nsq, 2 * P.rows);
+        P.nsq.assign((size_t)(2 * P.H), 0u);
+        for (int k = 0; k < P.rows; ++k) {
+            P.nsq[(size_t)k] = all[(size_t)k];
+            P.nsq[(size_t)(P.H + k)] = all[(size_t)(P.rows + k)];
+        }
+    }
     P.n0inv = neg_inv32(n[0]) & ((1u << kRadixBits) - 1u);
     // Z = z0 + z1*n (Z < n^2)  ->  the pair (z0, -z1 mod n)
     auto pair_of = [&](const Big& Z, std::vector<uint32_t>& out) {
@@ -609,7 +637,7 @@ inline bool big_invert_odd(const Big& a_in, const Big& N, Big& out) {
 // geometry of q^2
 inline bool split_part_holds(int G, int L) {
     const int* list = G == 16 ? kS16 : G == 8 ? kS8 : G == 4 ? kS4 : G == 2 ? kS2 : nullptr;
-    const int count = G == 16 ? 9 : G == 8 ? 5 : G == 4 ? 4 : G == 2 ? 3 : 0;
+    const int count = G == 16 ? 9 : G == 8 ? 5 : G == 4 ? 4 : G == 2 ? 3 : 0;  // (the lift has no whole-wave form: G = 64 is not asked here)
     for (int i = 0; i < count; ++i)
         if (list[i] == L) return true;
     return false;

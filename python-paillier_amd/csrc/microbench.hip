@@ -5,11 +5,18 @@
 // Montgomery kernels are made of (and of a few alternatives: 24-bit multiplies, f64 FMA), so that
 // bench.py's roofline.peak is a measured number.  Every test runs 8 independent dependency chains
 // per lane, 8 waves per SIMD, all CUs; results are printed as one JSON object.
+// Round 3: a loop trip now issues 64 instructions per lane (the 8 chains, 8 times over) instead of 8 — the three scalar
+// instructions and the taken branch of every trip cost ~6 cycles that 8 waves per SIMD did not hide (v_fma_f32 read 2.75
+// cycles per wave-instruction against the 2 of the 157 TFLOP/s fp32 peak; the same constant sat on every other row) —
+// and the report carries the cycle counts at the nominal AND at the measured shader clock.  New: an MFMA-only wave beside
+// a multiply-add-only wave on the same SIMD (k_side_by_side), the experiment that decides whether the matrix cores can
+// take work off the integer VALU.
 //
 //   hipcc --offload-arch=gfx950 -O3 microbench.hip -o phe_microbench && ./phe_microbench
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <string>
 #include <vector>
@@ -23,7 +30,8 @@
         }                                                                         \
     } while (0)
 
-constexpr int kIters = 16384;  // loop trips; each trip issues 8 (x OPS_PER) instructions per lane
+constexpr int kIters = 16384;  // instructions per chain; a loop trip issues kRepeat of them on each of the 8 chains
+constexpr int kRepeat = 8;
 constexpr int kChains = 8;
 
 #define KERNEL_BEGIN(NAME)                                                         \
@@ -41,7 +49,8 @@ constexpr int kChains = 8;
     KERNEL_BEGIN(NAME)                                                             \
         uint32_t x[kChains];                                                       \
         for (int i = 0; i < kChains; ++i) x[i] = a + i;                            \
-        for (int it = 0; it < kIters; ++it) {                                      \
+        for (int it = 0; it < kIters / kRepeat; ++it) {                            \
+            _Pragma("unroll") for (int rep = 0; rep < kRepeat; ++rep)              \
             _Pragma("unroll") for (int i = 0; i < kChains; ++i)                    \
                 asm volatile(ASM : "+v"(x[i]) : "v"(a), "v"(b) : "vcc", "s20", "s21");  \
         }                                                                          \
@@ -70,7 +79,8 @@ DEF_U32_TEST(k_alignbit, "v_alignbit_b32 %0, %0, %1, 30")
     KERNEL_BEGIN(NAME)                                                             \
         uint64_t x[kChains];                                                       \
         for (int i = 0; i < kChains; ++i) x[i] = ((uint64_t)b << 32) | (a + i);    \
-        for (int it = 0; it < kIters; ++it) {                                      \
+        for (int it = 0; it < kIters / kRepeat; ++it) {                            \
+            _Pragma("unroll") for (int rep = 0; rep < kRepeat; ++rep)              \
             _Pragma("unroll") for (int i = 0; i < kChains; ++i)                    \
                 asm volatile(ASM : "+v"(x[i]) : "v"(a), "v"(b) : "vcc");           \
         }                                                                          \
@@ -186,6 +196,47 @@ __global__ void __launch_bounds__(256) k_mix_mfma_mad(uint32_t* out, uint32_t se
     if ((uint32_t)(r ^ (r >> 32)) + (uint32_t)(s.x ^ s.y ^ s.z ^ s.w) == 0x12345678u) out[tid] = (uint32_t)r;
 }
 
+// --- an MFMA-only wave BESIDE a multiply-add-only wave on one SIMD --------------------------------------------------
+// 512-thread workgroups = 8 waves = two per SIMD.  `split` picks which waves are the matrix ones: 0 -> waves 4..7 (the
+// second wave of every SIMD if waves go round the SIMDs in order), 1 -> the odd waves; both are run so that the answer
+// does not hinge on the dispatch order.  mode bit 0: the multiply-add waves work, bit 1: the matrix waves work (an idle
+// wave leaves at once).  If the two pipes overlap, mode 3 takes about as long as the longer of modes 1 and 2; if a SIMD
+// issues one or the other, it takes their sum.
+constexpr int kSideIters = 4096;
+__global__ void __launch_bounds__(512) k_side_by_side(uint32_t* out, uint32_t seed, int mode, int split) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t wave = threadIdx.x >> 6;
+    const bool matrix_wave = split ? (wave & 1u) : (wave >= 4u);
+    if (matrix_wave) {
+        if (!(mode & 2)) return;
+        v4i a = {(int)(seed + tid), (int)(seed ^ tid), (int)tid, (int)seed}, b = {(int)tid, 3, (int)seed, 7};
+        v4i c[4] = {{0, 0, 0, 0}, {1, 1, 1, 1}, {2, 2, 2, 2}, {3, 3, 3, 3}};
+        for (int it = 0; it < kSideIters; ++it) {
+#pragma unroll
+            for (int rep = 0; rep < 4; ++rep)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c[i], 0, 0, 0);
+        }
+        const v4i r = c[0] + c[1] + c[2] + c[3];
+        if ((uint32_t)(r.x ^ r.y ^ r.z ^ r.w) == 0x12345678u) out[tid] = (uint32_t)r.x;
+    } else {
+        if (!(mode & 1)) return;
+        const uint32_t aa = seed * 2654435761u + tid, bb = (seed ^ tid) | 1u;
+        uint64_t x[kChains];
+        for (int i = 0; i < kChains; ++i) x[i] = ((uint64_t)bb << 32) | (aa + i);
+        for (int it = 0; it < kSideIters; ++it) {
+#pragma unroll
+            for (int rep = 0; rep < kRepeat; ++rep)
+#pragma unroll
+                for (int i = 0; i < kChains; ++i)
+                    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(x[i]) : "v"(aa), "v"(bb) : "vcc");
+        }
+        uint64_t r = 0;
+        for (int i = 0; i < kChains; ++i) r ^= x[i];
+        if ((uint32_t)(r ^ (r >> 32)) == 0x12345678u) out[tid] = (uint32_t)r;
+    }
+}
+
 // --- LDS: the broadcast read used for the multiplier limbs, and ds_bpermute ---------------------
 __global__ void __launch_bounds__(256) k_lds_bcast_b128(uint32_t* out, uint32_t seed) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[16 * 132];
@@ -281,7 +332,26 @@ int main() {
     unsigned long long ticks0 = 0;
     CK(hipMemcpy(&ticks0, dt, 8, hipMemcpyDeviceToHost));
     // each wave issues kIters*8 dependent v_add; 8 waves per SIMD interleave, so the kernel lasts ~ticks0 cycles
-    printf("{\"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, "
+    // cycles are also reported at the clock the chip really held, when the caller knows it (PHE_MB_CLOCK_MHZ: GRBM_GUI_ACTIVE
+    // per XCD / kernel time from a rocprofv3 --pmc pass over this binary; tools/gpu_profile_round.sh does that)
+    double measured_hz = prop.clockRate * 1e3;
+    if (const char* e = getenv("PHE_MB_CLOCK_MHZ")) {
+        const double mhz = atof(e);
+        if (mhz > 500 && mhz < 4000) measured_hz = mhz * 1e6;
+    }
+    {   // one wave per SIMD issuing DEPENDENT full-rate VALU instructions: the time per instruction is the issue interval of a
+        // lone wave (4 cycles if a wave64 instruction occupies its 16-lane SIMD for 4 cycles) — reported, not assumed
+        CK(hipEventRecord(e0));
+        k_clock<<<cus, 256>>>(dt, 3);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms1 = 0;
+        CK(hipEventElapsedTime(&ms1, e0, e1));
+        printf("{\"lone_wave_dependent_v_add_u32\": {\"kernel_ms\": %.4f, \"ns_per_instruction\": %.4f, \"cycles_at_clock_used\": %.3f}, "
+               "\"clock_used_mhz\": %.1f, ", ms1, ms1 * 1e6 / ((double)kIters * 8), ms1 * 1e-3 * measured_hz / ((double)kIters * 8),
+               measured_hz / 1e6);
+    }
+    printf("\"device\": \"%s\", \"gcn_arch\": \"%s\", \"cus\": %d, \"clock_mhz\": %d, "
            "\"clock_probe\": {\"s_memtime_ticks\": %llu, \"kernel_ms\": %.4f, \"ticks_per_us\": %.1f}, \"tests\": {",
            prop.name, prop.gcnArchName, cus, prop.clockRate / 1000, ticks0, clk_ms, (double)ticks0 / (clk_ms * 1e3));
     bool first = true;
@@ -303,9 +373,35 @@ int main() {
         const double lane_ops_per_s = lanes * kIters * t.instr_per_iter / (best * 1e-3);
         // cycles a SIMD spends per wave-instruction, at the nominal clock
         const double cyc = (double)cus * 4.0 * (prop.clockRate * 1e3) * (best * 1e-3) / wave_instr;
-        printf("%s\"%s\": {\"ms\": %.4f, \"lane_ops_per_s\": %.4e, \"cycles_per_wave_instr_per_simd\": %.3f}",
-               first ? "" : ", ", t.name, best, lane_ops_per_s, cyc);
+        printf("%s\"%s\": {\"ms\": %.4f, \"lane_ops_per_s\": %.4e, \"cycles_per_wave_instr_per_simd\": %.3f, "
+               "\"cycles_at_measured_clock\": %.3f}",
+               first ? "" : ", ", t.name, best, lane_ops_per_s, cyc, cyc * measured_hz / (prop.clockRate * 1e3));
         first = false;
+    }
+    printf("}, \"side_by_side_mfma_and_mad_waves\": {");
+    {
+        const int sblocks = cus;  // one 512-thread workgroup per CU: exactly two waves per SIMD
+        bool f2 = true;
+        for (int split = 0; split < 2; ++split) {
+            for (int mode = 1; mode <= 3; ++mode) {
+                k_side_by_side<<<sblocks, 512>>>(d, 1, mode, split);
+                CK(hipDeviceSynchronize());
+                float best = 1e30f;
+                for (int rep = 0; rep < 3; ++rep) {
+                    CK(hipEventRecord(e0));
+                    k_side_by_side<<<sblocks, 512>>>(d, rep + 2, mode, split);
+                    CK(hipEventRecord(e1));
+                    CK(hipEventSynchronize(e1));
+                    float ms = 0;
+                    CK(hipEventElapsedTime(&ms, e0, e1));
+                    if (ms < best) best = ms;
+                }
+                printf("%s\"%s_%s\": %.4f", f2 ? "" : ", ", split ? "odd_waves_matrix" : "waves_4to7_matrix",
+                       mode == 1 ? "mad_only_ms" : mode == 2 ? "mfma_only_ms" : "both_ms", best);
+                f2 = false;
+            }
+        }
+        printf(", \"per_wave\": {\"mads\": %d, \"mfmas\": %d}", kSideIters * kRepeat * kChains, kSideIters * 16);
     }
     printf("}}\n");
     CK(hipFree(d));

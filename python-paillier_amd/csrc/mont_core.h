@@ -48,7 +48,8 @@ using Lanes = wave::Lanes<G>;
 
 template <int G>
 struct GroupMasks {
-    static constexpr uint64_t lane0 = (G == 16) ? 0x0001000100010001ull
+    static constexpr uint64_t lane0 = (G == 64) ? 0x0000000000000001ull
+                                      : (G == 16) ? 0x0001000100010001ull
                                       : (G == 8) ? 0x0101010101010101ull
                                       : (G == 4) ? 0x1111111111111111ull
                                                  : 0x5555555555555555ull;
@@ -173,10 +174,12 @@ PHE_DEV void canonicalize(uint32_t (&t)[L], const uint32_t (&n)[L], const Lanes<
 // out = a * b * R^-1 (mod N), out < 2N almost-normalised.
 //   a : the group's S digits in LDS (almost-normalised, value < R);  b : registers, value < 2N
 //   (any a*b < R*N is fine: a < R with b < N, or both < 2N).
+// rows: digits of the multiplier that are swept, R = 2^(29 rows).  G*L for every geometry but the whole-wave one (G = 64),
+// whose numbers need not fill the 64*L limbs of the wave: lanes beyond `rows` limbs hold zeros and stay zero.
 template <int G, int L>
 PHE_DEV void montmul(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[L], const uint32_t (&n)[L],
-                     uint32_t n0inv, const Lanes<G>& ln) {
-    constexpr int S = G * L;
+                     uint32_t n0inv, const Lanes<G>& ln, int rows = G * L) {
+    const int S = rows;
     const uint32_t dmask = kLimbMask & ln.not_top;  // digit mask + "the top lane receives 0" as one v_and
     // kLimbMask as plain VGPR data (no lane of a group is both top and low): lets "dpp(x) & mask" be one v_and_b32_dpp
     const uint32_t vmask = kLimbMask & (ln.not_top | ln.not_low);
@@ -209,15 +212,17 @@ PHE_DEV void montmul(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[
 
 // ---- operand movement --------------------------------------------------------------------------------
 // 29-bit limbs [first_limb + g*L, +L) of the little-endian 32-bit-word number at p (limbs32 words)
+// (count: limbs of the chunk — positions at or beyond it read as zero; the default takes whatever the lanes cover)
 template <int L>
-PHE_DEV void load_u32_as_r29(uint32_t (&x)[L], const uint32_t* p, int limbs32, int first_limb, uint32_t g) {
+PHE_DEV void load_u32_as_r29(uint32_t (&x)[L], const uint32_t* p, int limbs32, int first_limb, uint32_t g, int count = 1 << 30) {
     g = wave::reread(g);  // offsets recomputed here instead of hoisted out of the element loop (wave_gfx950.h:reread)
 #pragma unroll
     for (int k = 0; k < L; ++k) {
-        const int bit = kRadixBits * (first_limb + (int)g * L + k);
+        const int pos = (int)g * L + k;
+        const int bit = kRadixBits * (first_limb + pos);
         const int q = bit >> 5, o = bit & 31;
-        const uint64_t w0 = (q < limbs32) ? p[q] : 0u;
-        const uint64_t w1 = (q + 1 < limbs32) ? p[q + 1] : 0u;
+        const uint64_t w0 = (q < limbs32 && pos < count) ? p[q] : 0u;
+        const uint64_t w1 = (q + 1 < limbs32 && pos < count) ? p[q + 1] : 0u;
         x[k] = (uint32_t)(((w1 << 32) | w0) >> o) & kLimbMask;
     }
 }

@@ -85,6 +85,7 @@ PHE_DECLARE_PART(g16b)
     int occ_split_unit(int L);                                                                    \
     int launch_split_unit(int L, int blocks, hipStream_t st, const SplitArgs& A);                 \
     int launch_pair(int L, int op, int blocks, hipStream_t st, const PairArgs& A);                \
+    int launch_split_halves(int L, int blocks, hipStream_t st, const SplitArgs& Ap, const SplitArgs& Aq); \
     }
 PHE_DECLARE_SPLIT_PART(s2a)
 PHE_DECLARE_SPLIT_PART(s2b)
@@ -98,6 +99,8 @@ PHE_DECLARE_SPLIT_PART(s8c)
 PHE_DECLARE_SPLIT_PART(s16a)
 PHE_DECLARE_SPLIT_PART(s16b)
 PHE_DECLARE_SPLIT_PART(s16c)
+PHE_DECLARE_SPLIT_PART(s64a)
+PHE_DECLARE_SPLIT_PART(s64b)
 #undef PHE_DECLARE_SPLIT_PART
 }  // namespace phe
 
@@ -153,44 +156,51 @@ struct SplitPart {
     int (*occ_split_unit)(int);
     int (*launch_split_unit)(int, int, hipStream_t, const SplitArgs&);
     int (*launch_pair)(int, int, int, hipStream_t, const PairArgs&);
+    int (*launch_split_halves)(int, int, hipStream_t, const SplitArgs&, const SplitArgs&);
 };
 static const SplitPart kSplitParts[] = {
     {2, phe::s2a::occ_split, phe::s2a::launch_split, phe::s2a::occ_var_split, phe::s2a::launch_var_split,
      phe::s2a::occ_multi_split, phe::s2a::launch_multi_split, phe::s2a::launch_multi_tables,
-     phe::s2a::launch_multi_lookup, phe::s2a::launch_mul_split, phe::s2a::launch_crt_lift, phe::s2a::occ_split_unit, phe::s2a::launch_split_unit, phe::s2a::launch_pair},
+     phe::s2a::launch_multi_lookup, phe::s2a::launch_mul_split, phe::s2a::launch_crt_lift, phe::s2a::occ_split_unit, phe::s2a::launch_split_unit, phe::s2a::launch_pair, phe::s2a::launch_split_halves},
     {2, phe::s2b::occ_split, phe::s2b::launch_split, phe::s2b::occ_var_split, phe::s2b::launch_var_split,
      phe::s2b::occ_multi_split, phe::s2b::launch_multi_split, phe::s2b::launch_multi_tables,
-     phe::s2b::launch_multi_lookup, phe::s2b::launch_mul_split, phe::s2b::launch_crt_lift, phe::s2b::occ_split_unit, phe::s2b::launch_split_unit, phe::s2b::launch_pair},
+     phe::s2b::launch_multi_lookup, phe::s2b::launch_mul_split, phe::s2b::launch_crt_lift, phe::s2b::occ_split_unit, phe::s2b::launch_split_unit, phe::s2b::launch_pair, phe::s2b::launch_split_halves},
     {2, phe::s2c::occ_split, phe::s2c::launch_split, phe::s2c::occ_var_split, phe::s2c::launch_var_split,
      phe::s2c::occ_multi_split, phe::s2c::launch_multi_split, phe::s2c::launch_multi_tables,
-     phe::s2c::launch_multi_lookup, phe::s2c::launch_mul_split, phe::s2c::launch_crt_lift, phe::s2c::occ_split_unit, phe::s2c::launch_split_unit, phe::s2c::launch_pair},
+     phe::s2c::launch_multi_lookup, phe::s2c::launch_mul_split, phe::s2c::launch_crt_lift, phe::s2c::occ_split_unit, phe::s2c::launch_split_unit, phe::s2c::launch_pair, phe::s2c::launch_split_halves},
     {4, phe::s4a::occ_split, phe::s4a::launch_split, phe::s4a::occ_var_split, phe::s4a::launch_var_split,
      phe::s4a::occ_multi_split, phe::s4a::launch_multi_split, phe::s4a::launch_multi_tables,
-     phe::s4a::launch_multi_lookup, phe::s4a::launch_mul_split, phe::s4a::launch_crt_lift, phe::s4a::occ_split_unit, phe::s4a::launch_split_unit, phe::s4a::launch_pair},
+     phe::s4a::launch_multi_lookup, phe::s4a::launch_mul_split, phe::s4a::launch_crt_lift, phe::s4a::occ_split_unit, phe::s4a::launch_split_unit, phe::s4a::launch_pair, phe::s4a::launch_split_halves},
     {4, phe::s4b::occ_split, phe::s4b::launch_split, phe::s4b::occ_var_split, phe::s4b::launch_var_split,
      phe::s4b::occ_multi_split, phe::s4b::launch_multi_split, phe::s4b::launch_multi_tables,
-     phe::s4b::launch_multi_lookup, phe::s4b::launch_mul_split, phe::s4b::launch_crt_lift, phe::s4b::occ_split_unit, phe::s4b::launch_split_unit, phe::s4b::launch_pair},
+     phe::s4b::launch_multi_lookup, phe::s4b::launch_mul_split, phe::s4b::launch_crt_lift, phe::s4b::occ_split_unit, phe::s4b::launch_split_unit, phe::s4b::launch_pair, phe::s4b::launch_split_halves},
     {4, phe::s4c::occ_split, phe::s4c::launch_split, phe::s4c::occ_var_split, phe::s4c::launch_var_split,
      phe::s4c::occ_multi_split, phe::s4c::launch_multi_split, phe::s4c::launch_multi_tables,
-     phe::s4c::launch_multi_lookup, phe::s4c::launch_mul_split, phe::s4c::launch_crt_lift, phe::s4c::occ_split_unit, phe::s4c::launch_split_unit, phe::s4c::launch_pair},
+     phe::s4c::launch_multi_lookup, phe::s4c::launch_mul_split, phe::s4c::launch_crt_lift, phe::s4c::occ_split_unit, phe::s4c::launch_split_unit, phe::s4c::launch_pair, phe::s4c::launch_split_halves},
     {8, phe::s8a::occ_split, phe::s8a::launch_split, phe::s8a::occ_var_split, phe::s8a::launch_var_split,
      phe::s8a::occ_multi_split, phe::s8a::launch_multi_split, phe::s8a::launch_multi_tables,
-     phe::s8a::launch_multi_lookup, phe::s8a::launch_mul_split, phe::s8a::launch_crt_lift, phe::s8a::occ_split_unit, phe::s8a::launch_split_unit, phe::s8a::launch_pair},
+     phe::s8a::launch_multi_lookup, phe::s8a::launch_mul_split, phe::s8a::launch_crt_lift, phe::s8a::occ_split_unit, phe::s8a::launch_split_unit, phe::s8a::launch_pair, phe::s8a::launch_split_halves},
     {8, phe::s8b::occ_split, phe::s8b::launch_split, phe::s8b::occ_var_split, phe::s8b::launch_var_split,
      phe::s8b::occ_multi_split, phe::s8b::launch_multi_split, phe::s8b::launch_multi_tables,
-     phe::s8b::launch_multi_lookup, phe::s8b::launch_mul_split, phe::s8b::launch_crt_lift, phe::s8b::occ_split_unit, phe::s8b::launch_split_unit, phe::s8b::launch_pair},
+     phe::s8b::launch_multi_lookup, phe::s8b::launch_mul_split, phe::s8b::launch_crt_lift, phe::s8b::occ_split_unit, phe::s8b::launch_split_unit, phe::s8b::launch_pair, phe::s8b::launch_split_halves},
     {8, phe::s8c::occ_split, phe::s8c::launch_split, phe::s8c::occ_var_split, phe::s8c::launch_var_split,
      phe::s8c::occ_multi_split, phe::s8c::launch_multi_split, phe::s8c::launch_multi_tables,
-     phe::s8c::launch_multi_lookup, phe::s8c::launch_mul_split, phe::s8c::launch_crt_lift, phe::s8c::occ_split_unit, phe::s8c::launch_split_unit, phe::s8c::launch_pair},
+     phe::s8c::launch_multi_lookup, phe::s8c::launch_mul_split, phe::s8c::launch_crt_lift, phe::s8c::occ_split_unit, phe::s8c::launch_split_unit, phe::s8c::launch_pair, phe::s8c::launch_split_halves},
     {16, phe::s16a::occ_split, phe::s16a::launch_split, phe::s16a::occ_var_split, phe::s16a::launch_var_split,
      phe::s16a::occ_multi_split, phe::s16a::launch_multi_split, phe::s16a::launch_multi_tables,
-     phe::s16a::launch_multi_lookup, phe::s16a::launch_mul_split, phe::s16a::launch_crt_lift, phe::s16a::occ_split_unit, phe::s16a::launch_split_unit, phe::s16a::launch_pair},
+     phe::s16a::launch_multi_lookup, phe::s16a::launch_mul_split, phe::s16a::launch_crt_lift, phe::s16a::occ_split_unit, phe::s16a::launch_split_unit, phe::s16a::launch_pair, phe::s16a::launch_split_halves},
     {16, phe::s16b::occ_split, phe::s16b::launch_split, phe::s16b::occ_var_split, phe::s16b::launch_var_split,
      phe::s16b::occ_multi_split, phe::s16b::launch_multi_split, phe::s16b::launch_multi_tables,
-     phe::s16b::launch_multi_lookup, phe::s16b::launch_mul_split, phe::s16b::launch_crt_lift, phe::s16b::occ_split_unit, phe::s16b::launch_split_unit, phe::s16b::launch_pair},
+     phe::s16b::launch_multi_lookup, phe::s16b::launch_mul_split, phe::s16b::launch_crt_lift, phe::s16b::occ_split_unit, phe::s16b::launch_split_unit, phe::s16b::launch_pair, phe::s16b::launch_split_halves},
     {16, phe::s16c::occ_split, phe::s16c::launch_split, phe::s16c::occ_var_split, phe::s16c::launch_var_split,
      phe::s16c::occ_multi_split, phe::s16c::launch_multi_split, phe::s16c::launch_multi_tables,
-     phe::s16c::launch_multi_lookup, phe::s16c::launch_mul_split, phe::s16c::launch_crt_lift, phe::s16c::occ_split_unit, phe::s16c::launch_split_unit, phe::s16c::launch_pair},
+     phe::s16c::launch_multi_lookup, phe::s16c::launch_mul_split, phe::s16c::launch_crt_lift, phe::s16c::occ_split_unit, phe::s16c::launch_split_unit, phe::s16c::launch_pair, phe::s16c::launch_split_halves},
+    {64, phe::s64a::occ_split, phe::s64a::launch_split, phe::s64a::occ_var_split, phe::s64a::launch_var_split,
+     phe::s64a::occ_multi_split, phe::s64a::launch_multi_split, phe::s64a::launch_multi_tables,
+     phe::s64a::launch_multi_lookup, phe::s64a::launch_mul_split, phe::s64a::launch_crt_lift, phe::s64a::occ_split_unit, phe::s64a::launch_split_unit, phe::s64a::launch_pair, phe::s64a::launch_split_halves},
+    {64, phe::s64b::occ_split, phe::s64b::launch_split, phe::s64b::occ_var_split, phe::s64b::launch_var_split,
+     phe::s64b::occ_multi_split, phe::s64b::launch_multi_split, phe::s64b::launch_multi_tables,
+     phe::s64b::launch_multi_lookup, phe::s64b::launch_mul_split, phe::s64b::launch_crt_lift, phe::s64b::occ_split_unit, phe::s64b::launch_split_unit, phe::s64b::launch_pair, phe::s64b::launch_split_halves},
 };
 #define PHE_SPLIT_BY_GROUP(G_, CALL2)                 \
     [&]() -> int {                                    \
@@ -256,6 +266,10 @@ __global__ void k_selftest_prims(uint32_t* out) {
     out[642 + lane] = wave::grp_down1<2>(lane + 100u, l2);
     out[706 + lane] = wave::grp_up1<2>(lane + 100u, l2);
     out[770 + lane] = wave::grp_bcast0<2>(lane + 100u, l2);
+    const wave::Lanes<64> l64(lane);  // the whole wavefront as one group: wave_shl / wave_shr / readfirstlane
+    out[834 + lane] = wave::grp_down1<64>(lane + 100u, l64);
+    out[898 + lane] = wave::grp_up1<64>(lane + 100u, l64);
+    out[962 + lane] = wave::grp_bcast0<64>(lane + 100u, l64);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -280,6 +294,7 @@ struct DevModulus {  // device copies of a host::ModulusPack
 };
 struct DevSplit {  // device copies of a host::SplitPack
     int G = 0, L = 0, H = 0;  // G == 0: no split kernel for this modulus
+    int rows = 0;             // limbs of a number (H, except on the whole-wave geometry: SplitPack::rows)
     uint32_t* blob = nullptr;  // n | r1 | e | nsq | conv
     SplitConsts c{};
 };
@@ -325,7 +340,6 @@ struct phe_hip_ctx {
     std::vector<PrivRung> priv_rungs;  // rungs 1.. of the private side
     bool force_unit = false;           // PHE_HIP_FORCE_UNIT=1: r^n through the scaled modulus whatever the batch size (tests)
     int force_group = 0;               // phe_hip_ctx_set_group: 0 = pick by batch size; G = the rung whose groups are G lanes wide
-    int fill_pct = 85;                 // a rung is taken when the batch gives every SIMD at least this % of a wave (PHE_HIP_FILL_PCT)
     // what the last launch on this context took (phe_hip_ctx_last_launch): tests assert the path they meant to exercise
     int last_path = 0, last_geom_pub = 0, last_geom_priv = 0;
     // one stream order per context: every *_dev call waits for the previous call's work when it is issued on another
@@ -343,8 +357,6 @@ struct phe_hip_ctx {
     unsigned long long* flags = nullptr;  // radix conversion: first offending row per error kind (2 words)
     uint32_t* table2 = nullptr;  // window tables of the q half when the two halves of a small decrypt run concurrently
     size_t table2_words = 0;
-    hipStream_t aux_stream = nullptr;  // created on first use
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t* lookup = nullptr;  // multi-exponentiation: the 2^w-ary tables of a whole vector (phe_hip_multiexp_csr_dev)
     size_t lookup_words = 0;
     uint32_t* partial = nullptr;  // multi-exponentiation: one product per chunk, joined in place by a k_mulmod tree
@@ -390,6 +402,7 @@ static int upload_split(const host::SplitPack& m, DevSplit& d) {
     d.G = m.G;
     d.L = m.L;
     d.H = m.H;
+    d.rows = m.rows;
     if (m.G == 0) return PHE_HIP_OK;
     std::vector<uint32_t> h;
     const std::vector<uint32_t>* parts[5] = {&m.n, &m.r1, &m.e, &m.nsq, &m.conv};
@@ -406,6 +419,7 @@ static int upload_split(const host::SplitPack& m, DevSplit& d) {
     d.c.nsq = d.blob + off[3];
     d.c.conv = d.blob + off[4];
     d.c.n0inv = m.n0inv;
+    d.c.rows = m.rows;
     return PHE_HIP_OK;
 }
 static int upload_schedule(const host::Schedule& s, DevSchedule& d) {
@@ -507,19 +521,17 @@ static int launch_uniform(phe_hip_ctx* ctx, const DevModulus& M, const DevSchedu
 
 static int chunks_for(int limbs32, int H) { return std::max(1, (32 * limbs32 + 29 * H - 1) / (29 * H)); }
 
-template <int MODE>
-static int launch_split(phe_hip_ctx* ctx, const DevSplit& M, const DevSchedule& E, const uint32_t* base, int base_limbs,
-                        const uint32_t* post, int post_limbs, uint32_t* out, int out_limbs, size_t batch,
-                        hipStream_t stream, bool second_table = false, bool unit = false) {
-    int per_cu = ctx->blocks_per_cu;
-    if (per_cu == 0) per_cu = unit ? PHE_SPLIT_BY_GROUP(M.G, occ_split_unit(M.L)) : PHE_SPLIT_BY_GROUP(M.G, occ_split(M.L, MODE));
+// arguments of one k_modexp_split launch: the grid (sized to the residency so that the window tables stay per resident
+// group) and the table scratch (table2: a second buffer, for a half that runs beside another)
+static int prepare_split(phe_hip_ctx* ctx, const DevSplit& M, const DevSchedule& E, const uint32_t* base, int base_limbs,
+                         const uint32_t* post, int post_limbs, uint32_t* out, int out_limbs, size_t batch, int per_cu,
+                         bool second_table, SplitArgs& A, int& blocks) {
     if (per_cu < 0) return fail(PHE_HIP_EINVAL, "unsupported split geometry");
-    const int blocks = grid_blocks(ctx, batch, M.G, per_cu);
+    blocks = grid_blocks(ctx, batch, M.G, per_cu);
     const size_t rows = (size_t)blocks * (size_t)(kBlock / M.G);
     uint32_t** tbl = second_table ? &ctx->table2 : &ctx->table;
     int rc = ensure_words(tbl, second_table ? &ctx->table2_words : &ctx->table_words, rows * (size_t)E.tbl_entries * 2 * M.H);
     if (rc) return rc;
-    SplitArgs A;
     A.mod = M.c;
     A.sched = E.ops;
     A.n_ops = E.n_ops;
@@ -527,17 +539,49 @@ static int launch_split(phe_hip_ctx* ctx, const DevSplit& M, const DevSchedule& 
     A.tbl_entries = E.tbl_entries;
     A.base = base;
     A.base_limbs = base_limbs;
-    A.base_chunks = chunks_for(base_limbs, M.H);
+    A.base_chunks = chunks_for(base_limbs, M.rows);
     A.post = post;
     A.post_limbs = post_limbs;
-    A.post_chunks = chunks_for(post_limbs, M.H);
+    A.post_chunks = chunks_for(post_limbs, M.rows);
     A.out = out;
     A.out_limbs = out_limbs;
     A.table = *tbl;
     A.batch = batch;
+    return PHE_HIP_OK;
+}
+
+template <int MODE>
+static int launch_split(phe_hip_ctx* ctx, const DevSplit& M, const DevSchedule& E, const uint32_t* base, int base_limbs,
+                        const uint32_t* post, int post_limbs, uint32_t* out, int out_limbs, size_t batch,
+                        hipStream_t stream, bool second_table = false, bool unit = false) {
+    int per_cu = ctx->blocks_per_cu;
+    if (per_cu == 0) per_cu = unit ? PHE_SPLIT_BY_GROUP(M.G, occ_split_unit(M.L)) : PHE_SPLIT_BY_GROUP(M.G, occ_split(M.L, MODE));
+    SplitArgs A;
+    int blocks = 0;
+    if (int rc = prepare_split(ctx, M, E, base, base_limbs, post, post_limbs, out, out_limbs, batch, per_cu, second_table, A, blocks))
+        return rc;
     if ((unit ? PHE_SPLIT_BY_GROUP(M.G, launch_split_unit(M.L, blocks, stream, A))
               : PHE_SPLIT_BY_GROUP(M.G, launch_split(M.L, MODE, blocks, stream, A))) < 0)
         return fail(PHE_HIP_EINVAL, "unsupported split geometry");
+    HIP_TRY(hipGetLastError());
+    return PHE_HIP_OK;
+}
+
+// both half-exponentiations (moduli Mp, Mq of the same geometry) as one grid: k_modexp_split_halves
+static int launch_split_halves(phe_hip_ctx* ctx, const DevSplit& Mp, const DevSchedule& Ep, const DevSplit& Mq, const DevSchedule& Eq,
+                               const uint32_t* base, int base_limbs, uint32_t* out_p, uint32_t* out_q, int out_limbs, size_t batch,
+                               hipStream_t stream) {
+    if (Mp.G != Mq.G || Mp.L != Mq.L) return fail(PHE_HIP_EINVAL, "the two halves need one geometry");
+    int per_cu = ctx->blocks_per_cu;
+    if (per_cu == 0) per_cu = PHE_SPLIT_BY_GROUP(Mp.G, occ_split(Mp.L, kModeHalfDecrypt));
+    SplitArgs Ap, Aq;
+    int bp = 0, bq = 0;
+    // each half gets half of the residency: together they are one kernel's worth of resident workgroups
+    const int half_cu = per_cu > 1 ? per_cu / 2 : per_cu;
+    int rc = prepare_split(ctx, Mp, Ep, base, base_limbs, nullptr, 0, out_p, out_limbs, batch, half_cu, false, Ap, bp);
+    if (!rc) rc = prepare_split(ctx, Mq, Eq, base, base_limbs, nullptr, 0, out_q, out_limbs, batch, half_cu, true, Aq, bq);
+    if (rc) return rc;
+    if (PHE_SPLIT_BY_GROUP(Mp.G, launch_split_halves(Mp.L, bp, stream, Ap, Aq)) < 0) return fail(PHE_HIP_EINVAL, "unsupported split geometry");
     HIP_TRY(hipGetLastError());
     return PHE_HIP_OK;
 }
@@ -549,7 +593,7 @@ static int launch_var_split(phe_hip_ctx* ctx, const DevSplit& M, const uint32_t*
     A.mod = M.c;
     A.base = base;
     A.base_limbs = base_limbs;
-    A.base_chunks = chunks_for(base_limbs, M.H);
+    A.base_chunks = chunks_for(base_limbs, M.rows);
     A.exps = e;
     A.exp_limbs = exp_limbs;
     A.window = host::pick_window(max_bits);
@@ -580,7 +624,7 @@ static int launch_multi_split(phe_hip_ctx* ctx, const DevSplit& M, const uint32_
     A.base = base;
     A.base_inv = base_inv;
     A.base_limbs = base_limbs;
-    A.base_chunks = chunks_for(base_limbs, M.H);
+    A.base_chunks = chunks_for(base_limbs, M.rows);
     A.exps = e;
     A.neg = neg;
     A.exp_limbs = exp_limbs;
@@ -670,7 +714,7 @@ static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, 
         B.b_stride = b_stride;
         B.out_stride = out_stride;
         B.limbs = limbs;
-        B.chunks = chunks_for(limbs, SP.H);
+        B.chunks = chunks_for(limbs, SP.rows);
         B.b_plain_limbs = b_plain_limbs;
         B.batch = batch;
         const int blocks = grid_blocks(ctx, batch, SP.G, 2);
@@ -689,41 +733,74 @@ static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, 
 }
 
 // ---- the geometry ladder --------------------------------------------------------------------------------------------
-// A launch of `batch` numbers on groups of G lanes occupies batch*G lanes; the chip has n_cus * 4 SIMDs * 64 lanes per wave
-// slot.  One wave per SIMD already runs these kernels at ~95 % of their two-wave rate, a SIMD without a wave
-// runs nothing: so the narrowest rung (fewest lanes per number, most limbs per lane, fewest instructions per multiply-add)
-// that still gives every SIMD fill_pct % of a wave wins, and below that the groups widen — each step halves the limbs per
-// lane and with them the length of the dependent chain of a product (at ~0.88x the multiply-adds per instruction).
-static bool fills_chip(const phe_hip_ctx* ctx, size_t batch, int G, int concurrent = 1) {
-    return batch * (size_t)G * (size_t)concurrent * 100 >= (size_t)ctx->n_cus * 256 * (size_t)ctx->fill_pct;
+// A launch of `batch` numbers on groups of G lanes occupies batch*G lanes; the chip offers n_cus * 4 SIMDs * 64 lanes per wave
+// slot.  A product is a chain of `rows` dependent digit steps of ~(19 L + 52) issue cycles each (4L multiply-adds at ~4.8
+// cycles + ~13 other instructions), so a rung's time for one residency of waves is rows * (19 L + 52), and a batch
+// that needs w waves per SIMD takes max(1, w) of those: the rung with the least estimated time wins.  One wave per SIMD runs
+// these kernels at ~95 % of their two-wave rate, a SIMD without a wave runs nothing — narrow groups (most limbs per lane,
+// fewest instructions per multiply-add) win as soon as they fill the chip, wide ones (short chains) below that; measured
+// crossovers: profiles/r03*_batch_sweep*.
+struct RungShape {
+    int G = 0, L = 0, rows = 0;  // G == 0: this rung has no kernel of the family asked for
+};
+static double rung_cost(const phe_hip_ctx* ctx, size_t batch, const RungShape& r, int concurrent) {
+    const double lanes = (double)ctx->n_cus * 256.0;
+    const double w = (double)batch * r.G * concurrent / lanes;
+    return (double)r.rows * (19.0 * r.L + 52.0) * std::max(1.0, w);
+}
+// rung index (0 = the members of the context, k >= 1 = the k-th extra rung): least estimated time for this batch
+template <class Shape>
+static int pick_rung(const phe_hip_ctx* ctx, size_t batch, int n_rungs, Shape shape, int concurrent = 1) {
+    if (ctx->force_group) {
+        for (int k = 0; k < n_rungs; ++k)
+            if (shape(k).G >= ctx->force_group) return k;
+        for (int k = n_rungs - 1; k >= 0; --k)
+            if (shape(k).G) return k;
+        return 0;
+    }
+    int best = -1;
+    double best_cost = 0;
+    for (int k = 0; k < n_rungs; ++k) {
+        const RungShape r = shape(k);
+        if (!r.G) continue;
+        const double c = rung_cost(ctx, batch, r, concurrent);
+        if (best < 0 || c < best_cost * 0.97) {  // a wider rung must be clearly better: ties go to the narrower one
+            best = k;
+            best_cost = c;
+        }
+    }
+    return best < 0 ? 0 : best;
 }
 static int light_group(const DevModulus& M) {
     int G, L;
     light_geometry(M, G, L);
     return G;
 }
-// rung index (0 = the members of the context, k >= 1 = pub_rungs[k-1]) whose width(rung) fills the chip, else the widest
-template <class Width>
-static int pick_rung(const phe_hip_ctx* ctx, size_t batch, int n_rungs, Width width, int concurrent = 1) {
-    if (ctx->force_group) {
-        for (int k = 0; k < n_rungs; ++k)
-            if (width(k) >= ctx->force_group) return k;
-        return n_rungs - 1;
-    }
-    for (int k = 0; k < n_rungs; ++k)
-        if (width(k) && fills_chip(ctx, batch, width(k), concurrent)) return k;
-    return n_rungs - 1;
-}
 static const DevModulus& nsq_rung(const phe_hip_ctx* ctx, int k) { return k == 0 ? ctx->d_nsq : ctx->pub_rungs[(size_t)k - 1].nsq; }
 static const DevSplit& nsplit_rung(const phe_hip_ctx* ctx, int k) { return k == 0 ? ctx->d_nsplit : ctx->pub_rungs[(size_t)k - 1].nsplit; }
 // the full-width kernels modulo n^2 (products; the second engine)
 static const DevModulus& pick_nsq(const phe_hip_ctx* ctx, size_t batch) {
-    const int k = pick_rung(ctx, batch, 1 + (int)ctx->pub_rungs.size(), [&](int r) { return nsq_rung(ctx, r).G ? light_group(nsq_rung(ctx, r)) : 0; });
+    const int k = pick_rung(ctx, batch, 1 + (int)ctx->pub_rungs.size(), [&](int r) {
+        RungShape sh;
+        const DevModulus& M = nsq_rung(ctx, r);
+        if (M.G) {
+            light_geometry(M, sh.G, sh.L);
+            sh.rows = M.S;
+        }
+        return sh;
+    });
     return nsq_rung(ctx, k);
+}
+static RungShape split_shape(const DevSplit& sp) {
+    RungShape sh;
+    sh.G = sp.G;
+    sh.L = sp.L;
+    sh.rows = sp.rows;
+    return sh;
 }
 // the pair-form kernels modulo n
 static int pick_nsplit_rung(const phe_hip_ctx* ctx, size_t batch) {
-    return pick_rung(ctx, batch, 1 + (int)ctx->pub_rungs.size(), [&](int r) { return nsplit_rung(ctx, r).G; });
+    return pick_rung(ctx, batch, 1 + (int)ctx->pub_rungs.size(), [&](int r) { return split_shape(nsplit_rung(ctx, r)); });
 }
 static const DevSplit& pick_nsplit(const phe_hip_ctx* ctx, size_t batch) { return nsplit_rung(ctx, pick_nsplit_rung(ctx, batch)); }
 static int geom_code(int G, int L) { return G * 100 + L; }
@@ -746,21 +823,24 @@ struct CtxOrder {
     phe_hip_ctx* ctx;
     hipStream_t st;
     int rc = PHE_HIP_OK;
+    // The event is recorded lazily, on the PREVIOUS stream at the moment a call arrives on a different one (it then covers
+    // everything queued there so far, the previous call included): a run of calls on one stream costs nothing extra.
     CtxOrder(phe_hip_ctx* c, void* stream) : ctx(c), st((hipStream_t)stream) {
-        if (ctx->busy_valid && ctx->busy_stream != st) {
-            const hipError_t e = hipStreamWaitEvent(st, ctx->ev_busy, 0);
-            if (e != hipSuccess) rc = fail(PHE_HIP_EHIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
+        if (!ctx->busy_valid || ctx->busy_stream == st) return;
+        hipError_t e = hipSuccess;
+        if (!ctx->ev_busy) e = hipEventCreateWithFlags(&ctx->ev_busy, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_busy, ctx->busy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->ev_busy, 0);
+        if (e != hipSuccess) {
+            // e.g. the previous stream no longer exists (its owner destroyed it): whatever ran there is ordered by a full drain
+            (void)hipGetLastError();
+            e = hipDeviceSynchronize();
+            if (e != hipSuccess) rc = fail(PHE_HIP_EHIP, std::string("stream order of the context: ") + hipGetErrorString(e));
         }
     }
     ~CtxOrder() {
-        if (!ctx->ev_busy && hipEventCreateWithFlags(&ctx->ev_busy, hipEventDisableTiming) != hipSuccess) ctx->ev_busy = nullptr;
-        if (ctx->ev_busy && hipEventRecord(ctx->ev_busy, st) == hipSuccess) {
-            ctx->busy_stream = st;
-            ctx->busy_valid = true;
-        } else {
-            (void)hipDeviceSynchronize();  // no event to order the next call by: drain instead
-            ctx->busy_valid = false;
-        }
+        ctx->busy_stream = st;
+        ctx->busy_valid = true;
     }
 };
 #define PHE_CTX_ORDER(ctx, stream)   \
@@ -804,13 +884,9 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
     if (!rc && !getenv("PHE_HIP_NO_UNIT")) rc = upload_split(ctx->pub.nunit, ctx->d_nunit);
     if (!rc) rc = upload_schedule(ctx->pub.exp_n, ctx->d_exp_n);
     ctx->force_unit = getenv("PHE_HIP_FORCE_UNIT") != nullptr;
-    if (const char* e = getenv("PHE_HIP_FILL_PCT")) {
-        const int v = atoi(e);
-        if (v >= 10 && v <= 400) ctx->fill_pct = v;
-    }
     if (!rc && !getenv("PHE_HIP_GROUP")) {
         // the wider rungs of the ladder: 8- and 16-lane groups where they differ from what is already there
-        for (int prefer : {8, 16}) {
+        for (int prefer : {8, 16, 64}) {
             try {
                 phe_hip_ctx::PubRung R;
                 R.plan = host::build_public(n, n_limbs, prefer);
@@ -824,7 +900,7 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
                 // drop by a fifth at least (padding to the compiled limb counts can eat the whole gain)
                 const host::PublicPlan& prev = ctx->pub_rungs.empty() ? ctx->pub : ctx->pub_rungs.back().plan;
                 const auto chain = [&](const host::PublicPlan& o) {
-                    return (ctx->use_split && o.nsplit.G) ? o.nsplit.H * o.nsplit.L : o.nsq.S * o.nsq.L;
+                    return (ctx->use_split && o.nsplit.G) ? o.nsplit.rows * o.nsplit.L : o.nsq.S * o.nsq.L;
                 };
                 if (chain(R.plan) * 5 > chain(prev) * 4) continue;
                 rc = upload_modulus(R.plan.nsq, R.nsq);
@@ -903,7 +979,7 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
     if (!rc) rc = upload_split(ctx->priv.psplit, ctx->d_psplit);
     if (!rc) rc = upload_split(ctx->priv.qsplit, ctx->d_qsplit);
     if (!rc && !getenv("PHE_HIP_GROUP")) {
-        for (int prefer : {4, 8, 16}) {
+        for (int prefer : {4, 8, 16, 64}) {
             try {
                 phe_hip_ctx::PrivRung R;
                 R.plan = host::build_private(p, q, hp, hq, p_inverse, pq_limbs, n_limbs, prefer);
@@ -916,7 +992,7 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
                 if (have) continue;
                 const host::PrivatePlan& prev = ctx->priv_rungs.empty() ? ctx->priv : ctx->priv_rungs.back().plan;
                 const auto chain = [&](const host::PrivatePlan& o) {
-                    return (ctx->use_split && o.qsplit.G) ? o.qsplit.H * o.qsplit.L : o.qsq.S * o.qsq.L;
+                    return (ctx->use_split && o.qsplit.G) ? o.qsplit.rows * o.qsplit.L : o.qsq.S * o.qsq.L;
                 };
                 if (chain(R.plan) * 5 > chain(prev) * 4) continue;  // see the public rungs
                 rc = upload_modulus(R.plan.psq, R.psq);
@@ -974,9 +1050,6 @@ void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
     for (hipStream_t st : pipes)
         if (st) (void)hipStreamDestroy(st);
     if (ctx->ev_busy) (void)hipEventDestroy(ctx->ev_busy);
-    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
-    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     delete ctx;
 }
 
@@ -1014,7 +1087,8 @@ int phe_hip_ctx_set_blocks_per_cu(phe_hip_ctx* ctx, int blocks_per_cu) {
 
 int phe_hip_ctx_set_group(phe_hip_ctx* ctx, int group) {
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
-    if (group != 0 && group != 2 && group != 4 && group != 8 && group != 16) return fail(PHE_HIP_EINVAL, "group must be 0 (by batch size), 2, 4, 8 or 16");
+    if (group != 0 && group != 2 && group != 4 && group != 8 && group != 16 && group != 64)
+        return fail(PHE_HIP_EINVAL, "group must be 0 (by batch size), 2, 4, 8, 16 or 64");
     ctx->force_group = group;
     return PHE_HIP_OK;
 }
@@ -1106,8 +1180,21 @@ int phe_hip_encrypt_owner_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_
     uint32_t* yp = ctx->scratch;
     uint32_t* yq = ctx->scratch + batch * (size_t)S;
     // always the throughput geometry of the halves: the lift's constants belong to it
-    rc = launch_split<kModeHalfDecrypt>(ctx, ctx->d_psplit, ctx->d_exp_n, r, ctx->pub.s1, nullptr, 0, yp, S, batch, st);
-    if (!rc) rc = launch_split<kModeHalfDecrypt>(ctx, ctx->d_qsplit, ctx->d_exp_n, r, ctx->pub.s1, nullptr, 0, yq, S, batch, st);
+    {
+        int occ = ctx->blocks_per_cu;
+        if (occ == 0) occ = PHE_SPLIT_BY_GROUP(ctx->d_psplit.G, occ_split(ctx->d_psplit.L, kModeHalfDecrypt));
+        const size_t per_wg = (size_t)(kBlock / ctx->d_psplit.G);
+        const size_t wg_per_half = (batch + per_wg - 1) / per_wg;
+        if (ctx->d_psplit.G == ctx->d_qsplit.G && ctx->d_psplit.L == ctx->d_qsplit.L &&
+            2 * wg_per_half <= (size_t)ctx->n_cus * (size_t)std::max(1, occ)) {
+            // both halves fit one residency: one grid (see phe_hip_decrypt_dev)
+            ctx->last_path |= kPathSideBySide;
+            rc = launch_split_halves(ctx, ctx->d_psplit, ctx->d_exp_n, ctx->d_qsplit, ctx->d_exp_n, r, ctx->pub.s1, yp, yq, S, batch, st);
+        } else {
+            rc = launch_split<kModeHalfDecrypt>(ctx, ctx->d_psplit, ctx->d_exp_n, r, ctx->pub.s1, nullptr, 0, yp, S, batch, st);
+            if (!rc) rc = launch_split<kModeHalfDecrypt>(ctx, ctx->d_qsplit, ctx->d_exp_n, r, ctx->pub.s1, nullptr, 0, yq, S, batch, st);
+        }
+    }
     if (rc) return rc;
     const int QS = ctx->d_qsq.S;
     CrtLiftArgs A;
@@ -1192,37 +1279,37 @@ int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t
     uint32_t* xq = ctx->scratch + batch * (size_t)S;
     hipStream_t st = (hipStream_t)stream;
     // the rung of the halves: the two exponentiations are independent, so a batch that cannot fill the chip with one of them
-    // runs both side by side (the q half on an internal stream with its own window tables) and needs only half the lanes
+    // runs both side by side (one grid, the q half with its own window tables) and needs only half the lanes
     const int n_rungs = 1 + (int)ctx->priv_rungs.size();
     const auto psplit_of = [&](int k) -> const DevSplit& { return k == 0 ? ctx->d_psplit : ctx->priv_rungs[(size_t)k - 1].psplit; };
     const auto qsplit_of = [&](int k) -> const DevSplit& { return k == 0 ? ctx->d_qsplit : ctx->priv_rungs[(size_t)k - 1].qsplit; };
     const auto psq_of = [&](int k) -> const DevModulus& { return k == 0 ? ctx->d_psq : ctx->priv_rungs[(size_t)k - 1].psq; };
     const auto qsq_of = [&](int k) -> const DevModulus& { return k == 0 ? ctx->d_qsq : ctx->priv_rungs[(size_t)k - 1].qsq; };
     const bool split_ok = ctx->use_split && ctx->d_psplit.G && ctx->d_qsplit.G;
-    const auto width = [&](int k) { return split_ok ? psplit_of(k).G : psq_of(k).G; };
-    int rung = pick_rung(ctx, batch, n_rungs, width, split_ok ? 2 : 1);
+    const auto shape = [&](int k) {
+        if (split_ok) return split_shape(qsplit_of(k));
+        RungShape sh;
+        sh.G = qsq_of(k).G;
+        sh.L = qsq_of(k).L;
+        sh.rows = qsq_of(k).S;
+        return sh;
+    };
+    int rung = pick_rung(ctx, batch, n_rungs, shape, split_ok ? 2 : 1);
     if (split_ok && !(psplit_of(rung).G && qsplit_of(rung).G)) rung = 0;
     const DevSplit& sp_p = psplit_of(rung);
     const DevSplit& sp_q = qsplit_of(rung);
-    // side by side unless one half alone already gives every SIMD two waves
-    const bool side_by_side = split_ok && !fills_chip(ctx, batch, sp_p.G / 2 > 0 ? sp_p.G / 2 : 1);
+    // side by side (one grid, k_modexp_split_halves) while both halves together fit one residency of workgroups; beyond that
+    // each half fills the GPU on its own and they run one after the other
+    int occ = ctx->blocks_per_cu;
+    if (occ == 0 && split_ok) occ = PHE_SPLIT_BY_GROUP(sp_p.G, occ_split(sp_p.L, kModeHalfDecrypt));
+    const size_t wg_per_half = (batch + (size_t)(kBlock / std::max(1, sp_p.G)) - 1) / (size_t)(kBlock / std::max(1, sp_p.G));
+    const bool side_by_side = split_ok && sp_p.G == sp_q.G && sp_p.L == sp_q.L &&
+                              2 * wg_per_half <= (size_t)ctx->n_cus * (size_t)std::max(1, occ);
     ctx->last_geom_priv = split_ok ? geom_code(sp_p.G, sp_p.L) : geom_code(psq_of(rung).G, psq_of(rung).L);
     ctx->last_path = side_by_side ? kPathSideBySide : 0;
     if (side_by_side) {
-        if (!ctx->aux_stream) {
-            HIP_TRY(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
-        }
-        // size both table buffers before anything is in flight (growing one synchronises the device)
-        HIP_TRY(hipEventRecord(ctx->ev_fork, st));
-        HIP_TRY(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-        rc = launch_split<kModeHalfDecrypt>(ctx, sp_q, ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0, xq, S, batch, ctx->aux_stream, true);
+        rc = launch_split_halves(ctx, sp_p, ctx->d_exp_p, sp_q, ctx->d_exp_q, c, ctx->pub.s2, xp, xq, S, batch, st);
         if (rc) return rc;
-        HIP_TRY(hipEventRecord(ctx->ev_join, ctx->aux_stream));
-        rc = launch_split<kModeHalfDecrypt>(ctx, sp_p, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0, xp, S, batch, st);
-        if (rc) return rc;
-        HIP_TRY(hipStreamWaitEvent(st, ctx->ev_join, 0));
     } else {
         if (split_ok)
             rc = launch_split<kModeHalfDecrypt>(ctx, sp_p, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0, xp, S, batch, st);
@@ -1296,7 +1383,10 @@ int phe_hip_add_plain_dev(phe_hip_ctx* ctx, const uint32_t* c, const uint32_t* m
 // The rows are H | H limbs of rung 0's pair geometry; a wider rung with the same H can serve a small batch of them.
 static const DevSplit& pick_pair_split(const phe_hip_ctx* ctx, size_t batch) {
     const int n_rungs = 1 + (int)ctx->pub_rungs.size();
-    const int k = pick_rung(ctx, batch, n_rungs, [&](int r) { return nsplit_rung(ctx, r).H == ctx->d_nsplit.H ? nsplit_rung(ctx, r).G : 0; });
+    const int k = pick_rung(ctx, batch, n_rungs, [&](int r) {
+        const DevSplit& sp = nsplit_rung(ctx, r);
+        return (sp.H == ctx->d_nsplit.H && sp.rows == sp.H) ? split_shape(sp) : RungShape();
+    });
     const DevSplit& sp = nsplit_rung(ctx, k);
     return sp.H == ctx->d_nsplit.H ? sp : ctx->d_nsplit;
 }
@@ -1311,7 +1401,7 @@ static int pair_launch(phe_hip_ctx* ctx, int op, const uint32_t* a, const uint32
     A.out = out;
     A.b_stride = b_stride;
     A.limbs = ctx->pub.s2;
-    A.chunks = chunks_for(ctx->pub.s2, sp.H);
+    A.chunks = chunks_for(ctx->pub.s2, sp.rows);
     A.b_limbs = b_limbs;
     A.batch = batch;
     ctx->last_geom_pub = geom_code(sp.G, sp.L);
@@ -1536,7 +1626,7 @@ int phe_hip_multiexp_csr_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint3
         T.base = base;
         T.base_inv = base_inv;
         T.base_limbs = ctx->pub.s2;
-        T.base_chunks = chunks_for(ctx->pub.s2, M.H);
+        T.base_chunks = chunks_for(ctx->pub.s2, M.rows);
         T.window = w;
         T.table = ctx->lookup;
         T.batch = batch;
@@ -2176,6 +2266,10 @@ int phe_hip_stream_destroy(phe_hip_ctx* ctx, void* stream) {
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
     if (!stream) return PHE_HIP_OK;
     if (int rc = bind_device(ctx)) return rc;
+    if (ctx->busy_valid && ctx->busy_stream == (hipStream_t)stream) {  // the context's last work ran here: finish it, forget the stream
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        ctx->busy_valid = false;
+    }
     HIP_TRY(hipStreamDestroy((hipStream_t)stream));
     return PHE_HIP_OK;
 }
@@ -2279,10 +2373,10 @@ int phe_hip_selftest_prims(int device, uint32_t* out) {
     if (!out) return fail(PHE_HIP_EINVAL, "null out");
     HIP_TRY(hipSetDevice(device));
     uint32_t* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, 834 * 4));
+    HIP_TRY(hipMalloc((void**)&d, 1026 * 4));
     k_selftest_prims<<<dim3(1), dim3(64), 0, nullptr>>>(d);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpy(out, d, 834 * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(out, d, 1026 * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipFree(d));
     return PHE_HIP_OK;
 }

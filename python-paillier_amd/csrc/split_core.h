@@ -49,6 +49,7 @@ struct SplitConsts {
     const uint32_t* conv;  // chunk j: D0_j | D1_j             (R^(j+2) mod n^2 = D0 - n*D1)
     const uint32_t* nsq;   // n^2, 2H limbs
     uint32_t n0inv;        // -n^-1 mod 2^29
+    int rows;              // limbs of a number (= G*L, except on the whole-wave geometry G = 64: key_setup.h SplitPack::rows)
 };
 
 // Same contract as UniformArgs (mont_core.h): batch-uniform exponent given as a sliding-window schedule,
@@ -75,13 +76,12 @@ struct SplitArgs {
 // out = (a*b + m*n) / R with the quotient digits m_i stored to m_row (LDS, H words); a: H digits in LDS.
 template <int G, int L, bool U = false>
 PHE_DEV void montmul_q(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[L], uint32_t* m_row,
-                       const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln) {
-    constexpr int H = G * L;
+                       const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln, int rows = G * L) {
     uint64_t acc[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) acc[k] = 0;
 #pragma unroll 1
-    for (int i = 0; i < H; i += L) {
+    for (int i = 0; i < rows; i += L) {
         uint32_t mq[L];
 #pragma unroll
         for (int j = 0; j < L; ++j) {
@@ -112,13 +112,12 @@ PHE_DEV void montmul_q(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b
 // out = (a*b + m*g + m2*n) / R;  a and m: H digits each in LDS
 template <int G, int L>
 PHE_DEV void montmac2(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[L], const uint32_t* m_row,
-                      const uint32_t (&gm)[L], const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln) {
-    constexpr int H = G * L;
+                      const uint32_t (&gm)[L], const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln, int rows = G * L) {
     uint64_t acc[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) acc[k] = 0;
 #pragma unroll 1
-    for (int i = 0; i < H; i += L) {
+    for (int i = 0; i < rows; i += L) {
 #pragma unroll
         for (int j = 0; j < L; ++j) {
             const uint32_t ai = a[i + j];
@@ -147,15 +146,14 @@ PHE_DEV void montmac2(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)
 // montmul_q: the second word of a pair product when the sweeps are not fused)
 template <int G, int L, bool U = false>
 PHE_DEV void montmul_addend(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[L], const uint32_t* addend_row,
-                            const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln) {
-    constexpr int H = G * L;
+                            const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln, int rows = G * L) {
     const uint32_t dmask = kLimbMask & ln.not_top;
     const uint32_t vmask = kLimbMask & (ln.not_top | ln.not_low);
     uint64_t acc[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) acc[k] = addend_row[ln.g * L + k];
 #pragma unroll 1
-    for (int i = 0; i < H; i += L) {
+    for (int i = 0; i < rows; i += L) {
 #pragma unroll
         for (int j = 0; j < L; ++j) {
             const uint32_t ai = a[i + j];
@@ -181,13 +179,12 @@ PHE_DEV void montmul_addend(uint32_t (&out)[L], const uint32_t* a, const uint32_
 // hi: almost-normalised.
 template <int G, int L>
 PHE_DEV void mul_wide(uint32_t (&hi)[L], const uint32_t* a, const uint32_t (&b)[L], const uint32_t (&addend)[L],
-                      uint32_t* lo_row, const Lanes<G>& ln) {
-    constexpr int H = G * L;
+                      uint32_t* lo_row, const Lanes<G>& ln, int rows = G * L) {
     uint64_t acc[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) acc[k] = addend[k];
 #pragma unroll 1
-    for (int i = 0; i < H; i += L) {
+    for (int i = 0; i < rows; i += L) {
         uint32_t dq[L];
 #pragma unroll
         for (int j = 0; j < L; ++j) {
@@ -246,12 +243,20 @@ PHE_DEV void shift_row(uint64_t (&acc)[L], int j, uint32_t dmask) {
     q[j] += (uint64_t)(mraw & lane0); /* quotient digit i of the first sum = digit i of the addend m */
 #endif
 
+// Digits a fused sweep takes per loop trip.  The accumulators rotate by renaming with period L, so a trip is a multiple of L
+// digits: L for the throughput geometries (two waves per SIMD hide the LDS latency of the digit reads).  The whole-wave
+// geometry (G = 64) runs ONE wave per SIMD and little work per digit: it takes 4-10 digits per trip and fetches the next
+// trip's digits before it starts on the current ones, so that no digit read is waited for (SplitPack::rows is a multiple).
+template <int G, int L>
+struct Trip {
+    static constexpr int kDigits = (G == 64) ? (L == 1 ? 4 : 2) * L : L;
+};
+
 // z0 = (a*b0 + m*n) / R,   z1 = (m + a*b1 + m2*n) / R.     a: H digits in LDS.
 // Squaring: b0 = X0, b1 = 2*X1.  Conversion of a plain chunk a: (b0, b1) = pair(R^(j+2)).
 template <int G, int L, bool U = false>
 PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a, const uint32_t (&b0)[L],
-                        const uint32_t (&b1)[L], const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln) {
-    constexpr int H = G * L;
+                        const uint32_t (&b1)[L], const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln, int rows = G * L) {
     const uint32_t lane0 = kLimbMask & ~ln.not_low;  // digit mask in lane 0 of the group, 0 elsewhere
     const uint32_t dmask = kLimbMask & ln.not_top;
     // = kLimbMask in every lane (no lane of a group of >= 2 is both top and low), but plain VGPR data to the compiler,
@@ -260,11 +265,27 @@ PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
     uint64_t p[L], q[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) p[k] = q[k] = 0;
-#pragma unroll 1
-    for (int i = 0; i < H; i += L) {
+    constexpr int kT = Trip<G, L>::kDigits;
+    uint32_t ahead_a[kT];
+    if constexpr (G == 64) {
 #pragma unroll
-        for (int j = 0; j < L; ++j) {
-            const uint32_t ai = a[i + j];
+        for (int t = 0; t < kT; ++t) ahead_a[t] = a[t];
+    }
+#pragma unroll 1
+    for (int i = 0; i < rows; i += kT) {
+        uint32_t dig_a[kT];
+        if constexpr (G == 64) {
+            const int nx = (i + kT < rows) ? i + kT : i;
+#pragma unroll
+            for (int t = 0; t < kT; ++t) {
+                dig_a[t] = ahead_a[t];
+                ahead_a[t] = a[nx + t];
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < kT; ++jj) {
+            const int j = jj % L;
+            const uint32_t ai = (G == 64) ? dig_a[jj] : a[i + jj];
 #pragma unroll
             for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(ai, b0[k], p[(k + j) % L]);
 #pragma unroll
@@ -288,20 +309,40 @@ PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
 template <int G, int L, bool U = false>
 PHE_DEV void pair_pass3(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a, const uint32_t* c,
                         const uint32_t (&b0)[L], const uint32_t (&b1)[L], const uint32_t (&n)[L], uint32_t n0inv,
-                        const Lanes<G>& ln) {
-    constexpr int H = G * L;
+                        const Lanes<G>& ln, int rows = G * L) {
     const uint32_t lane0 = kLimbMask & ~ln.not_low;
     const uint32_t dmask = kLimbMask & ln.not_top;
     const uint32_t vmask = kLimbMask & (ln.not_top | ln.not_low);
     uint64_t p[L], q[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) p[k] = q[k] = 0;
-#pragma unroll 1
-    for (int i = 0; i < H; i += L) {
+    constexpr int kT = Trip<G, L>::kDigits;
+    uint32_t ahead_a[kT], ahead_c[kT];
+    if constexpr (G == 64) {
 #pragma unroll
-        for (int j = 0; j < L; ++j) {
-            const uint32_t ai = a[i + j];
-            const uint32_t ci = c[i + j];
+        for (int t = 0; t < kT; ++t) {
+            ahead_a[t] = a[t];
+            ahead_c[t] = c[t];
+        }
+    }
+#pragma unroll 1
+    for (int i = 0; i < rows; i += kT) {
+        uint32_t dig_a[kT], dig_c[kT];
+        if constexpr (G == 64) {
+            const int nx = (i + kT < rows) ? i + kT : i;
+#pragma unroll
+            for (int t = 0; t < kT; ++t) {
+                dig_a[t] = ahead_a[t];
+                dig_c[t] = ahead_c[t];
+                ahead_a[t] = a[nx + t];
+                ahead_c[t] = c[nx + t];
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < kT; ++jj) {
+            const int j = jj % L;
+            const uint32_t ai = (G == 64) ? dig_a[jj] : a[i + jj];
+            const uint32_t ci = (G == 64) ? dig_c[jj] : c[i + jj];
 #pragma unroll
             for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(ai, b0[k], p[(k + j) % L]);
 #pragma unroll
@@ -328,6 +369,11 @@ struct SplitLane {  // what every pass needs, loaded once per kernel (U: the mod
     uint32_t n0inv;
     uint32_t* row_a;  // H words: digits of X0 (or of a plain multiplier)
     uint32_t* row_c;  // H words: digits of X1 (quotient digits in split_exit)
+    int rows_;        // G = 64 only: limbs the numbers really have (R = 2^(29 rows)); every other geometry fills its G*L limbs
+    PHE_DEV int rows() const {
+        if constexpr (G == 64) return rows_;
+        else return G * L;
+    }
 };
 
 // (z0, z1) = (a*b0 + m*n, m + a*b1 + m2*n) / R with a already in row_a: one fused sweep, or two single sweeps with the
@@ -336,12 +382,12 @@ template <int G, int L, bool U>
 PHE_DEV void pair_mul_plain(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t (&b0)[L], const uint32_t (&b1)[L],
                             const SplitLane<G, L, U>& K, const Lanes<G>& ln) {
     if constexpr (L <= kMaxFusedL) {
-        pair_pass2<G, L, U>(z0, z1, K.row_a, b0, b1, K.n, K.n0inv, ln);
+        pair_pass2<G, L, U>(z0, z1, K.row_a, b0, b1, K.n, K.n0inv, ln, K.rows());
     } else {
         uint32_t u[L];
-        montmul_q<G, L, U>(u, K.row_a, b0, K.row_c, K.n, K.n0inv, ln);
+        montmul_q<G, L, U>(u, K.row_a, b0, K.row_c, K.n, K.n0inv, ln, K.rows());
         wave::lds_fence();
-        montmul_addend<G, L, U>(z1, K.row_a, b1, K.row_c, K.n, K.n0inv, ln);
+        montmul_addend<G, L, U>(z1, K.row_a, b1, K.row_c, K.n, K.n0inv, ln, K.rows());
 #pragma unroll
         for (int k = 0; k < L; ++k) z0[k] = u[k];
     }
@@ -368,13 +414,13 @@ PHE_DEV void split_mul(uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t (&Y0
             K.row_c[ln.g * L + k] = X1[k];
         }
         wave::lds_fence();
-        pair_pass3<G, L, U>(X0, X1, K.row_a, K.row_c, Y0, Y1, K.n, K.n0inv, ln);
+        pair_pass3<G, L, U>(X0, X1, K.row_a, K.row_c, Y0, Y1, K.n, K.n0inv, ln, K.rows());
     } else {
         // three single sweeps: X1*Y0, then (X0*Y0 with its quotient) and (quotient + X0*Y1); the second word stays
         // below 3n instead of 2n, which every operation accepts
         uint32_t t[L];
         lds_put<L>(K.row_a, X1, ln.g);
-        montmul<G, L>(t, K.row_a, Y0, K.n, K.n0inv, ln);
+        montmul<G, L>(t, K.row_a, Y0, K.n, K.n0inv, ln, K.rows());
         lds_put<L>(K.row_a, X0, ln.g);
         pair_mul_plain<G, L>(X0, X1, Y0, Y1, K, ln);
         add_normalize<G, L>(X1, t, ln);
@@ -388,7 +434,7 @@ PHE_DEV void split_conv(uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t* sr
     constexpr int H = G * L;
     uint32_t tmp[L], d0[L], d1[L], u[L], t[L];
     for (int j = 0; j < chunks; ++j) {
-        load_u32_as_r29<L>(tmp, src, limbs32, j * H, ln.g);
+        load_u32_as_r29<L>(tmp, src, limbs32, j * K.rows(), ln.g, K.rows());
         lds_put<L>(K.row_a, tmp, ln.g);
         load_row<L>(d0, wave::reread_ptr(C.conv) + (size_t)(2 * j) * H, ln.g);
         load_row<L>(d1, wave::reread_ptr(C.conv) + (size_t)(2 * j + 1) * H, ln.g);
@@ -455,8 +501,9 @@ PHE_DEV void cond_sub_pair(uint32_t (&lo)[L], uint32_t (&hi)[L], const uint32_t 
 // canonical limbs (lo, hi) -> little-endian 32-bit words at p, repacked through the group's 2H-word LDS row
 template <int G, int L>
 PHE_DEV void store_pair_as_u32(uint32_t* p, int limbs32, const uint32_t (&lo)[L], const uint32_t (&hi)[L],
-                               uint32_t* row, uint32_t g, bool live) {
-    constexpr int H = G * L, S2 = 2 * H;
+                               uint32_t* row, uint32_t g, bool live, int rows = G * L) {
+    constexpr int H = G * L;
+    const int S2 = 2 * rows;  // limbs of the number lo + hi * 2^(29 rows); limb q sits at row[q] (q < rows) or row[H + q - rows]
     g = wave::reread(g);
     wave::lds_fence();
 #pragma unroll
@@ -466,12 +513,11 @@ PHE_DEV void store_pair_as_u32(uint32_t* p, int limbs32, const uint32_t (&lo)[L]
     }
     wave::lds_fence();
     if (live) {
+        const auto limb = [&](int q) -> uint64_t { return q < S2 ? row[q < rows ? q : H + (q - rows)] : 0u; };
         for (int j = (int)g; j < limbs32; j += G) {
             const int bit = 32 * j;
             const int q = bit / kRadixBits, o = bit - q * kRadixBits;
-            uint64_t v = (q < S2) ? row[q] : 0u;
-            if (q + 1 < S2) v |= (uint64_t)row[q + 1] << kRadixBits;
-            if (q + 2 < S2) v |= (uint64_t)row[q + 2] << (2 * kRadixBits);
+            const uint64_t v = limb(q) | (limb(q + 1) << kRadixBits) | (limb(q + 2) << (2 * kRadixBits));
             p[j] = (uint32_t)(v >> o);
         }
     }
@@ -489,42 +535,46 @@ PHE_DEV void split_exit(uint32_t* out, int out_limbs, uint32_t (&X0)[L], uint32_
     lds_put<L>(K.row_a, X0, g);
 #pragma unroll
     for (int k = 0; k < L; ++k) cst[k] = (g == 0u && k == 0) ? 1u : 0u;
-    montmul_q<G, L>(u, K.row_a, cst, K.row_c, K.n, K.n0inv, ln);
+    montmul_q<G, L>(u, K.row_a, cst, K.row_c, K.n, K.n0inv, ln, K.rows());
     // t = -(X1 + m) / R = (X1 + m) * (n - 1) / R   (mod n)
     lds_put<L>(K.row_a, X1, g);  // (its fences also order the quotient digits in row_c)
 #pragma unroll
     for (int k = 0; k < L; ++k) cst[k] = K.n[k] - ((g == 0u && k == 0) ? 1u : 0u);  // n is odd: no borrow
     if constexpr (L <= kMaxFusedL) {
-        montmac2<G, L>(t, K.row_a, cst, K.row_c, cst, K.n, K.n0inv, ln);
+        montmac2<G, L>(t, K.row_a, cst, K.row_c, cst, K.n, K.n0inv, ln, K.rows());
     } else {
         uint32_t t2[L];
-        montmul<G, L>(t, K.row_a, cst, K.n, K.n0inv, ln);
-        montmul<G, L>(t2, K.row_c, cst, K.n, K.n0inv, ln);
+        montmul<G, L>(t, K.row_a, cst, K.n, K.n0inv, ln, K.rows());
+        montmul<G, L>(t2, K.row_c, cst, K.n, K.n0inv, ln, K.rows());
         add_normalize<G, L>(t, t2, ln);
     }
     if (mp != nullptr) {  // + mp * X0 / R: the plaintext term of (1 + n*mp), phe/paillier.py:134
         uint32_t w[L];
-        load_u32_as_r29<L>(w, mp, mp_limbs, 0, g);
+        load_u32_as_r29<L>(w, mp, mp_limbs, 0, g, K.rows());
         lds_put<L>(K.row_a, w, g);
-        montmul<G, L>(w, K.row_a, X0, K.n, K.n0inv, ln);
+        montmul<G, L>(w, K.row_a, X0, K.n, K.n0inv, ln, K.rows());
         add_normalize<G, L>(t, w, ln);
     }
     // t mod n, canonical
     lds_put<L>(K.row_a, t, g);
     load_row<L>(cst, wave::reread_ptr(C.r1), g);
-    montmul<G, L>(t, K.row_a, cst, K.n, K.n0inv, ln);
+    montmul<G, L>(t, K.row_a, cst, K.n, K.n0inv, ln, K.rows());
     canonicalize<G, L>(t, K.n, ln);
     // v = u + n*t  (< n^2 + 2n), then the canonical residue
     lds_put<L>(K.row_a, t, g);
     uint32_t hi[L], lo[L];
-    mul_wide<G, L>(hi, K.row_a, K.n, u, K.row_c, ln);
+    mul_wide<G, L>(hi, K.row_a, K.n, u, K.row_c, ln, K.rows());
     wave::lds_fence();
     load_row<L>(lo, K.row_c, g);
+    if constexpr (G == 64) {  // the sweep wrote `rows` digits: what lies beyond in the row is not part of the number
+#pragma unroll
+        for (int k = 0; k < L; ++k) lo[k] = ((int)g * L + k < K.rows()) ? lo[k] : 0u;
+    }
     normalize_full<G, L>(hi, ln);
     load_row<L>(cst, wave::reread_ptr(C.nsq), g);
     load_row<L>(t, wave::reread_ptr(C.nsq) + H, g);
     cond_sub_pair<G, L>(lo, hi, cst, t, ln);
-    store_pair_as_u32<G, L>(out, out_limbs, lo, hi, K.row_a, g, live);
+    store_pair_as_u32<G, L>(out, out_limbs, lo, hi, K.row_a, g, live, K.rows());
 }
 
 // ---- the batched exponentiation -------------------------------------------------------------------------------
@@ -537,6 +587,7 @@ PHE_DEV void modexp_split_body(const SplitArgs& A, uint32_t* lds_row, uint32_t s
     SplitLane<G, L, U> K;
     load_row<L>(K.n, A.mod.n, g);
     K.n0inv = A.mod.n0inv;
+    K.rows_ = A.mod.rows;
     K.row_a = lds_row;
     K.row_c = lds_row + H;
     uint32_t* tbl = A.table + (size_t)slot * (size_t)A.tbl_entries * S2;
@@ -614,6 +665,7 @@ PHE_DEV void mulmod_split_body(const SplitMulArgs& A, uint32_t* lds_row, uint32_
     SplitLane<G, L> K;
     load_row<L>(K.n, A.mod.n, g);
     K.n0inv = A.mod.n0inv;
+    K.rows_ = A.mod.rows;
     K.row_a = lds_row;
     K.row_c = lds_row + H;
     const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
@@ -665,6 +717,7 @@ PHE_DEV void to_pair_body(const PairArgs& A, uint32_t* lds_row, uint32_t slot, u
     SplitLane<G, L> K;
     load_row<L>(K.n, A.mod.n, g);
     K.n0inv = A.mod.n0inv;
+    K.rows_ = A.mod.rows;
     K.row_a = lds_row;
     K.row_c = lds_row + H;
     const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
@@ -689,6 +742,7 @@ PHE_DEV void from_pair_body(const PairArgs& A, uint32_t* lds_row, uint32_t slot,
     SplitLane<G, L> K;
     load_row<L>(K.n, A.mod.n, g);
     K.n0inv = A.mod.n0inv;
+    K.rows_ = A.mod.rows;
     K.row_a = lds_row;
     K.row_c = lds_row + H;
     const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
@@ -712,6 +766,7 @@ PHE_DEV void pair_mul_body(const PairArgs& A, uint32_t* lds_row, uint32_t slot, 
     SplitLane<G, L> K;
     load_row<L>(K.n, A.mod.n, g);
     K.n0inv = A.mod.n0inv;
+    K.rows_ = A.mod.rows;
     K.row_a = lds_row;
     K.row_c = lds_row + H;
     const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
@@ -819,6 +874,7 @@ PHE_DEV void modexp_var_split_body(const SplitVarArgs& A, uint32_t* lds_row, uin
     SplitLane<G, L> K;
     load_row<L>(K.n, A.mod.n, g);
     K.n0inv = A.mod.n0inv;
+    K.rows_ = A.mod.rows;
     K.row_a = lds_row;
     K.row_c = lds_row + H;
     const int tbl_entries = 1 << A.window;
@@ -853,10 +909,14 @@ PHE_DEV void modexp_var_split_body(const SplitVarArgs& A, uint32_t* lds_row, uin
         load_row<L>(X1, tbl + (size_t)d * S2 + H, g);
         for (int wi = A.n_windows - 2; wi >= 0; --wi) {
             for (int s = 0; s < A.window; ++s) split_square<G, L>(X0, X1, K, ln);
-            d = exp_digit(e, A.exp_limbs, wi * A.window, A.window);
+            // (the exponent row, the table and the lane position are re-read where they are used: left to itself the compiler
+            //  keeps their derived addresses alive across the sweeps and spills other values inside this loop for them)
+            d = exp_digit(wave::reread_vptr(e), A.exp_limbs, wi * A.window, A.window);
             if (wave::ballot(d != 0) != 0) {  // wave-uniform: skip when every group has a zero digit
-                load_row<L>(Y0, tbl + (size_t)d * S2, g);
-                load_row<L>(Y1, tbl + (size_t)d * S2 + H, g);
+                const uint32_t* entry = wave::reread_vptr(tbl) + (size_t)d * S2;
+                const uint32_t gi = wave::reread(g);
+                load_row<L>(Y0, entry, gi);
+                load_row<L>(Y1, entry + H, gi);
                 split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
             }
         }
@@ -910,6 +970,7 @@ PHE_DEV void multiexp_split_body(const SplitMultiArgs& A, uint32_t* lds_row, uin
     SplitLane<G, L> K;
     load_row<L>(K.n, A.mod.n, g);
     K.n0inv = A.mod.n0inv;
+    K.rows_ = A.mod.rows;
     K.row_a = lds_row;
     K.row_c = lds_row + H;
     const int per = (1 << A.window) - 1;  // table of one element: base^1 .. base^(2^w - 1)
@@ -1008,6 +1069,7 @@ PHE_DEV void multiexp_tables_body(const SplitTableArgs& A, uint32_t* lds_row, ui
     SplitLane<G, L> K;
     load_row<L>(K.n, A.mod.n, g);
     K.n0inv = A.mod.n0inv;
+    K.rows_ = A.mod.rows;
     K.row_a = lds_row;
     K.row_c = lds_row + H;
     const int per = (1 << A.window) - 1;
@@ -1066,6 +1128,7 @@ PHE_DEV void multiexp_lookup_body(const SplitLookupArgs& A, uint32_t* lds_row, u
     SplitLane<G, L> K;
     load_row<L>(K.n, A.mod.n, g);
     K.n0inv = A.mod.n0inv;
+    K.rows_ = A.mod.rows;
     K.row_a = lds_row;
     K.row_c = lds_row + H;
     const int per = (1 << A.window) - 1;

@@ -9,6 +9,11 @@
 //   grp_up1    v_mov_b32_dpp row_shr:1   bound_ctrl:0   lane g <- lane g-1   (lane 0  <- 0)
 //   grp_bcast0 v_mov_b32_dpp row_newbcast:0             lane g <- lane 0 of its group
 // (groups of 8 lanes add one v_and / a second DPP; see the templates below)
+// G = 64, the whole wavefront as ONE group (the latency rung: one number per wave, see key_setup.h kS64), uses the
+// wavefront-wide DPP shifts of the GFX9 family and a scalar broadcast:
+//   grp_down1  v_mov_b32_dpp wave_shl:1  bound_ctrl:0   lane i <- lane i+1   (lane 63 <- 0)
+//   grp_up1    v_mov_b32_dpp wave_shr:1  bound_ctrl:0   lane i <- lane i-1   (lane 0  <- 0)
+//   grp_bcast0 v_readfirstlane_b32                      every lane <- lane 0 (through an SGPR)
 //
 // tests/emu/wave_emu.h provides the same names on the host (fibers) so tests can run
 // mont_core.h on the CPU; tests/test_gpu_parity.py::test_wave_primitives checks these semantics on the real GPU.
@@ -52,7 +57,8 @@ PHE_DEV uint32_t dpp_row_shr1(uint32_t x) {  // lane i <- lane i-1 in the 16-lan
 // lane g <- lane g+1 of its group; the group's top lane receives 0
 template <int G>
 PHE_DEV uint32_t grp_down1(uint32_t x, const Lanes<G>& l) {
-    if constexpr (G == 16) return dpp_row_shl1(x);
+    if constexpr (G == 64) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
+    else if constexpr (G == 16) return dpp_row_shl1(x);
     else if constexpr (G == 8) return dpp_row_shl1(x) & l.not_top;
     else if constexpr (G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9 /*quad_perm:[1,2,3,3]*/, 0xf, 0xf, true) & l.not_top;
     else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF5 /*quad_perm:[1,1,3,3]*/, 0xf, 0xf, true) & l.not_top;
@@ -61,14 +67,16 @@ PHE_DEV uint32_t grp_down1(uint32_t x, const Lanes<G>& l) {
 // fold "& not_top" into a mask they apply anyway
 template <int G>
 PHE_DEV uint32_t grp_down1_raw(uint32_t x) {
-    if constexpr (G >= 8) return dpp_row_shl1(x);
+    if constexpr (G == 64) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
+    else if constexpr (G >= 8) return dpp_row_shl1(x);
     else if constexpr (G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9 /*quad_perm:[1,2,3,3]*/, 0xf, 0xf, true);
     else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF5 /*quad_perm:[1,1,3,3]*/, 0xf, 0xf, true);
 }
 // lane g <- lane g-1 of its group; the group's lane 0 receives 0
 template <int G>
 PHE_DEV uint32_t grp_up1(uint32_t x, const Lanes<G>& l) {
-    if constexpr (G == 16) return dpp_row_shr1(x);
+    if constexpr (G == 64) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+    else if constexpr (G == 16) return dpp_row_shr1(x);
     else if constexpr (G == 8) return dpp_row_shr1(x) & l.not_low;
     else if constexpr (G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x90 /*quad_perm:[0,0,1,2]*/, 0xf, 0xf, true) & l.not_low;
     else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xA0 /*quad_perm:[0,0,2,2]*/, 0xf, 0xf, true) & l.not_low;
@@ -76,7 +84,9 @@ PHE_DEV uint32_t grp_up1(uint32_t x, const Lanes<G>& l) {
 // every lane <- lane 0 of its group
 template <int G>
 PHE_DEV uint32_t grp_bcast0(uint32_t x, const Lanes<G>&) {
-    if constexpr (G == 16) {
+    if constexpr (G == 64) {
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);  // all 64 lanes are active in these kernels
+    } else if constexpr (G == 16) {
         return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 /*row_newbcast:0*/, 0xf, 0xf, true);
     } else if constexpr (G == 4) {
         return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x00 /*quad_perm:[0,0,0,0]*/, 0xf, 0xf, true);
@@ -126,6 +136,13 @@ PHE_DEV uint32_t reread(uint32_t x) {
 // into registers that would stay live — and be spilled — across every product.
 PHE_DEV const uint32_t* reread_ptr(const uint32_t* p) {
     asm volatile("" : "+s"(p));
+    return p;
+}
+
+// ... and for a per-lane pointer (a group's window table, an element's exponent row)
+template <class T>
+PHE_DEV T* reread_vptr(T* p) {
+    asm volatile("" : "+v"(p));
     return p;
 }
 

@@ -654,6 +654,6 @@ def miller_rabin(n, base, device=0):
 
 
 def selftest_prims(device=0):
-    out = np.zeros(834, np.uint32)
+    out = np.zeros(1026, np.uint32)
     _check(lib().phe_hip_selftest_prims(device, _ptr(out)))
     return out

@@ -26,6 +26,10 @@ static thread_local std::string g_err;
 
 #define DISPATCH_GL(G_, L_, CALL)                                                     \
     switch ((G_) * 100 + (L_)) {                                                      \
+        case 6401: { constexpr int GG = 64, LL = 1; CALL; break; }                    \
+        case 6402: { constexpr int GG = 64, LL = 2; CALL; break; }                    \
+        case 6403: { constexpr int GG = 64, LL = 3; CALL; break; }                    \
+        case 6405: { constexpr int GG = 64, LL = 5; CALL; break; }                    \
         case 1601: { constexpr int GG = 16, LL = 1; CALL; break; }                    \
         case 1602: { constexpr int GG = 16, LL = 2; CALL; break; }                    \
         case 1603: { constexpr int GG = 16, LL = 3; CALL; break; }                    \
@@ -146,6 +150,10 @@ static void run_mul(MulArgs A) {
 // geometries of the split-modulus kernels (key_setup.h: kS2 / kS4 / kS8 / kS16)
 #define DISPATCH_SPLIT(G_, L_, CALL)                                                  \
     switch ((G_) * 100 + (L_)) {                                                      \
+        case 6401: { constexpr int GG = 64, LL = 1; CALL; break; }                    \
+        case 6402: { constexpr int GG = 64, LL = 2; CALL; break; }                    \
+        case 6403: { constexpr int GG = 64, LL = 3; CALL; break; }                    \
+        case 6405: { constexpr int GG = 64, LL = 5; CALL; break; }                    \
         case 1601: { constexpr int GG = 16, LL = 1; CALL; break; }                    \
         case 1602: { constexpr int GG = 16, LL = 2; CALL; break; }                    \
         case 1603: { constexpr int GG = 16, LL = 3; CALL; break; }                    \
@@ -173,7 +181,7 @@ static void run_mul(MulArgs A) {
 static SplitConsts split_consts_of(const host::SplitPack& m) {
     SplitConsts c;
     c.n = m.n.data(); c.r1 = m.r1.data();
-    c.e = m.e.data(); c.conv = m.conv.data(); c.nsq = m.nsq.data(); c.n0inv = m.n0inv;
+    c.e = m.e.data(); c.conv = m.conv.data(); c.nsq = m.nsq.data(); c.n0inv = m.n0inv; c.rows = m.rows;
     return c;
 }
 static int chunks_for(int limbs32, int H) { return std::max(1, (32 * limbs32 + 29 * H - 1) / (29 * H)); }
@@ -344,7 +352,7 @@ uint64_t emu_mad_count(int reset) {
 
 const char* emu_last_error() { return g_err.c_str(); }
 
-void emu_set_group(int g) { g_prefer_group = (g == 2 || g == 4 || g == 8 || g == 16) ? g : 0; }
+void emu_set_group(int g) { g_prefer_group = (g == 2 || g == 4 || g == 8 || g == 16 || g == 64) ? g : 0; }
 
 // 64/G independent products a[r]*b[r]*R^-1 (mod N), one per limb group.  All arrays hold 29-bit limbs,
 // G*L words per number; a < R, b < 2N; the result is < 2N, almost-normalised (limbs < 2^29 + 2^8).
@@ -388,7 +396,7 @@ int emu_encrypt(const uint32_t* n, int n_limbs, const uint32_t* m, const uint32_
             A.mod = split_consts_of(M);
             A.sched = P.exp_n.ops.data(); A.n_ops = (int)P.exp_n.ops.size();
             A.first_idx = P.exp_n.first_idx; A.tbl_entries = P.exp_n.tbl_entries;
-            A.base = r; A.base_limbs = P.s1; A.base_chunks = chunks_for(P.s1, M.H);
+            A.base = r; A.base_limbs = P.s1; A.base_chunks = chunks_for(P.s1, M.rows);
             A.post = nullptr; A.post_limbs = P.s1; A.post_chunks = 1;
             A.out = t16; A.out_limbs = W; A.batch = B;
             DISPATCH_SPLIT(M.G, M.L, (run_split<GG, LL, kModeEncrypt, true>(A)));
@@ -409,8 +417,8 @@ int emu_encrypt(const uint32_t* n, int n_limbs, const uint32_t* m, const uint32_
             A.mod = split_consts_of(M);
             A.sched = P.exp_n.ops.data(); A.n_ops = (int)P.exp_n.ops.size();
             A.first_idx = P.exp_n.first_idx; A.tbl_entries = P.exp_n.tbl_entries;
-            A.base = r; A.base_limbs = P.s1; A.base_chunks = chunks_for(P.s1, M.H);
-            A.post = c_in ? c_in : m; A.post_limbs = c_in ? P.s2 : P.s1; A.post_chunks = chunks_for(A.post_limbs, M.H);
+            A.base = r; A.base_limbs = P.s1; A.base_chunks = chunks_for(P.s1, M.rows);
+            A.post = c_in ? c_in : m; A.post_limbs = c_in ? P.s2 : P.s1; A.post_chunks = chunks_for(A.post_limbs, M.rows);
             A.out = c_out; A.out_limbs = P.s2; A.batch = B;
             if (c_in) { DISPATCH_SPLIT(M.G, M.L, (run_split<GG, LL, kModeObfuscate>(A))); }
             else { DISPATCH_SPLIT(M.G, M.L, (run_split<GG, LL, kModeEncrypt>(A))); }
@@ -453,7 +461,7 @@ int emu_encrypt_owner(const uint32_t* n, const uint32_t* p, const uint32_t* q, c
             A.mod = split_consts_of(SP);
             A.sched = PUB.exp_n.ops.data(); A.n_ops = (int)PUB.exp_n.ops.size();
             A.first_idx = PUB.exp_n.first_idx; A.tbl_entries = PUB.exp_n.tbl_entries;
-            A.base = r; A.base_limbs = P.s1; A.base_chunks = chunks_for(P.s1, SP.H);
+            A.base = r; A.base_limbs = P.s1; A.base_chunks = chunks_for(P.s1, SP.rows);
             A.out = half ? yq.data() : yp.data(); A.out_limbs = S; A.batch = B;
             DISPATCH_SPLIT(SP.G, SP.L, (run_split<GG, LL, kModeHalfDecrypt>(A)));
         }
@@ -493,7 +501,7 @@ int emu_decrypt(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const 
                 A.mod = split_consts_of(SP);
                 A.sched = E.ops.data(); A.n_ops = (int)E.ops.size();
                 A.first_idx = E.first_idx; A.tbl_entries = E.tbl_entries;
-                A.base = c; A.base_limbs = P.s2; A.base_chunks = chunks_for(P.s2, SP.H);
+                A.base = c; A.base_limbs = P.s2; A.base_chunks = chunks_for(P.s2, SP.rows);
                 A.out = half ? xq.data() : xp.data(); A.out_limbs = S; A.batch = B;
                 DISPATCH_SPLIT(SP.G, SP.L, (run_split<GG, LL, kModeHalfDecrypt>(A)));
                 continue;
@@ -546,7 +554,7 @@ int emu_mulmod_n2_split(const uint32_t* n, int n_limbs, const uint32_t* a, const
         SplitMulArgs A;
         memset(&A, 0, sizeof A);
         A.mod = split_consts_of(M);
-        A.a = a; A.b = b; A.out = out; A.limbs = 2 * n_limbs; A.chunks = chunks_for(2 * n_limbs, M.H);
+        A.a = a; A.b = b; A.out = out; A.limbs = 2 * n_limbs; A.chunks = chunks_for(2 * n_limbs, M.rows);
         A.a_stride = A.out_stride = (size_t)(2 * n_limbs);
         A.b_stride = b_plain ? (size_t)n_limbs : (size_t)(2 * n_limbs);
         A.b_plain_limbs = b_plain ? n_limbs : 0;
@@ -628,6 +636,7 @@ int emu_split_pair_op(int G, int L, const uint32_t* n, int n_limbs, int op, cons
                 SplitLane<GG, LL> K;
                 load_row<LL>(K.n, C.n, g);
                 K.n0inv = C.n0inv;
+                K.rows_ = C.rows;
                 K.row_a = lds.data() + grp * (S2 + kLdsPad);
                 K.row_c = K.row_a + H;
                 uint32_t x0[LL], x1[LL], y0[LL], y1[LL];
@@ -665,13 +674,13 @@ int emu_pair_op(const uint32_t* n, int n_limbs, int op, int group, const uint32_
         host::SplitPack M = P0.nsplit;
         if (group > 0) {
             M = host::build_public(n, n_limbs, group).nsplit;
-            if (M.G == 0 || M.H != P0.nsplit.H) return 2;
+            if (M.G == 0 || M.H != P0.nsplit.H || M.rows != M.H) return 2;
         }
         PairArgs A;
         memset(&A, 0, sizeof A);
         A.mod = split_consts_of(M);
         A.a = a; A.b = b; A.out = out;
-        A.limbs = P0.s2; A.chunks = chunks_for(P0.s2, M.H);
+        A.limbs = P0.s2; A.chunks = chunks_for(P0.s2, M.rows);
         A.b_stride = (op == 2 && !b_is_row) ? (size_t)(2 * M.H) : 0;
         A.b_limbs = (op == 1 && b) ? P0.s1 : 0;
         A.batch = B;
@@ -695,7 +704,7 @@ int emu_powmod_n2(const uint32_t* n, int n_limbs, const uint32_t* base, const ui
             SplitVarArgs A;
             memset(&A, 0, sizeof A);
             A.mod = split_consts_of(M);
-            A.base = base; A.base_limbs = P.s2; A.base_chunks = chunks_for(P.s2, M.H);
+            A.base = base; A.base_limbs = P.s2; A.base_chunks = chunks_for(P.s2, M.rows);
             A.exps = exps; A.exp_limbs = exp_limbs;
             A.window = host::pick_window(max_bits);
             A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
@@ -730,7 +739,7 @@ int emu_multiexp_n2(const uint32_t* n, int n_limbs, const uint32_t* base, const 
         SplitMultiArgs A;
         memset(&A, 0, sizeof A);
         A.mod = split_consts_of(M);
-        A.base = base; A.base_inv = base_inv; A.base_limbs = P.s2; A.base_chunks = chunks_for(P.s2, M.H);
+        A.base = base; A.base_inv = base_inv; A.base_limbs = P.s2; A.base_chunks = chunks_for(P.s2, M.rows);
         A.exps = exps; A.neg = neg; A.exp_limbs = exp_limbs;
         A.window = host::pick_multi_window(max_bits);
         A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
@@ -762,7 +771,7 @@ int emu_multiexp_csr(const uint32_t* n, int n_limbs, const uint32_t* base, const
         SplitTableArgs T;
         memset(&T, 0, sizeof T);
         T.mod = split_consts_of(M);
-        T.base = base; T.base_inv = base_inv; T.base_limbs = P.s2; T.base_chunks = chunks_for(P.s2, M.H);
+        T.base = base; T.base_inv = base_inv; T.base_limbs = P.s2; T.base_chunks = chunks_for(P.s2, M.rows);
         T.window = w; T.table = table.data(); T.batch = B;
         DISPATCH_SPLIT(M.G, M.L, (run_multi_tables<GG, LL>(T)));
         SplitLookupArgs A;

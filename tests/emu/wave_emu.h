@@ -205,6 +205,8 @@ inline void async_copy16_to_lds(const uint32_t* gsrc, uint32_t* lds_wave_base, b
 inline void wait_async_copies() { lds_fence(); }
 
 inline const uint32_t* reread_ptr(const uint32_t* p) { return p; }
+template <class T>
+inline T* reread_vptr(T* p) { return p; }
 inline uint32_t reread(uint32_t x) { return x; }  // see wave_gfx950.h: an optimisation barrier on the device, nothing here
 
 // every mad64 is one v_mad_u64_u32 lane-operation on the device: counted here so that tools/count_executed_mads.py can

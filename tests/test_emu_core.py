@@ -120,6 +120,8 @@ def test_reference_kat(emu):
     ("split", 256, None, 16), ("split", 256, None, 8), ("split", 1024, 5, 0), ("split", 1024, 3, 16),
     ("split", 1024, 3, 4), ("split", 1024, 3, 8), ("split", 2048, 3, 0), ("split", 2048, 2, 8), ("split", 2048, 2, 16),
     ("split", 3072, 2, 0), ("split", 3072, 1, 8),
+    # the whole wavefront as one limb group (G = 64, the latency rung): numbers of 36 / 72 / 108 limbs on 64 x 1 / 2 / 2 lanes
+    ("split", 256, None, 64), ("split", 1024, 3, 64), ("split", 2048, 2, 64), ("split", 3072, 1, 64),
     ("full", 256, None, 16), ("full", 256, None, 8), ("full", 1024, 3, 0), ("full", 1024, 2, 4), ("full", 2048, 2, 0),
     ("full", 3072, 1, 0)])
 def test_golden_through_emulator(emu, engine, key_bits, count, group):
@@ -174,7 +176,7 @@ def test_homomorphic_ops_through_emulator(emu, engine):
     emu.set_engine(True)
 
 
-@pytest.mark.parametrize("key_bits,group", [(1024, 0), (1024, 8), (2048, 0)])
+@pytest.mark.parametrize("key_bits,group", [(1024, 0), (1024, 8), (2048, 0), (1024, 64), (2048, 64)])
 def test_powmod_n2_split_engine(emu, key_bits, group):
     """per-element exponents through k_modexp_var_split's body: 0, 1, short, long and full-width exponents; bases
     0, 1, n^2 - 1, multiples of n and random residues"""

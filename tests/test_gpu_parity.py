@@ -41,7 +41,7 @@ def test_wave_primitives(native):
     """The DPP group operations mean what csrc/wave_gfx950.h (and the CPU emulator) say they mean."""
     out = native.selftest_prims(0)
     lanes = np.arange(64)
-    for G, base in ((16, 0), (8, 258), (4, 450), (2, 642)):
+    for G, base in ((16, 0), (8, 258), (4, 450), (2, 642), (64, 834)):
         down = np.where(lanes % G == G - 1, 0, lanes + 1 + 100)
         up = np.where(lanes % G == 0, 0, lanes - 1 + 100)
         bc = (lanes // G) * G + 100

@@ -9,7 +9,7 @@ region): the steady rate of a stream of batches of that size, launch gaps includ
 trip decrypt(encrypt(m)) = m on the device, a strided sample of every op against the libgmp oracle.
 
   python tools/bench_sweep.py [--key-bits 2048] [--min 10] [--max 20] [--group G]  > profiles/rNN_batch_sweep.json
-(--group G pins every size to one rung; PHE_HIP_FILL_PCT moves the ladder's thresholds)"""
+(--group G pins every size to one rung)"""
 import argparse
 import json
 import os
@@ -91,14 +91,14 @@ def main():
         return a.elapsed_time(b) / reps, reps
 
     # rough per-row costs (ms) to size the repetitions; refined from the first measurement of each op
-    est = {"encrypt": 1.8e-3, "decrypt": 0.5e-3, "add": 4e-6, "mul": 7e-5, "pair_add": 1.5e-6}
+    est = {"encrypt": 1.8e-3, "decrypt": 0.5e-3, "add": 4e-6, "mul": 7e-5, "pair_add": 1.5e-6, "pair_add_rowb": 1.5e-6}
     points = []
     for lg in range(args.min, args.max + 1):
         B = 1 << lg
         row = {"log2_batch": lg, "batch": B}
         idx = torch.arange(0, B, max(1, B // 24), device=dev)[:24]
         for op in ops:
-            if op == "pair_add" and not pair_words:
+            if op.startswith("pair_add") and not pair_words:
                 continue
             if op == "encrypt":
                 fn = lambda: ctx.encrypt_dev(m.data_ptr(), r.data_ptr(), out.data_ptr(), B, st)
@@ -108,12 +108,14 @@ def main():
                 fn = lambda: ctx.mulmod_dev(c.data_ptr(), c2.data_ptr(), out.data_ptr(), B, st)
             elif op == "mul":
                 fn = lambda: ctx.powmod_dev(c.data_ptr(), e.data_ptr(), 2, 56, out.data_ptr(), B, st)
+            elif op == "pair_add_rowb":                          # diagnostic: the second operand is ONE row (a third of the traffic)
+                fn = lambda: ctx.pair_mul_dev(pa.data_ptr(), pb.data_ptr(), True, pout.data_ptr(), B, st)
             else:
                 fn = lambda: ctx.pair_mul_dev(pa.data_ptr(), pb.data_ptr(), False, pout.data_ptr(), B, st)
             ms, reps = timed(fn, est[op] * B)
             info = ctx.last_launch()
             entry = {"per_s": B / ms * 1e3, "ms": ms, "reps": reps}
-            if op in ("encrypt", "mul", "pair_add", "add"):
+            if op in ("encrypt", "mul", "pair_add", "pair_add_rowb", "add"):
                 entry["geom"] = info["geom_pub"] if op != "add" else None
             if op == "encrypt":
                 entry["scaled_modulus"] = bool(info["path"] & ctx.PATH_UNIT)
@@ -133,7 +135,8 @@ def main():
             else:
                 ctx.from_pair_dev(pout.data_ptr(), None, out.data_ptr(), B, st)
                 torch.cuda.synchronize()
-                ok = np.array_equal(to_np(out[idx]), orc.add(n_arr, to_np(c[idx]), to_np(c2[idx]), nthreads=8))
+                other = to_np(c2[idx]) if op == "pair_add" else np.repeat(to_np(c2[:1]), len(idx), axis=0)
+                ok = np.array_equal(to_np(out[idx]), orc.add(n_arr, to_np(c[idx]), other, nthreads=8))
             entry["bit_exact"] = bool(ok)
             row[op] = entry
         points.append(row)
@@ -144,7 +147,7 @@ def main():
                 row[op]["frac_of_largest"] = row[op]["per_s"] / last[op]["per_s"]
     pub, priv = ctx.ladder()
     res = {"key_bits": args.key_bits, "ladder_pub": pub, "ladder_priv": priv, "forced_group": args.group,
-           "fill_pct": int(os.environ.get("PHE_HIP_FILL_PCT", "85")), "timing": "HIP events around `reps` back-to-back launches, one stream",
+           "timing": "HIP events around `reps` back-to-back launches, one stream",
            "device": torch.cuda.get_device_name(0), "points": points,
            "all_bit_exact": all(row[op]["bit_exact"] for row in points for op in ops if op in row)}
     worst = {}
