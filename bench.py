@@ -191,6 +191,9 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=0, help="elements for the CPU baseline (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ops", action="store_true", help="skip the configs[2] leg")
+    ap.add_argument("--only", choices=["encrypt", "decrypt"], default=None,
+                    help="profiling aid (tools/gpu_profile_round.sh): time just this region and print a short line, so that a "
+                         "rocprofv3 kernel trace of the run holds one leg's launches only; not a bench line")
     ap.add_argument("--config4", action="store_true", help="(kept for old command lines: the configs[3] leg now always runs)")
     ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--config4-key-bits", type=int, default=3072, choices=[256, 1024, 2048, 3072])
@@ -302,6 +305,16 @@ class HipBackend:
 
     def encrypt_owner(self, ctx, m, r, c, rows):
         ctx.encrypt_owner_dev(m.data_ptr(), r.data_ptr(), c.data_ptr(), rows, self.stream)
+
+    # resident rows in the pair form (include/phe_hip.h "pair form")
+    def to_pair(self, ctx, c, pair, rows):
+        ctx.to_pair_dev(c.data_ptr(), pair.data_ptr(), rows, self.stream)
+
+    def pair_mul(self, ctx, a, b, out, rows):
+        ctx.pair_mul_dev(a.data_ptr(), b.data_ptr(), False, out.data_ptr(), rows, self.stream)
+
+    def from_pair(self, ctx, pair, out, rows):
+        ctx.from_pair_dev(pair.data_ptr(), None, out.data_ptr(), rows, self.stream)
 
     def upload(self, arr):
         import numpy as np
@@ -489,6 +502,17 @@ def main():
 
     enc_step = lambda: be.encrypt(ctx, m, r, c, B)
     dec_step = lambda: be.decrypt(ctx, c, m_back, B)
+    if args.only:
+        enc_step()                                              # (the decrypt leg needs ciphertexts; one launch, outside the timed region)
+        step = enc_step if args.only == "encrypt" else dec_step
+        for _ in range(args.warmup):
+            step()
+        dt, launch_ms = timed(step, args.steps)
+        if rank == 0:
+            print(json.dumps({"profiling_aid_not_a_bench_line": True, "only": args.only, "batch": B, "key_bits": args.key_bits,
+                              "steps": args.steps, "per_s": B * args.steps * world / dt, "launch_ms": launch_ms,
+                              "decrypt_round_trip": be.equal(m_back, m) if args.only == "decrypt" else None}))
+        return
     for _ in range(args.warmup):
         enc_step()
     enc_dt, enc_launch_ms = timed(enc_step, args.steps)
@@ -574,6 +598,41 @@ def main():
                              "per pass: 8 additions at one Montgomery product each + 1 settling product; `value` counts passes")
             ops["raw_add_resident_chain"]["additions_per_s"] = ops["raw_add_resident_chain"]["value"] * chain
             del tmp
+        if hasattr(be, "pair_mul") and getattr(ctx, "pair_words", lambda: 0)():
+            # resident vectors in the engine's own format (the pair form the exponentiation kernels compute in): an addition is
+            # ONE half-width pair product, nothing to settle, no word <-> limb conversion between steps.  Timed like the chain
+            # above: c2 + 8 x c on rows that are already resident in pair form = 8 pair products + ONE exit to the canonical
+            # residue, checked as c2 * c^8 mod n^2 against libgmp.  The conversion INTO the form (once per vector, like the
+            # upload) is timed on its own.
+            chain, pw = 8, ctx.pair_words()
+            pc, pc2, pt1, pt2 = (be.empty(B, pw) for _ in range(4))
+            be.to_pair(ctx, c, pc, B)
+            be.to_pair(ctx, c2, pc2, B)
+
+            def pair_chain(k):
+                src = pc2
+                for i in range(chain):
+                    dst = pt1 if i % 2 == 0 else pt2
+                    be.pair_mul(ctx, src, pc, dst, k)
+                    src = dst
+                be.from_pair(ctx, src, out, k)
+
+            def check_pair():
+                sc = np.zeros((len(idx), s1), np.uint32)
+                sc[:, 0] = chain
+                want = orc.add(n_arr, orc.mul(n_arr, ca_s(), sc, nthreads=cores), be.np(be.take(c2, idx)), nthreads=cores)
+                return bool(np.array_equal(be.np(be.take(out, idx)), want))
+            ops_ok &= run_op("raw_add_resident_pair_form", pair_chain, 4, check_pair,
+                             "per pass: 8 additions at one pair product each + 1 exit to the canonical residue; `value` counts passes")
+            ops["raw_add_resident_pair_form"]["additions_per_s"] = ops["raw_add_resident_pair_form"]["value"] * chain
+            def check_conversion():                                  # out of the form again: every row must be the ciphertext it came from
+                be.from_pair(ctx, pt1, out, B)
+                be.sync()
+                return be.equal(out, c)
+            ops_ok &= run_op("to_pair_form", lambda k: be.to_pair(ctx, c, pt1, k), 4, check_conversion,
+                             "conversion of resident ciphertext rows into the pair form (once per vector); check = the whole batch "
+                             "converted back equals the ciphertexts")
+            del pc, pc2, pt1, pt2
         if hasattr(be, "encrypt_owner") and getattr(ctx, "owner_encrypt_offered", lambda: False)():
             # raw_encrypt by the holder of the private key: r^n from its CRT halves (half-width numbers), lifted to n^2 —
             # NOT the headline (that is the public-key path above); the whole batch must equal the public path's ciphertexts
@@ -789,6 +848,20 @@ def main():
             canon["raw_encrypt_key_owner"] = enc_mac
             for name, rec in ops.items():
                 per_gpu = rec["value"] / world
+                if name in ("raw_add_resident_pair_form", "to_pair_form"):
+                    # executed multiply-adds, exact: a pair product is 5 H^2 (pair_pass3), the exit 8 H^2 (montmul_q 2, montmac2 3,
+                    # montmul 2, mul_wide 1), the conversion in 13 H^2 (two chunk sweeps of 4 and one pair product), H = limbs of n
+                    Hn = ctx.pair_words() // 2
+                    if name == "to_pair_form":
+                        ex = 13 * Hn * Hn
+                        rec["roofline"] = {"bound": "valu_int32", "executed_mad_per_op": ex, "frac": ex * per_gpu / peak}
+                    else:
+                        adds = rec["additions_per_s"] / world
+                        ex_pass = (8 * 5 + 8) * Hn * Hn
+                        rec["roofline"] = {"bound": "valu_int32", "canonical_mac32_per_op": canon["raw_add"],
+                                           "executed_mad_per_addition": ex_pass / 8, "frac": ex_pass / 8 * adds / peak,
+                                           "hbm_algorithmic_GBps": (3 * ctx.pair_words() * 4 * 8 + (ctx.pair_words() + s2) * 4) / 8 * adds / 1e9}
+                    continue
                 if name == "raw_add_resident_chain":
                     adds = rec["additions_per_s"] / world
                     half = (counted["raw_add"] / 2) if counted else None      # one of the two products of the plain form

@@ -65,6 +65,7 @@ DEF_U32_TEST(k_mul_hi_u32, "v_mul_hi_u32 %0, %0, %2")
 DEF_U32_TEST(k_mad_u32_u24, "v_mad_u32_u24 %0, %1, %2, %0")
 DEF_U32_TEST(k_mul_hi_u32_u24, "v_mul_hi_u32_u24 %0, %0, %2")
 DEF_U32_TEST(k_fma_f32, "v_fma_f32 %0, %1, %2, %0")
+DEF_U32_TEST(k_fmac_f32, "v_fmac_f32 %0, %1, %2")   // the same operation in the 4-byte VOP2 encoding (half the instruction bytes)
 DEF_U32_TEST(k_dpp_row_shl1, "v_mov_b32_dpp %0, %0 row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
 DEF_U32_TEST(k_dpp_newbcast, "v_mov_b32_dpp %0, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf")
 DEF_U32_TEST(k_addc_chain, "v_addc_co_u32 %0, vcc, %0, %1, vcc")
@@ -237,6 +238,71 @@ __global__ void __launch_bounds__(512) k_side_by_side(uint32_t* out, uint32_t se
     }
 }
 
+// The same question with the VALU SATURATED: 768-thread workgroups = 12 waves = three per SIMD (waves go round the SIMDs:
+// wave w runs on SIMD w % 4 — k_side_by_side's timings above are consistent with that and with nothing else); waves 0..3 are
+// the matrix waves (one per SIMD), waves 4..11 the multiply-add waves (two per SIMD: enough to keep the VALU issuing
+// back to back).  Besides the wall time, a multiply-add wave and a matrix wave each report the shader cycles (s_memtime)
+// their own loop took, which no clock assumption enters.
+__global__ void __launch_bounds__(768) k_side_by_side_saturated(uint32_t* out, uint32_t seed, int mode, unsigned long long* ticks) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t wave = threadIdx.x >> 6;
+    if (wave < 4u) {
+        if (!(mode & 2)) return;
+        v4i a = {(int)(seed + tid), (int)(seed ^ tid), (int)tid, (int)seed}, b = {(int)tid, 3, (int)seed, 7};
+        v4i c[4] = {{0, 0, 0, 0}, {1, 1, 1, 1}, {2, 2, 2, 2}, {3, 3, 3, 3}};
+        const unsigned long long t0 = clock64();
+        for (int it = 0; it < kSideIters; ++it) {
+#pragma unroll
+            for (int rep = 0; rep < 4; ++rep)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) c[i] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c[i], 0, 0, 0);
+        }
+        const v4i r = c[0] + c[1] + c[2] + c[3];
+        const unsigned long long t1 = clock64();
+        if (blockIdx.x == 0 && threadIdx.x == 0) ticks[1] = t1 - t0;
+        if ((uint32_t)(r.x ^ r.y ^ r.z ^ r.w) == 0x12345678u) out[tid] = (uint32_t)r.x;
+    } else {
+        if (!(mode & 1)) return;
+        const uint32_t aa = seed * 2654435761u + tid, bb = (seed ^ tid) | 1u;
+        uint64_t x[kChains];
+        for (int i = 0; i < kChains; ++i) x[i] = ((uint64_t)bb << 32) | (aa + i);
+        const unsigned long long t0 = clock64();
+        for (int it = 0; it < kSideIters; ++it) {
+#pragma unroll
+            for (int rep = 0; rep < kRepeat; ++rep)
+#pragma unroll
+                for (int i = 0; i < kChains; ++i)
+                    asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(x[i]) : "v"(aa), "v"(bb) : "vcc");
+        }
+        uint64_t r = 0;
+        for (int i = 0; i < kChains; ++i) r ^= x[i];
+        const unsigned long long t1 = clock64();
+        if (blockIdx.x == 0 && threadIdx.x == 256) ticks[0] = t1 - t0;
+        if ((uint32_t)(r ^ (r >> 32)) == 0x12345678u) out[tid] = (uint32_t)r;
+    }
+}
+
+// shader cycles one wave needs for its own stream of independent v_mad_u64_u32 when `blockDim / 256` waves share its SIMD
+__global__ void __launch_bounds__(1024) k_mad_cycles(uint32_t* out, uint32_t seed, unsigned long long* ticks) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t aa = seed * 2654435761u + tid, bb = (seed ^ tid) | 1u;
+    uint64_t x[kChains];
+    for (int i = 0; i < kChains; ++i) x[i] = ((uint64_t)bb << 32) | (aa + i);
+    const unsigned long long t0 = clock64();
+    for (int it = 0; it < kSideIters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < kRepeat; ++rep)
+#pragma unroll
+            for (int i = 0; i < kChains; ++i)
+                asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(x[i]) : "v"(aa), "v"(bb) : "vcc");
+    }
+    uint64_t r = 0;
+    for (int i = 0; i < kChains; ++i) r ^= x[i];
+    const unsigned long long t1 = clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) ticks[0] = t1 - t0;
+    if ((uint32_t)(r ^ (r >> 32)) == 0x12345678u) out[tid] = (uint32_t)r;
+}
+
 // --- LDS: the broadcast read used for the multiplier limbs, and ds_bpermute ---------------------
 __global__ void __launch_bounds__(256) k_lds_bcast_b128(uint32_t* out, uint32_t seed) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[16 * 132];
@@ -301,6 +367,7 @@ int main() {
         {"v_mad_u32_u24", k_mad_u32_u24, kChains},
         {"v_mul_hi_u32_u24", k_mul_hi_u32_u24, kChains},
         {"v_fma_f32", k_fma_f32, kChains},
+        {"v_fmac_f32_vop2", k_fmac_f32, kChains},
         {"v_fma_f64", k_fma_f64, kChains},
         {"v_lshl_add_u64", k_lshl_add_u64, kChains},
         {"v_lshrrev_b64", k_lshrrev_b64, kChains},
@@ -402,6 +469,42 @@ int main() {
             }
         }
         printf(", \"per_wave\": {\"mads\": %d, \"mfmas\": %d}", kSideIters * kRepeat * kChains, kSideIters * 16);
+    }
+    printf("}, \"side_by_side_saturated_valu\": {");
+    {
+        const double mads = (double)kSideIters * kRepeat * kChains, mfmas = (double)kSideIters * 16;
+        for (int mode = 1; mode <= 3; ++mode) {
+            CK(hipMemset(dt, 0, 16));
+            k_side_by_side_saturated<<<cus, 768>>>(d, 1, mode, dt);
+            CK(hipDeviceSynchronize());
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                CK(hipEventRecord(e0));
+                k_side_by_side_saturated<<<cus, 768>>>(d, rep + 2, mode, dt);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+                float ms = 0;
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) best = ms;
+            }
+            unsigned long long tk[2] = {0, 0};
+            CK(hipMemcpy(tk, dt, 16, hipMemcpyDeviceToHost));
+            printf("%s\"%s\": {\"ms\": %.4f, \"mad_wave_cycles_per_mad\": %.3f, \"matrix_wave_cycles_per_mfma\": %.3f}", mode == 1 ? "" : ", ",
+                   mode == 1 ? "two_mad_waves_per_simd_alone" : mode == 2 ? "one_matrix_wave_per_simd_alone" : "both",
+                   best, (mode & 1) ? (double)tk[0] / mads : 0.0, (mode & 2) ? (double)tk[1] / mfmas : 0.0);
+        }
+    }
+    printf("}, \"mad_cycles_by_waves_per_simd\": {");
+    for (int w = 1; w <= 4; w *= 2) {
+        CK(hipMemset(dt, 0, 16));
+        k_mad_cycles<<<cus, 256 * w>>>(d, 1, dt);
+        CK(hipDeviceSynchronize());
+        k_mad_cycles<<<cus, 256 * w>>>(d, 2, dt);
+        CK(hipDeviceSynchronize());
+        unsigned long long tk = 0;
+        CK(hipMemcpy(&tk, dt, 8, hipMemcpyDeviceToHost));
+        const double per_wave = (double)tk / ((double)kSideIters * kRepeat * kChains);
+        printf("%s\"%d\": {\"cycles_per_mad_in_one_wave\": %.3f, \"simd_cycles_per_mad\": %.3f}", w == 1 ? "" : ", ", w, per_wave, per_wave / w);
     }
     printf("}}\n");
     CK(hipFree(d));

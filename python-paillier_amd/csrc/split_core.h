@@ -231,15 +231,23 @@ PHE_DEV void shift_row(uint64_t (&acc)[L], int j, uint32_t dmask) {
 // +2.7 % encrypts/s, -2.2 % VALU instructions, profiles/r02h_ab_sweep_variants.txt).  PHE_VARIANT_QMAD: measurement-only
 // variant of DESIGN 6.1 (the digit enters by one more multiply-add), built by tools/exp/build_variants.sh, never shipped.
 #define PHE_SECOND_QUOTIENT(x) (U ? (uint32_t)(x) : (uint32_t)(x) * n0inv)
+// lane 0's digit to every lane of the group, masked to 29 bits.  Groups inside a wave: the mask rides on the DPP move (vmask
+// is VGPR data for that reason).  The whole wave (G = 64): the value passes through an SGPR anyway, so the mask is a
+// scalar AND off the vector pipe — one dependent VALU step less in a chain that a lone wave cannot hide.
+template <int G>
+PHE_DEV uint32_t bcast_digit(uint32_t x, uint32_t vmask, const Lanes<G>& ln) {
+    if constexpr (G == 64) return wave::grp_bcast0<G>(x, ln) & kLimbMask;
+    else return wave::grp_bcast0<G>(x, ln) & vmask;
+}
 #if defined(PHE_VARIANT_QMAD)
 #define PHE_QUOTIENT_STEP()                                                                  \
     const uint32_t mraw = U ? (uint32_t)p[j] : (uint32_t)p[j] * n0inv;                       \
-    const uint32_t m = wave::grp_bcast0<G>(mraw, ln) & vmask;                                \
+    const uint32_t m = bcast_digit<G>(mraw, vmask, ln);                                      \
     q[j] = wave::mad64(m, wave::reread(lane0 ? 1u : 0u), q[j]);
 #else
 #define PHE_QUOTIENT_STEP()                                                                  \
     const uint32_t mraw = U ? (uint32_t)p[j] : (uint32_t)p[j] * n0inv;                       \
-    const uint32_t m = wave::grp_bcast0<G>(mraw, ln) & vmask;                                \
+    const uint32_t m = bcast_digit<G>(mraw, vmask, ln);                                      \
     q[j] += (uint64_t)(mraw & lane0); /* quotient digit i of the first sum = digit i of the addend m */
 #endif
 
@@ -293,7 +301,7 @@ PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
             PHE_QUOTIENT_STEP()
 #pragma unroll
             for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(m, n[k], p[(k + j) % L]);
-            const uint32_t m2 = wave::grp_bcast0<G>(PHE_SECOND_QUOTIENT(q[j]), ln) & vmask;
+            const uint32_t m2 = bcast_digit<G>(PHE_SECOND_QUOTIENT(q[j]), vmask, ln);
 #pragma unroll
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(m2, n[k], q[(k + j) % L]);
             shift_row<G, L>(p, j, dmask);
@@ -352,7 +360,7 @@ PHE_DEV void pair_pass3(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
             PHE_QUOTIENT_STEP()
 #pragma unroll
             for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(m, n[k], p[(k + j) % L]);
-            const uint32_t m2 = wave::grp_bcast0<G>(PHE_SECOND_QUOTIENT(q[j]), ln) & vmask;
+            const uint32_t m2 = bcast_digit<G>(PHE_SECOND_QUOTIENT(q[j]), vmask, ln);
 #pragma unroll
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(m2, n[k], q[(k + j) % L]);
             shift_row<G, L>(p, j, dmask);

@@ -814,19 +814,24 @@ class Engine:
             row = rows[power] = DeviceArray.from_host(self.ctx, self.cipher_limbs([pow(self._mont_radix(), power, self.nsquare)]))
         return row
 
-    def montmul_dev(self, a, b):
-        """row-wise a * b / R mod n^2 (canonical): the debts of the operands add up, plus one"""
+    def montmul_dev(self, a, b, stream=None):
+        """row-wise a * b / R mod n^2 (canonical): the debts of the operands add up, plus one.  stream: queue the launch
+        there and return without waiting (the caller synchronises that stream once, at the end of its chain; blocks freed in
+        between are only reused by later launches of the SAME stream, i.e. in order); None: complete on return"""
         out = DeviceArray(self.ctx, a.rows, self.ct_limbs)
-        self.ctx.montmul_dev(a.ptr, b.ptr, False, out.ptr, a.rows)
-        self.ctx.sync()
+        self.ctx.montmul_dev(a.ptr, b.ptr, False, out.ptr, a.rows, stream or 0)
+        if stream is None:
+            self.ctx.sync()
         return out
 
-    def scale_dev(self, a, power):
+    def scale_dev(self, a, power, stream=None):
         """row-wise a * R^power mod n^2 by one product with the constant R^(power + 1): power = d settles a debt of d,
         a negative power takes a row further into debt (to meet a partner's)"""
+        const = self._mont_const_row(power + 1)                 # (uploaded with a blocking copy: complete before the launch)
         out = DeviceArray(self.ctx, a.rows, self.ct_limbs)
-        self.ctx.montmul_dev(a.ptr, self._mont_const_row(power + 1).ptr, True, out.ptr, a.rows)
-        self.ctx.sync()
+        self.ctx.montmul_dev(a.ptr, const.ptr, True, out.ptr, a.rows, stream or 0)
+        if stream is None:
+            self.ctx.sync()
         return out
 
     def add_plain_dev(self, c, plaintexts):

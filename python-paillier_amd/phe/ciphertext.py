@@ -149,7 +149,11 @@ class EncryptedNumber(object):
 class EncryptedVector(object):
     """A batch of Paillier ciphertexts under one public key, stored as little-endian uint32 limbs — either a
     host numpy array or a device-resident DeviceArray (`device=True` / `.to_device()`), in which case every
-    operation below runs on HBM-resident operands and only plaintext-sized data crosses PCIe."""
+    operation below runs on HBM-resident operands and only plaintext-sized data crosses PCIe.
+
+    A vector is a plain mutable container like the reference's EncryptedNumber: reading its rows may convert a lazy
+    resident form back in place (`_limbs`), obfuscate() rewrites them — share one between threads only behind a lock of
+    your own (the per-key engine serialises the native calls, not the vector's own fields)."""
 
     def __init__(self, public_key, limbs, exponents, obfuscated=False, _debt=0, _pair=False):
         self.public_key = public_key
@@ -525,19 +529,23 @@ class EncryptedVector(object):
         if self.on_device and eng.lazy_products():
             # the pairwise tree at ONE Montgomery product per node: a level turns rows of debt d into rows of debt 2d + 1
             # (an odd row out is taken to the same debt by a product with a constant); settled once, at the root
+            # every level is queued on the engine's launch stream, nothing is waited for until the root is there: a level's
+            # output block holds one spare row, so that an unpaired last row joins it by ONE product written in place
             store, debt, exp = cur._store, cur._debt, int(cur._exps[0])
+            st = eng._launch_stream() or None
+            keep = [store]                                       # operands stay alive until the final synchronisation
             while store.rows > 1:
-                half = store.rows // 2
-                merged = eng.montmul_dev(store.rows_view(0, half), store.rows_view(half, 2 * half))
-                if store.rows % 2:
-                    odd = eng.scale_dev(store.rows_view(2 * half, 2 * half + 1), -(debt + 1))
-                    grown = DeviceArray(eng.ctx, half + 1, store.cols)
-                    eng.ctx.d2d(grown.ptr, merged.ptr, merged.nbytes)
-                    eng.ctx.d2d(grown.ptr + merged.nbytes, odd.ptr, odd.nbytes)
-                    eng.ctx.sync()
-                    merged = grown
+                half, odd = store.rows // 2, store.rows % 2
+                merged = DeviceArray(eng.ctx, half + odd, store.cols)
+                eng.ctx.montmul_dev(store.rows_view(0, half).ptr, store.rows_view(half, 2 * half).ptr, False, merged.ptr, half, st or 0)
+                if odd:                                           # the row left over is taken to the new debt: * R^-(debt+1)
+                    const = eng._mont_const_row(-(debt + 1) + 1)
+                    eng.ctx.montmul_dev(store.rows_view(2 * half, 2 * half + 1).ptr, const.ptr, True,
+                                        merged.rows_view(half, half + 1).ptr, 1, st or 0)
+                keep.append(merged)
                 store, debt = merged, 2 * debt + 1
-            root = eng.scale_dev(store, debt) if debt else store
+            root = eng.scale_dev(store, debt, stream=st) if debt else store
+            eng.ctx.sync(st or 0)
             return EncryptedNumber(pk, eng.to_ints(root.to_host())[0], exp)
         limbs, exp = cur._limbs, int(cur._exps[0])
         if self.on_device:
