@@ -86,6 +86,7 @@ PHE_DECLARE_PART(g16b)
     int launch_split_unit(int L, int blocks, hipStream_t st, const SplitArgs& A);                 \
     int launch_pair(int L, int op, int blocks, hipStream_t st, const PairArgs& A);                \
     int launch_split_halves(int L, int blocks, hipStream_t st, const SplitArgs& Ap, const SplitArgs& Aq); \
+    int launch_split_ab(int L, int mode, int numbers, int halves, hipStream_t st, const SplitArgs& Ap, const SplitArgs& Aq); \
     }
 PHE_DECLARE_SPLIT_PART(s2a)
 PHE_DECLARE_SPLIT_PART(s2b)
@@ -157,50 +158,51 @@ struct SplitPart {
     int (*launch_split_unit)(int, int, hipStream_t, const SplitArgs&);
     int (*launch_pair)(int, int, int, hipStream_t, const PairArgs&);
     int (*launch_split_halves)(int, int, hipStream_t, const SplitArgs&, const SplitArgs&);
+    int (*launch_split_ab)(int, int, int, int, hipStream_t, const SplitArgs&, const SplitArgs&);
 };
 static const SplitPart kSplitParts[] = {
     {2, phe::s2a::occ_split, phe::s2a::launch_split, phe::s2a::occ_var_split, phe::s2a::launch_var_split,
      phe::s2a::occ_multi_split, phe::s2a::launch_multi_split, phe::s2a::launch_multi_tables,
-     phe::s2a::launch_multi_lookup, phe::s2a::launch_mul_split, phe::s2a::launch_crt_lift, phe::s2a::occ_split_unit, phe::s2a::launch_split_unit, phe::s2a::launch_pair, phe::s2a::launch_split_halves},
+     phe::s2a::launch_multi_lookup, phe::s2a::launch_mul_split, phe::s2a::launch_crt_lift, phe::s2a::occ_split_unit, phe::s2a::launch_split_unit, phe::s2a::launch_pair, phe::s2a::launch_split_halves, phe::s2a::launch_split_ab},
     {2, phe::s2b::occ_split, phe::s2b::launch_split, phe::s2b::occ_var_split, phe::s2b::launch_var_split,
      phe::s2b::occ_multi_split, phe::s2b::launch_multi_split, phe::s2b::launch_multi_tables,
-     phe::s2b::launch_multi_lookup, phe::s2b::launch_mul_split, phe::s2b::launch_crt_lift, phe::s2b::occ_split_unit, phe::s2b::launch_split_unit, phe::s2b::launch_pair, phe::s2b::launch_split_halves},
+     phe::s2b::launch_multi_lookup, phe::s2b::launch_mul_split, phe::s2b::launch_crt_lift, phe::s2b::occ_split_unit, phe::s2b::launch_split_unit, phe::s2b::launch_pair, phe::s2b::launch_split_halves, phe::s2b::launch_split_ab},
     {2, phe::s2c::occ_split, phe::s2c::launch_split, phe::s2c::occ_var_split, phe::s2c::launch_var_split,
      phe::s2c::occ_multi_split, phe::s2c::launch_multi_split, phe::s2c::launch_multi_tables,
-     phe::s2c::launch_multi_lookup, phe::s2c::launch_mul_split, phe::s2c::launch_crt_lift, phe::s2c::occ_split_unit, phe::s2c::launch_split_unit, phe::s2c::launch_pair, phe::s2c::launch_split_halves},
+     phe::s2c::launch_multi_lookup, phe::s2c::launch_mul_split, phe::s2c::launch_crt_lift, phe::s2c::occ_split_unit, phe::s2c::launch_split_unit, phe::s2c::launch_pair, phe::s2c::launch_split_halves, phe::s2c::launch_split_ab},
     {4, phe::s4a::occ_split, phe::s4a::launch_split, phe::s4a::occ_var_split, phe::s4a::launch_var_split,
      phe::s4a::occ_multi_split, phe::s4a::launch_multi_split, phe::s4a::launch_multi_tables,
-     phe::s4a::launch_multi_lookup, phe::s4a::launch_mul_split, phe::s4a::launch_crt_lift, phe::s4a::occ_split_unit, phe::s4a::launch_split_unit, phe::s4a::launch_pair, phe::s4a::launch_split_halves},
+     phe::s4a::launch_multi_lookup, phe::s4a::launch_mul_split, phe::s4a::launch_crt_lift, phe::s4a::occ_split_unit, phe::s4a::launch_split_unit, phe::s4a::launch_pair, phe::s4a::launch_split_halves, phe::s4a::launch_split_ab},
     {4, phe::s4b::occ_split, phe::s4b::launch_split, phe::s4b::occ_var_split, phe::s4b::launch_var_split,
      phe::s4b::occ_multi_split, phe::s4b::launch_multi_split, phe::s4b::launch_multi_tables,
-     phe::s4b::launch_multi_lookup, phe::s4b::launch_mul_split, phe::s4b::launch_crt_lift, phe::s4b::occ_split_unit, phe::s4b::launch_split_unit, phe::s4b::launch_pair, phe::s4b::launch_split_halves},
+     phe::s4b::launch_multi_lookup, phe::s4b::launch_mul_split, phe::s4b::launch_crt_lift, phe::s4b::occ_split_unit, phe::s4b::launch_split_unit, phe::s4b::launch_pair, phe::s4b::launch_split_halves, phe::s4b::launch_split_ab},
     {4, phe::s4c::occ_split, phe::s4c::launch_split, phe::s4c::occ_var_split, phe::s4c::launch_var_split,
      phe::s4c::occ_multi_split, phe::s4c::launch_multi_split, phe::s4c::launch_multi_tables,
-     phe::s4c::launch_multi_lookup, phe::s4c::launch_mul_split, phe::s4c::launch_crt_lift, phe::s4c::occ_split_unit, phe::s4c::launch_split_unit, phe::s4c::launch_pair, phe::s4c::launch_split_halves},
+     phe::s4c::launch_multi_lookup, phe::s4c::launch_mul_split, phe::s4c::launch_crt_lift, phe::s4c::occ_split_unit, phe::s4c::launch_split_unit, phe::s4c::launch_pair, phe::s4c::launch_split_halves, phe::s4c::launch_split_ab},
     {8, phe::s8a::occ_split, phe::s8a::launch_split, phe::s8a::occ_var_split, phe::s8a::launch_var_split,
      phe::s8a::occ_multi_split, phe::s8a::launch_multi_split, phe::s8a::launch_multi_tables,
-     phe::s8a::launch_multi_lookup, phe::s8a::launch_mul_split, phe::s8a::launch_crt_lift, phe::s8a::occ_split_unit, phe::s8a::launch_split_unit, phe::s8a::launch_pair, phe::s8a::launch_split_halves},
+     phe::s8a::launch_multi_lookup, phe::s8a::launch_mul_split, phe::s8a::launch_crt_lift, phe::s8a::occ_split_unit, phe::s8a::launch_split_unit, phe::s8a::launch_pair, phe::s8a::launch_split_halves, phe::s8a::launch_split_ab},
     {8, phe::s8b::occ_split, phe::s8b::launch_split, phe::s8b::occ_var_split, phe::s8b::launch_var_split,
      phe::s8b::occ_multi_split, phe::s8b::launch_multi_split, phe::s8b::launch_multi_tables,
-     phe::s8b::launch_multi_lookup, phe::s8b::launch_mul_split, phe::s8b::launch_crt_lift, phe::s8b::occ_split_unit, phe::s8b::launch_split_unit, phe::s8b::launch_pair, phe::s8b::launch_split_halves},
+     phe::s8b::launch_multi_lookup, phe::s8b::launch_mul_split, phe::s8b::launch_crt_lift, phe::s8b::occ_split_unit, phe::s8b::launch_split_unit, phe::s8b::launch_pair, phe::s8b::launch_split_halves, phe::s8b::launch_split_ab},
     {8, phe::s8c::occ_split, phe::s8c::launch_split, phe::s8c::occ_var_split, phe::s8c::launch_var_split,
      phe::s8c::occ_multi_split, phe::s8c::launch_multi_split, phe::s8c::launch_multi_tables,
-     phe::s8c::launch_multi_lookup, phe::s8c::launch_mul_split, phe::s8c::launch_crt_lift, phe::s8c::occ_split_unit, phe::s8c::launch_split_unit, phe::s8c::launch_pair, phe::s8c::launch_split_halves},
+     phe::s8c::launch_multi_lookup, phe::s8c::launch_mul_split, phe::s8c::launch_crt_lift, phe::s8c::occ_split_unit, phe::s8c::launch_split_unit, phe::s8c::launch_pair, phe::s8c::launch_split_halves, phe::s8c::launch_split_ab},
     {16, phe::s16a::occ_split, phe::s16a::launch_split, phe::s16a::occ_var_split, phe::s16a::launch_var_split,
      phe::s16a::occ_multi_split, phe::s16a::launch_multi_split, phe::s16a::launch_multi_tables,
-     phe::s16a::launch_multi_lookup, phe::s16a::launch_mul_split, phe::s16a::launch_crt_lift, phe::s16a::occ_split_unit, phe::s16a::launch_split_unit, phe::s16a::launch_pair, phe::s16a::launch_split_halves},
+     phe::s16a::launch_multi_lookup, phe::s16a::launch_mul_split, phe::s16a::launch_crt_lift, phe::s16a::occ_split_unit, phe::s16a::launch_split_unit, phe::s16a::launch_pair, phe::s16a::launch_split_halves, phe::s16a::launch_split_ab},
     {16, phe::s16b::occ_split, phe::s16b::launch_split, phe::s16b::occ_var_split, phe::s16b::launch_var_split,
      phe::s16b::occ_multi_split, phe::s16b::launch_multi_split, phe::s16b::launch_multi_tables,
-     phe::s16b::launch_multi_lookup, phe::s16b::launch_mul_split, phe::s16b::launch_crt_lift, phe::s16b::occ_split_unit, phe::s16b::launch_split_unit, phe::s16b::launch_pair, phe::s16b::launch_split_halves},
+     phe::s16b::launch_multi_lookup, phe::s16b::launch_mul_split, phe::s16b::launch_crt_lift, phe::s16b::occ_split_unit, phe::s16b::launch_split_unit, phe::s16b::launch_pair, phe::s16b::launch_split_halves, phe::s16b::launch_split_ab},
     {16, phe::s16c::occ_split, phe::s16c::launch_split, phe::s16c::occ_var_split, phe::s16c::launch_var_split,
      phe::s16c::occ_multi_split, phe::s16c::launch_multi_split, phe::s16c::launch_multi_tables,
-     phe::s16c::launch_multi_lookup, phe::s16c::launch_mul_split, phe::s16c::launch_crt_lift, phe::s16c::occ_split_unit, phe::s16c::launch_split_unit, phe::s16c::launch_pair, phe::s16c::launch_split_halves},
+     phe::s16c::launch_multi_lookup, phe::s16c::launch_mul_split, phe::s16c::launch_crt_lift, phe::s16c::occ_split_unit, phe::s16c::launch_split_unit, phe::s16c::launch_pair, phe::s16c::launch_split_halves, phe::s16c::launch_split_ab},
     {64, phe::s64a::occ_split, phe::s64a::launch_split, phe::s64a::occ_var_split, phe::s64a::launch_var_split,
      phe::s64a::occ_multi_split, phe::s64a::launch_multi_split, phe::s64a::launch_multi_tables,
-     phe::s64a::launch_multi_lookup, phe::s64a::launch_mul_split, phe::s64a::launch_crt_lift, phe::s64a::occ_split_unit, phe::s64a::launch_split_unit, phe::s64a::launch_pair, phe::s64a::launch_split_halves},
+     phe::s64a::launch_multi_lookup, phe::s64a::launch_mul_split, phe::s64a::launch_crt_lift, phe::s64a::occ_split_unit, phe::s64a::launch_split_unit, phe::s64a::launch_pair, phe::s64a::launch_split_halves, phe::s64a::launch_split_ab},
     {64, phe::s64b::occ_split, phe::s64b::launch_split, phe::s64b::occ_var_split, phe::s64b::launch_var_split,
      phe::s64b::occ_multi_split, phe::s64b::launch_multi_split, phe::s64b::launch_multi_tables,
-     phe::s64b::launch_multi_lookup, phe::s64b::launch_mul_split, phe::s64b::launch_crt_lift, phe::s64b::occ_split_unit, phe::s64b::launch_split_unit, phe::s64b::launch_pair, phe::s64b::launch_split_halves},
+     phe::s64b::launch_multi_lookup, phe::s64b::launch_mul_split, phe::s64b::launch_crt_lift, phe::s64b::occ_split_unit, phe::s64b::launch_split_unit, phe::s64b::launch_pair, phe::s64b::launch_split_halves, phe::s64b::launch_split_ab},
 };
 #define PHE_SPLIT_BY_GROUP(G_, CALL2)                 \
     [&]() -> int {                                    \
@@ -338,6 +340,7 @@ struct phe_hip_ctx {
     };
     std::vector<PubRung> pub_rungs;    // rungs 1.. of the public side, by increasing group width
     std::vector<PrivRung> priv_rungs;  // rungs 1.. of the private side
+    bool no_wave_pairs = false;        // PHE_HIP_NO_WAVE_PAIRS=1: a handful of numbers stays on the single-wave kernels (A/B measurements, tests)
     bool force_unit = false;           // PHE_HIP_FORCE_UNIT=1: r^n through the scaled modulus whatever the batch size (tests)
     int force_group = 0;               // phe_hip_ctx_set_group: 0 = pick by batch size; G = the rung whose groups are G lanes wide
     // what the last launch on this context took (phe_hip_ctx_last_launch): tests assert the path they meant to exercise
@@ -586,6 +589,50 @@ static int launch_split_halves(phe_hip_ctx* ctx, const DevSplit& Mp, const DevSc
     return PHE_HIP_OK;
 }
 
+// One number on a pair of wavefronts (k_modexp_split_ab, whole-wave geometry only): `halves` == 2 runs Mp/Ep on the even
+// workgroups and Mq/Eq on the odd ones (the two CRT halves of a decrypt), else Mp/Ep alone.  The window tables are per NUMBER
+// here (tbl_entries + 1 pairs each), in ctx->table / ctx->table2.
+static bool ab_offered(const phe_hip_ctx* ctx, const DevSplit& M, size_t batch, int halves) {
+    // while every wave of every number still finds a SIMD of its own (2 roles x halves x batch waves)
+    return !ctx->no_wave_pairs && M.G == 64 && M.L <= kMaxFusedL && batch * 2 * (size_t)halves <= (size_t)ctx->n_cus * 4;
+}
+static int launch_split_ab(phe_hip_ctx* ctx, int mode, const DevSplit& Mp, const DevSchedule& Ep, const DevSplit* Mq, const DevSchedule* Eq,
+                           const uint32_t* base, int base_limbs, const uint32_t* post, int post_limbs, uint32_t* out_p, uint32_t* out_q,
+                           int out_limbs, size_t batch, hipStream_t stream) {
+    const int halves = Mq ? 2 : 1;
+    if (Mq && (Mq->G != Mp.G || Mq->L != Mp.L)) return fail(PHE_HIP_EINVAL, "the two halves need one geometry");
+    SplitArgs Ap, Aq;
+    const auto fill = [&](SplitArgs& A, const DevSplit& M, const DevSchedule& E, uint32_t* out, bool second) -> int {
+        uint32_t** tbl = second ? &ctx->table2 : &ctx->table;
+        int rc = ensure_words(tbl, second ? &ctx->table2_words : &ctx->table_words, batch * (size_t)(E.tbl_entries + 1) * 2 * M.H);
+        if (rc) return rc;
+        A.mod = M.c;
+        A.sched = E.ops;
+        A.n_ops = E.n_ops;
+        A.first_idx = E.first_idx;
+        A.tbl_entries = E.tbl_entries;
+        A.base = base;
+        A.base_limbs = base_limbs;
+        A.base_chunks = chunks_for(base_limbs, M.rows);
+        A.post = post;
+        A.post_limbs = post_limbs;
+        A.post_chunks = chunks_for(post_limbs, M.rows);
+        A.out = out;
+        A.out_limbs = out_limbs;
+        A.table = *tbl;
+        A.batch = batch;
+        return PHE_HIP_OK;
+    };
+    int rc = fill(Ap, Mp, Ep, out_p, false);
+    if (!rc && Mq) rc = fill(Aq, *Mq, *Eq, out_q, true);
+    if (rc) return rc;
+    if (!Mq) Aq = Ap;
+    if (PHE_SPLIT_BY_GROUP(Mp.G, launch_split_ab(Mp.L, mode, (int)batch, halves, stream, Ap, Aq)) < 0)
+        return fail(PHE_HIP_EINVAL, "no wave-pair kernel for this geometry");
+    HIP_TRY(hipGetLastError());
+    return PHE_HIP_OK;
+}
+
 static int launch_var_split(phe_hip_ctx* ctx, const DevSplit& M, const uint32_t* base, int base_limbs,
                             const uint32_t* e, int exp_limbs, int max_bits, uint32_t* out, int out_limbs, size_t batch,
                             hipStream_t stream) {
@@ -804,7 +851,7 @@ static int pick_nsplit_rung(const phe_hip_ctx* ctx, size_t batch) {
 }
 static const DevSplit& pick_nsplit(const phe_hip_ctx* ctx, size_t batch) { return nsplit_rung(ctx, pick_nsplit_rung(ctx, batch)); }
 static int geom_code(int G, int L) { return G * 100 + L; }
-enum : int { kPathUnit = 1, kPathOwner = 2, kPathSideBySide = 4, kPathPipelined = 8, kPathFusedObfuscate = 16 };
+enum : int { kPathUnit = 1, kPathOwner = 2, kPathSideBySide = 4, kPathPipelined = 8, kPathFusedObfuscate = 16, kPathWavePairs = 32 };
 
 static int check_ctx(const phe_hip_ctx* ctx) {
     if (!ctx) return fail(PHE_HIP_EINVAL, "null context");
@@ -884,6 +931,7 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
     if (!rc && !getenv("PHE_HIP_NO_UNIT")) rc = upload_split(ctx->pub.nunit, ctx->d_nunit);
     if (!rc) rc = upload_schedule(ctx->pub.exp_n, ctx->d_exp_n);
     ctx->force_unit = getenv("PHE_HIP_FORCE_UNIT") != nullptr;
+    ctx->no_wave_pairs = getenv("PHE_HIP_NO_WAVE_PAIRS") != nullptr;
     if (!rc && !getenv("PHE_HIP_GROUP")) {
         // the wider rungs of the ladder: 8- and 16-lane groups where they differ from what is already there
         for (int prefer : {8, 16, 64}) {
@@ -1152,6 +1200,11 @@ int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, 
     }
     if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G) {
         ctx->last_geom_pub = geom_code(sp.G, sp.L);
+        if (ab_offered(ctx, sp, batch, 1)) {
+            ctx->last_path = kPathWavePairs;
+            return launch_split_ab(ctx, kModeEncrypt, sp, ctx->d_exp_n, nullptr, nullptr, r, ctx->pub.s1, m, ctx->pub.s1, c, nullptr,
+                                   ctx->pub.s2, batch, (hipStream_t)stream);
+        }
         return launch_split<kModeEncrypt>(ctx, sp, ctx->d_exp_n, r, ctx->pub.s1, m, ctx->pub.s1, c, ctx->pub.s2, batch,
                                           (hipStream_t)stream);
     }
@@ -1307,7 +1360,12 @@ int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t
                               2 * wg_per_half <= (size_t)ctx->n_cus * (size_t)std::max(1, occ);
     ctx->last_geom_priv = split_ok ? geom_code(sp_p.G, sp_p.L) : geom_code(psq_of(rung).G, psq_of(rung).L);
     ctx->last_path = side_by_side ? kPathSideBySide : 0;
-    if (side_by_side) {
+    if (split_ok && sp_p.G == sp_q.G && sp_p.L == sp_q.L && ab_offered(ctx, sp_p, batch, 2)) {
+        // a handful of ciphertexts: every half-exponentiation on a PAIR of wavefronts (about half the time per product)
+        ctx->last_path = kPathSideBySide | kPathWavePairs;
+        rc = launch_split_ab(ctx, kModeHalfDecrypt, sp_p, ctx->d_exp_p, &sp_q, &ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0, xp, xq, S, batch, st);
+        if (rc) return rc;
+    } else if (side_by_side) {
         rc = launch_split_halves(ctx, sp_p, ctx->d_exp_p, sp_q, ctx->d_exp_q, c, ctx->pub.s2, xp, xq, S, batch, st);
         if (rc) return rc;
     } else {

@@ -649,6 +649,237 @@ PHE_DEV void modexp_split_body(const SplitArgs& A, uint32_t* lds_row, uint32_t s
     }
 }
 
+// ---- one number on TWO wavefronts (the lowest-latency form, for a handful of numbers) ---------------------------------
+// A pair product is two coupled chains per digit: the first word's (p += a*b0, quotient digit m, p += m*n, shift) and the
+// second word's (q += a*b1 [+ c*b0] + m, its own quotient digit m2, q += m2*n, shift).  On the whole-wave geometry a wave
+// issues ~18 vector instructions per digit for both and is issue-bound even alone on its SIMD ("whole-wave
+// groups").  But the FIRST word never looks at the second: x~ = X0 - n*X1, and X0 of a product is the plain half-width
+// Montgomery product of the X0's.  So wave A runs the first words of all products of an exponentiation — an ordinary
+// Montgomery ladder modulo n — and leaves, per product, the multiplier's digits and its quotient digits in LDS; wave B, one
+// product behind, runs the second words from those.  Two LDS slots and ONE workgroup barrier per product keep them in step
+// (A fills slot k&1 and arrives; B arrives and reads it while A fills the other).  Each wave issues ~9-10 instructions per
+// digit: about half the time per product.  The conversion in and the way out need both words: B hands its word over in LDS.
+// Only for G = 64 (one number per wave pair) and fused-sweep widths.
+template <int L, bool U = false>
+PHE_DEV void ab_first_word(uint32_t (&z0)[L], const uint32_t* a, const uint32_t (&b0)[L], uint32_t* m_row, const uint32_t (&n)[L],
+                           uint32_t n0inv, const Lanes<64>& ln, int rows) {
+    constexpr int G = 64, kT = Trip<G, L>::kDigits;
+    const uint32_t dmask = kLimbMask & ln.not_top;
+    uint64_t p[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) p[k] = 0;
+    uint32_t ahead_a[kT];
+#pragma unroll
+    for (int t = 0; t < kT; ++t) ahead_a[t] = a[t];
+#pragma unroll 1
+    for (int i = 0; i < rows; i += kT) {
+        uint32_t dig_a[kT], mq[kT];
+        const int nx = (i + kT < rows) ? i + kT : i;
+#pragma unroll
+        for (int t = 0; t < kT; ++t) {
+            dig_a[t] = ahead_a[t];
+            ahead_a[t] = a[nx + t];
+        }
+#pragma unroll
+        for (int jj = 0; jj < kT; ++jj) {
+            const int j = jj % L;
+#pragma unroll
+            for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(dig_a[jj], b0[k], p[(k + j) % L]);
+            const uint32_t m = bcast_digit<G>(U ? (uint32_t)p[j] : (uint32_t)p[j] * n0inv, 0u, ln);
+            mq[jj] = m;
+#pragma unroll
+            for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(m, n[k], p[(k + j) % L]);
+            shift_row<G, L>(p, j, dmask);
+        }
+        if (ln.g == 0u) {
+#pragma unroll
+            for (int t = 0; t < kT; ++t) m_row[i + t] = mq[t];
+        }
+    }
+    normalize_partial<G, L>(z0, p, ln);
+}
+
+// z1 = (m + a*b1 [+ c*b0] + m2*n) / R with the digits of a, c and of the first word's quotient m in LDS
+template <int L, bool MUL, bool U = false>
+PHE_DEV void ab_second_word(uint32_t (&z1)[L], const uint32_t* a, const uint32_t* c, const uint32_t* m_row, const uint32_t (&b0)[L],
+                            const uint32_t (&b1)[L], const uint32_t (&n)[L], uint32_t n0inv, const Lanes<64>& ln, int rows) {
+    constexpr int G = 64, kT = Trip<G, L>::kDigits;
+    const uint32_t lane0 = kLimbMask & ~ln.not_low;
+    const uint32_t dmask = kLimbMask & ln.not_top;
+    uint64_t q[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) q[k] = 0;
+    uint32_t ahead_a[kT], ahead_c[kT], ahead_m[kT];
+#pragma unroll
+    for (int t = 0; t < kT; ++t) {
+        ahead_a[t] = a[t];
+        ahead_m[t] = m_row[t];
+        ahead_c[t] = MUL ? c[t] : 0u;
+    }
+#pragma unroll 1
+    for (int i = 0; i < rows; i += kT) {
+        uint32_t dig_a[kT], dig_c[kT], dig_m[kT];
+        const int nx = (i + kT < rows) ? i + kT : i;
+#pragma unroll
+        for (int t = 0; t < kT; ++t) {
+            dig_a[t] = ahead_a[t];
+            dig_m[t] = ahead_m[t];
+            dig_c[t] = ahead_c[t];
+            ahead_a[t] = a[nx + t];
+            ahead_m[t] = m_row[nx + t];
+            if constexpr (MUL) ahead_c[t] = c[nx + t];
+        }
+#pragma unroll
+        for (int jj = 0; jj < kT; ++jj) {
+            const int j = jj % L;
+#pragma unroll
+            for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(dig_a[jj], b1[k], q[(k + j) % L]);
+            if constexpr (MUL) {
+#pragma unroll
+                for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(dig_c[jj], b0[k], q[(k + j) % L]);
+            }
+            q[j] += (uint64_t)(dig_m[jj] & lane0);  // quotient digit i of the first word = digit i of the addend m
+            const uint32_t m2 = bcast_digit<G>(U ? (uint32_t)q[j] : (uint32_t)q[j] * n0inv, 0u, ln);
+#pragma unroll
+            for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(m2, n[k], q[(k + j) % L]);
+            shift_row<G, L>(q, j, dmask);
+        }
+    }
+    normalize_partial<G, L>(z1, q, ln);
+}
+
+// The batched exponentiation of modexp_split_body for ONE number on a wave pair: role 0 = first words (A), 1 = second (B).
+// lds: 6*H words of the workgroup (two slots of a-digits | m-digits, B's own digit row, one row for words handed over);
+// tbl: (tbl_entries + 1) * 2H words of global scratch for this number (the extra entry carries base^2 during the table build).
+template <int L, int MODE, bool U = false>
+PHE_DEV void modexp_split_ab_body(const SplitArgs& A, uint32_t* lds, uint32_t* tbl, uint64_t item, bool live, uint32_t role,
+                                  uint32_t lane) {
+    constexpr int G = 64, H = G * L, S2 = 2 * H;
+    const Lanes<G> ln(lane);
+    const uint32_t g = ln.g;
+    const bool first = role == 0u;
+    uint32_t n[L];
+    load_row<L>(n, A.mod.n, g);
+    const uint32_t n0inv = A.mod.n0inv;
+    const int rows = A.mod.rows;
+    uint32_t* own_c = lds + 4 * H;  // B: digits of its word X1 (the c operand of a product)
+    uint32_t* mail = lds + 5 * H;   // a word handed from one role to the other
+    int k = 0;                      // products so far: slot k & 1
+    const auto slot_a = [&](int kk) { return lds + (kk & 1) * S2; };
+    const auto slot_m = [&](int kk) { return lds + (kk & 1) * S2 + H; };
+    uint32_t W[L], V[L], Y0[L];     // this role's word of X; of the factor Y; (B only) the FIRST word of Y
+    // one product step: A publishes `dig` (the multiplier's first word) and sweeps it against b0; B, one barrier later, sweeps
+    // the second word.  MUL: the factor is the pair (Y0, V); else the multiplier's own pair (squaring) or a plain chunk.
+    const auto step_plain = [&](const uint32_t (&dig)[L], const uint32_t (&b)[L], uint32_t (&out)[L]) {
+        if (first) {
+            lds_put<L>(slot_a(k), dig, g);
+            ab_first_word<L, U>(out, slot_a(k), b, slot_m(k), n, n0inv, ln, rows);
+            wave::block_barrier();
+        } else {
+            wave::block_barrier();
+            ab_second_word<L, false, U>(out, slot_a(k), nullptr, slot_m(k), b, b, n, n0inv, ln, rows);
+        }
+        ++k;
+    };
+    const auto square = [&]() {
+        if (first) {
+            step_plain(W, W, W);
+        } else {
+            uint32_t d[L];
+#pragma unroll
+            for (int t = 0; t < L; ++t) d[t] = W[t];
+            add_normalize<G, L>(d, W, ln);  // 2*X1
+            step_plain(d, d, W);
+        }
+    };
+    // X <- X*Y: A has (W = X0, V = Y0), B has (W = X1, V = Y1) and needs Y0 too.  y0_late: where B reads Y0 AFTER the barrier
+    // — for a Y that A has only just stored (its store precedes A's arrival at this barrier); nullptr: B holds Y0 already
+    const auto multiply = [&](const uint32_t* y0_late) {
+        if (first) {
+            lds_put<L>(slot_a(k), W, g);
+            ab_first_word<L, U>(W, slot_a(k), V, slot_m(k), n, n0inv, ln, rows);
+            wave::block_barrier();
+        } else {
+            lds_put<L>(own_c, W, g);
+            wave::block_barrier();
+            if (y0_late) load_row<L>(Y0, y0_late, g);
+            ab_second_word<L, true, U>(W, slot_a(k), own_c, slot_m(k), Y0, V, n, n0inv, ln, rows);
+        }
+        ++k;
+    };
+    const auto load_entry = [&](uint32_t (&dst)[L], int e, uint32_t word) { load_row<L>(dst, tbl + (size_t)e * S2 + word * H, g); };
+    const auto store_entry = [&](int e) { store_row<L>(tbl + (size_t)e * S2 + role * H, W, g); };
+
+    // ---- the base into the pair form (split_conv): chunk j times pair(R^(j+2)), summed; one product with pair(1) if summed ----
+    {
+        const uint32_t* src = A.base + item * (uint64_t)A.base_limbs;
+        for (int j = 0; j < A.base_chunks; ++j) {
+            uint32_t dig[L], cst[L], t[L];
+            load_u32_as_r29<L>(dig, src, A.base_limbs, j * rows, g, rows);
+            load_row<L>(cst, A.mod.conv + (size_t)(2 * j + (int)role) * H, g);
+            if (j == 0) {
+                step_plain(dig, cst, W);
+            } else {
+                step_plain(dig, cst, t);
+                add_normalize<G, L>(W, t, ln);
+            }
+        }
+        if (A.base_chunks > 1) {
+            load_row<L>(V, A.mod.e + role * H, g);
+            if (!first) load_row<L>(Y0, A.mod.e, g);
+            multiply(nullptr);
+        }
+    }
+    // ---- odd powers base^1, base^3, ... ----------------------------------------------------------------------------
+    store_entry(0);
+    if (A.tbl_entries > 1) {
+        const int extra = A.tbl_entries;  // base^2: its first word travels to B through this entry
+        uint32_t keep[L];
+#pragma unroll
+        for (int t = 0; t < L; ++t) keep[t] = W[t];
+        square();
+        store_entry(extra);
+#pragma unroll
+        for (int t = 0; t < L; ++t) {
+            V[t] = W[t];
+            W[t] = keep[t];
+        }
+        for (int j = 1; j < A.tbl_entries; ++j) {
+            multiply(j == 1 ? tbl + (size_t)extra * S2 : nullptr);  // base^2's first word: A stored it before it came to this barrier
+            store_entry(j);
+        }
+    }
+    // ---- left-to-right sliding window ------------------------------------------------------------------------------
+    load_entry(W, A.first_idx, role);
+    for (int op = 0; op < A.n_ops; ++op) {
+        const uint32_t w = A.sched[op];
+        const int nsq = (int)(w >> 8), sel = (int)(w & 0xffu);
+        if (sel) {  // the factor's words are fetched before the squarings: they arrive under them
+            load_entry(V, sel - 1, role);
+            if (!first) load_entry(Y0, sel - 1, 0u);
+        }
+        for (int sq = 0; sq < nsq; ++sq) square();
+        if (sel) multiply(nullptr);
+    }
+    // ---- the way out: both words with A ------------------------------------------------------------------------------
+    if (!first) lds_put<L>(mail, W, g);
+    wave::block_barrier();
+    if (first) {
+        uint32_t X1[L];
+        load_row<L>(X1, mail, g);
+        SplitLane<G, L, U> K;
+#pragma unroll
+        for (int t = 0; t < L; ++t) K.n[t] = n[t];
+        K.n0inv = n0inv;
+        K.rows_ = rows;
+        K.row_a = lds;
+        K.row_c = lds + H;
+        const uint32_t* mp = nullptr;
+        if (MODE == kModeEncrypt) mp = A.post ? A.post + item * (uint64_t)A.post_limbs : nullptr;
+        split_exit<G, L>(A.out + item * (uint64_t)A.out_limbs, A.out_limbs, W, X1, mp, A.post_limbs, A.mod, K, ln, live);
+    }
+}
+
 // Element-wise product modulo n^2 on the pair representation, for key widths whose n^2 has no full-width geometry
 // (mont_core.h stops at 16 x 18 = 288 limbs ~ 8344 bits, i.e. keys up to ~4170 bits; examples/benchmarks.py:88-90 of the
 // reference times 8192-bit keys): both factors enter the pair form, one pair product, the canonical residue leaves

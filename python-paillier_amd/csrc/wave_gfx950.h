@@ -110,6 +110,15 @@ PHE_DEV void lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Barrier of the whole workgroup (s_barrier), ordering LDS and global stores before it against loads after it for the waves
+// of the group.  Only the two-waves-per-number kernels use it (split_core.h "one number on two wavefronts"); every other
+// kernel here keeps its waves independent.
+PHE_DEV void block_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 // Asynchronous 16-byte copy global -> LDS without a register round trip (global_load_lds_dwordx4, "LDS-DMA"): lane l
 // of the wave lands at lds_wave_base + 16*l bytes — the destination is wave-uniform base + lane*16, the SOURCE is per
 // lane.  Lanes for which `active` is false copy nothing.  The data may be read after wait_async_copies().

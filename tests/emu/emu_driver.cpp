@@ -202,6 +202,30 @@ static void run_split(SplitArgs A) {
     }
 }
 
+// k_modexp_split_ab: one number on a PAIR of waves (role 0 = first words, 1 = second words), the two waves in two host
+// threads joined by wave::block_barrier; one table of (tbl_entries + 1) pairs per number.  G = 64 only.
+template <int L, int MODE>
+static void run_split_ab(SplitArgs A) {
+    constexpr int H = 64 * L;
+    std::vector<uint32_t> table((size_t)A.batch * (size_t)(A.tbl_entries + 1) * 2 * H);
+    for (uint64_t item = 0; item < A.batch; ++item) {
+        std::vector<uint32_t> lds(6 * H + kLdsPad, 0xdeadbeefu);   // LDS is not zero on the device either
+        uint32_t* tbl = table.data() + (size_t)item * (size_t)(A.tbl_entries + 1) * 2 * H;
+        wave::run_block(2, [&](uint32_t role, uint32_t lane) {
+            modexp_split_ab_body<L, MODE>(A, lds.data(), tbl, item, true, role, lane);
+        });
+    }
+}
+#define DISPATCH_AB(L_, CALL)                                                         \
+    switch (L_) {                                                                     \
+        case 1: { constexpr int LL = 1; CALL; break; }                                \
+        case 2: { constexpr int LL = 2; CALL; break; }                                \
+        case 3: { constexpr int LL = 3; CALL; break; }                                \
+        case 5: { constexpr int LL = 5; CALL; break; }                                \
+        default: throw std::invalid_argument("no wave-pair kernel for this L");       \
+    }
+static int g_wave_pairs = 0;  // 1: whole-wave geometry runs every exponentiation on a wave pair (the library's choice for a handful of numbers)
+
 template <int G, int L>
 static void run_var_split(SplitVarArgs A) {
     constexpr int S2 = 2 * G * L, kPer = 64 / G;
@@ -338,6 +362,7 @@ extern "C" {
 void emu_set_engine(int e) { g_engine = e ? 1 : 0; }
 void emu_set_mul_io(int e) { g_mul_io = e ? 1 : 0; }
 void emu_set_unit(int e) { g_unit = e ? 1 : 0; }
+void emu_set_wave_pairs(int e) { g_wave_pairs = e ? 1 : 0; }
 int emu_unit_offered(const uint32_t* n, int n_limbs) {
     try { return host::build_public(n, n_limbs, g_prefer_group).nunit.G ? 1 : 0; } catch (...) { return 0; }
 }
@@ -420,6 +445,7 @@ int emu_encrypt(const uint32_t* n, int n_limbs, const uint32_t* m, const uint32_
             A.base = r; A.base_limbs = P.s1; A.base_chunks = chunks_for(P.s1, M.rows);
             A.post = c_in ? c_in : m; A.post_limbs = c_in ? P.s2 : P.s1; A.post_chunks = chunks_for(A.post_limbs, M.rows);
             A.out = c_out; A.out_limbs = P.s2; A.batch = B;
+            if (!c_in && M.G == 64 && g_wave_pairs) { DISPATCH_AB(M.L, (run_split_ab<LL, kModeEncrypt>(A))); return 0; }
             if (c_in) { DISPATCH_SPLIT(M.G, M.L, (run_split<GG, LL, kModeObfuscate>(A))); }
             else { DISPATCH_SPLIT(M.G, M.L, (run_split<GG, LL, kModeEncrypt>(A))); }
             return 0;
@@ -503,6 +529,7 @@ int emu_decrypt(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const 
                 A.first_idx = E.first_idx; A.tbl_entries = E.tbl_entries;
                 A.base = c; A.base_limbs = P.s2; A.base_chunks = chunks_for(P.s2, SP.rows);
                 A.out = half ? xq.data() : xp.data(); A.out_limbs = S; A.batch = B;
+                if (SP.G == 64 && g_wave_pairs) { DISPATCH_AB(SP.L, (run_split_ab<LL, kModeHalfDecrypt>(A))); continue; }
                 DISPATCH_SPLIT(SP.G, SP.L, (run_split<GG, LL, kModeHalfDecrypt>(A)));
                 continue;
             }

@@ -9,9 +9,11 @@
 #pragma once
 #include <stdint.h>
 #include <stdlib.h>
+#include <pthread.h>
 #include <ucontext.h>
 
 #include <functional>
+#include <vector>
 
 #define PHE_DEV inline
 
@@ -188,6 +190,46 @@ inline uint64_t ballot(bool p) {
     for (int i = 0; i < kLanes; ++i) m |= (uint64_t)(e->box[ph][i] & 1u) << i;
     return m;
 }
+// Workgroup barrier between waves that run in DIFFERENT host threads (run_block below): every lane of the wave reaches this
+// point (one yield, as in lds_fence), then lane 0 — always the first lane to be resumed — waits for the other waves' lane 0
+// on the shared pthread barrier; the remaining lanes resume only after it has passed.
+inline pthread_barrier_t*& block_barrier_object() {
+    static pthread_barrier_t* b = nullptr;
+    return b;
+}
+inline void block_barrier() {
+    Emu* e = emu();
+    e->lane_phase[e->cur]++;
+    yield_all();
+    if (e->cur == 0 && block_barrier_object()) pthread_barrier_wait(block_barrier_object());
+}
+
+// run `body(wave, lane)` for the waves of one workgroup, one host thread per wave; block_barrier() joins them
+inline void run_block(int n_waves, const std::function<void(uint32_t, uint32_t)>& body) {
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, nullptr, (unsigned)n_waves);
+    block_barrier_object() = &bar;
+    struct Arg {
+        const std::function<void(uint32_t, uint32_t)>* body;
+        uint32_t wave;
+    };
+    std::vector<pthread_t> th((size_t)n_waves);
+    std::vector<Arg> args((size_t)n_waves);
+    for (int w = 0; w < n_waves; ++w) {
+        args[(size_t)w] = Arg{&body, (uint32_t)w};
+        pthread_create(&th[(size_t)w], nullptr, [](void* p) -> void* {
+            Arg* a = (Arg*)p;
+            const uint32_t wv = a->wave;
+            const auto* fn = a->body;
+            run_wave([&](uint32_t lane) { (*fn)(wv, lane); });
+            return nullptr;
+        }, &args[(size_t)w]);
+    }
+    for (int w = 0; w < n_waves; ++w) pthread_join(th[(size_t)w], nullptr);
+    block_barrier_object() = nullptr;
+    pthread_barrier_destroy(&bar);
+}
+
 inline void lds_fence() {
     Emu* e = emu();
     e->lane_phase[e->cur]++;

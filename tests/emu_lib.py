@@ -28,6 +28,14 @@ class Emu:
     def set_group(self, g):
         self.L.emu_set_group(int(g))
 
+    def set_wave_pairs(self, on):
+        """True: on the whole-wave geometry (set_group(64)) encrypt / decrypt run every number on a PAIR of waves"""
+        self.L.emu_set_wave_pairs(1 if on else 0)
+
+    def set_unit(self, on):
+        """True (default): r^n through the scaled modulus where the key offers it, as the library's large-batch path does"""
+        self.L.emu_set_unit(1 if on else 0)
+
     def set_engine(self, split):
         """True: split-modulus kernels where a geometry exists (the product default); False: full-width only"""
         self.L.emu_set_engine(1 if split else 0)

@@ -299,3 +299,33 @@ def test_key_owner_encryption_with_obfuscators_that_share_a_factor_with_n(emu):
     want = [(1 + n * m) * pow(r, n, N) % N for m, r in zip(ms, rs)]
     assert limbs_to_ints(out) == want
     assert limbs_to_ints(emu.encrypt(int_to_limbs(n, 8), ints_to_limbs(ms, 8), ints_to_limbs(rs, 8))) == want
+
+
+@pytest.mark.parametrize("key_bits,count", [(256, None), (1024, 3), (2048, 2), (3072, 1)])
+def test_one_number_on_a_wave_pair(emu, key_bits, count):
+    """k_modexp_split_ab's body (split_core.h "one number on TWO wavefronts"): wave A runs the first words of every pair
+    product, wave B — one product behind, through two LDS slots and one workgroup barrier per product — the second words.
+    The two waves run in two host threads here; encrypt and both decrypt halves must give the golden bits."""
+    emu.set_engine(True)
+    emu.set_group(64)
+    emu.set_unit(False)
+    emu.set_wave_pairs(True)
+    try:
+        g = load_golden(key_bits)
+        s1, s2, h = key_bits // 32, key_bits // 16, key_bits // 64
+        n = int_to_limbs(H(g["n"]), s1)
+        enc = g["raw_encrypt"]
+        if count:
+            enc = enc[:2] + enc[7:7 + count]                  # m = 0, 1 and a few random ones (r = 1 and n - 1 are further down)
+        c = emu.encrypt(n, ints_to_limbs([H(e["m"]) for e in enc], s1), ints_to_limbs([H(e["r"]) for e in enc], s1))
+        assert limbs_to_ints(c) == [H(e["c"]) for e in enc]
+        dec = g["raw_decrypt"]
+        if count:
+            dec = dec[-count:]
+        key = [int_to_limbs(H(g[k]), h) for k in ("p", "q", "hp", "hq", "p_inverse")]
+        m = emu.decrypt(*key, s1, ints_to_limbs([H(e["c"]) for e in dec], s2))
+        assert limbs_to_ints(m) == [H(e["m"]) for e in dec]
+    finally:
+        emu.set_wave_pairs(False)
+        emu.set_unit(True)
+        emu.set_group(0)

@@ -123,6 +123,39 @@ def test_the_rung_follows_the_batch_size(native, c_oracle):
     assert widths_priv[-1][0] == priv[0] // 100
 
 
+@pytest.mark.parametrize("key_bits", [1024, 2048, 3072])
+def test_a_handful_of_numbers_runs_on_wave_pairs(native, c_oracle, key_bits, monkeypatch):
+    """1 ... 60 numbers: every exponentiation on a PAIR of wavefronts (k_modexp_split_ab: first words on one wave, second words
+    one product behind on the other) — asserted through last_launch, bit-exact against the golden vectors and libgmp, and
+    equal to what the single-wave kernels give (PHE_HIP_NO_WAVE_PAIRS)"""
+    g = load_golden(key_bits)
+    s1, s2 = key_bits // 32, key_bits // 16
+    n_int = H(g["n"])
+    n = native.int_to_limbs(n_int, s1)
+    p, q = native.int_to_limbs(H(g["p"]), s1 // 2), native.int_to_limbs(H(g["q"]), s1 // 2)
+    ctx = make_ctx(native, g)
+    seen = golden_hot_path(native, ctx, g)                       # a few dozen rows per call: the wave-pair path
+    assert seen["encrypt"]["path"] & ctx.PATH_WAVE_PAIRS and seen["encrypt"]["geom_pub"] // 100 == 64, seen
+    assert seen["decrypt"]["path"] & ctx.PATH_WAVE_PAIRS and seen["decrypt"]["geom_priv"] // 100 == 64, seen
+    rng = random.Random(key_bits)
+    monkeypatch.setenv("PHE_HIP_NO_WAVE_PAIRS", "1")
+    single = make_ctx(native, g)
+    for batch in (1, 2, 7, 60):
+        m = native.ints_to_limbs([rng.randrange(0, n_int) for _ in range(batch)], s1)
+        r = native.ints_to_limbs([rng.randrange(1, n_int) for _ in range(batch)], s1)
+        c = ctx.encrypt(m, r)
+        assert ctx.last_launch()["path"] & ctx.PATH_WAVE_PAIRS
+        assert np.array_equal(c, c_oracle.encrypt(n, m, r, nthreads=4)), batch
+        junk = native.ints_to_limbs([rng.randrange(1, n_int * n_int) for _ in range(batch)], s2)
+        both = np.concatenate([c, junk])
+        got = ctx.decrypt(both)
+        assert ctx.last_launch()["path"] & ctx.PATH_WAVE_PAIRS
+        assert np.array_equal(got, c_oracle.decrypt(n, p, q, both, nthreads=4)), batch
+        assert np.array_equal(got[:batch], m)
+        assert np.array_equal(single.encrypt(m, r), c) and np.array_equal(single.decrypt(both), got)
+    assert not single.last_launch()["path"] & ctx.PATH_WAVE_PAIRS
+
+
 @pytest.mark.parametrize("key_bits", [2048, 3072])
 def test_scaled_modulus_path_on_the_golden_vectors(native, key_bits, monkeypatch):
     """PHE_HIP_FORCE_UNIT: r^n modulo the scaled modulus k*n for small batches too — every golden raw_encrypt / obfuscate
