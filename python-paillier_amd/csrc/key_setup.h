@@ -339,17 +339,25 @@ struct SplitPack {
 };
 
 // max_input_bits: widest number that will be converted into the pair representation (a ciphertext).
-inline SplitPack build_split(const Big& n_any, int max_input_bits, int prefer_group = 0) {
+// whole_L / whole_rows (both or none): a whole-wave pack (G = 64) with exactly that lane width and that many limbs per number
+inline SplitPack build_split(const Big& n_any, int max_input_bits, int prefer_group = 0, int whole_L = 0, int whole_rows = 0) {
     SplitPack P;
     P.bits = big_bits(n_any);
     const int w = (P.bits + 31) / 32;
-    const Geometry geo = pick_geometry_split(P.bits, prefer_group);
+    Geometry geo = pick_geometry_split(P.bits, prefer_group);
+    if (whole_L) {
+        geo.G = 64;
+        geo.L = whole_L;
+    }
     if (geo.G == 0) return P;  // caller falls back to the full-width kernels
     P.G = geo.G;
     P.L = geo.L;
     P.H = geo.S();
     P.rows = P.H;
-    if (P.G == 64) {
+    if (whole_L) {
+        if (whole_rows % whole_L || whole_rows > P.H || kRadixBits * whole_rows < P.bits + 4) throw std::invalid_argument("bad whole-wave rows");
+        P.rows = whole_rows;
+    } else if (P.G == 64) {
         // a multiple of the digits a whole-wave sweep takes per trip (split_core.h Trip<64, L>: 4, 4, 6, 10)
         const int need = (P.bits + 4 + kRadixBits - 1) / kRadixBits;
         const int trip = (P.L == 1 ? 4 : 2) * P.L;
@@ -394,6 +402,62 @@ inline SplitPack build_split(const Big& n_any, int max_input_bits, int prefer_gr
         pair_of(Z, P.conv);
     }
     return P;
+}
+
+// One number on a PAIR of wavefronts (split_core.h modexp_split_ab_body): the sweeps run modulo the scaled modulus
+// n~ = k*n, k = -n^-1 mod 2^29, so that n~ = -1 (mod 2^29) and a quotient digit is the accumulator's low digit as it is; the
+// pair form inside is the one modulo n~^2 (n^2 divides it), and the way out works modulo the true n with the same
+// R = 2^(29 rows): X0 - n~*X1 = X0 - n*(k*X1), so split_exit multiplies X1 by k*(n-1) where it multiplies by n-1 otherwise.
+// rows covers n~ with the 4 bits of slack the lazy bounds need: one limb more than n's own, no rounding to a trip length.
+struct QuickPack {
+    SplitPack scaled;            // constants modulo n~ (G = 64)
+    SplitPack exit;              // constants modulo n, same L and rows
+    std::vector<uint32_t> nbar;  // (n~ + 1) / 2^29, H limbs
+    std::vector<uint32_t> kx;    // k*(n - 1) mod n, H limbs
+    bool ok() const { return scaled.G == 64; }
+};
+
+// lane width a QuickPack of this modulus needs (0: wider than the whole-wave kernels go)
+inline int quick_lane_width(const Big& n_any) {
+    const int need = (big_bits(n_any) + kRadixBits + 4 + kRadixBits - 1) / kRadixBits;
+    for (int L : kS64)
+        if (64 * L > (need + L - 1) / L * L) return L;
+    return 0;
+}
+
+inline QuickPack build_quick(const Big& n_any, int max_input_bits, int L) {
+    QuickPack Q;
+    if (L == 0) return Q;
+    const int bits = big_bits(n_any), w = (bits + 31) / 32;
+    const Big n = big_resize(n_any, w);
+    if ((n[0] & 1u) == 0u) throw std::invalid_argument("modulus must be odd");
+    const uint32_t k = neg_inv32(n[0]) & ((1u << kRadixBits) - 1u);
+    Big nk = big_mul(n, Big(1, k));
+    const int kbits = big_bits(nk);
+    nk = big_resize(nk, (kbits + 31) / 32);
+    const int need = (kbits + 4 + kRadixBits - 1) / kRadixBits;
+    const int rows = (need + L - 1) / L * L;
+    // a sweep is at least two trips (split_core.h AbTrip), and word `rows` of a digit row is used (the quotient row has rows + 1 words)
+    if (rows + 1 > 64 * L || rows < (L == 1 ? 4 : 2) * L) return Q;
+    Q.scaled = build_split(nk, max_input_bits, 64, L, rows);
+    Q.exit = build_split(n, max_input_bits, 64, L, rows);
+    if (Q.scaled.n0inv != 1u) throw std::logic_error("scaled modulus is not -1 modulo the radix");
+    {   // (n~ + 1) / 2^29: limb 0 of n~ + 1 is zero
+        Big one(nk.size() + 1, 0u), up = big_resize(nk, (int)nk.size() + 1);
+        one[0] = 1;
+        big_add_inplace(up, one);
+        const std::vector<uint32_t> all = to_r29(up, 64 * L + 1);
+        if (all[0] != 0u) throw std::logic_error("scaled modulus + 1 is not a multiple of the radix");
+        Q.nbar.assign(all.begin() + 1, all.end());
+    }
+    {   // k*(n - 1) mod n
+        Big one((size_t)w, 0u), nm1 = n, quo, rem;
+        one[0] = 1;
+        big_sub_inplace(nm1, one);
+        big_divmod(big_mul(nm1, Big(1, k)), n, quo, rem);
+        Q.kx = to_r29(big_resize(rem, w), 64 * L);
+    }
+    return Q;
 }
 
 // Left-to-right sliding-window schedule for a batch-uniform exponent e > 0.
@@ -522,6 +586,7 @@ struct PublicPlan {
     // geometry of n^2 can take the result modulo n'^2 in (G == 0: not offered).  unit_words: 32-bit words of such a row.
     SplitPack nunit;
     int unit_words = 0;
+    QuickPack nquick;    // whole-wave plans only: one number on a wave pair
     Schedule exp_n;
 };
 
@@ -543,6 +608,7 @@ inline PublicPlan build_public(const uint32_t* n, int n_limbs, int prefer_group 
         P.nsq = ModulusPack();
     }
     P.exp_n = build_schedule(P.n);
+    if (P.nsplit.G == 64) P.nquick = build_quick(P.n, 32 * P.s2, quick_lane_width(P.n));
     if (P.nsplit.G && P.nsq.G) {
         Big k(1, P.nsplit.n0inv);                       // -n^-1 mod 2^29
         Big nk = big_mul(P.n, k);                       // n' = k*n = -1 (mod 2^29)
@@ -563,6 +629,7 @@ struct PrivatePlan {
     int s1 = 0, s2 = 0;
     ModulusPack psq, qsq;  // same L
     SplitPack psplit, qsplit;  // pair arithmetic modulo p / q for the two CRT half-exponentiations
+    QuickPack pquick, qquick;  // whole-wave plans only: one number on a wave pair (one lane width for both)
     Schedule exp_p, exp_q;
     TailPack tail;
 };
@@ -584,6 +651,13 @@ inline PrivatePlan build_private(const uint32_t* p, const uint32_t* q, const uin
     if (P.psq.L != P.qsq.L || P.psq.G != P.qsq.G) throw std::invalid_argument("p and q too unbalanced");
     P.psplit = build_split(bp, 32 * P.s2, prefer_group);
     P.qsplit = build_split(bq, 32 * P.s2, prefer_group);
+    if (P.psplit.G == 64 && P.qsplit.G == 64) {
+        const int Lp = quick_lane_width(bp), Lq = quick_lane_width(bq), Lw = std::max(Lp, Lq);
+        if (Lp && Lq) {
+            P.pquick = build_quick(bp, 32 * P.s2, Lw);
+            P.qquick = build_quick(bq, 32 * P.s2, Lw);
+        }
+    }
     Big one((size_t)pq_limbs, 0u);
     one[0] = 1;
     Big pm1 = bp, qm1 = bq;

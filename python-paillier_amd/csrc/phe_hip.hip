@@ -297,8 +297,12 @@ struct DevModulus {  // device copies of a host::ModulusPack
 struct DevSplit {  // device copies of a host::SplitPack
     int G = 0, L = 0, H = 0;  // G == 0: no split kernel for this modulus
     int rows = 0;             // limbs of a number (H, except on the whole-wave geometry: SplitPack::rows)
-    uint32_t* blob = nullptr;  // n | r1 | e | nsq | conv
+    uint32_t* blob = nullptr;  // n | r1 | e | nsq | conv [| the QuickPack's rows]
     SplitConsts c{};
+    // one number on a wave pair (host::QuickPack; whole-wave packs only): constants modulo the scaled modulus and, for the
+    // way out, modulo the true one; q_L == 0: not offered
+    int q_L = 0, q_H = 0, q_rows = 0;
+    SplitConsts q_scaled{}, q_exit{};
 };
 struct DevSchedule {
     uint32_t* ops = nullptr;
@@ -401,16 +405,23 @@ static int upload_modulus(const host::ModulusPack& m, DevModulus& d) {
     d.c.n0inv = m.n0inv;
     return PHE_HIP_OK;
 }
-static int upload_split(const host::SplitPack& m, DevSplit& d) {
+static int upload_split(const host::SplitPack& m, DevSplit& d, const host::QuickPack* quick = nullptr) {
     d.G = m.G;
     d.L = m.L;
     d.H = m.H;
     d.rows = m.rows;
     if (m.G == 0) return PHE_HIP_OK;
     std::vector<uint32_t> h;
-    const std::vector<uint32_t>* parts[5] = {&m.n, &m.r1, &m.e, &m.nsq, &m.conv};
-    size_t off[5];
-    for (int i = 0; i < 5; ++i) {
+    const bool q = quick && quick->ok() && m.G == 64;
+    const std::vector<uint32_t>* parts[15] = {&m.n, &m.r1, &m.e, &m.nsq, &m.conv};
+    int n_parts = 5;
+    if (q) {
+        const host::SplitPack &S = quick->scaled, &E = quick->exit;
+        const std::vector<uint32_t>* more[10] = {&S.n, &S.r1, &S.e, &S.nsq, &S.conv, &quick->nbar, &E.n, &E.r1, &E.nsq, &quick->kx};
+        for (int i = 0; i < 10; ++i) parts[n_parts++] = more[i];
+    }
+    size_t off[15];
+    for (int i = 0; i < n_parts; ++i) {
         off[i] = h.size();
         h.insert(h.end(), parts[i]->begin(), parts[i]->end());
     }
@@ -423,6 +434,27 @@ static int upload_split(const host::SplitPack& m, DevSplit& d) {
     d.c.conv = d.blob + off[4];
     d.c.n0inv = m.n0inv;
     d.c.rows = m.rows;
+    if (q) {
+        const host::SplitPack &S = quick->scaled, &E = quick->exit;
+        d.q_L = S.L;
+        d.q_H = S.H;
+        d.q_rows = S.rows;
+        d.q_scaled.n = d.blob + off[5];
+        d.q_scaled.r1 = d.blob + off[6];
+        d.q_scaled.e = d.blob + off[7];
+        d.q_scaled.nsq = d.blob + off[8];
+        d.q_scaled.conv = d.blob + off[9];
+        d.q_scaled.nbar = d.blob + off[10];
+        d.q_scaled.n0inv = S.n0inv;
+        d.q_scaled.rows = S.rows;
+        d.q_exit.n = d.blob + off[11];
+        d.q_exit.r1 = d.blob + off[12];
+        d.q_exit.nsq = d.blob + off[13];
+        d.q_exit.kx = d.blob + off[14];
+        d.q_exit.e = d.q_exit.conv = nullptr;
+        d.q_exit.n0inv = E.n0inv;
+        d.q_exit.rows = E.rows;
+    }
     return PHE_HIP_OK;
 }
 static int upload_schedule(const host::Schedule& s, DevSchedule& d) {
@@ -594,29 +626,30 @@ static int launch_split_halves(phe_hip_ctx* ctx, const DevSplit& Mp, const DevSc
 // here (tbl_entries + 1 pairs each), in ctx->table / ctx->table2.
 static bool ab_offered(const phe_hip_ctx* ctx, const DevSplit& M, size_t batch, int halves) {
     // while every wave of every number still finds a SIMD of its own (2 roles x halves x batch waves)
-    return !ctx->no_wave_pairs && M.G == 64 && M.L <= kMaxFusedL && batch * 2 * (size_t)halves <= (size_t)ctx->n_cus * 4;
+    return !ctx->no_wave_pairs && M.G == 64 && M.q_L != 0 && batch * 2 * (size_t)halves <= (size_t)ctx->n_cus * 4;
 }
 static int launch_split_ab(phe_hip_ctx* ctx, int mode, const DevSplit& Mp, const DevSchedule& Ep, const DevSplit* Mq, const DevSchedule* Eq,
                            const uint32_t* base, int base_limbs, const uint32_t* post, int post_limbs, uint32_t* out_p, uint32_t* out_q,
                            int out_limbs, size_t batch, hipStream_t stream) {
     const int halves = Mq ? 2 : 1;
-    if (Mq && (Mq->G != Mp.G || Mq->L != Mp.L)) return fail(PHE_HIP_EINVAL, "the two halves need one geometry");
+    if (Mp.q_L == 0 || (Mq && Mq->q_L != Mp.q_L)) return fail(PHE_HIP_EINVAL, "the two halves need one wave-pair geometry");
     SplitArgs Ap, Aq;
     const auto fill = [&](SplitArgs& A, const DevSplit& M, const DevSchedule& E, uint32_t* out, bool second) -> int {
         uint32_t** tbl = second ? &ctx->table2 : &ctx->table;
-        int rc = ensure_words(tbl, second ? &ctx->table2_words : &ctx->table_words, batch * (size_t)(E.tbl_entries + 1) * 2 * M.H);
+        int rc = ensure_words(tbl, second ? &ctx->table2_words : &ctx->table_words, batch * (size_t)(E.tbl_entries + 1) * 2 * M.q_H);
         if (rc) return rc;
-        A.mod = M.c;
+        A.mod = M.q_scaled;
+        A.exit_mod = M.q_exit;
         A.sched = E.ops;
         A.n_ops = E.n_ops;
         A.first_idx = E.first_idx;
         A.tbl_entries = E.tbl_entries;
         A.base = base;
         A.base_limbs = base_limbs;
-        A.base_chunks = chunks_for(base_limbs, M.rows);
+        A.base_chunks = chunks_for(base_limbs, M.q_rows);
         A.post = post;
         A.post_limbs = post_limbs;
-        A.post_chunks = chunks_for(post_limbs, M.rows);
+        A.post_chunks = chunks_for(post_limbs, M.q_rows);
         A.out = out;
         A.out_limbs = out_limbs;
         A.table = *tbl;
@@ -627,7 +660,7 @@ static int launch_split_ab(phe_hip_ctx* ctx, int mode, const DevSplit& Mp, const
     if (!rc && Mq) rc = fill(Aq, *Mq, *Eq, out_q, true);
     if (rc) return rc;
     if (!Mq) Aq = Ap;
-    if (PHE_SPLIT_BY_GROUP(Mp.G, launch_split_ab(Mp.L, mode, (int)batch, halves, stream, Ap, Aq)) < 0)
+    if (PHE_SPLIT_BY_GROUP(64, launch_split_ab(Mp.q_L, mode, (int)batch, halves, stream, Ap, Aq)) < 0)
         return fail(PHE_HIP_EINVAL, "no wave-pair kernel for this geometry");
     HIP_TRY(hipGetLastError());
     return PHE_HIP_OK;
@@ -927,7 +960,7 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
     }
     if (ctx->pub.nsq.G == 0) ctx->use_split = true;  // wide keys have the pair form only
     int rc = upload_modulus(ctx->pub.nsq, ctx->d_nsq);
-    if (!rc) rc = upload_split(ctx->pub.nsplit, ctx->d_nsplit);
+    if (!rc) rc = upload_split(ctx->pub.nsplit, ctx->d_nsplit, &ctx->pub.nquick);
     if (!rc && !getenv("PHE_HIP_NO_UNIT")) rc = upload_split(ctx->pub.nunit, ctx->d_nunit);
     if (!rc) rc = upload_schedule(ctx->pub.exp_n, ctx->d_exp_n);
     ctx->force_unit = getenv("PHE_HIP_FORCE_UNIT") != nullptr;
@@ -952,7 +985,7 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
                 };
                 if (chain(R.plan) * 5 > chain(prev) * 4) continue;
                 rc = upload_modulus(R.plan.nsq, R.nsq);
-                if (!rc) rc = upload_split(R.plan.nsplit, R.nsplit);
+                if (!rc) rc = upload_split(R.plan.nsplit, R.nsplit, &R.plan.nquick);
                 if (rc) break;
                 ctx->pub_rungs.push_back(R);
             } catch (const std::exception&) {
@@ -1024,8 +1057,8 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
     }
     if (!rc) rc = upload_modulus(ctx->priv.psq, ctx->d_psq);
     if (!rc) rc = upload_modulus(ctx->priv.qsq, ctx->d_qsq);
-    if (!rc) rc = upload_split(ctx->priv.psplit, ctx->d_psplit);
-    if (!rc) rc = upload_split(ctx->priv.qsplit, ctx->d_qsplit);
+    if (!rc) rc = upload_split(ctx->priv.psplit, ctx->d_psplit, &ctx->priv.pquick);
+    if (!rc) rc = upload_split(ctx->priv.qsplit, ctx->d_qsplit, &ctx->priv.qquick);
     if (!rc && !getenv("PHE_HIP_GROUP")) {
         for (int prefer : {4, 8, 16, 64}) {
             try {
@@ -1045,8 +1078,8 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
                 if (chain(R.plan) * 5 > chain(prev) * 4) continue;  // see the public rungs
                 rc = upload_modulus(R.plan.psq, R.psq);
                 if (!rc) rc = upload_modulus(R.plan.qsq, R.qsq);
-                if (!rc) rc = upload_split(R.plan.psplit, R.psplit);
-                if (!rc) rc = upload_split(R.plan.qsplit, R.qsplit);
+                if (!rc) rc = upload_split(R.plan.psplit, R.psplit, &R.plan.pquick);
+                if (!rc) rc = upload_split(R.plan.qsplit, R.qsplit, &R.plan.qquick);
                 if (rc) break;
                 ctx->priv_rungs.push_back(R);
             } catch (const std::exception&) {

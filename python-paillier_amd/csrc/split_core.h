@@ -50,12 +50,16 @@ struct SplitConsts {
     const uint32_t* nsq;   // n^2, 2H limbs
     uint32_t n0inv;        // -n^-1 mod 2^29
     int rows;              // limbs of a number (= G*L, except on the whole-wave geometry G = 64: key_setup.h SplitPack::rows)
+    // wave-pair kernels only (key_setup.h QuickPack), null elsewhere:
+    const uint32_t* nbar;  // scaled constants: (n~ + 1) / 2^29 for n~ = k*n = -1 (mod 2^29), H limbs
+    const uint32_t* kx;    // exit constants: k*(n - 1) mod n, H limbs (the second word of a pair modulo n~ is X1/k modulo n)
 };
 
 // Same contract as UniformArgs (mont_core.h): batch-uniform exponent given as a sliding-window schedule,
 // all user-visible numbers are little-endian 32-bit-word rows.
 struct SplitArgs {
     SplitConsts mod;
+    SplitConsts exit_mod;  // wave-pair kernels: `mod` is the scaled modulus n~, this one the true n with the same R (the way out)
     const uint32_t* sched;
     int n_ops;
     int first_idx;
@@ -535,7 +539,8 @@ PHE_DEV void store_pair_as_u32(uint32_t* p, int limbs32, const uint32_t (&lo)[L]
 // pair -> canonical residue of x * (1 + n*mp) mod n^2 (mp == nullptr: of x), written as 32-bit words
 template <int G, int L, bool U>
 PHE_DEV void split_exit(uint32_t* out, int out_limbs, uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t* mp,
-                        int mp_limbs, const SplitConsts& C, const SplitLane<G, L, U>& K, const Lanes<G>& ln, bool live) {
+                        int mp_limbs, const SplitConsts& C, const SplitLane<G, L, U>& K, const Lanes<G>& ln, bool live,
+                        const uint32_t* x1_factor = nullptr) {
     constexpr int H = G * L;
     const uint32_t g = ln.g;
     uint32_t u[L], t[L], cst[L];
@@ -549,7 +554,13 @@ PHE_DEV void split_exit(uint32_t* out, int out_limbs, uint32_t (&X0)[L], uint32_
 #pragma unroll
     for (int k = 0; k < L; ++k) cst[k] = K.n[k] - ((g == 0u && k == 0) ? 1u : 0u);  // n is odd: no borrow
     if constexpr (L <= kMaxFusedL) {
-        montmac2<G, L>(t, K.row_a, cst, K.row_c, cst, K.n, K.n0inv, ln, K.rows());
+        if (x1_factor != nullptr) {  // the pair came from the scaled modulus n~ = k*n: its second word is X1/k, so (n-1) -> k*(n-1)
+            uint32_t kx[L];
+            load_row<L>(kx, x1_factor, g);
+            montmac2<G, L>(t, K.row_a, kx, K.row_c, cst, K.n, K.n0inv, ln, K.rows());
+        } else {
+            montmac2<G, L>(t, K.row_a, cst, K.row_c, cst, K.n, K.n0inv, ln, K.rows());
+        }
     } else {
         uint32_t t2[L];
         montmul<G, L>(t, K.row_a, cst, K.n, K.n0inv, ln, K.rows());
@@ -657,113 +668,288 @@ PHE_DEV void modexp_split_body(const SplitArgs& A, uint32_t* lds_row, uint32_t s
 // Montgomery product of the X0's.  So wave A runs the first words of all products of an exponentiation — an ordinary
 // Montgomery ladder modulo n — and leaves, per product, the multiplier's digits and its quotient digits in LDS; wave B, one
 // product behind, runs the second words from those.  Two LDS slots and ONE workgroup barrier per product keep them in step
-// (A fills slot k&1 and arrives; B arrives and reads it while A fills the other).  Each wave issues ~9-10 instructions per
-// digit: about half the time per product.  The conversion in and the way out need both words: B hands its word over in LDS.
-// Only for G = 64 (one number per wave pair) and fused-sweep widths.
-template <int L, bool U = false>
-PHE_DEV void ab_first_word(uint32_t (&z0)[L], const uint32_t* a, const uint32_t (&b0)[L], uint32_t* m_row, const uint32_t (&n)[L],
-                           uint32_t n0inv, const Lanes<64>& ln, int rows) {
-    constexpr int G = 64, kT = Trip<G, L>::kDigits;
+// (A fills slot k&1 and arrives; B arrives and reads it while A fills the other).  The conversion in and the way out need
+// both words: B hands its word over in LDS.  Only for G = 64 (one number per wave pair) and fused-sweep widths.
+//
+// A lone wave issues in order and hides nothing, so what counts here is the dependent chain per digit.  The textbook row
+// (acc += a_i*b; m = acc0 * (-n^-1); acc += m*n; shift) is ONE chain: multiply-add -> v_mul_lo -> lane 0 to an SGPR ->
+// multiply-add -> lane shift -> next row, ~118 cycles per digit measured (profiles/r03d_latency_*).  These sweeps run modulo
+// the SCALED modulus n~ = k*n, k = -n^-1 mod 2^29 (key_setup.h QuickPack: n~ = -1 mod 2^29, the pair form is the one
+// modulo n~^2), in the order
+//      q_i     = S_i mod 2^29                                   (the low digit as it is: no multiply)
+//      S_(i+1) = (S_i - q_i) / 2^29  +  q_i * nbar  +  a_i * b  (nbar = (n~ + 1) / 2^29;  S_i + q_i*n~ = S_i - q_i + q_i*2^29*nbar)
+// i.e. the quotient's product enters AFTER the shift: lane 0's digit travels to its SGPR while the lanes shift and take a_i*b
+// in, and one multiply-add closes the row.  With S_0 = 0 (q_0 = 0) and a_rows = 0 this is rows quotient steps and rows
+// products a_i*b, and S*R = a*b + Q*n~ for Q = sum q_(i+1) 2^(29 i) exactly as in the textbook order — the second word takes
+// those digits of Q as its addend.  The way out (split_exit) works modulo the true n with the same R: X0 - n~*X1 = X0 - n*(k*X1).
+#ifndef PHE_AB_GENERIC_STEPS
+#define PHE_AB_GENERIC_STEPS 0  // 1 (tools/latency_probe.hip only): the one-limb-per-lane sweeps take the general step as well
+#endif
+// Step s = 0 ... rows of a sweep:   s > 0: q = S mod 2^29, S <- (S - q) / 2^29;   s < rows: S += a_s * b (+ ...);   s > 0: S += q * nbar.
+// Steps come in trips of kSteps (digit s is word s of its LDS row: a trip reads ONE aligned block of every digit row); the
+// first trip's step 0 has no quotient part (FIRST), the last trip has (rows + 1) - kSteps * (trips - 1) steps of which the
+// last has no digit (LAST).  The quotient digit q of step s is digit s - 1 of Q, word s - 1 of the quotient row: a block of that
+// row is the last kSteps - 1 digits of one trip and the first of the next (the one-limb sweeps keep them in registers and store
+// the block with one aligned 16-byte store); the second word adds digit s of Q at its step s.
+template <int L>
+struct AbTrip {
+    static constexpr int kSteps = (L == 1 ? 4 : 2) * L;
+};
+// LDS of a wave pair, in words: two slots of (a-digits | quotient digits), B's own digit row, one row for words handed over,
+// and the area the lanes other than lane 0 write their (meaningless) copies of the quotient digits to, so that the store of
+// a trip's quotient digits is an ordinary all-lane store instead of a branch around a one-lane store
+// ... and H + 16 zero words: what the lanes above lane 0 read where lane 0 reads the first word's quotient digits
+template <int L>
+constexpr int ab_lds_words() { return 6 * 64 * L + (4 * 64 + 64 * L + 16) + (64 * L + 16); }
+
+template <int N, class P>
+PHE_DEV void ab_load_block(uint32_t (&d)[N], P p) {
+#pragma unroll
+    for (int t = 0; t < N; ++t) d[t] = p[t];
+}
+
+// one trip of the first word: N steps on the digit block dig_a; w: this trip's block of the quotient row (step jj's digit is
+// w[jj - 1]); held: the previous trip's last kSteps - 1 quotient digits, not stored yet (one-limb sweeps)
+template <int L, int N, bool FIRST, bool LAST>
+PHE_DEV void ab_first_steps(uint64_t (&p)[L], const uint32_t (&dig_a)[AbTrip<L>::kSteps], wave::lds_u32* w, uint32_t (&held)[3],
+                            const uint32_t (&b0)[L], const uint32_t (&nbar)[L], uint32_t dmask, const Lanes<64>& ln) {
+    constexpr int G = 64;
+    if constexpr (L == 1 && !PHE_AB_GENERIC_STEPS) {
+        // one limb per lane: the accumulator stays below 2^61 (a carry, a digit and two products), so the carry p >> 29 is a
+        // 32-bit number (one v_alignbit) and carry + received digit one 32-bit addition: no 64-bit shift, no 64-bit add
+        uint32_t tq[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int jj = 0; jj < N; ++jj) {
+            const bool quot = !(FIRST && jj == 0), digit = !(LAST && jj == N - 1);
+            uint32_t m = 0;
+            if (quot) {
+                const uint32_t t = wave::reread((uint32_t)p[0] & kLimbMask);  // (kept on the vector side: the lane shift takes it there)
+                m = wave::grp_bcast0<G>(t, ln);
+                tq[jj] = t;  // lane 0's copy is the quotient digit
+                p[0] = (uint64_t)(wave::grp_down1_raw<G>(t) + (uint32_t)(p[0] >> kRadixBits));
+                if (jj == 0) wave::lds_store4(w - 4, held[0], held[1], held[2], t);  // the previous block of the quotient row is complete
+            }
+            if (digit) p[0] = wave::reread64(wave::mad64(dig_a[jj], b0[0], p[0]));  // (the digit's product first: the quotient digit is still on its way)
+            if (quot) p[0] = wave::mad64(m, nbar[0], p[0]);
+        }
+        if constexpr (LAST) {
+#pragma unroll
+            for (int jj = 1; jj < N; ++jj) w[jj - 1] = tq[jj];
+        } else {
+#pragma unroll
+            for (int jj = 1; jj < 4; ++jj) held[jj - 1] = tq[jj];
+        }
+        return;
+    }
+#pragma unroll
+    for (int jj = 0; jj < N; ++jj) {
+        const bool quot = !(FIRST && jj == 0), digit = !(LAST && jj == N - 1);
+        const int j = jj % L, jl = (jj + L - 1) % L;  // lowest column after / before this step's shift
+        uint32_t m = 0;
+        if (quot) {
+            m = bcast_digit<G>((uint32_t)p[jl], 0u, ln);
+            w[jj - 1] = m;
+            shift_row<G, L>(p, jl, dmask);
+        }
+        if (digit) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(dig_a[jj], b0[k], p[(k + j) % L]);
+        }
+        if (quot) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(m, nbar[k], p[(k + j) % L]);
+        }
+    }
+}
+
+// z0 = (a*b0 + Q*n~) / R; the digits of Q go to m_row (H words of LDS; `dump`: 4*64 + H + 16 words for the other lanes' copies)
+template <int L>
+PHE_DEV void ab_first_word(uint32_t (&z0)[L], const uint32_t* a, const uint32_t (&b0)[L], uint32_t* m_row, uint32_t* dump,
+                           const uint32_t (&nbar)[L], const Lanes<64>& ln, int rows) {
+    constexpr int G = 64, kT = AbTrip<L>::kSteps;
     const uint32_t dmask = kLimbMask & ln.not_top;
     uint64_t p[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) p[k] = 0;
-    uint32_t ahead_a[kT];
-#pragma unroll
-    for (int t = 0; t < kT; ++t) ahead_a[t] = a[t];
+    wave::lds_u32* const w = wave::as_lds(ln.g == 0u ? m_row : dump + 4 * ln.g + 8);
+    const int trips = (rows + kT) / kT;  // ceil((rows + 1) / kT) >= 2 (key_setup.h build_quick)
+    uint32_t blk_a[kT], blk_b[kT], held[3] = {0u, 0u, 0u};
+    ab_load_block<kT>(blk_a, a);
+    ab_load_block<kT>(blk_b, a + kT);
+    ab_first_steps<L, kT, true, false>(p, blk_a, w, held, b0, nbar, dmask, ln);
+    int t = 1;
 #pragma unroll 1
-    for (int i = 0; i < rows; i += kT) {
-        uint32_t dig_a[kT], mq[kT];
-        const int nx = (i + kT < rows) ? i + kT : i;
+    for (; t + 2 < trips; t += 2) {  // two full trips: the digit blocks change roles, nothing is copied
+        ab_load_block<kT>(blk_a, a + (t + 1) * kT);
+        ab_first_steps<L, kT, false, false>(p, blk_b, w + t * kT, held, b0, nbar, dmask, ln);
+        ab_load_block<kT>(blk_b, a + (t + 2) * kT);
+        ab_first_steps<L, kT, false, false>(p, blk_a, w + (t + 1) * kT, held, b0, nbar, dmask, ln);
+    }
+    if (t + 1 < trips) {
+        ab_load_block<kT>(blk_a, a + (t + 1) * kT);
+        ab_first_steps<L, kT, false, false>(p, blk_b, w + t * kT, held, b0, nbar, dmask, ln);
+        ++t;
 #pragma unroll
-        for (int t = 0; t < kT; ++t) {
-            dig_a[t] = ahead_a[t];
-            ahead_a[t] = a[nx + t];
-        }
-#pragma unroll
-        for (int jj = 0; jj < kT; ++jj) {
-            const int j = jj % L;
-#pragma unroll
-            for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(dig_a[jj], b0[k], p[(k + j) % L]);
-            const uint32_t m = bcast_digit<G>(U ? (uint32_t)p[j] : (uint32_t)p[j] * n0inv, 0u, ln);
-            mq[jj] = m;
-#pragma unroll
-            for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(m, n[k], p[(k + j) % L]);
-            shift_row<G, L>(p, j, dmask);
-        }
-        if (ln.g == 0u) {
-#pragma unroll
-            for (int t = 0; t < kT; ++t) m_row[i + t] = mq[t];
+        for (int i = 0; i < kT; ++i) blk_b[i] = blk_a[i];
+    }
+    {   // the last trip: its last step takes no digit
+        const int left = rows + 1 - t * kT;
+        wave::lds_u32* const wl = w + t * kT;
+        if constexpr (L == 1) {
+            switch (left) {
+                case 1: ab_first_steps<L, 1, false, true>(p, blk_b, wl, held, b0, nbar, dmask, ln); break;
+                case 2: ab_first_steps<L, 2, false, true>(p, blk_b, wl, held, b0, nbar, dmask, ln); break;
+                case 3: ab_first_steps<L, 3, false, true>(p, blk_b, wl, held, b0, nbar, dmask, ln); break;
+                default: ab_first_steps<L, 4, false, true>(p, blk_b, wl, held, b0, nbar, dmask, ln); break;
+            }
+        } else {  // rows is a multiple of L: 1 or L + 1 steps
+            if (left == 1) ab_first_steps<L, 1, false, true>(p, blk_b, wl, held, b0, nbar, dmask, ln);
+            else ab_first_steps<L, L + 1, false, true>(p, blk_b, wl, held, b0, nbar, dmask, ln);
         }
     }
     normalize_partial<G, L>(z0, p, ln);
 }
 
-// z1 = (m + a*b1 [+ c*b0] + m2*n) / R with the digits of a, c and of the first word's quotient m in LDS
-template <int L, bool MUL, bool U = false>
-PHE_DEV void ab_second_word(uint32_t (&z1)[L], const uint32_t* a, const uint32_t* c, const uint32_t* m_row, const uint32_t (&b0)[L],
-                            const uint32_t (&b1)[L], const uint32_t (&n)[L], uint32_t n0inv, const Lanes<64>& ln, int rows) {
-    constexpr int G = 64, kT = Trip<G, L>::kDigits;
-    const uint32_t lane0 = kLimbMask & ~ln.not_low;
-    const uint32_t dmask = kLimbMask & ln.not_top;
-    uint64_t q[L];
+template <int L, int N, bool FIRST, bool LAST, bool MUL>
+PHE_DEV void ab_second_steps(uint64_t (&q)[L], const uint32_t (&dig_a)[AbTrip<L>::kSteps], const uint32_t (&dig_c)[AbTrip<L>::kSteps],
+                             const uint32_t (&m_cur)[AbTrip<L>::kSteps], const uint32_t (&b0)[L], const uint32_t (&b1)[L],
+                             const uint32_t (&nbar)[L], uint32_t dmask, const Lanes<64>& ln) {
+    constexpr int G = 64;
+    // the lanes other than lane 0 read zeros where lane 0 reads the quotient row (ab_second_word): the digit is added as it comes
+    const auto dig_m = [&](int jj) { return m_cur[jj]; };
+    if constexpr (L == 1 && !PHE_AB_GENERIC_STEPS) {  // (see ab_first_steps: 32-bit carry; the digit of Q rides on the same addition)
 #pragma unroll
-    for (int k = 0; k < L; ++k) q[k] = 0;
-    uint32_t ahead_a[kT], ahead_c[kT], ahead_m[kT];
-#pragma unroll
-    for (int t = 0; t < kT; ++t) {
-        ahead_a[t] = a[t];
-        ahead_m[t] = m_row[t];
-        ahead_c[t] = MUL ? c[t] : 0u;
-    }
-#pragma unroll 1
-    for (int i = 0; i < rows; i += kT) {
-        uint32_t dig_a[kT], dig_c[kT], dig_m[kT];
-        const int nx = (i + kT < rows) ? i + kT : i;
-#pragma unroll
-        for (int t = 0; t < kT; ++t) {
-            dig_a[t] = ahead_a[t];
-            dig_m[t] = ahead_m[t];
-            dig_c[t] = ahead_c[t];
-            ahead_a[t] = a[nx + t];
-            ahead_m[t] = m_row[nx + t];
-            if constexpr (MUL) ahead_c[t] = c[nx + t];
+        for (int jj = 0; jj < N; ++jj) {
+            const bool quot = !(FIRST && jj == 0), digit = !(LAST && jj == N - 1);
+            uint32_t m2 = 0, sum = digit ? dig_m(jj) : 0u;
+            if (quot) {
+                const uint32_t t = wave::reread((uint32_t)q[0] & kLimbMask);
+                m2 = wave::grp_bcast0<G>(t, ln);
+                sum += wave::grp_down1_raw<G>(t) + (uint32_t)(q[0] >> kRadixBits);
+            }
+            q[0] = (uint64_t)sum;
+            if (digit) {
+                q[0] = wave::mad64(dig_a[jj], b1[0], q[0]);
+                if constexpr (MUL) q[0] = wave::mad64(dig_c[jj], b0[0], q[0]);
+                q[0] = wave::reread64(q[0]);
+            }
+            if (quot) q[0] = wave::mad64(m2, nbar[0], q[0]);
         }
+        return;
+    }
 #pragma unroll
-        for (int jj = 0; jj < kT; ++jj) {
-            const int j = jj % L;
+    for (int jj = 0; jj < N; ++jj) {
+        const bool quot = !(FIRST && jj == 0), digit = !(LAST && jj == N - 1);
+        const int j = jj % L, jl = (jj + L - 1) % L;
+        uint32_t m2 = 0;
+        if (quot) {
+            m2 = bcast_digit<G>((uint32_t)q[jl], 0u, ln);
+            shift_row<G, L>(q, jl, dmask);
+        }
+        if (digit) {
 #pragma unroll
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(dig_a[jj], b1[k], q[(k + j) % L]);
             if constexpr (MUL) {
 #pragma unroll
                 for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(dig_c[jj], b0[k], q[(k + j) % L]);
             }
-            q[j] += (uint64_t)(dig_m[jj] & lane0);  // quotient digit i of the first word = digit i of the addend m
-            const uint32_t m2 = bcast_digit<G>(U ? (uint32_t)q[j] : (uint32_t)q[j] * n0inv, 0u, ln);
+            q[j] += (uint64_t)dig_m(jj);  // digit s of the first word's quotient Q (zero in the lanes above lane 0)
+        }
+        if (quot) {
 #pragma unroll
-            for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(m2, n[k], q[(k + j) % L]);
-            shift_row<G, L>(q, j, dmask);
+            for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(m2, nbar[k], q[(k + j) % L]);
+        }
+    }
+}
+
+// z1 = (Q + a*b1 [+ c*b0] + Q2*n~) / R with the digits of a, c and of the first word's quotient Q in LDS
+// (zeros: H + 16 zero words of LDS: what the lanes above lane 0 read in place of the quotient row)
+template <int L, bool MUL>
+PHE_DEV void ab_second_word(uint32_t (&z1)[L], const uint32_t* a, const uint32_t* c, uint32_t* m_row, uint32_t* zeros,
+                            const uint32_t (&b0)[L], const uint32_t (&b1)[L], const uint32_t (&nbar)[L], const Lanes<64>& ln, int rows) {
+    constexpr int G = 64, kT = AbTrip<L>::kSteps;
+    const uint32_t dmask = kLimbMask & ln.not_top;
+    uint64_t q[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) q[k] = 0;
+    const int trips = (rows + kT) / kT;
+    const wave::lds_u32* const mz = wave::as_lds(ln.g == 0u ? m_row : zeros);
+    uint32_t a_a[kT], a_b[kT], c_a[kT], c_b[kT], m_a[kT], m_b[kT];
+    const auto load = [&](uint32_t (&da)[kT], uint32_t (&dc)[kT], uint32_t (&dm)[kT], int t) {
+        ab_load_block<kT>(da, a + t * kT);
+        ab_load_block<kT>(dm, mz + t * kT);
+        if constexpr (MUL) ab_load_block<kT>(dc, c + t * kT);
+    };
+#pragma unroll
+    for (int i = 0; i < kT; ++i) c_a[i] = c_b[i] = 0u;
+    load(a_a, c_a, m_a, 0);
+    load(a_b, c_b, m_b, 1);
+    ab_second_steps<L, kT, true, false, MUL>(q, a_a, c_a, m_a, b0, b1, nbar, dmask, ln);
+    int t = 1;
+#pragma unroll 1
+    for (; t + 2 < trips; t += 2) {  // two full trips: the digit blocks change roles, nothing is copied
+        load(a_a, c_a, m_a, t + 1);
+        ab_second_steps<L, kT, false, false, MUL>(q, a_b, c_b, m_b, b0, b1, nbar, dmask, ln);
+        load(a_b, c_b, m_b, t + 2);
+        ab_second_steps<L, kT, false, false, MUL>(q, a_a, c_a, m_a, b0, b1, nbar, dmask, ln);
+    }
+    if (t + 1 < trips) {
+        load(a_a, c_a, m_a, t + 1);
+        ab_second_steps<L, kT, false, false, MUL>(q, a_b, c_b, m_b, b0, b1, nbar, dmask, ln);
+        ++t;
+#pragma unroll
+        for (int i = 0; i < kT; ++i) {
+            a_b[i] = a_a[i];
+            c_b[i] = c_a[i];
+            m_b[i] = m_a[i];
+        }
+    }
+    {   // the last trip: its last step takes no digits
+        const int left = rows + 1 - t * kT;
+        if constexpr (L == 1) {
+            switch (left) {
+                case 1: ab_second_steps<L, 1, false, true, MUL>(q, a_b, c_b, m_b, b0, b1, nbar, dmask, ln); break;
+                case 2: ab_second_steps<L, 2, false, true, MUL>(q, a_b, c_b, m_b, b0, b1, nbar, dmask, ln); break;
+                case 3: ab_second_steps<L, 3, false, true, MUL>(q, a_b, c_b, m_b, b0, b1, nbar, dmask, ln); break;
+                default: ab_second_steps<L, 4, false, true, MUL>(q, a_b, c_b, m_b, b0, b1, nbar, dmask, ln); break;
+            }
+        } else {
+            if (left == 1) ab_second_steps<L, 1, false, true, MUL>(q, a_b, c_b, m_b, b0, b1, nbar, dmask, ln);
+            else ab_second_steps<L, L + 1, false, true, MUL>(q, a_b, c_b, m_b, b0, b1, nbar, dmask, ln);
         }
     }
     normalize_partial<G, L>(z1, q, ln);
 }
 
 // The batched exponentiation of modexp_split_body for ONE number on a wave pair: role 0 = first words (A), 1 = second (B).
-// lds: 6*H words of the workgroup (two slots of a-digits | m-digits, B's own digit row, one row for words handed over);
-// tbl: (tbl_entries + 1) * 2H words of global scratch for this number (the extra entry carries base^2 during the table build).
-template <int L, int MODE, bool U = false>
-PHE_DEV void modexp_split_ab_body(const SplitArgs& A, uint32_t* lds, uint32_t* tbl, uint64_t item, bool live, uint32_t role,
-                                  uint32_t lane) {
+// lds: ab_lds_words<L>() words of the workgroup (two slots of a-digits | m-digits, B's own digit row, one row for words handed
+// over, the area for the other lanes' quotient-digit copies);
+// tbl: (tbl_entries + 1) * 2H words for this number's window table (the extra entry carries base^2 during the table build);
+// sched: the exponent's schedule (A.sched, or a copy of it).  Both live in LDS where they fit (split_kernels.inc): a global
+// load per window would be waited for at the very next workgroup barrier (its release fence drains the memory counters),
+// i.e. a full memory latency per window — as long as three products of a 2048-bit key.
+constexpr int kAbTableEntries = 33;   // LDS window table: 2^5 odd powers + base^2 (windows of up to 6 bits)
+constexpr int kAbSchedWords = 1024;   // LDS copy of the schedule
+template <int L, int MODE>
+PHE_DEV void modexp_split_ab_body(const SplitArgs& A, uint32_t* lds, uint32_t* tbl, const uint32_t* sched, uint64_t item, bool live,
+                                  uint32_t role, uint32_t lane) {
     constexpr int G = 64, H = G * L, S2 = 2 * H;
     const Lanes<G> ln(lane);
     const uint32_t g = ln.g;
     const bool first = role == 0u;
-    uint32_t n[L];
-    load_row<L>(n, A.mod.n, g);
-    const uint32_t n0inv = A.mod.n0inv;
+    uint32_t nbar[L];  // (n~ + 1) / 2^29 of the scaled modulus: what the sweeps multiply the quotient digits by
+    load_row<L>(nbar, A.mod.nbar, g);
     const int rows = A.mod.rows;
     uint32_t* own_c = lds + 4 * H;  // B: digits of its word X1 (the c operand of a product)
     uint32_t* mail = lds + 5 * H;   // a word handed from one role to the other
+    uint32_t* dump = lds + 6 * H;   // ab_first_word: where the lanes other than lane 0 leave their copies of the quotient digits
+    uint32_t* zeros = dump + 4 * G + H + 16;  // ab_second_word: H + 16 zero words
+    if (!first) {
+#pragma unroll
+        for (int t = 0; t < L; ++t) zeros[g * L + t] = 0u;
+        if (g < 16u) zeros[H + g] = 0u;
+        wave::lds_fence();
+    }
     int k = 0;                      // products so far: slot k & 1
     const auto slot_a = [&](int kk) { return lds + (kk & 1) * S2; };
     const auto slot_m = [&](int kk) { return lds + (kk & 1) * S2 + H; };
@@ -773,11 +959,11 @@ PHE_DEV void modexp_split_ab_body(const SplitArgs& A, uint32_t* lds, uint32_t* t
     const auto step_plain = [&](const uint32_t (&dig)[L], const uint32_t (&b)[L], uint32_t (&out)[L]) {
         if (first) {
             lds_put<L>(slot_a(k), dig, g);
-            ab_first_word<L, U>(out, slot_a(k), b, slot_m(k), n, n0inv, ln, rows);
+            ab_first_word<L>(out, slot_a(k), b, slot_m(k), dump, nbar, ln, rows);
             wave::block_barrier();
         } else {
             wave::block_barrier();
-            ab_second_word<L, false, U>(out, slot_a(k), nullptr, slot_m(k), b, b, n, n0inv, ln, rows);
+            ab_second_word<L, false>(out, slot_a(k), nullptr, slot_m(k), zeros, b, b, nbar, ln, rows);
         }
         ++k;
     };
@@ -797,13 +983,13 @@ PHE_DEV void modexp_split_ab_body(const SplitArgs& A, uint32_t* lds, uint32_t* t
     const auto multiply = [&](const uint32_t* y0_late) {
         if (first) {
             lds_put<L>(slot_a(k), W, g);
-            ab_first_word<L, U>(W, slot_a(k), V, slot_m(k), n, n0inv, ln, rows);
+            ab_first_word<L>(W, slot_a(k), V, slot_m(k), dump, nbar, ln, rows);
             wave::block_barrier();
         } else {
             lds_put<L>(own_c, W, g);
             wave::block_barrier();
             if (y0_late) load_row<L>(Y0, y0_late, g);
-            ab_second_word<L, true, U>(W, slot_a(k), own_c, slot_m(k), Y0, V, n, n0inv, ln, rows);
+            ab_second_word<L, true>(W, slot_a(k), own_c, slot_m(k), zeros, Y0, V, nbar, ln, rows);
         }
         ++k;
     };
@@ -852,7 +1038,7 @@ PHE_DEV void modexp_split_ab_body(const SplitArgs& A, uint32_t* lds, uint32_t* t
     // ---- left-to-right sliding window ------------------------------------------------------------------------------
     load_entry(W, A.first_idx, role);
     for (int op = 0; op < A.n_ops; ++op) {
-        const uint32_t w = A.sched[op];
+        const uint32_t w = wave::grp_bcast0<G>(sched[op], ln);  // (wave-uniform: the loops below are scalar loops)
         const int nsq = (int)(w >> 8), sel = (int)(w & 0xffu);
         if (sel) {  // the factor's words are fetched before the squarings: they arrive under them
             load_entry(V, sel - 1, role);
@@ -867,16 +1053,16 @@ PHE_DEV void modexp_split_ab_body(const SplitArgs& A, uint32_t* lds, uint32_t* t
     if (first) {
         uint32_t X1[L];
         load_row<L>(X1, mail, g);
-        SplitLane<G, L, U> K;
-#pragma unroll
-        for (int t = 0; t < L; ++t) K.n[t] = n[t];
-        K.n0inv = n0inv;
+        SplitLane<G, L, false> K;  // the way out works modulo the true n (same R): X0 - n~*X1 = X0 - n*(k*X1)
+        load_row<L>(K.n, A.exit_mod.n, g);
+        K.n0inv = A.exit_mod.n0inv;
         K.rows_ = rows;
         K.row_a = lds;
         K.row_c = lds + H;
         const uint32_t* mp = nullptr;
         if (MODE == kModeEncrypt) mp = A.post ? A.post + item * (uint64_t)A.post_limbs : nullptr;
-        split_exit<G, L>(A.out + item * (uint64_t)A.out_limbs, A.out_limbs, W, X1, mp, A.post_limbs, A.mod, K, ln, live);
+        split_exit<G, L>(A.out + item * (uint64_t)A.out_limbs, A.out_limbs, W, X1, mp, A.post_limbs, A.exit_mod, K, ln, live,
+                         A.exit_mod.kx);
     }
 }
 

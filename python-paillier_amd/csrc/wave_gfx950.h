@@ -155,6 +155,23 @@ PHE_DEV T* reread_vptr(T* p) {
     return p;
 }
 
+// ... and for a 64-bit accumulator: what was added to it so far stays one value (the optimiser does not re-associate a chain
+// of multiply-adds across this point) — the latency sweeps of split_core.h order their dependent chain by hand
+PHE_DEV uint64_t reread64(uint64_t x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+
+// A generic pointer that is known to point into LDS, as an LDS pointer: ds_* instructions where the compiler cannot see the
+// address space itself (a per-lane choice between two LDS areas) instead of flat_* ones.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+PHE_DEV lds_u32* as_lds(uint32_t* p) { return (lds_u32*)p; }
+// four words to a 16-byte aligned LDS address as one ds_write_b128
+PHE_DEV void lds_store4(lds_u32* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+    *(__attribute__((address_space(3))) u32x4*)p = (u32x4){a, b, c, d};
+}
+
 // 32x32+64 -> 64 multiply-accumulate: v_mad_u64_u32 with a full 64-bit addend.  The radix-2^29 core
 // keeps every accumulator below 2^64 by construction, so the carry-out is never needed.
 PHE_DEV uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }

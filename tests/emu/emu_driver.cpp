@@ -180,9 +180,17 @@ static void run_mul(MulArgs A) {
 
 static SplitConsts split_consts_of(const host::SplitPack& m) {
     SplitConsts c;
+    c.nbar = c.kx = nullptr;
     c.n = m.n.data(); c.r1 = m.r1.data();
     c.e = m.e.data(); c.conv = m.conv.data(); c.nsq = m.nsq.data(); c.n0inv = m.n0inv; c.rows = m.rows;
     return c;
+}
+// the wave-pair kernels' two constant sets (key_setup.h QuickPack): the scaled modulus into A.mod, the true one into A.exit_mod
+static void quick_consts_into(SplitArgs& A, const host::QuickPack& Q) {
+    A.mod = split_consts_of(Q.scaled);
+    A.mod.nbar = Q.nbar.data();
+    A.exit_mod = split_consts_of(Q.exit);
+    A.exit_mod.kx = Q.kx.data();
 }
 static int chunks_for(int limbs32, int H) { return std::max(1, (32 * limbs32 + 29 * H - 1) / (29 * H)); }
 
@@ -209,10 +217,10 @@ static void run_split_ab(SplitArgs A) {
     constexpr int H = 64 * L;
     std::vector<uint32_t> table((size_t)A.batch * (size_t)(A.tbl_entries + 1) * 2 * H);
     for (uint64_t item = 0; item < A.batch; ++item) {
-        std::vector<uint32_t> lds(6 * H + kLdsPad, 0xdeadbeefu);   // LDS is not zero on the device either
+        std::vector<uint32_t> lds(ab_lds_words<L>(), 0xdeadbeefu);   // LDS is not zero on the device either
         uint32_t* tbl = table.data() + (size_t)item * (size_t)(A.tbl_entries + 1) * 2 * H;
         wave::run_block(2, [&](uint32_t role, uint32_t lane) {
-            modexp_split_ab_body<L, MODE>(A, lds.data(), tbl, item, true, role, lane);
+            modexp_split_ab_body<L, MODE>(A, lds.data(), tbl, A.sched, item, true, role, lane);
         });
     }
 }
@@ -445,7 +453,14 @@ int emu_encrypt(const uint32_t* n, int n_limbs, const uint32_t* m, const uint32_
             A.base = r; A.base_limbs = P.s1; A.base_chunks = chunks_for(P.s1, M.rows);
             A.post = c_in ? c_in : m; A.post_limbs = c_in ? P.s2 : P.s1; A.post_chunks = chunks_for(A.post_limbs, M.rows);
             A.out = c_out; A.out_limbs = P.s2; A.batch = B;
-            if (!c_in && M.G == 64 && g_wave_pairs) { DISPATCH_AB(M.L, (run_split_ab<LL, kModeEncrypt>(A))); return 0; }
+            if (!c_in && M.G == 64 && g_wave_pairs && !P.nquick.ok()) throw std::invalid_argument("no wave-pair constants for this key");
+            if (!c_in && M.G == 64 && g_wave_pairs) {
+                quick_consts_into(A, P.nquick);
+                A.base_chunks = chunks_for(P.s1, P.nquick.scaled.rows);
+                A.post_chunks = chunks_for(A.post_limbs, P.nquick.scaled.rows);
+                DISPATCH_AB(P.nquick.scaled.L, (run_split_ab<LL, kModeEncrypt>(A)));
+                return 0;
+            }
             if (c_in) { DISPATCH_SPLIT(M.G, M.L, (run_split<GG, LL, kModeObfuscate>(A))); }
             else { DISPATCH_SPLIT(M.G, M.L, (run_split<GG, LL, kModeEncrypt>(A))); }
             return 0;
@@ -529,7 +544,14 @@ int emu_decrypt(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const 
                 A.first_idx = E.first_idx; A.tbl_entries = E.tbl_entries;
                 A.base = c; A.base_limbs = P.s2; A.base_chunks = chunks_for(P.s2, SP.rows);
                 A.out = half ? xq.data() : xp.data(); A.out_limbs = S; A.batch = B;
-                if (SP.G == 64 && g_wave_pairs) { DISPATCH_AB(SP.L, (run_split_ab<LL, kModeHalfDecrypt>(A))); continue; }
+                const host::QuickPack& QP = half ? P.qquick : P.pquick;
+                if (SP.G == 64 && g_wave_pairs && !QP.ok()) throw std::invalid_argument("no wave-pair constants for this key");
+                if (SP.G == 64 && g_wave_pairs) {
+                    quick_consts_into(A, QP);
+                    A.base_chunks = chunks_for(P.s2, QP.scaled.rows);
+                    DISPATCH_AB(QP.scaled.L, (run_split_ab<LL, kModeHalfDecrypt>(A)));
+                    continue;
+                }
                 DISPATCH_SPLIT(SP.G, SP.L, (run_split<GG, LL, kModeHalfDecrypt>(A)));
                 continue;
             }

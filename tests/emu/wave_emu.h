@@ -250,6 +250,10 @@ inline const uint32_t* reread_ptr(const uint32_t* p) { return p; }
 template <class T>
 inline T* reread_vptr(T* p) { return p; }
 inline uint32_t reread(uint32_t x) { return x; }  // see wave_gfx950.h: an optimisation barrier on the device, nothing here
+inline uint64_t reread64(uint64_t x) { return x; }
+typedef uint32_t lds_u32;  // wave_gfx950.h: an LDS-address-space pointer on the device
+inline lds_u32* as_lds(uint32_t* p) { return p; }
+inline void lds_store4(lds_u32* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 
 // every mad64 is one v_mad_u64_u32 lane-operation on the device: counted here so that tools/count_executed_mads.py can
 // state EXACTLY how many multiply-adds a kernel issues per element (bench.py's roofline.executed), not a hand model
