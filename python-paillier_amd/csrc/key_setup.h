@@ -550,6 +550,7 @@ inline Schedule build_schedule(const Big& e, int window = 0) {
 struct TailPack {
     int h = 0;
     Big p, q, pinvw, qinvw, hp_r, hq_r, pinvq_r;
+    Big hp, hq, pinvq;  // the plain values (for build_tail_wave, which has its own R)
     uint32_t p0inv = 0, q0inv = 0;
 };
 
@@ -564,6 +565,9 @@ inline TailPack build_tail(const Big& p_any, const Big& q_any, const Big& hp_any
     Big hp = big_resize(hp_any, t.h), hq = big_resize(hq_any, t.h), pinv = big_resize(pinv_any, t.h);
     if (big_cmp(hp, t.p) >= 0 || big_cmp(hq, t.q) >= 0 || big_cmp(pinv, t.q) >= 0)
         throw std::invalid_argument("hp/hq/p_inverse out of range");
+    t.hp = hp;
+    t.hq = hq;
+    t.pinvq = pinv;
     t.pinvw = inv_mod_pow2(t.p, t.h);
     t.qinvw = inv_mod_pow2(t.q, t.h);
     t.hp_r = big_shift_mod(hp, 32 * t.h, t.p);
@@ -572,6 +576,47 @@ inline TailPack build_tail(const Big& p_any, const Big& q_any, const Big& hp_any
     t.p0inv = neg_inv32(t.p[0]);
     t.q0inv = neg_inv32(t.q[0]);
     return t;
+}
+
+// The same constants for the tail on one WAVEFRONT per ciphertext (split_core.h decrypt_tail_wave_body): rows of H = 64 L
+// limbs of 29 bits, R = 2^(29 rows).  L == 0: p, q wider than the whole-wave kernels go (the per-thread tail serves).
+struct TailWavePack {
+    int L = 0, H = 0, rows = 0;
+    std::vector<uint32_t> p, q, pinv, qinv, hp_r, hq_r, pinvq_r;  // H limbs each
+    uint32_t p0inv = 0, q0inv = 0;                                 // -p^-1, -q^-1 mod 2^29
+    bool ok() const { return L != 0; }
+};
+
+inline TailWavePack build_tail_wave(const TailPack& t) {
+    TailWavePack W;
+    const int bits = big_bits(t.q);  // p < q
+    const int need = (bits + 4 + kRadixBits - 1) / kRadixBits;
+    for (int L : kS64)
+        if ((need + L - 1) / L * L < 64 * L) {
+            W.L = L;
+            break;
+        }
+    if (W.L == 0) return W;
+    W.H = 64 * W.L;
+    W.rows = (need + W.L - 1) / W.L * W.L;
+    const int rbits = kRadixBits * W.rows, rw = (rbits + 31) / 32;
+    const uint32_t mask = (1u << kRadixBits) - 1u;
+    // n^-1 mod R: the inverse modulo 2^(32 rw), cut to rbits bits
+    const auto inv_mod_r = [&](const Big& n) {
+        Big x = inv_mod_pow2(big_resize(n, rw), rw);
+        if (rbits & 31) x[(size_t)rw - 1] &= (1u << (rbits & 31)) - 1u;
+        return to_r29(x, W.H);
+    };
+    W.p = to_r29(t.p, W.H);
+    W.q = to_r29(t.q, W.H);
+    W.pinv = inv_mod_r(t.p);
+    W.qinv = inv_mod_r(t.q);
+    W.hp_r = to_r29(big_shift_mod(t.hp, rbits, t.p), W.H);
+    W.hq_r = to_r29(big_shift_mod(t.hq, rbits, t.q), W.H);
+    W.pinvq_r = to_r29(big_shift_mod(t.pinvq, rbits, t.q), W.H);
+    W.p0inv = neg_inv32(t.p[0]) & mask;
+    W.q0inv = neg_inv32(t.q[0]) & mask;
+    return W;
 }
 
 // Public-key side: modulus n^2, exponent n (phe/paillier.py:137, :622), aux = n*R for 1 + n*m.

@@ -87,6 +87,7 @@ PHE_DECLARE_PART(g16b)
     int launch_pair(int L, int op, int blocks, hipStream_t st, const PairArgs& A);                \
     int launch_split_halves(int L, int blocks, hipStream_t st, const SplitArgs& Ap, const SplitArgs& Aq); \
     int launch_split_ab(int L, int mode, int numbers, int halves, hipStream_t st, const SplitArgs& Ap, const SplitArgs& Aq); \
+    int launch_tail_wave(int L, int numbers, hipStream_t st, const TailWaveArgs& A);              \
     }
 PHE_DECLARE_SPLIT_PART(s2a)
 PHE_DECLARE_SPLIT_PART(s2b)
@@ -159,50 +160,51 @@ struct SplitPart {
     int (*launch_pair)(int, int, int, hipStream_t, const PairArgs&);
     int (*launch_split_halves)(int, int, hipStream_t, const SplitArgs&, const SplitArgs&);
     int (*launch_split_ab)(int, int, int, int, hipStream_t, const SplitArgs&, const SplitArgs&);
+    int (*launch_tail_wave)(int, int, hipStream_t, const TailWaveArgs&);
 };
 static const SplitPart kSplitParts[] = {
     {2, phe::s2a::occ_split, phe::s2a::launch_split, phe::s2a::occ_var_split, phe::s2a::launch_var_split,
      phe::s2a::occ_multi_split, phe::s2a::launch_multi_split, phe::s2a::launch_multi_tables,
-     phe::s2a::launch_multi_lookup, phe::s2a::launch_mul_split, phe::s2a::launch_crt_lift, phe::s2a::occ_split_unit, phe::s2a::launch_split_unit, phe::s2a::launch_pair, phe::s2a::launch_split_halves, phe::s2a::launch_split_ab},
+     phe::s2a::launch_multi_lookup, phe::s2a::launch_mul_split, phe::s2a::launch_crt_lift, phe::s2a::occ_split_unit, phe::s2a::launch_split_unit, phe::s2a::launch_pair, phe::s2a::launch_split_halves, phe::s2a::launch_split_ab, phe::s2a::launch_tail_wave},
     {2, phe::s2b::occ_split, phe::s2b::launch_split, phe::s2b::occ_var_split, phe::s2b::launch_var_split,
      phe::s2b::occ_multi_split, phe::s2b::launch_multi_split, phe::s2b::launch_multi_tables,
-     phe::s2b::launch_multi_lookup, phe::s2b::launch_mul_split, phe::s2b::launch_crt_lift, phe::s2b::occ_split_unit, phe::s2b::launch_split_unit, phe::s2b::launch_pair, phe::s2b::launch_split_halves, phe::s2b::launch_split_ab},
+     phe::s2b::launch_multi_lookup, phe::s2b::launch_mul_split, phe::s2b::launch_crt_lift, phe::s2b::occ_split_unit, phe::s2b::launch_split_unit, phe::s2b::launch_pair, phe::s2b::launch_split_halves, phe::s2b::launch_split_ab, phe::s2b::launch_tail_wave},
     {2, phe::s2c::occ_split, phe::s2c::launch_split, phe::s2c::occ_var_split, phe::s2c::launch_var_split,
      phe::s2c::occ_multi_split, phe::s2c::launch_multi_split, phe::s2c::launch_multi_tables,
-     phe::s2c::launch_multi_lookup, phe::s2c::launch_mul_split, phe::s2c::launch_crt_lift, phe::s2c::occ_split_unit, phe::s2c::launch_split_unit, phe::s2c::launch_pair, phe::s2c::launch_split_halves, phe::s2c::launch_split_ab},
+     phe::s2c::launch_multi_lookup, phe::s2c::launch_mul_split, phe::s2c::launch_crt_lift, phe::s2c::occ_split_unit, phe::s2c::launch_split_unit, phe::s2c::launch_pair, phe::s2c::launch_split_halves, phe::s2c::launch_split_ab, phe::s2c::launch_tail_wave},
     {4, phe::s4a::occ_split, phe::s4a::launch_split, phe::s4a::occ_var_split, phe::s4a::launch_var_split,
      phe::s4a::occ_multi_split, phe::s4a::launch_multi_split, phe::s4a::launch_multi_tables,
-     phe::s4a::launch_multi_lookup, phe::s4a::launch_mul_split, phe::s4a::launch_crt_lift, phe::s4a::occ_split_unit, phe::s4a::launch_split_unit, phe::s4a::launch_pair, phe::s4a::launch_split_halves, phe::s4a::launch_split_ab},
+     phe::s4a::launch_multi_lookup, phe::s4a::launch_mul_split, phe::s4a::launch_crt_lift, phe::s4a::occ_split_unit, phe::s4a::launch_split_unit, phe::s4a::launch_pair, phe::s4a::launch_split_halves, phe::s4a::launch_split_ab, phe::s4a::launch_tail_wave},
     {4, phe::s4b::occ_split, phe::s4b::launch_split, phe::s4b::occ_var_split, phe::s4b::launch_var_split,
      phe::s4b::occ_multi_split, phe::s4b::launch_multi_split, phe::s4b::launch_multi_tables,
-     phe::s4b::launch_multi_lookup, phe::s4b::launch_mul_split, phe::s4b::launch_crt_lift, phe::s4b::occ_split_unit, phe::s4b::launch_split_unit, phe::s4b::launch_pair, phe::s4b::launch_split_halves, phe::s4b::launch_split_ab},
+     phe::s4b::launch_multi_lookup, phe::s4b::launch_mul_split, phe::s4b::launch_crt_lift, phe::s4b::occ_split_unit, phe::s4b::launch_split_unit, phe::s4b::launch_pair, phe::s4b::launch_split_halves, phe::s4b::launch_split_ab, phe::s4b::launch_tail_wave},
     {4, phe::s4c::occ_split, phe::s4c::launch_split, phe::s4c::occ_var_split, phe::s4c::launch_var_split,
      phe::s4c::occ_multi_split, phe::s4c::launch_multi_split, phe::s4c::launch_multi_tables,
-     phe::s4c::launch_multi_lookup, phe::s4c::launch_mul_split, phe::s4c::launch_crt_lift, phe::s4c::occ_split_unit, phe::s4c::launch_split_unit, phe::s4c::launch_pair, phe::s4c::launch_split_halves, phe::s4c::launch_split_ab},
+     phe::s4c::launch_multi_lookup, phe::s4c::launch_mul_split, phe::s4c::launch_crt_lift, phe::s4c::occ_split_unit, phe::s4c::launch_split_unit, phe::s4c::launch_pair, phe::s4c::launch_split_halves, phe::s4c::launch_split_ab, phe::s4c::launch_tail_wave},
     {8, phe::s8a::occ_split, phe::s8a::launch_split, phe::s8a::occ_var_split, phe::s8a::launch_var_split,
      phe::s8a::occ_multi_split, phe::s8a::launch_multi_split, phe::s8a::launch_multi_tables,
-     phe::s8a::launch_multi_lookup, phe::s8a::launch_mul_split, phe::s8a::launch_crt_lift, phe::s8a::occ_split_unit, phe::s8a::launch_split_unit, phe::s8a::launch_pair, phe::s8a::launch_split_halves, phe::s8a::launch_split_ab},
+     phe::s8a::launch_multi_lookup, phe::s8a::launch_mul_split, phe::s8a::launch_crt_lift, phe::s8a::occ_split_unit, phe::s8a::launch_split_unit, phe::s8a::launch_pair, phe::s8a::launch_split_halves, phe::s8a::launch_split_ab, phe::s8a::launch_tail_wave},
     {8, phe::s8b::occ_split, phe::s8b::launch_split, phe::s8b::occ_var_split, phe::s8b::launch_var_split,
      phe::s8b::occ_multi_split, phe::s8b::launch_multi_split, phe::s8b::launch_multi_tables,
-     phe::s8b::launch_multi_lookup, phe::s8b::launch_mul_split, phe::s8b::launch_crt_lift, phe::s8b::occ_split_unit, phe::s8b::launch_split_unit, phe::s8b::launch_pair, phe::s8b::launch_split_halves, phe::s8b::launch_split_ab},
+     phe::s8b::launch_multi_lookup, phe::s8b::launch_mul_split, phe::s8b::launch_crt_lift, phe::s8b::occ_split_unit, phe::s8b::launch_split_unit, phe::s8b::launch_pair, phe::s8b::launch_split_halves, phe::s8b::launch_split_ab, phe::s8b::launch_tail_wave},
     {8, phe::s8c::occ_split, phe::s8c::launch_split, phe::s8c::occ_var_split, phe::s8c::launch_var_split,
      phe::s8c::occ_multi_split, phe::s8c::launch_multi_split, phe::s8c::launch_multi_tables,
-     phe::s8c::launch_multi_lookup, phe::s8c::launch_mul_split, phe::s8c::launch_crt_lift, phe::s8c::occ_split_unit, phe::s8c::launch_split_unit, phe::s8c::launch_pair, phe::s8c::launch_split_halves, phe::s8c::launch_split_ab},
+     phe::s8c::launch_multi_lookup, phe::s8c::launch_mul_split, phe::s8c::launch_crt_lift, phe::s8c::occ_split_unit, phe::s8c::launch_split_unit, phe::s8c::launch_pair, phe::s8c::launch_split_halves, phe::s8c::launch_split_ab, phe::s8c::launch_tail_wave},
     {16, phe::s16a::occ_split, phe::s16a::launch_split, phe::s16a::occ_var_split, phe::s16a::launch_var_split,
      phe::s16a::occ_multi_split, phe::s16a::launch_multi_split, phe::s16a::launch_multi_tables,
-     phe::s16a::launch_multi_lookup, phe::s16a::launch_mul_split, phe::s16a::launch_crt_lift, phe::s16a::occ_split_unit, phe::s16a::launch_split_unit, phe::s16a::launch_pair, phe::s16a::launch_split_halves, phe::s16a::launch_split_ab},
+     phe::s16a::launch_multi_lookup, phe::s16a::launch_mul_split, phe::s16a::launch_crt_lift, phe::s16a::occ_split_unit, phe::s16a::launch_split_unit, phe::s16a::launch_pair, phe::s16a::launch_split_halves, phe::s16a::launch_split_ab, phe::s16a::launch_tail_wave},
     {16, phe::s16b::occ_split, phe::s16b::launch_split, phe::s16b::occ_var_split, phe::s16b::launch_var_split,
      phe::s16b::occ_multi_split, phe::s16b::launch_multi_split, phe::s16b::launch_multi_tables,
-     phe::s16b::launch_multi_lookup, phe::s16b::launch_mul_split, phe::s16b::launch_crt_lift, phe::s16b::occ_split_unit, phe::s16b::launch_split_unit, phe::s16b::launch_pair, phe::s16b::launch_split_halves, phe::s16b::launch_split_ab},
+     phe::s16b::launch_multi_lookup, phe::s16b::launch_mul_split, phe::s16b::launch_crt_lift, phe::s16b::occ_split_unit, phe::s16b::launch_split_unit, phe::s16b::launch_pair, phe::s16b::launch_split_halves, phe::s16b::launch_split_ab, phe::s16b::launch_tail_wave},
     {16, phe::s16c::occ_split, phe::s16c::launch_split, phe::s16c::occ_var_split, phe::s16c::launch_var_split,
      phe::s16c::occ_multi_split, phe::s16c::launch_multi_split, phe::s16c::launch_multi_tables,
-     phe::s16c::launch_multi_lookup, phe::s16c::launch_mul_split, phe::s16c::launch_crt_lift, phe::s16c::occ_split_unit, phe::s16c::launch_split_unit, phe::s16c::launch_pair, phe::s16c::launch_split_halves, phe::s16c::launch_split_ab},
+     phe::s16c::launch_multi_lookup, phe::s16c::launch_mul_split, phe::s16c::launch_crt_lift, phe::s16c::occ_split_unit, phe::s16c::launch_split_unit, phe::s16c::launch_pair, phe::s16c::launch_split_halves, phe::s16c::launch_split_ab, phe::s16c::launch_tail_wave},
     {64, phe::s64a::occ_split, phe::s64a::launch_split, phe::s64a::occ_var_split, phe::s64a::launch_var_split,
      phe::s64a::occ_multi_split, phe::s64a::launch_multi_split, phe::s64a::launch_multi_tables,
-     phe::s64a::launch_multi_lookup, phe::s64a::launch_mul_split, phe::s64a::launch_crt_lift, phe::s64a::occ_split_unit, phe::s64a::launch_split_unit, phe::s64a::launch_pair, phe::s64a::launch_split_halves, phe::s64a::launch_split_ab},
+     phe::s64a::launch_multi_lookup, phe::s64a::launch_mul_split, phe::s64a::launch_crt_lift, phe::s64a::occ_split_unit, phe::s64a::launch_split_unit, phe::s64a::launch_pair, phe::s64a::launch_split_halves, phe::s64a::launch_split_ab, phe::s64a::launch_tail_wave},
     {64, phe::s64b::occ_split, phe::s64b::launch_split, phe::s64b::occ_var_split, phe::s64b::launch_var_split,
      phe::s64b::occ_multi_split, phe::s64b::launch_multi_split, phe::s64b::launch_multi_tables,
-     phe::s64b::launch_multi_lookup, phe::s64b::launch_mul_split, phe::s64b::launch_crt_lift, phe::s64b::occ_split_unit, phe::s64b::launch_split_unit, phe::s64b::launch_pair, phe::s64b::launch_split_halves, phe::s64b::launch_split_ab},
+     phe::s64b::launch_multi_lookup, phe::s64b::launch_mul_split, phe::s64b::launch_crt_lift, phe::s64b::occ_split_unit, phe::s64b::launch_split_unit, phe::s64b::launch_pair, phe::s64b::launch_split_halves, phe::s64b::launch_split_ab, phe::s64b::launch_tail_wave},
 };
 #define PHE_SPLIT_BY_GROUP(G_, CALL2)                 \
     [&]() -> int {                                    \
@@ -356,6 +358,11 @@ struct phe_hip_ctx {
     bool busy_valid = false;
     DevSchedule d_exp_n, d_exp_p, d_exp_q;
     DevTail d_tail;
+    // the CRT tail on one wavefront per ciphertext (small batches; key_setup.h TailWavePack); tail_wave_L == 0: not offered
+    host::TailWavePack tail_wave;
+    uint32_t* tail_wave_blob = nullptr;
+    TailWaveConsts d_tail_wave{};
+    int tail_wave_L = 0;
     // grow-only device scratch
     uint32_t* table = nullptr;
     size_t table_words = 0;
@@ -483,6 +490,31 @@ static int upload_tail(const host::TailPack& t, DevTail& d) {
     d.k.pinvq_r = d.blob + 6 * h;
     d.k.p0inv = t.p0inv;
     d.k.q0inv = t.q0inv;
+    return PHE_HIP_OK;
+}
+
+static int upload_tail_wave(phe_hip_ctx* ctx) {
+    ctx->tail_wave = host::build_tail_wave(ctx->priv.tail);
+    const host::TailWavePack& W = ctx->tail_wave;
+    if (!W.ok()) return PHE_HIP_OK;
+    const std::vector<uint32_t>* parts[7] = {&W.p, &W.q, &W.pinv, &W.qinv, &W.hp_r, &W.hq_r, &W.pinvq_r};
+    std::vector<uint32_t> h;
+    for (int i = 0; i < 7; ++i) h.insert(h.end(), parts[i]->begin(), parts[i]->end());
+    HIP_TRY(hipMalloc((void**)&ctx->tail_wave_blob, h.size() * 4));
+    HIP_TRY(hipMemcpy(ctx->tail_wave_blob, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    const uint32_t* b = ctx->tail_wave_blob;
+    TailWaveConsts& k = ctx->d_tail_wave;
+    k.p = b;
+    k.q = b + W.H;
+    k.pinv = b + 2 * W.H;
+    k.qinv = b + 3 * W.H;
+    k.hp_r = b + 4 * W.H;
+    k.hq_r = b + 5 * W.H;
+    k.pinvq_r = b + 6 * W.H;
+    k.p0inv = W.p0inv;
+    k.q0inv = W.q0inv;
+    k.rows = W.rows;
+    ctx->tail_wave_L = W.L;
     return PHE_HIP_OK;
 }
 
@@ -884,7 +916,7 @@ static int pick_nsplit_rung(const phe_hip_ctx* ctx, size_t batch) {
 }
 static const DevSplit& pick_nsplit(const phe_hip_ctx* ctx, size_t batch) { return nsplit_rung(ctx, pick_nsplit_rung(ctx, batch)); }
 static int geom_code(int G, int L) { return G * 100 + L; }
-enum : int { kPathUnit = 1, kPathOwner = 2, kPathSideBySide = 4, kPathPipelined = 8, kPathFusedObfuscate = 16, kPathWavePairs = 32 };
+enum : int { kPathUnit = 1, kPathOwner = 2, kPathSideBySide = 4, kPathPipelined = 8, kPathFusedObfuscate = 16, kPathWavePairs = 32, kPathWaveTail = 64 };
 
 static int check_ctx(const phe_hip_ctx* ctx) {
     if (!ctx) return fail(PHE_HIP_EINVAL, "null context");
@@ -1089,6 +1121,7 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
     if (!rc) rc = upload_schedule(ctx->priv.exp_p, ctx->d_exp_p);
     if (!rc) rc = upload_schedule(ctx->priv.exp_q, ctx->d_exp_q);
     if (!rc) rc = upload_tail(ctx->priv.tail, ctx->d_tail);
+    if (!rc && !getenv("PHE_HIP_NO_WAVE_TAIL")) rc = upload_tail_wave(ctx);
     if (!rc) {
         const size_t lds = (size_t)tail_ws_words(ctx->priv.tail.h) * tail_block(ctx->priv.tail.h) * 4;
         if (lds > 160 * 1024) rc = fail(PHE_HIP_EINVAL, "p/q too wide for the CRT tail kernel");
@@ -1113,7 +1146,7 @@ void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
     std::vector<uint32_t*> bufs = {ctx->d_nsplit.blob, ctx->d_psplit.blob, ctx->d_qsplit.blob,
                         ctx->d_nsq.blob, ctx->d_psq.blob, ctx->d_qsq.blob, ctx->d_exp_n.ops, ctx->d_exp_p.ops,
                         ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->table2, ctx->scratch, ctx->partial, ctx->lookup, (uint32_t*)ctx->flags, ctx->stage[0],
-                        ctx->stage[1], ctx->stage[2], ctx->owner_blob, ctx->d_nunit.blob, ctx->unit_tmp};
+                        ctx->stage[1], ctx->stage[2], ctx->owner_blob, ctx->d_nunit.blob, ctx->unit_tmp, ctx->tail_wave_blob};
     for (const auto& R : ctx->pub_rungs) { bufs.push_back(R.nsq.blob); bufs.push_back(R.nsplit.blob); }
     for (const auto& R : ctx->priv_rungs) { bufs.push_back(R.psq.blob); bufs.push_back(R.qsq.blob); bufs.push_back(R.psplit.blob); bufs.push_back(R.qsplit.blob); }
     for (uint32_t* b : bufs)
@@ -1412,6 +1445,23 @@ int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t
         else
             rc = launch_uniform<kModeHalfDecrypt>(ctx, qsq_of(rung), ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0, xq, S, batch, st);
         if (rc) return rc;
+    }
+    // the tail: one ciphertext per thread is a long serial chain (0.4 ms at 2048-bit keys) that a large batch hides and a small
+    // one waits for; while there are SIMDs to spare it runs one ciphertext per wavefront instead (same bits)
+    if (ctx->tail_wave_L && batch <= (size_t)ctx->n_cus * 16) {
+        TailWaveArgs W;
+        W.k = ctx->d_tail_wave;
+        W.xp = xp;
+        W.xq = xq;
+        W.x_stride = S;
+        W.m_out = m;
+        W.out_limbs = ctx->pub.s1;
+        W.batch = batch;
+        if (PHE_SPLIT_BY_GROUP(64, launch_tail_wave(ctx->tail_wave_L, (int)batch, st, W)) < 0)
+            return fail(PHE_HIP_EINVAL, "no wave tail kernel for this width");
+        HIP_TRY(hipGetLastError());
+        ctx->last_path |= kPathWaveTail;
+        return PHE_HIP_OK;
     }
     TailArgs T;
     T.k = ctx->d_tail.k;

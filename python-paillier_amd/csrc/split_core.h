@@ -1593,4 +1593,102 @@ PHE_DEV void multiexp_lookup_body(const SplitLookupArgs& A, uint32_t* lds_row, u
     }
 }
 
+// ---- the tail of CRT decryption, one ciphertext per WAVEFRONT ----------------------------------------------------------
+// decrypt_tail.h runs the O(h^2) tail (L-function, * hp, CRT) one ciphertext per thread: < 0.1 % of a large batch's work, but
+// a serial chain of ~5 h^2 multiply-adds through LDS — 0.38 ms at 2048-bit keys, a fifth of the time of ONE decryption on a
+// wave pair.  For small batches the same steps run here on the whole-wave geometry (G = 64, limbs of 29 bits, R = 2^(29 rows)),
+// on the sweeps of this file and of mont_core.h:
+//     L_p = (x_p - 1) / p          exact: ((x_p + R - 1) mod R) * p^-1 mod R, the low half of one plain product (mul_wide)
+//     m_p = L_p * hp mod p         one Montgomery product against hp*R mod p, made canonical      (same for q)
+//     u   = (m_q - m_p) * p^-1 mod q   with m_q - m_p + q formed as m_q + q + (R - 1 - m_p) + 1 - R: no borrow across lanes
+//     m   = m_p + u * p            one plain product with m_p as its addend
+// Reference: phe/paillier.py:346-354 (raw_decrypt), :362-364 (l_function), :366-374 (crt).  Same bits as decrypt_tail_one.
+struct TailWaveConsts {
+    const uint32_t *p, *q;          // H limbs each
+    const uint32_t *pinv, *qinv;    // p^-1, q^-1 mod R
+    const uint32_t *hp_r, *hq_r;    // hp * R mod p, hq * R mod q        (hp, hq: phe/paillier.py:234-235)
+    const uint32_t* pinvq_r;        // p_inverse * R mod q               (p_inverse: phe/paillier.py:233)
+    uint32_t p0inv, q0inv;          // -p^-1, -q^-1 mod 2^29
+    int rows;                       // limbs of a number here (covers q with 4 spare bits, rows < H)
+};
+struct TailWaveArgs {
+    TailWaveConsts k;
+    const uint32_t* xp;  // (batch, x_stride) c^(p-1) mod p^2, canonical 32-bit words
+    const uint32_t* xq;
+    int x_stride;
+    uint32_t* m_out;     // (batch, out_limbs)
+    int out_limbs;
+    uint64_t batch;
+};
+
+// lds: 2H + kLdsPad words of the wave
+template <int L>
+PHE_DEV void decrypt_tail_wave_body(const TailWaveArgs& A, uint32_t* lds, uint64_t item, uint32_t lane) {
+    constexpr int G = 64, H = G * L;
+    const Lanes<G> ln(lane);
+    const uint32_t g = ln.g;
+    const int rows = A.k.rows;
+    uint32_t* row_a = lds;
+    uint32_t* row_lo = lds + H;
+    bool in[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) in[k] = (int)g * L + k < rows;
+    uint32_t zero[L], mp[L], mq[L], np[L], nq[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) zero[k] = 0u;
+    load_row<L>(np, A.k.p, g);
+    load_row<L>(nq, A.k.q, g);
+    // m_n = ((x - 1) / n) * h mod n for one CRT half
+    const auto half = [&](uint32_t (&out)[L], const uint32_t* x, const uint32_t (&n)[L], uint32_t n0inv, const uint32_t* ninv_row,
+                          const uint32_t* h_row) {
+        uint32_t a[L], t[L], cst[L], hi[L];
+        load_u32_as_r29<L>(a, x, A.x_stride, 0, g, rows);  // x mod R
+#pragma unroll
+        for (int k = 0; k < L; ++k) t[k] = in[k] ? kLimbMask : 0u;
+        add_normalize<G, L>(a, t, ln);  // + (R - 1): x - 1 modulo R ...
+#pragma unroll
+        for (int k = 0; k < L; ++k) a[k] = in[k] ? a[k] : 0u;  // ... the carry out of R dropped
+        lds_put<L>(row_a, a, g);
+        load_row<L>(cst, ninv_row, g);
+        mul_wide<G, L>(hi, row_a, cst, zero, row_lo, ln, rows);  // row_lo: (x - 1) * n^-1 mod R = (x - 1) / n, canonical digits
+        wave::lds_fence();
+        load_row<L>(cst, h_row, g);
+        montmul<G, L>(out, row_lo, cst, n, n0inv, ln, rows);
+        canonicalize<G, L>(out, n, ln);
+    };
+    half(mp, A.xp + item * (uint64_t)A.x_stride, np, A.k.p0inv, A.k.pinv, A.k.hp_r);
+    half(mq, A.xq + item * (uint64_t)A.x_stride, nq, A.k.q0inv, A.k.qinv, A.k.hq_r);
+    // d = m_q - m_p + q  (0 < d < 2q)
+    uint32_t d[L], t[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        d[k] = mq[k];
+        t[k] = in[k] ? (kLimbMask - mp[k]) : 0u;  // R - 1 - m_p
+    }
+    add_normalize<G, L>(d, nq, ln);
+    add_normalize<G, L>(d, t, ln);
+#pragma unroll
+    for (int k = 0; k < L; ++k) t[k] = (g == 0u && k == 0) ? 1u : 0u;
+    add_normalize<G, L>(d, t, ln);
+    normalize_full<G, L>(d, ln);  // = d + R exactly: limb `rows` is 1
+#pragma unroll
+    for (int k = 0; k < L; ++k) d[k] = in[k] ? d[k] : 0u;
+    // u = d * p^-1 mod q
+    uint32_t u[L], cst[L];
+    lds_put<L>(row_a, d, g);
+    load_row<L>(cst, A.k.pinvq_r, g);
+    montmul<G, L>(u, row_a, cst, nq, A.k.q0inv, ln, rows);
+    canonicalize<G, L>(u, nq, ln);
+    // m = m_p + u * p
+    uint32_t hi[L], lo[L];
+    lds_put<L>(row_a, u, g);
+    mul_wide<G, L>(hi, row_a, np, mp, row_lo, ln, rows);
+    wave::lds_fence();
+    load_row<L>(lo, row_lo, g);
+#pragma unroll
+    for (int k = 0; k < L; ++k) lo[k] = in[k] ? lo[k] : 0u;
+    normalize_full<G, L>(hi, ln);
+    store_pair_as_u32<G, L>(A.m_out + item * (uint64_t)A.out_limbs, A.out_limbs, lo, hi, lds, g, true, rows);
+}
+
 }  // namespace phe

@@ -232,6 +232,7 @@ static void run_split_ab(SplitArgs A) {
         case 5: { constexpr int LL = 5; CALL; break; }                                \
         default: throw std::invalid_argument("no wave-pair kernel for this L");       \
     }
+static int g_wave_tail = 0;   // 1: the CRT tail of a decrypt runs one ciphertext per wavefront (the library's choice for small batches)
 static int g_wave_pairs = 0;  // 1: whole-wave geometry runs every exponentiation on a wave pair (the library's choice for a handful of numbers)
 
 template <int G, int L>
@@ -371,6 +372,7 @@ void emu_set_engine(int e) { g_engine = e ? 1 : 0; }
 void emu_set_mul_io(int e) { g_mul_io = e ? 1 : 0; }
 void emu_set_unit(int e) { g_unit = e ? 1 : 0; }
 void emu_set_wave_pairs(int e) { g_wave_pairs = e ? 1 : 0; }
+void emu_set_wave_tail(int e) { g_wave_tail = e ? 1 : 0; }
 int emu_unit_offered(const uint32_t* n, int n_limbs) {
     try { return host::build_public(n, n_limbs, g_prefer_group).nunit.G ? 1 : 0; } catch (...) { return 0; }
 }
@@ -563,6 +565,22 @@ int emu_decrypt(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const 
             A.base = c; A.base_limbs = P.s2;
             A.out = half ? xq.data() : xp.data(); A.out_limbs = S; A.batch = B;
             DISPATCH_GL(M.G, M.L, (run_uniform<GG, LL, kModeHalfDecrypt>(A)));
+        }
+        if (g_wave_tail) {
+            // the library's tail for small batches: one ciphertext per wavefront (split_core.h decrypt_tail_wave_body)
+            const host::TailWavePack TW = host::build_tail_wave(P.tail);
+            if (!TW.ok()) throw std::invalid_argument("no wave tail for this key width");
+            TailWaveArgs W;
+            memset(&W, 0, sizeof W);
+            W.k.p = TW.p.data(); W.k.q = TW.q.data(); W.k.pinv = TW.pinv.data(); W.k.qinv = TW.qinv.data();
+            W.k.hp_r = TW.hp_r.data(); W.k.hq_r = TW.hq_r.data(); W.k.pinvq_r = TW.pinvq_r.data();
+            W.k.p0inv = TW.p0inv; W.k.q0inv = TW.q0inv; W.k.rows = TW.rows;
+            W.xp = xp.data(); W.xq = xq.data(); W.x_stride = S; W.m_out = m_out; W.out_limbs = P.s1; W.batch = B;
+            for (uint64_t i = 0; i < B; ++i) {
+                std::vector<uint32_t> lds(2 * 64 * TW.L + kLdsPad, 0xdeadbeefu);
+                DISPATCH_AB(TW.L, (wave::run_wave([&](uint32_t lane) { decrypt_tail_wave_body<LL>(W, lds.data(), i, lane); })));
+            }
+            return 0;
         }
         TailArgs T;
         memset(&T, 0, sizeof T);

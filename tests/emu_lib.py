@@ -32,6 +32,10 @@ class Emu:
         """True: on the whole-wave geometry (set_group(64)) encrypt / decrypt run every number on a PAIR of waves"""
         self.L.emu_set_wave_pairs(1 if on else 0)
 
+    def set_wave_tail(self, on):
+        """True: the CRT tail of decrypt runs one ciphertext per wavefront (the library's choice for small batches)"""
+        self.L.emu_set_wave_tail(1 if on else 0)
+
     def set_unit(self, on):
         """True (default): r^n through the scaled modulus where the key offers it, as the library's large-batch path does"""
         self.L.emu_set_unit(1 if on else 0)

@@ -329,3 +329,26 @@ def test_one_number_on_a_wave_pair(emu, key_bits, count):
         emu.set_wave_pairs(False)
         emu.set_unit(True)
         emu.set_group(0)
+
+
+@pytest.mark.parametrize("key_bits", [256, 1024, 2048, 3072])
+def test_decrypt_tail_on_one_wave_per_ciphertext(emu, key_bits):
+    """split_core.h decrypt_tail_wave_body (the tail the library takes for small batches): L-function, * hp, CRT on the
+    whole-wave sweeps; same plaintexts as the per-thread tail on every golden raw_decrypt vector, incl. m = 0, 1, n - 1."""
+    emu.set_engine(True)
+    emu.set_wave_tail(True)
+    try:
+        g = load_golden(key_bits)
+        s1, s2, h = key_bits // 32, key_bits // 16, key_bits // 64
+        dec = g["raw_decrypt"] if key_bits <= 1024 else g["raw_decrypt"][:6]
+        key = [int_to_limbs(H(g[k]), h) for k in ("p", "q", "hp", "hq", "p_inverse")]
+        n = H(g["n"])
+        cts = [H(e["c"]) for e in dec]
+        want = [H(e["m"]) for e in dec]
+        N = n * n
+        for m in (0, 1, n - 1, n - 2):                                  # edge plaintexts: c = (1 + n*m) * 2^n
+            cts.append((1 + n * m) * pow(2, n, N) % N)
+            want.append(m)
+        assert limbs_to_ints(emu.decrypt(*key, s1, ints_to_limbs(cts, s2))) == want
+    finally:
+        emu.set_wave_tail(False)

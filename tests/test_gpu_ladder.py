@@ -156,6 +156,39 @@ def test_a_handful_of_numbers_runs_on_wave_pairs(native, c_oracle, key_bits, mon
     assert not single.last_launch()["path"] & ctx.PATH_WAVE_PAIRS
 
 
+@pytest.mark.parametrize("key_bits", [1024, 2048, 3072])
+def test_crt_tail_on_one_wavefront_per_ciphertext(native, c_oracle, key_bits, monkeypatch):
+    """Small batches take the L-function / CRT tail one ciphertext per WAVEFRONT (k_decrypt_tail_wave; the per-thread tail is
+    a 0.4 ms serial chain at 2048 bits): asserted through last_launch, same plaintexts as libgmp and as the per-thread tail
+    (PHE_HIP_NO_WAVE_TAIL) on the golden vectors, edge plaintexts and junk ciphertexts; large batches keep the per-thread tail."""
+    g = load_golden(key_bits)
+    s1, s2 = key_bits // 32, key_bits // 16
+    n_int = H(g["n"])
+    N = n_int * n_int
+    n = native.int_to_limbs(n_int, s1)
+    p, q = native.int_to_limbs(H(g["p"]), s1 // 2), native.int_to_limbs(H(g["q"]), s1 // 2)
+    ctx = make_ctx(native, g)
+    monkeypatch.setenv("PHE_HIP_NO_WAVE_TAIL", "1")
+    plain = make_ctx(native, g)
+    rng = random.Random(key_bits + 1)
+    edge = [0, 1, 2, n_int - 1, n_int - 2, H(g["p"]), H(g["q"]), n_int // 2]
+    cts = [H(e["c"]) for e in g["raw_decrypt"]] + [(1 + n_int * m) * pow(3, n_int, N) % N for m in edge]
+    want = [H(e["m"]) for e in g["raw_decrypt"]] + edge
+    cts += [rng.randrange(1, N) for _ in range(40)]                # not ciphertexts of anything: whatever libgmp's arithmetic gives
+    c = native.ints_to_limbs(cts, s2)
+    for batch in (1, 3, len(cts)):
+        got = ctx.decrypt(c[:batch])
+        assert ctx.last_launch()["path"] & ctx.PATH_WAVE_TAIL, batch
+        assert np.array_equal(got, c_oracle.decrypt(n, p, q, c[:batch], nthreads=4)), batch
+        assert np.array_equal(got, plain.decrypt(c[:batch])), batch
+        assert not plain.last_launch()["path"] & ctx.PATH_WAVE_TAIL
+    assert native.limbs_to_ints(ctx.decrypt(c))[:len(want)] == want
+    big = np.tile(c, (6000 // len(cts) + 1, 1))[:6000]                 # beyond the small-batch threshold: one ciphertext per thread
+    got = ctx.decrypt(big)
+    assert not ctx.last_launch()["path"] & ctx.PATH_WAVE_TAIL
+    assert np.array_equal(got[:len(cts)], ctx.decrypt(c))
+
+
 @pytest.mark.parametrize("key_bits", [2048, 3072])
 def test_scaled_modulus_path_on_the_golden_vectors(native, key_bits, monkeypatch):
     """PHE_HIP_FORCE_UNIT: r^n modulo the scaled modulus k*n for small batches too — every golden raw_encrypt / obfuscate
