@@ -673,6 +673,26 @@ def main():
                                                      orc.obfuscate(n_arr, ca_s(), be.np(be.take(r, idx)), nthreads=cores))))
         del c2, out, inv, base
 
+    # ---- the reference's own benchmark shape: ONE operation at a time (examples/benchmarks.py:12-29) ------------------------
+    # device time of a call on 1 / 256 resident rows (HIP events around back-to-back calls): what the scalar API pays per number
+    latency, latency_ok = None, True
+    if not args.no_ops and be.name == "hip" and rank == 0:
+        latency = {"unit": "ms of device time per call, rows resident", "reps": 10}
+        for name, fn, rows in (("raw_decrypt_1_row", dec_step, 1), ("raw_decrypt_256_rows", dec_step, 256), ("raw_encrypt_1_row", enc_step, 1)):
+            call = (lambda k: be.decrypt(ctx, c, m_back, k)) if fn is dec_step else (lambda k: be.encrypt(ctx, m, r, c, k))
+            call(rows)
+            be.sync()
+            evs = be.events(1)
+            be.record(evs[0][0])
+            for _ in range(10):
+                call(rows)
+            be.record(evs[0][1])
+            be.sync()
+            latency[name + "_ms"] = be.elapsed_ms(*evs[0]) / 10
+            latency[name + "_path"] = ctx.last_launch() if hasattr(ctx, "last_launch") else None
+        latency_ok = be.equal(m_back, m)                       # rows rewritten by the small calls still equal the batch's
+        latency["bit_exact"] = bool(latency_ok)
+
     # ---- configs[3]: a shard per GPU under a 3072-bit key + ONE all-gather of the ciphertext shards ---------------
     cfg4, cfg4_ok = None, True
     if not args.no_config4:
@@ -894,7 +914,7 @@ def main():
             "bit_exact": {"roundtrip_full_batch": roundtrip_ok, "strided_sample_vs_gmp_oracle": sample_ok,
                           "strided_sample_rows": sample_rows},
             "roofline": roofline,
-            "ops": ops, "config4": cfg4,
+            "ops": ops, "latency": latency, "config4": cfg4,
             "cpu_baseline": cpu,
         }
         if cpu:

@@ -1282,6 +1282,65 @@ int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, 
 
 // raw_encrypt by the holder of the private key: r^n mod n^2 from r^n mod p^2 and r^n mod q^2 (the half-exponentiation
 // kernels with the exponent n), lifted by k_crt_lift, times 1 + n*m by the product kernel.  Same bits as phe_hip_encrypt_dev.
+// The two half-exponentiations base^e_p mod p^2 -> xp, base^e_q mod q^2 -> xq (rows of S words) of a decrypt (e = p - 1, q - 1)
+// or of the key owner's encryption (e = n for both): the rung of the ladder for this batch, the two halves as one grid while
+// they fit one residency together, one number on a pair of wavefronts for a handful of numbers.  Sets last_geom_priv and the
+// path bits it took (|= into ctx->last_path).
+static int launch_crt_halves(phe_hip_ctx* ctx, const DevSchedule& Ep, const DevSchedule& Eq, const uint32_t* base, int base_limbs,
+                             uint32_t* xp, uint32_t* xq, int S, size_t batch, hipStream_t st) {
+    int rc = PHE_HIP_OK;
+    // the rung of the halves: the two exponentiations are independent, so a batch that cannot fill the chip with one of them
+    // runs both side by side (one grid, the q half with its own window tables) and needs only half the lanes
+    const int n_rungs = 1 + (int)ctx->priv_rungs.size();
+    const auto psplit_of = [&](int k) -> const DevSplit& { return k == 0 ? ctx->d_psplit : ctx->priv_rungs[(size_t)k - 1].psplit; };
+    const auto qsplit_of = [&](int k) -> const DevSplit& { return k == 0 ? ctx->d_qsplit : ctx->priv_rungs[(size_t)k - 1].qsplit; };
+    const auto psq_of = [&](int k) -> const DevModulus& { return k == 0 ? ctx->d_psq : ctx->priv_rungs[(size_t)k - 1].psq; };
+    const auto qsq_of = [&](int k) -> const DevModulus& { return k == 0 ? ctx->d_qsq : ctx->priv_rungs[(size_t)k - 1].qsq; };
+    const bool split_ok = ctx->use_split && ctx->d_psplit.G && ctx->d_qsplit.G;
+    const auto shape = [&](int k) {
+        if (split_ok) return split_shape(qsplit_of(k));
+        RungShape sh;
+        sh.G = qsq_of(k).G;
+        sh.L = qsq_of(k).L;
+        sh.rows = qsq_of(k).S;
+        return sh;
+    };
+    int rung = pick_rung(ctx, batch, n_rungs, shape, split_ok ? 2 : 1);
+    if (split_ok && !(psplit_of(rung).G && qsplit_of(rung).G)) rung = 0;
+    const DevSplit& sp_p = psplit_of(rung);
+    const DevSplit& sp_q = qsplit_of(rung);
+    // side by side (one grid, k_modexp_split_halves) while both halves together fit one residency of workgroups; beyond that
+    // each half fills the GPU on its own and they run one after the other
+    int occ = ctx->blocks_per_cu;
+    if (occ == 0 && split_ok) occ = PHE_SPLIT_BY_GROUP(sp_p.G, occ_split(sp_p.L, kModeHalfDecrypt));
+    const size_t wg_per_half = (batch + (size_t)(kBlock / std::max(1, sp_p.G)) - 1) / (size_t)(kBlock / std::max(1, sp_p.G));
+    const bool side_by_side = split_ok && sp_p.G == sp_q.G && sp_p.L == sp_q.L &&
+                              2 * wg_per_half <= (size_t)ctx->n_cus * (size_t)std::max(1, occ);
+    ctx->last_geom_priv = split_ok ? geom_code(sp_p.G, sp_p.L) : geom_code(psq_of(rung).G, psq_of(rung).L);
+    ctx->last_path |= side_by_side ? kPathSideBySide : 0;
+    if (split_ok && sp_p.G == sp_q.G && sp_p.L == sp_q.L && ab_offered(ctx, sp_p, batch, 2)) {
+        // a handful of ciphertexts: every half-exponentiation on a PAIR of wavefronts (about half the time per product)
+        ctx->last_path |= kPathSideBySide | kPathWavePairs;
+        rc = launch_split_ab(ctx, kModeHalfDecrypt, sp_p, Ep, &sp_q, &Eq, base, base_limbs, nullptr, 0, xp, xq, S, batch, st);
+        if (rc) return rc;
+    } else if (side_by_side) {
+        rc = launch_split_halves(ctx, sp_p, Ep, sp_q, Eq, base, base_limbs, xp, xq, S, batch, st);
+        if (rc) return rc;
+    } else {
+        if (split_ok)
+            rc = launch_split<kModeHalfDecrypt>(ctx, sp_p, Ep, base, base_limbs, nullptr, 0, xp, S, batch, st);
+        else
+            rc = launch_uniform<kModeHalfDecrypt>(ctx, psq_of(rung), Ep, base, base_limbs, nullptr, 0, xp, S, batch, st);
+        if (rc) return rc;
+        if (split_ok)
+            rc = launch_split<kModeHalfDecrypt>(ctx, sp_q, Eq, base, base_limbs, nullptr, 0, xq, S, batch, st);
+        else
+            rc = launch_uniform<kModeHalfDecrypt>(ctx, qsq_of(rung), Eq, base, base_limbs, nullptr, 0, xq, S, batch, st);
+        if (rc) return rc;
+    }
+    return PHE_HIP_OK;
+}
+
 int phe_hip_encrypt_owner_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch, void* stream) {
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
     if (!ctx->has_private) return fail(PHE_HIP_EINVAL, "owner encryption needs a private-key context");
@@ -1292,28 +1351,13 @@ int phe_hip_encrypt_owner_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_
     PHE_CTX_ORDER(ctx, stream);
     hipStream_t st = (hipStream_t)stream;
     ctx->last_path = kPathOwner;
-    ctx->last_geom_priv = geom_code(ctx->d_psplit.G, ctx->d_psplit.L);
     const int S = (std::max(ctx->priv.psq.bits, ctx->priv.qsq.bits) + 31) / 32;
     int rc = ensure_words(&ctx->scratch, &ctx->scratch_words, (size_t)2 * batch * S);
     if (rc) return rc;
     uint32_t* yp = ctx->scratch;
     uint32_t* yq = ctx->scratch + batch * (size_t)S;
-    // always the throughput geometry of the halves: the lift's constants belong to it
-    {
-        int occ = ctx->blocks_per_cu;
-        if (occ == 0) occ = PHE_SPLIT_BY_GROUP(ctx->d_psplit.G, occ_split(ctx->d_psplit.L, kModeHalfDecrypt));
-        const size_t per_wg = (size_t)(kBlock / ctx->d_psplit.G);
-        const size_t wg_per_half = (batch + per_wg - 1) / per_wg;
-        if (ctx->d_psplit.G == ctx->d_qsplit.G && ctx->d_psplit.L == ctx->d_qsplit.L &&
-            2 * wg_per_half <= (size_t)ctx->n_cus * (size_t)std::max(1, occ)) {
-            // both halves fit one residency: one grid (see phe_hip_decrypt_dev)
-            ctx->last_path |= kPathSideBySide;
-            rc = launch_split_halves(ctx, ctx->d_psplit, ctx->d_exp_n, ctx->d_qsplit, ctx->d_exp_n, r, ctx->pub.s1, yp, yq, S, batch, st);
-        } else {
-            rc = launch_split<kModeHalfDecrypt>(ctx, ctx->d_psplit, ctx->d_exp_n, r, ctx->pub.s1, nullptr, 0, yp, S, batch, st);
-            if (!rc) rc = launch_split<kModeHalfDecrypt>(ctx, ctx->d_qsplit, ctx->d_exp_n, r, ctx->pub.s1, nullptr, 0, yq, S, batch, st);
-        }
-    }
+    // the halves on the rung this batch size calls for (the lift below takes canonical residues: any rung's will do)
+    rc = launch_crt_halves(ctx, ctx->d_exp_n, ctx->d_exp_n, r, ctx->pub.s1, yp, yq, S, batch, st);
     if (rc) return rc;
     const int QS = ctx->d_qsq.S;
     CrtLiftArgs A;
@@ -1397,55 +1441,9 @@ int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t
     uint32_t* xp = ctx->scratch;
     uint32_t* xq = ctx->scratch + batch * (size_t)S;
     hipStream_t st = (hipStream_t)stream;
-    // the rung of the halves: the two exponentiations are independent, so a batch that cannot fill the chip with one of them
-    // runs both side by side (one grid, the q half with its own window tables) and needs only half the lanes
-    const int n_rungs = 1 + (int)ctx->priv_rungs.size();
-    const auto psplit_of = [&](int k) -> const DevSplit& { return k == 0 ? ctx->d_psplit : ctx->priv_rungs[(size_t)k - 1].psplit; };
-    const auto qsplit_of = [&](int k) -> const DevSplit& { return k == 0 ? ctx->d_qsplit : ctx->priv_rungs[(size_t)k - 1].qsplit; };
-    const auto psq_of = [&](int k) -> const DevModulus& { return k == 0 ? ctx->d_psq : ctx->priv_rungs[(size_t)k - 1].psq; };
-    const auto qsq_of = [&](int k) -> const DevModulus& { return k == 0 ? ctx->d_qsq : ctx->priv_rungs[(size_t)k - 1].qsq; };
-    const bool split_ok = ctx->use_split && ctx->d_psplit.G && ctx->d_qsplit.G;
-    const auto shape = [&](int k) {
-        if (split_ok) return split_shape(qsplit_of(k));
-        RungShape sh;
-        sh.G = qsq_of(k).G;
-        sh.L = qsq_of(k).L;
-        sh.rows = qsq_of(k).S;
-        return sh;
-    };
-    int rung = pick_rung(ctx, batch, n_rungs, shape, split_ok ? 2 : 1);
-    if (split_ok && !(psplit_of(rung).G && qsplit_of(rung).G)) rung = 0;
-    const DevSplit& sp_p = psplit_of(rung);
-    const DevSplit& sp_q = qsplit_of(rung);
-    // side by side (one grid, k_modexp_split_halves) while both halves together fit one residency of workgroups; beyond that
-    // each half fills the GPU on its own and they run one after the other
-    int occ = ctx->blocks_per_cu;
-    if (occ == 0 && split_ok) occ = PHE_SPLIT_BY_GROUP(sp_p.G, occ_split(sp_p.L, kModeHalfDecrypt));
-    const size_t wg_per_half = (batch + (size_t)(kBlock / std::max(1, sp_p.G)) - 1) / (size_t)(kBlock / std::max(1, sp_p.G));
-    const bool side_by_side = split_ok && sp_p.G == sp_q.G && sp_p.L == sp_q.L &&
-                              2 * wg_per_half <= (size_t)ctx->n_cus * (size_t)std::max(1, occ);
-    ctx->last_geom_priv = split_ok ? geom_code(sp_p.G, sp_p.L) : geom_code(psq_of(rung).G, psq_of(rung).L);
-    ctx->last_path = side_by_side ? kPathSideBySide : 0;
-    if (split_ok && sp_p.G == sp_q.G && sp_p.L == sp_q.L && ab_offered(ctx, sp_p, batch, 2)) {
-        // a handful of ciphertexts: every half-exponentiation on a PAIR of wavefronts (about half the time per product)
-        ctx->last_path = kPathSideBySide | kPathWavePairs;
-        rc = launch_split_ab(ctx, kModeHalfDecrypt, sp_p, ctx->d_exp_p, &sp_q, &ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0, xp, xq, S, batch, st);
-        if (rc) return rc;
-    } else if (side_by_side) {
-        rc = launch_split_halves(ctx, sp_p, ctx->d_exp_p, sp_q, ctx->d_exp_q, c, ctx->pub.s2, xp, xq, S, batch, st);
-        if (rc) return rc;
-    } else {
-        if (split_ok)
-            rc = launch_split<kModeHalfDecrypt>(ctx, sp_p, ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0, xp, S, batch, st);
-        else
-            rc = launch_uniform<kModeHalfDecrypt>(ctx, psq_of(rung), ctx->d_exp_p, c, ctx->pub.s2, nullptr, 0, xp, S, batch, st);
-        if (rc) return rc;
-        if (split_ok)
-            rc = launch_split<kModeHalfDecrypt>(ctx, sp_q, ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0, xq, S, batch, st);
-        else
-            rc = launch_uniform<kModeHalfDecrypt>(ctx, qsq_of(rung), ctx->d_exp_q, c, ctx->pub.s2, nullptr, 0, xq, S, batch, st);
-        if (rc) return rc;
-    }
+    ctx->last_path = 0;
+    rc = launch_crt_halves(ctx, ctx->d_exp_p, ctx->d_exp_q, c, ctx->pub.s2, xp, xq, S, batch, st);
+    if (rc) return rc;
     // the tail: one ciphertext per thread is a long serial chain (0.4 ms at 2048-bit keys) that a large batch hides and a small
     // one waits for; while there are SIMDs to spare it runs one ciphertext per wavefront instead (same bits)
     if (ctx->tail_wave_L && batch <= (size_t)ctx->n_cus * 16) {

@@ -262,6 +262,10 @@ PHE_DEV uint32_t bcast_digit(uint32_t x, uint32_t vmask, const Lanes<G>& ln) {
 template <int G, int L>
 struct Trip {
     static constexpr int kDigits = (G == 64) ? (L == 1 ? 4 : 2) * L : L;
+    // fetch the next trip's digits before starting on this one's: the whole-wave geometry only.  Tried on the narrow-lane rungs
+    // (L <= 9, one wave per SIMD at the batch sizes that take them) in round 3: the register copies of the hand-over cost more
+    // than the LDS latency they hide — g16x5 -15 %, g16x3 -20 %, g8x9 -3 % (profiles/r03f_batch_sweep_digit_prefetch_on_small_rungs.txt)
+    static constexpr bool kAhead = (G == 64);
 };
 
 // z0 = (a*b0 + m*n) / R,   z1 = (m + a*b1 + m2*n) / R.     a: H digits in LDS.
@@ -279,14 +283,14 @@ PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
     for (int k = 0; k < L; ++k) p[k] = q[k] = 0;
     constexpr int kT = Trip<G, L>::kDigits;
     uint32_t ahead_a[kT];
-    if constexpr (G == 64) {
+    if constexpr (Trip<G, L>::kAhead) {
 #pragma unroll
         for (int t = 0; t < kT; ++t) ahead_a[t] = a[t];
     }
 #pragma unroll 1
     for (int i = 0; i < rows; i += kT) {
         uint32_t dig_a[kT];
-        if constexpr (G == 64) {
+        if constexpr (Trip<G, L>::kAhead) {
             const int nx = (i + kT < rows) ? i + kT : i;
 #pragma unroll
             for (int t = 0; t < kT; ++t) {
@@ -297,7 +301,7 @@ PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
 #pragma unroll
         for (int jj = 0; jj < kT; ++jj) {
             const int j = jj % L;
-            const uint32_t ai = (G == 64) ? dig_a[jj] : a[i + jj];
+            const uint32_t ai = Trip<G, L>::kAhead ? dig_a[jj] : a[i + jj];
 #pragma unroll
             for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(ai, b0[k], p[(k + j) % L]);
 #pragma unroll
@@ -330,7 +334,7 @@ PHE_DEV void pair_pass3(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
     for (int k = 0; k < L; ++k) p[k] = q[k] = 0;
     constexpr int kT = Trip<G, L>::kDigits;
     uint32_t ahead_a[kT], ahead_c[kT];
-    if constexpr (G == 64) {
+    if constexpr (Trip<G, L>::kAhead) {
 #pragma unroll
         for (int t = 0; t < kT; ++t) {
             ahead_a[t] = a[t];
@@ -340,7 +344,7 @@ PHE_DEV void pair_pass3(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
 #pragma unroll 1
     for (int i = 0; i < rows; i += kT) {
         uint32_t dig_a[kT], dig_c[kT];
-        if constexpr (G == 64) {
+        if constexpr (Trip<G, L>::kAhead) {
             const int nx = (i + kT < rows) ? i + kT : i;
 #pragma unroll
             for (int t = 0; t < kT; ++t) {
@@ -353,8 +357,8 @@ PHE_DEV void pair_pass3(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
 #pragma unroll
         for (int jj = 0; jj < kT; ++jj) {
             const int j = jj % L;
-            const uint32_t ai = (G == 64) ? dig_a[jj] : a[i + jj];
-            const uint32_t ci = (G == 64) ? dig_c[jj] : c[i + jj];
+            const uint32_t ai = Trip<G, L>::kAhead ? dig_a[jj] : a[i + jj];
+            const uint32_t ci = Trip<G, L>::kAhead ? dig_c[jj] : c[i + jj];
 #pragma unroll
             for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(ai, b0[k], p[(k + j) % L]);
 #pragma unroll

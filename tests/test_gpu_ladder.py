@@ -153,6 +153,10 @@ def test_a_handful_of_numbers_runs_on_wave_pairs(native, c_oracle, key_bits, mon
         assert np.array_equal(got, c_oracle.decrypt(n, p, q, both, nthreads=4)), batch
         assert np.array_equal(got[:batch], m)
         assert np.array_equal(single.encrypt(m, r), c) and np.array_equal(single.decrypt(both), got)
+        if ctx.owner_encrypt_offered():                          # the key owner's r^n: its two CRT halves on wave pairs as well
+            assert np.array_equal(ctx.encrypt_owner(m, r), c), batch
+            path = ctx.last_launch()["path"]
+            assert path & ctx.PATH_OWNER and path & ctx.PATH_WAVE_PAIRS, path
     assert not single.last_launch()["path"] & ctx.PATH_WAVE_PAIRS
 
 
