@@ -712,57 +712,74 @@ PHE_DEV void ab_load_block(uint32_t (&d)[N], P p) {
     for (int t = 0; t < N; ++t) d[t] = p[t];
 }
 
-// one trip of the first word: N steps on the digit block dig_a; w: this trip's block of the quotient row (step jj's digit is
-// w[jj - 1]); held: the previous trip's last kSteps - 1 quotient digits, not stored yet (one-limb sweeps)
-template <int L, int N, bool FIRST, bool LAST>
-PHE_DEV void ab_first_steps(uint64_t (&p)[L], const uint32_t (&dig_a)[AbTrip<L>::kSteps], wave::lds_u32* w, uint32_t (&held)[3],
-                            const uint32_t (&b0)[L], const uint32_t (&nbar)[L], uint32_t dmask, const Lanes<64>& ln) {
-    constexpr int G = 64;
-    if constexpr (L == 1 && !PHE_AB_GENERIC_STEPS) {
-        // one limb per lane: the accumulator stays below 2^61 (a carry, a digit and two products), so the carry p >> 29 is a
-        // 32-bit number (one v_alignbit) and carry + received digit one 32-bit addition: no 64-bit shift, no 64-bit add
-        uint32_t tq[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int jj = 0; jj < N; ++jj) {
-            const bool quot = !(FIRST && jj == 0), digit = !(LAST && jj == N - 1);
-            uint32_t m = 0;
-            if (quot) {
-                const uint32_t t = wave::reread((uint32_t)p[0] & kLimbMask);  // (kept on the vector side: the lane shift takes it there)
-                m = wave::grp_bcast0<G>(t, ln);
-                tq[jj] = t;  // lane 0's copy is the quotient digit
-                p[0] = (uint64_t)(wave::grp_down1_raw<G>(t) + (uint32_t)(p[0] >> kRadixBits));
-                if (jj == 0) wave::lds_store4(w - 4, held[0], held[1], held[2], t);  // the previous block of the quotient row is complete
-            }
-            if (digit) p[0] = wave::reread64(wave::mad64(dig_a[jj], b0[0], p[0]));  // (the digit's product first: the quotient digit is still on its way)
-            if (quot) p[0] = wave::mad64(m, nbar[0], p[0]);
-        }
-        if constexpr (LAST) {
-#pragma unroll
-            for (int jj = 1; jj < N; ++jj) w[jj - 1] = tq[jj];
-        } else {
-#pragma unroll
-            for (int jj = 1; jj < 4; ++jj) held[jj - 1] = tq[jj];
-        }
-        return;
+// one shift of a column-accumulator set whose columns stay below 2^61 (at most 7 products of < 2^58 each between two shifts):
+// the carry low >> 29 is a 32-bit number — one v_alignbit and a 32-bit-into-64-bit add instead of a 64-bit shift and add.
+// t = low & mask (already formed by the caller, who also broadcasts it)
+template <int L>
+PHE_DEV void ab_shift_narrow(uint64_t (&acc)[L], int j, uint32_t t, uint32_t extra) {
+    const uint32_t carry = (uint32_t)(acc[j] >> kRadixBits);
+    const uint32_t recv = wave::grp_down1_raw<64>(t);  // (lane 63 receives 0)
+    if constexpr (L > 1) {
+        acc[(j + 1) % L] += (uint64_t)(carry + extra);
+        acc[j] = (uint64_t)recv;
+    } else {
+        acc[0] = (uint64_t)(recv + carry + extra);
     }
+}
+
+// one trip of the first word: N steps on the digit block dig_a; w: this trip's block of the quotient row (step jj's digit is
+// w[jj - 1]); held: the previous trip's last kSteps - 1 quotient digits, not stored yet
+template <int L, int N, bool FIRST, bool LAST>
+PHE_DEV void ab_first_steps(uint64_t (&p)[L], const uint32_t (&dig_a)[AbTrip<L>::kSteps], wave::lds_u32* w,
+                            uint32_t (&held)[AbTrip<L>::kSteps - 1], const uint32_t (&b0)[L], const uint32_t (&nbar)[L], uint32_t dmask,
+                            const Lanes<64>& ln) {
+    constexpr int G = 64, kT = AbTrip<L>::kSteps;
+    constexpr bool kNarrow = 2 * L <= 7 && !PHE_AB_GENERIC_STEPS;  // two products per column and step
+    uint32_t tq[kT];
+#pragma unroll
+    for (int jj = 0; jj < kT; ++jj) tq[jj] = 0u;
 #pragma unroll
     for (int jj = 0; jj < N; ++jj) {
         const bool quot = !(FIRST && jj == 0), digit = !(LAST && jj == N - 1);
         const int j = jj % L, jl = (jj + L - 1) % L;  // lowest column after / before this step's shift
         uint32_t m = 0;
         if (quot) {
-            m = bcast_digit<G>((uint32_t)p[jl], 0u, ln);
-            w[jj - 1] = m;
-            shift_row<G, L>(p, jl, dmask);
+            if constexpr (kNarrow) {
+                const uint32_t t = wave::reread((uint32_t)p[jl] & kLimbMask);  // (kept on the vector side: the lane shift takes it there)
+                m = wave::grp_bcast0<G>(t, ln);
+                tq[jj] = t;  // lane 0's copy is the quotient digit
+                ab_shift_narrow<L>(p, jl, t, 0u);
+            } else {
+                m = bcast_digit<G>((uint32_t)p[jl], 0u, ln);
+                tq[jj] = m;
+                shift_row<G, L>(p, jl, dmask);
+            }
+            if (jj == 0) {  // the previous block of the quotient row is complete: one 16-byte store, or 8-byte ones (kSteps * 4 bytes apart)
+                if constexpr (kT == 4) {
+                    wave::lds_store4(w - 4, held[0], held[1], held[2], tq[0]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i + 2 < kT; i += 2) wave::lds_store2(w - kT + i, held[i], held[i + 1]);
+                    wave::lds_store2(w - 2, held[kT - 2], tq[0]);
+                }
+            }
         }
         if (digit) {
 #pragma unroll
             for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(dig_a[jj], b0[k], p[(k + j) % L]);
+            if constexpr (L == 1) p[0] = wave::reread64(p[0]);  // (the digit's product first: the quotient digit is still on its way)
         }
         if (quot) {
 #pragma unroll
             for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(m, nbar[k], p[(k + j) % L]);
         }
+    }
+    if constexpr (LAST) {
+#pragma unroll
+        for (int jj = 1; jj < N; ++jj) w[jj - 1] = tq[jj];
+    } else {
+#pragma unroll
+        for (int jj = 1; jj < kT; ++jj) held[jj - 1] = tq[jj];
     }
 }
 
@@ -777,7 +794,9 @@ PHE_DEV void ab_first_word(uint32_t (&z0)[L], const uint32_t* a, const uint32_t 
     for (int k = 0; k < L; ++k) p[k] = 0;
     wave::lds_u32* const w = wave::as_lds(ln.g == 0u ? m_row : dump + 4 * ln.g + 8);
     const int trips = (rows + kT) / kT;  // ceil((rows + 1) / kT) >= 2 (key_setup.h build_quick)
-    uint32_t blk_a[kT], blk_b[kT], held[3] = {0u, 0u, 0u};
+    uint32_t blk_a[kT], blk_b[kT], held[kT - 1];
+#pragma unroll
+    for (int i = 0; i + 1 < kT; ++i) held[i] = 0u;
     ab_load_block<kT>(blk_a, a);
     ab_load_block<kT>(blk_b, a + kT);
     ab_first_steps<L, kT, true, false>(p, blk_a, w, held, b0, nbar, dmask, ln);
@@ -819,36 +838,27 @@ PHE_DEV void ab_second_steps(uint64_t (&q)[L], const uint32_t (&dig_a)[AbTrip<L>
                              const uint32_t (&m_cur)[AbTrip<L>::kSteps], const uint32_t (&b0)[L], const uint32_t (&b1)[L],
                              const uint32_t (&nbar)[L], uint32_t dmask, const Lanes<64>& ln) {
     constexpr int G = 64;
-    // the lanes other than lane 0 read zeros where lane 0 reads the quotient row (ab_second_word): the digit is added as it comes
-    const auto dig_m = [&](int jj) { return m_cur[jj]; };
-    if constexpr (L == 1 && !PHE_AB_GENERIC_STEPS) {  // (see ab_first_steps: 32-bit carry; the digit of Q rides on the same addition)
-#pragma unroll
-        for (int jj = 0; jj < N; ++jj) {
-            const bool quot = !(FIRST && jj == 0), digit = !(LAST && jj == N - 1);
-            uint32_t m2 = 0, sum = digit ? dig_m(jj) : 0u;
-            if (quot) {
-                const uint32_t t = wave::reread((uint32_t)q[0] & kLimbMask);
-                m2 = wave::grp_bcast0<G>(t, ln);
-                sum += wave::grp_down1_raw<G>(t) + (uint32_t)(q[0] >> kRadixBits);
-            }
-            q[0] = (uint64_t)sum;
-            if (digit) {
-                q[0] = wave::mad64(dig_a[jj], b1[0], q[0]);
-                if constexpr (MUL) q[0] = wave::mad64(dig_c[jj], b0[0], q[0]);
-                q[0] = wave::reread64(q[0]);
-            }
-            if (quot) q[0] = wave::mad64(m2, nbar[0], q[0]);
-        }
-        return;
-    }
+    constexpr bool kNarrow = (MUL ? 3 : 2) * L <= 7 && !PHE_AB_GENERIC_STEPS;  // see ab_shift_narrow
+    // the lanes other than lane 0 read zeros where lane 0 reads the quotient row (ab_second_word): the digit of Q is added as it
+    // comes — with narrow carries it rides on the carry's addition
 #pragma unroll
     for (int jj = 0; jj < N; ++jj) {
         const bool quot = !(FIRST && jj == 0), digit = !(LAST && jj == N - 1);
         const int j = jj % L, jl = (jj + L - 1) % L;
+        const uint32_t dm = digit ? m_cur[jj] : 0u;
         uint32_t m2 = 0;
         if (quot) {
-            m2 = bcast_digit<G>((uint32_t)q[jl], 0u, ln);
-            shift_row<G, L>(q, jl, dmask);
+            if constexpr (kNarrow) {
+                const uint32_t t = wave::reread((uint32_t)q[jl] & kLimbMask);
+                m2 = wave::grp_bcast0<G>(t, ln);
+                ab_shift_narrow<L>(q, jl, t, dm);
+            } else {
+                m2 = bcast_digit<G>((uint32_t)q[jl], 0u, ln);
+                shift_row<G, L>(q, jl, dmask);
+                q[j] += (uint64_t)dm;
+            }
+        } else {
+            q[j] += (uint64_t)dm;
         }
         if (digit) {
 #pragma unroll
@@ -857,7 +867,7 @@ PHE_DEV void ab_second_steps(uint64_t (&q)[L], const uint32_t (&dig_a)[AbTrip<L>
 #pragma unroll
                 for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(dig_c[jj], b0[k], q[(k + j) % L]);
             }
-            q[j] += (uint64_t)dig_m(jj);  // digit s of the first word's quotient Q (zero in the lanes above lane 0)
+            if constexpr (L == 1) q[0] = wave::reread64(q[0]);  // (the digits' products first: the quotient digit is still on its way)
         }
         if (quot) {
 #pragma unroll

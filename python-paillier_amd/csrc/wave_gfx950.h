@@ -166,6 +166,11 @@ PHE_DEV uint64_t reread64(uint64_t x) {
 // address space itself (a per-lane choice between two LDS areas) instead of flat_* ones.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 PHE_DEV lds_u32* as_lds(uint32_t* p) { return (lds_u32*)p; }
+// two words to an 8-byte aligned LDS address as one ds_write_b64
+PHE_DEV void lds_store2(lds_u32* p, uint32_t a, uint32_t b) {
+    typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+    *(__attribute__((address_space(3))) u32x2*)p = (u32x2){a, b};
+}
 // four words to a 16-byte aligned LDS address as one ds_write_b128
 PHE_DEV void lds_store4(lds_u32* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
     typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;

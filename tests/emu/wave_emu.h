@@ -253,6 +253,7 @@ inline uint32_t reread(uint32_t x) { return x; }  // see wave_gfx950.h: an optim
 inline uint64_t reread64(uint64_t x) { return x; }
 typedef uint32_t lds_u32;  // wave_gfx950.h: an LDS-address-space pointer on the device
 inline lds_u32* as_lds(uint32_t* p) { return p; }
+inline void lds_store2(lds_u32* p, uint32_t a, uint32_t b) { p[0] = a; p[1] = b; }
 inline void lds_store4(lds_u32* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 
 // every mad64 is one v_mad_u64_u32 lane-operation on the device: counted here so that tools/count_executed_mads.py can

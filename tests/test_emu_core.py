@@ -352,3 +352,36 @@ def test_decrypt_tail_on_one_wave_per_ciphertext(emu, key_bits):
         assert limbs_to_ints(emu.decrypt(*key, s1, ints_to_limbs(cts, s2))) == want
     finally:
         emu.set_wave_tail(False)
+
+
+def test_wave_pair_sweeps_with_three_limbs_per_lane(emu):
+    """A 4096-bit key (primes of tests/golden/paillier_4096_primes.json, made by gen_primes_4096.py): n~ needs 143 limbs = three per
+    lane, the width at which the first word's columns still carry 32-bit carries and the second word's (three products per step
+    in a multiplication) no longer do (split_core.h ab_shift_narrow); its CRT halves run two limbs per lane.  One encryption and
+    its decryption on wave pairs, the tail on one wave, against CPython's pow."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "paillier_4096_primes.json")) as f:
+        pq = json.load(f)
+    p, q = int(pq["p"], 16), int(pq["q"], 16)
+    rng = random.Random(4096)
+    n = p * q
+    N = n * n
+    hp = pow((pow(n + 1, p - 1, p * p) - 1) // p, -1, p)                # phe/paillier.py:234-235, h_function
+    hq = pow((pow(n + 1, q - 1, q * q) - 1) // q, -1, q)
+    key = [int_to_limbs(v, 64) for v in (p, q, hp, hq, pow(p, -1, q))]
+    m, r = rng.randrange(n), rng.randrange(1, n)
+    emu.set_engine(True)
+    emu.set_group(64)
+    emu.set_unit(False)
+    emu.set_wave_pairs(True)
+    emu.set_wave_tail(True)
+    try:
+        c = emu.encrypt(int_to_limbs(n, 128), ints_to_limbs([m], 128), ints_to_limbs([r], 128))
+        assert limbs_to_ints(c) == [(1 + n * m) * pow(r, n, N) % N]
+        assert limbs_to_ints(emu.decrypt(*key, 128, c)) == [m]
+    finally:
+        emu.set_wave_tail(False)
+        emu.set_wave_pairs(False)
+        emu.set_unit(True)
+        emu.set_group(0)
