@@ -346,6 +346,7 @@ struct phe_hip_ctx {
     };
     std::vector<PubRung> pub_rungs;    // rungs 1.. of the public side, by increasing group width
     std::vector<PrivRung> priv_rungs;  // rungs 1.. of the private side
+    int wave_pair_depth = 1;           // waves per SIMD up to which a batch stays on the wave-pair kernels (PHE_HIP_WAVE_PAIR_DEPTH)
     bool no_wave_pairs = false;        // PHE_HIP_NO_WAVE_PAIRS=1: a handful of numbers stays on the single-wave kernels (A/B measurements, tests)
     bool force_unit = false;           // PHE_HIP_FORCE_UNIT=1: r^n through the scaled modulus whatever the batch size (tests)
     int force_group = 0;               // phe_hip_ctx_set_group: 0 = pick by batch size; G = the rung whose groups are G lanes wide
@@ -657,8 +658,12 @@ static int launch_split_halves(phe_hip_ctx* ctx, const DevSplit& Mp, const DevSc
 // workgroups and Mq/Eq on the odd ones (the two CRT halves of a decrypt), else Mp/Ep alone.  The window tables are per NUMBER
 // here (tbl_entries + 1 pairs each), in ctx->table / ctx->table2.
 static bool ab_offered(const phe_hip_ctx* ctx, const DevSplit& M, size_t batch, int halves) {
-    // while every wave of every number still finds a SIMD of its own (2 roles x halves x batch waves)
-    return !ctx->no_wave_pairs && M.G == 64 && M.q_L != 0 && batch * 2 * (size_t)halves <= (size_t)ctx->n_cus * 4;
+    // while every wave of every number still finds a SIMD of its own (2 roles x halves x batch waves) — two waves per SIMD for
+    // the one-limb-per-lane sweeps, whose dependent chain leaves half the issue slots free: 512 decrypts at 2048 bits 305 k/s
+    // against 198 k/s on the single-wave kernels, while two limbs per lane lose 19 % that way
+    // (profiles/r03g_wave_pairs_beyond_one_wave_per_simd.txt; PHE_HIP_WAVE_PAIR_DEPTH multiplies the bound, for measurements)
+    const size_t per_simd = (size_t)(M.q_L == 1 ? 2 : 1) * (size_t)ctx->wave_pair_depth;
+    return !ctx->no_wave_pairs && M.G == 64 && M.q_L != 0 && batch * 2 * (size_t)halves <= (size_t)ctx->n_cus * 4 * per_simd;
 }
 static int launch_split_ab(phe_hip_ctx* ctx, int mode, const DevSplit& Mp, const DevSchedule& Ep, const DevSplit* Mq, const DevSchedule* Eq,
                            const uint32_t* base, int base_limbs, const uint32_t* post, int post_limbs, uint32_t* out_p, uint32_t* out_q,
@@ -997,6 +1002,7 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
     if (!rc) rc = upload_schedule(ctx->pub.exp_n, ctx->d_exp_n);
     ctx->force_unit = getenv("PHE_HIP_FORCE_UNIT") != nullptr;
     ctx->no_wave_pairs = getenv("PHE_HIP_NO_WAVE_PAIRS") != nullptr;
+    if (const char* d = getenv("PHE_HIP_WAVE_PAIR_DEPTH")) ctx->wave_pair_depth = std::max(1, atoi(d));
     if (!rc && !getenv("PHE_HIP_GROUP")) {
         // the wider rungs of the ladder: 8- and 16-lane groups where they differ from what is already there
         for (int prefer : {8, 16, 64}) {

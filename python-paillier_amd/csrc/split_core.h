@@ -702,9 +702,10 @@ struct AbTrip {
 // LDS of a wave pair, in words: two slots of (a-digits | quotient digits), B's own digit row, one row for words handed over,
 // and the area the lanes other than lane 0 write their (meaningless) copies of the quotient digits to, so that the store of
 // a trip's quotient digits is an ordinary all-lane store instead of a branch around a one-lane store
-// ... and H + 16 zero words: what the lanes above lane 0 read where lane 0 reads the first word's quotient digits
+// ... and H + 48 zero words: what the lanes above lane 0 read where lane 0 reads the first word's quotient digits (the digit
+// blocks are fetched up to two trips ahead of the last digit: rows + 3 trips <= H + 30 words are touched)
 template <int L>
-constexpr int ab_lds_words() { return 6 * 64 * L + (4 * 64 + 64 * L + 16) + (64 * L + 16); }
+constexpr int ab_lds_words() { return 6 * 64 * L + (4 * 64 + 64 * L + 16) + (64 * L + 48); }
 
 template <int N, class P>
 PHE_DEV void ab_load_block(uint32_t (&d)[N], P p) {
@@ -877,7 +878,7 @@ PHE_DEV void ab_second_steps(uint64_t (&q)[L], const uint32_t (&dig_a)[AbTrip<L>
 }
 
 // z1 = (Q + a*b1 [+ c*b0] + Q2*n~) / R with the digits of a, c and of the first word's quotient Q in LDS
-// (zeros: H + 16 zero words of LDS: what the lanes above lane 0 read in place of the quotient row)
+// (zeros: H + 48 zero words of LDS: what the lanes above lane 0 read in place of the quotient row)
 template <int L, bool MUL>
 PHE_DEV void ab_second_word(uint32_t (&z1)[L], const uint32_t* a, const uint32_t* c, uint32_t* m_row, uint32_t* zeros,
                             const uint32_t (&b0)[L], const uint32_t (&b1)[L], const uint32_t (&nbar)[L], const Lanes<64>& ln, int rows) {
@@ -957,11 +958,11 @@ PHE_DEV void modexp_split_ab_body(const SplitArgs& A, uint32_t* lds, uint32_t* t
     uint32_t* own_c = lds + 4 * H;  // B: digits of its word X1 (the c operand of a product)
     uint32_t* mail = lds + 5 * H;   // a word handed from one role to the other
     uint32_t* dump = lds + 6 * H;   // ab_first_word: where the lanes other than lane 0 leave their copies of the quotient digits
-    uint32_t* zeros = dump + 4 * G + H + 16;  // ab_second_word: H + 16 zero words
+    uint32_t* zeros = dump + 4 * G + H + 16;  // ab_second_word: H + 48 zero words
     if (!first) {
 #pragma unroll
         for (int t = 0; t < L; ++t) zeros[g * L + t] = 0u;
-        if (g < 16u) zeros[H + g] = 0u;
+        if (g < 48u) zeros[H + g] = 0u;
         wave::lds_fence();
     }
     int k = 0;                      // products so far: slot k & 1

@@ -385,3 +385,39 @@ def test_wave_pair_sweeps_with_three_limbs_per_lane(emu):
         emu.set_wave_pairs(False)
         emu.set_unit(True)
         emu.set_group(0)
+
+
+@pytest.mark.parametrize("key_bits", [1600, 2100, 2240])
+def test_wave_pair_sweeps_on_key_sizes_off_the_grid(emu, key_bits):
+    """Key sizes whose limb counts are not round (primes of tests/golden/paillier_odd_sizes_primes.json): the sweeps of a wave
+    pair end in a trip of 1, 2, 3 or 4 steps (a compile-time variant each, split_core.h ab_first_word) — the golden key sizes
+    hit 2, 3 and 4 for the CRT halves, these hit 1 (2240 bits, also for n on two limbs per lane), 2 (1600) and 3 (2100).
+    One encryption and its decryption (tail on one wave), plus m = 0 and m = n - 1, against CPython's pow."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "paillier_odd_sizes_primes.json")) as f:
+        pq = json.load(f)[str(key_bits)]
+    p, q = int(pq["p"], 16), int(pq["q"], 16)
+    n = p * q
+    N = n * n
+    s1 = 2 * ((key_bits + 63) // 64)                                    # limbs of n: even, so that p and q take half each
+    hp = pow((pow(n + 1, p - 1, p * p) - 1) // p, -1, p)                # phe/paillier.py:234-235, h_function
+    hq = pow((pow(n + 1, q - 1, q * q) - 1) // q, -1, q)
+    key = [int_to_limbs(v, s1 // 2) for v in (p, q, hp, hq, pow(p, -1, q))]
+    rng = random.Random(key_bits)
+    ms = [rng.randrange(n), 0, n - 1]
+    rs = [rng.randrange(1, n), n - 1, rng.randrange(1, n)]
+    emu.set_engine(True)
+    emu.set_group(64)
+    emu.set_unit(False)
+    emu.set_wave_pairs(True)
+    emu.set_wave_tail(True)
+    try:
+        c = emu.encrypt(int_to_limbs(n, s1), ints_to_limbs(ms, s1), ints_to_limbs(rs, s1))
+        assert limbs_to_ints(c) == [(1 + n * m) * pow(r, n, N) % N for m, r in zip(ms, rs)]
+        assert limbs_to_ints(emu.decrypt(*key, s1, c)) == ms
+    finally:
+        emu.set_wave_tail(False)
+        emu.set_wave_pairs(False)
+        emu.set_unit(True)
+        emu.set_group(0)

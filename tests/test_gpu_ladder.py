@@ -160,6 +160,44 @@ def test_a_handful_of_numbers_runs_on_wave_pairs(native, c_oracle, key_bits, mon
     assert not single.last_launch()["path"] & ctx.PATH_WAVE_PAIRS
 
 
+@pytest.mark.parametrize("key_bits", [1600, 2100, 2240])
+def test_wave_pairs_on_key_sizes_off_the_grid(native, c_oracle, key_bits):
+    """Keys whose limb counts are not round (primes of tests/golden/paillier_odd_sizes_primes.json; the key derived as
+    phe/paillier.py:224-235 derives it): the last trip of a wave-pair sweep has 1 (2240 bits), 2 (1600) or 3 (2100) steps, a
+    compile-time variant each.  A handful of numbers through encrypt, the key owner's encrypt and decrypt: libgmp's bits, and
+    the large-batch kernels' (one launch of 3000 rows: another rung of the ladder) on the same rows."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "paillier_odd_sizes_primes.json")) as f:
+        pq = json.load(f)[str(key_bits)]
+    p_int, q_int = int(pq["p"], 16), int(pq["q"], 16)
+    n_int = p_int * q_int
+    s1 = 2 * ((key_bits + 63) // 64)
+    p, q, hp, hq, pinv = c_oracle.private_constants(n_int, p_int, q_int, s1, s1 // 2)
+    ctx = native.Context(n_int, p, q, hp, hq, pinv, n_limbs=s1)
+    n = native.int_to_limbs(n_int, s1)
+    pl, ql = native.int_to_limbs(p_int, s1 // 2), native.int_to_limbs(q_int, s1 // 2)
+    rng = random.Random(key_bits)
+    ms = [0, 1, n_int - 1] + [rng.randrange(n_int) for _ in range(9)]
+    rs = [n_int - 1, 1, 2] + [rng.randrange(1, n_int) for _ in range(9)]
+    m, r = native.ints_to_limbs(ms, s1), native.ints_to_limbs(rs, s1)
+    c = ctx.encrypt(m, r)
+    assert ctx.last_launch()["path"] & ctx.PATH_WAVE_PAIRS
+    assert np.array_equal(c, c_oracle.encrypt(n, m, r, nthreads=4))
+    if ctx.owner_encrypt_offered():
+        assert np.array_equal(ctx.encrypt_owner(m, r), c)
+        assert ctx.last_launch()["path"] & ctx.PATH_WAVE_PAIRS
+    got = ctx.decrypt(c)
+    path = ctx.last_launch()["path"]
+    assert path & ctx.PATH_WAVE_PAIRS and path & ctx.PATH_WAVE_TAIL, path
+    assert np.array_equal(got, m) and np.array_equal(got, c_oracle.decrypt(n, pl, ql, c, nthreads=4))
+    big_m, big_r = np.tile(m, (250, 1)), np.tile(r, (250, 1))        # 3000 rows: a throughput rung
+    big = ctx.encrypt(big_m, big_r)
+    assert not ctx.last_launch()["path"] & ctx.PATH_WAVE_PAIRS
+    assert np.array_equal(big[:len(ms)], c) and np.array_equal(big[-len(ms):], c)
+    assert np.array_equal(ctx.decrypt(big), big_m)
+
+
 @pytest.mark.parametrize("key_bits", [1024, 2048, 3072])
 def test_crt_tail_on_one_wavefront_per_ciphertext(native, c_oracle, key_bits, monkeypatch):
     """Small batches take the L-function / CRT tail one ciphertext per WAVEFRONT (k_decrypt_tail_wave; the per-thread tail is

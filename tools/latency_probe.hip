@@ -55,12 +55,12 @@ __global__ void __launch_bounds__(64) k_first(uint32_t* out, unsigned long long*
 template <int L, bool MUL>
 __global__ void __launch_bounds__(64) k_second(uint32_t* out, unsigned long long* ticks, int rows, int reps, uint32_t seed) {
     constexpr int H = 64 * L;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[5 * H + 32];
+    __shared__ __attribute__((aligned(16))) uint32_t lds[5 * H + 64];
     const uint32_t lane = threadIdx.x;
     const Lanes<64> ln(lane);
     uint32_t w[L], v[L], nbar[L];
     for (int k = 0; k < L; ++k) lds[3 * H + lane * L + k] = 0u;
-    if (lane < 16u) lds[4 * H + lane] = 0u;
+    if (lane < 48u) lds[4 * H + lane] = 0u;
     for (int k = 0; k < L; ++k) {
         const bool in = (int)(lane * L + k) < rows;
         w[k] = in ? ((seed * 2654435761u + lane * 97u + k) & kLimbMask) : 0u;
@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(128) k_pair(uint32_t* out, unsigned long long*
     uint32_t* zeros = dump + 4 * 64 + H + 16;
     if (role) {
         for (int k = 0; k < L; ++k) zeros[lane * L + k] = 0u;
-        if (lane < 16u) zeros[H + lane] = 0u;
+        if (lane < 48u) zeros[H + lane] = 0u;
     }
     __syncthreads();
     const unsigned long long t0 = clock64();
