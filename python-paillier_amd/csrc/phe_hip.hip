@@ -338,6 +338,7 @@ struct phe_hip_ctx {
         host::PublicPlan plan;
         DevModulus nsq;
         DevSplit nsplit;
+        DevSplit nunit;  // the scaled modulus on this rung's geometry (G == 0: not offered there)
     };
     struct PrivRung {
         host::PrivatePlan plan;
@@ -1024,6 +1025,7 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
                 if (chain(R.plan) * 5 > chain(prev) * 4) continue;
                 rc = upload_modulus(R.plan.nsq, R.nsq);
                 if (!rc) rc = upload_split(R.plan.nsplit, R.nsplit, &R.plan.nquick);
+                if (!rc && R.plan.nunit.G && R.plan.nsplit.G != 64 && !getenv("PHE_HIP_NO_UNIT")) rc = upload_split(R.plan.nunit, R.nunit);
                 if (rc) break;
                 ctx->pub_rungs.push_back(R);
             } catch (const std::exception&) {
@@ -1153,7 +1155,7 @@ void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
                         ctx->d_nsq.blob, ctx->d_psq.blob, ctx->d_qsq.blob, ctx->d_exp_n.ops, ctx->d_exp_p.ops,
                         ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->table2, ctx->scratch, ctx->partial, ctx->lookup, (uint32_t*)ctx->flags, ctx->stage[0],
                         ctx->stage[1], ctx->stage[2], ctx->owner_blob, ctx->d_nunit.blob, ctx->unit_tmp, ctx->tail_wave_blob};
-    for (const auto& R : ctx->pub_rungs) { bufs.push_back(R.nsq.blob); bufs.push_back(R.nsplit.blob); }
+    for (const auto& R : ctx->pub_rungs) { bufs.push_back(R.nsq.blob); bufs.push_back(R.nsplit.blob); bufs.push_back(R.nunit.blob); }
     for (const auto& R : ctx->priv_rungs) { bufs.push_back(R.psq.blob); bufs.push_back(R.qsq.blob); bufs.push_back(R.psplit.blob); bufs.push_back(R.qsplit.blob); }
     for (uint32_t* b : bufs)
         if (b) (void)hipFree(b);
@@ -1240,16 +1242,26 @@ int phe_hip_ctx_last_launch(const phe_hip_ctx* ctx, int* path, int* geom_pub, in
 
 // ---- device-pointer entry points -----------------------------------------------------------------
 // the bare power r^n through the scaled modulus (key_setup.h PublicPlan::nunit): throughput geometry only
-static bool unit_power_offered(const phe_hip_ctx* ctx, size_t batch) {
-    if (!(ctx->use_split && ctx->d_nunit.G && ctx->d_nsq.G)) return false;
-    return ctx->force_unit || pick_nsplit_rung(ctx, batch) == 0;
+// r^n modulo the scaled modulus n' = k*n on the rung this batch takes (every rung but the whole-wave one may carry it:
+// key_setup.h PublicPlan::nunit); -1: not offered — the plain kernels then.  PHE_HIP_FORCE_UNIT: rung 0's whatever the batch.
+static int unit_rung(const phe_hip_ctx* ctx, size_t batch) {
+    if (!ctx->use_split) return -1;
+    const auto has = [&](int k) {
+        const DevSplit& u = k == 0 ? ctx->d_nunit : ctx->pub_rungs[(size_t)k - 1].nunit;
+        return u.G != 0 && nsq_rung(ctx, k).G != 0;
+    };
+    if (ctx->force_unit) return has(0) ? 0 : -1;
+    const int k = pick_nsplit_rung(ctx, batch);
+    return has(k) ? k : -1;
 }
-static int unit_power(phe_hip_ctx* ctx, const uint32_t* r, size_t batch, hipStream_t st) {
-    const size_t w = (size_t)ctx->pub.unit_words;
+static const DevSplit& nunit_rung(const phe_hip_ctx* ctx, int k) { return k == 0 ? ctx->d_nunit : ctx->pub_rungs[(size_t)k - 1].nunit; }
+static int unit_words_rung(const phe_hip_ctx* ctx, int k) { return k == 0 ? ctx->pub.unit_words : ctx->pub_rungs[(size_t)k - 1].plan.unit_words; }
+static int unit_power(phe_hip_ctx* ctx, int rung, const uint32_t* r, size_t batch, hipStream_t st) {
+    const size_t w = (size_t)unit_words_rung(ctx, rung);
     int rc = ensure_words(&ctx->unit_tmp, &ctx->unit_tmp_words, batch * w);
     if (rc) return rc;
-    return launch_split<kModeEncrypt>(ctx, ctx->d_nunit, ctx->d_exp_n, r, ctx->pub.s1, nullptr, ctx->pub.s1, ctx->unit_tmp,
-                                      ctx->pub.unit_words, batch, st, false, true);
+    return launch_split<kModeEncrypt>(ctx, nunit_rung(ctx, rung), ctx->d_exp_n, r, ctx->pub.s1, nullptr, ctx->pub.s1, ctx->unit_tmp,
+                                      (int)w, batch, st, false, true);
 }
 
 int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch, void* stream) {
@@ -1259,16 +1271,16 @@ int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, 
     if (int rc = bind_device(ctx)) return rc;
     PHE_CTX_ORDER(ctx, stream);
     ctx->last_path = 0;
-    if (unit_power_offered(ctx, batch)) {
+    if (const int ur = unit_rung(ctx, batch); ur >= 0) {
         ctx->last_path = kPathUnit;
-        ctx->last_geom_pub = geom_code(ctx->d_nunit.G, ctx->d_nunit.L);
+        ctx->last_geom_pub = geom_code(nunit_rung(ctx, ur).G, nunit_rung(ctx, ur).L);
         // r^n modulo the scaled modulus n'^2 (no multiply per quotient digit), then ONE pass of the product kernel takes
         // the residue modulo n'^2 to (1 + n*m) * r^n mod n^2 (it accepts any a < R): the same canonical ciphertext
-        int rc = unit_power(ctx, r, batch, (hipStream_t)stream);
+        int rc = unit_power(ctx, ur, r, batch, (hipStream_t)stream);
         if (rc) return rc;
-        const size_t s1 = (size_t)ctx->pub.s1, s2 = (size_t)ctx->pub.s2, w = (size_t)ctx->pub.unit_words;
-        return launch_mul(ctx, ctx->d_nsq, ctx->unit_tmp, w, m, s1, c, s2, ctx->pub.s2, batch, (hipStream_t)stream, ctx->pub.s1, 0,
-                          ctx->pub.unit_words);
+        const size_t s1 = (size_t)ctx->pub.s1, s2 = (size_t)ctx->pub.s2, w = (size_t)unit_words_rung(ctx, ur);
+        return launch_mul(ctx, nsq_rung(ctx, ur), ctx->unit_tmp, w, m, s1, c, s2, ctx->pub.s2, batch, (hipStream_t)stream, ctx->pub.s1, 0,
+                          (int)w);
     }
     if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G) {
         ctx->last_geom_pub = geom_code(sp.G, sp.L);
@@ -1402,16 +1414,16 @@ int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t
     if (int rc = bind_device(ctx)) return rc;
     PHE_CTX_ORDER(ctx, stream);
     ctx->last_path = 0;
-    if (unit_power_offered(ctx, batch) && !getenv("PHE_HIP_FUSED_OBFUSCATE")) {
+    if (const int ur = unit_rung(ctx, batch); ur >= 0 && !getenv("PHE_HIP_FUSED_OBFUSCATE")) {
         ctx->last_path = kPathUnit;
-        ctx->last_geom_pub = geom_code(ctx->d_nunit.G, ctx->d_nunit.L);
+        ctx->last_geom_pub = geom_code(nunit_rung(ctx, ur).G, nunit_rung(ctx, ur).L);
         // r^n modulo the scaled modulus, then the product with the ciphertext brings it to n^2 (in-place calls included:
         // the power sits in its own buffer)
-        int rc = unit_power(ctx, r, batch, (hipStream_t)stream);
+        int rc = unit_power(ctx, ur, r, batch, (hipStream_t)stream);
         if (rc) return rc;
-        const size_t s2 = (size_t)ctx->pub.s2, w = (size_t)ctx->pub.unit_words;
-        return launch_mul(ctx, ctx->d_nsq, ctx->unit_tmp, w, c_in, s2, c_out, s2, ctx->pub.s2, batch, (hipStream_t)stream, 0, 0,
-                          ctx->pub.unit_words);
+        const size_t s2 = (size_t)ctx->pub.s2, w = (size_t)unit_words_rung(ctx, ur);
+        return launch_mul(ctx, nsq_rung(ctx, ur), ctx->unit_tmp, w, c_in, s2, c_out, s2, ctx->pub.s2, batch, (hipStream_t)stream, 0, 0,
+                          (int)w);
     }
     if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G) {
         ctx->last_geom_pub = geom_code(sp.G, sp.L);
