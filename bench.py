@@ -316,6 +316,9 @@ class HipBackend:
     def from_pair(self, ctx, pair, out, rows):
         ctx.from_pair_dev(pair.data_ptr(), None, out.data_ptr(), rows, self.stream)
 
+    def pair_powmod(self, ctx, a, e, bits, out, rows):
+        ctx.pair_powmod_dev(a.data_ptr(), e.data_ptr(), e.shape[1], bits, out.data_ptr(), rows, self.stream)
+
     def upload(self, arr):
         import numpy as np
         return self.torch.from_numpy(np.ascontiguousarray(arr).view(np.int32)).to(self.dev)
@@ -650,6 +653,25 @@ def main():
                 sc[:, :2] = be.np(be.take(e, idx))
                 return bool(np.array_equal(be.np(be.take(out, idx)), orc.mul(n_arr, ca_s(), sc, nthreads=cores)))
             ops_ok &= run_op(name, lambda k, e=e, bits=bits: be.powmod(ctx, c, e, bits, out, k), 3 if be.name == "hip" else 1, check)
+        if hasattr(be, "pair_powmod") and hasattr(ctx, "pair_powmod_dev") and getattr(ctx, "pair_words", lambda: 0)():
+            # the same 56-bit scalar multiplication on rows that are resident in the pair form, result in the pair form: no
+            # conversion in, no exit (include/phe_hip.h phe_hip_pair_powmod_dev).  Checked by leaving the form once, outside
+            # the timed passes: every row must equal what the plain raw_mul_float56 gave (already checked against libgmp).
+            pw = ctx.pair_words()
+            pc, pout = be.empty(B, pw), be.empty(B, pw)
+            be.to_pair(ctx, c, pc, B)
+            e56 = scal["raw_mul_float56"]
+            ref = be.empty(B, s2)
+            be.powmod(ctx, c, e56, 56, ref, B)
+
+            def check_pair_mul():
+                be.from_pair(ctx, pout, out, B)
+                be.sync()
+                return be.equal(out, ref)
+            ops_ok &= run_op("raw_mul_float56_resident_pair_form", lambda k: be.pair_powmod(ctx, pc, e56, 56, pout, k), 3, check_pair_mul,
+                             "rows resident in the pair form, result in the pair form; check = every row, converted back, equals "
+                             "raw_mul_float56's (itself sampled against libgmp)")
+            del pc, pout, ref
         # 10 % negative scalars: those rows take invert(c, n^2) as the base and n - s as the exponent (phe/paillier.py:745-749);
         # composed as Engine.raw_mul_signed_dev composes it: one simultaneous inversion of the vector, a per-row select, one powmod
         e = scal["raw_mul_float56"]

@@ -214,6 +214,10 @@ int phe_hip_mont_radix_bits(phe_hip_ctx* ctx, int* bits);
  *   phe_hip_from_pair_dev : pair rows -> the canonical residue mod n^2, bit-identical to what the chain of _raw_add returns;
  *                           with m != NULL (plaintexts, (batch, n_limbs)) the residue of x * (1 + n*m): raw_encrypt(m, r)
  *                           from r^n kept in the pair form (phe/paillier.py:134-139), or adding a plaintext (:673-675).
+ *   phe_hip_pair_powmod_dev : out[i] = a[i]^e[i] (pair rows in and out; e: (batch, exp_limbs) words, max_exp_bits as for
+ *                           phe_hip_powmod_dev): EncryptedNumber.__mul__ / _raw_mul by a non-negative scalar
+ *                           (phe/paillier.py:721-751) on resident rows, without the conversion in and the exit that
+ *                           phe_hip_powmod_dev pays per element (6 % of a 56-bit scalar multiplication).
  * The contents of a pair row are NOT canonical (lazy reduction): compare ciphertexts only after from_pair.
  * EINVAL without the split-modulus engine (PHE_HIP_ENGINE=full or a key width it has no kernel for). */
 int phe_hip_pair_words(const phe_hip_ctx* ctx, int* words);
@@ -221,6 +225,8 @@ int phe_hip_to_pair_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* pair, siz
 int phe_hip_pair_mul_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, int b_is_row, uint32_t* out, size_t batch,
                          void* stream);
 int phe_hip_from_pair_dev(phe_hip_ctx* ctx, const uint32_t* pair, const uint32_t* m, uint32_t* c, size_t batch, void* stream);
+int phe_hip_pair_powmod_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* e, int exp_limbs, int max_exp_bits, uint32_t* out,
+                            size_t batch, void* stream);
 /* out (ONE pair row) = the product of all `batch` pair rows: the homomorphic sum of a resident vector — sum(enc_list) in
  * the reference is a chain of _raw_add (phe/paillier.py:705-719); the product of residues is independent of the order —
  * as a pairwise tree of log2(batch) launches queued back to back on `stream`, no host round trip between the levels. */

@@ -706,8 +706,9 @@ static int launch_split_ab(phe_hip_ctx* ctx, int mode, const DevSplit& Mp, const
 
 static int launch_var_split(phe_hip_ctx* ctx, const DevSplit& M, const uint32_t* base, int base_limbs,
                             const uint32_t* e, int exp_limbs, int max_bits, uint32_t* out, int out_limbs, size_t batch,
-                            hipStream_t stream) {
+                            hipStream_t stream, bool pair_io = false) {
     SplitVarArgs A;
+    A.pair_io = pair_io ? 1 : 0;
     A.mod = M.c;
     A.base = base;
     A.base_limbs = base_limbs;
@@ -1602,6 +1603,22 @@ int phe_hip_pair_mul_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b,
     if (int rc = bind_device(ctx)) return rc;
     PHE_CTX_ORDER(ctx, stream);
     return pair_launch(ctx, 2, a, b, b_is_row ? 0 : (size_t)2 * ctx->d_nsplit.H, 0, out, batch, (hipStream_t)stream);
+}
+
+// out[i] = a[i]^e[i] on rows in the pair form (both): _raw_mul of resident vectors (phe/paillier.py:751) without the conversion
+// into the pair form and the exit from it that phe_hip_powmod_dev pays per element
+int phe_hip_pair_powmod_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* e, int exp_limbs, int max_exp_bits, uint32_t* out,
+                            size_t batch, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (batch == 0) return PHE_HIP_OK;
+    if (!a || !e || !out || exp_limbs < 1) return fail(PHE_HIP_EINVAL, "null buffer / exp_limbs");
+    if (max_exp_bits <= 0 || max_exp_bits > 32 * exp_limbs) max_exp_bits = 32 * exp_limbs;
+    if (int rc = bind_device(ctx)) return rc;
+    if (!(ctx->use_split && ctx->d_nsplit.G)) return fail(PHE_HIP_EINVAL, "the pair form needs the split-modulus engine");
+    PHE_CTX_ORDER(ctx, stream);
+    const DevSplit& sp = pick_pair_split(ctx, batch);
+    ctx->last_geom_pub = geom_code(sp.G, sp.L);
+    return launch_var_split(ctx, sp, a, 0, e, exp_limbs, max_exp_bits, out, 0, batch, (hipStream_t)stream, true);
 }
 
 // out = the product of all `batch` pair rows (one pair row): the pairwise tree of EncryptedVector.sum() — sum(enc_list) in the

@@ -1303,9 +1303,11 @@ struct SplitVarArgs {
     int out_limbs;
     uint32_t* table;  // scratch: total_groups * 2^w * 2H words
     uint64_t batch;
+    int pair_io;      // 1: base and out are rows in the pair form (2H limbs each, "resident rows in the pair form"): no conversion
+                      // in (13 H^2 multiply-adds) and no exit (8 H^2) — the PAIR instantiation of the kernel
 };
 
-template <int G, int L>
+template <int G, int L, bool PAIR = false>
 PHE_DEV void modexp_var_split_body(const SplitVarArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots,
                                    uint32_t lane) {
     constexpr int H = G * L, S2 = 2 * H;
@@ -1325,7 +1327,12 @@ PHE_DEV void modexp_var_split_body(const SplitVarArgs& A, uint32_t* lds_row, uin
         const bool live = item < A.batch;
         if (!live) item = A.batch - 1;
         uint32_t X0[L], X1[L], Y0[L], Y1[L];
-        split_conv<G, L>(Y0, Y1, A.base + item * (uint64_t)A.base_limbs, A.base_limbs, A.base_chunks, A.mod, K, ln);
+        if constexpr (PAIR) {
+            load_row<L>(Y0, A.base + item * (uint64_t)S2, g);
+            load_row<L>(Y1, A.base + item * (uint64_t)S2 + H, g);
+        } else {
+            split_conv<G, L>(Y0, Y1, A.base + item * (uint64_t)A.base_limbs, A.base_limbs, A.base_chunks, A.mod, K, ln);
+        }
         // table: base^0 (the pair of 1) .. base^(2^w - 1)
         load_row<L>(X0, wave::reread_ptr(A.mod.e), g);
         load_row<L>(X1, wave::reread_ptr(A.mod.e) + H, g);
@@ -1360,7 +1367,14 @@ PHE_DEV void modexp_var_split_body(const SplitVarArgs& A, uint32_t* lds_row, uin
                 split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
             }
         }
-        split_exit<G, L>(A.out + item * (uint64_t)A.out_limbs, A.out_limbs, X0, X1, nullptr, 0, A.mod, K, ln, live);
+        if constexpr (PAIR) {
+            if (live) {
+                store_row<L>(A.out + item * (uint64_t)S2, X0, g);
+                store_row<L>(A.out + item * (uint64_t)S2 + H, X1, g);
+            }
+        } else {
+            split_exit<G, L>(A.out + item * (uint64_t)A.out_limbs, A.out_limbs, X0, X1, nullptr, 0, A.mod, K, ln, live);
+        }
     }
 }
 

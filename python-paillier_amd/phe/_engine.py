@@ -649,6 +649,16 @@ class Engine:
         self.ctx.sync()
         return out
 
+    def pair_mul_scalars_dev(self, pair, mag):
+        """row-wise power a[i]^mag[i] of a pair-form vector, the result in pair form: _raw_mul by non-negative scalars on resident
+        rows, without the conversion in and the exit of powmod_dev"""
+        exps, bits = self._mag_limbs(mag)
+        e = DeviceArray.from_host(self.ctx, exps)
+        out = DeviceArray(self.ctx, pair.rows, pair.cols)
+        self.ctx.pair_powmod_dev(pair.ptr, e.ptr, exps.shape[1], bits, out.ptr, pair.rows)
+        self.ctx.sync()
+        return out
+
     def pair_reduce_dev(self, pair):
         """the product of all rows of a pair-form vector as one pair row (the tree of EncryptedVector.sum, one call)"""
         out = DeviceArray(self.ctx, 1, pair.cols)

@@ -98,6 +98,7 @@ def lib():
         L.phe_hip_pair_mul_dev.argtypes = [vp, vp, vp, ci, vp, sz, vp]
         L.phe_hip_from_pair_dev.argtypes = [vp, vp, vp, vp, sz, vp]
         L.phe_hip_pair_reduce_dev.argtypes = [vp, vp, sz, vp, vp]
+        L.phe_hip_pair_powmod_dev.argtypes = [vp, vp, vp, ci, ci, vp, sz, vp]
         _lib = L
     return _lib
 
@@ -117,6 +118,7 @@ EXPORTED_SYMBOLS = [
     "phe_hip_encrypt_owner", "phe_hip_encrypt_owner_dev", "phe_hip_ctx_owner_encrypt",
     "phe_hip_ctx_ladder", "phe_hip_ctx_set_group", "phe_hip_ctx_last_launch", "phe_hip_ctx_release_scratch",
     "phe_hip_pair_words", "phe_hip_to_pair_dev", "phe_hip_pair_mul_dev", "phe_hip_from_pair_dev", "phe_hip_pair_reduce_dev",
+    "phe_hip_pair_powmod_dev",
 ]
 
 
@@ -300,6 +302,9 @@ class Context:
 
     def from_pair_dev(self, pair_ptr, m_ptr, c_ptr, batch, stream=0):
         _check(lib().phe_hip_from_pair_dev(self._h, pair_ptr, m_ptr, c_ptr, batch, stream))
+
+    def pair_powmod_dev(self, a_ptr, e_ptr, exp_limbs, max_exp_bits, out_ptr, batch, stream=0):
+        _check(lib().phe_hip_pair_powmod_dev(self._h, a_ptr, e_ptr, exp_limbs, max_exp_bits, out_ptr, batch, stream))
 
     def pair_reduce_dev(self, pair_ptr, batch, out_ptr, stream=0):
         _check(lib().phe_hip_pair_reduce_dev(self._h, pair_ptr, batch, out_ptr, stream))

@@ -487,6 +487,10 @@ class EncryptedVector(object):
         signed = EncodedNumber.encode_signed(values) if eng.n_limbs >= 4 else None
         if signed is not None:
             mag, neg, exps = signed
+            if self.on_device and self._pair and eng.pair_form() and not neg.any() and hasattr(eng, "pair_mul_scalars_dev"):
+                # rows in the engine's pair form and no negative scalar (those take invert(c), phe/paillier.py:745-749, which
+                # wants residues): the powers stay in the pair form — no conversion in, no exit
+                return EncryptedVector(pk, eng.pair_mul_scalars_dev(self._store, mag), self._exps + exps, _pair=True)
             limbs = eng.raw_mul_signed_dev(self._limbs, mag, neg) if self.on_device else eng.raw_mul_signed(self._limbs, mag, neg)
             return self._like(limbs, self._exps + exps)
         if isinstance(values, np.ndarray) or not any(isinstance(v, EncodedNumber) for v in values):

@@ -235,7 +235,7 @@ static void run_split_ab(SplitArgs A) {
 static int g_wave_tail = 0;   // 1: the CRT tail of a decrypt runs one ciphertext per wavefront (the library's choice for small batches)
 static int g_wave_pairs = 0;  // 1: whole-wave geometry runs every exponentiation on a wave pair (the library's choice for a handful of numbers)
 
-template <int G, int L>
+template <int G, int L, bool PAIR = false>
 static void run_var_split(SplitVarArgs A) {
     constexpr int S2 = 2 * G * L, kPer = 64 / G;
     const int n_waves = waves_for(A.batch, G);
@@ -246,7 +246,7 @@ static void run_var_split(SplitVarArgs A) {
         std::vector<uint32_t> lds(kPer * (S2 + kLdsPad));
         wave::run_wave([&](uint32_t lane) {
             const uint32_t grp = lane / G;
-            modexp_var_split_body<G, L>(A, lds.data() + grp * (S2 + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
+            modexp_var_split_body<G, L, PAIR>(A, lds.data() + grp * (S2 + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
         });
     }
 }
@@ -752,6 +752,35 @@ int emu_pair_op(const uint32_t* n, int n_limbs, int op, int group, const uint32_
         A.b_limbs = (op == 1 && b) ? P0.s1 : 0;
         A.batch = B;
         DISPATCH_SPLIT(M.G, M.L, (run_pair<GG, LL>(op, A)));
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+// out[i] = a[i]^exps[i] on pair-form rows (phe_hip_pair_powmod_dev); group as in emu_pair_op
+int emu_pair_powmod(const uint32_t* n, int n_limbs, int group, const uint32_t* a, const uint32_t* exps, int exp_limbs, uint32_t* out,
+                    uint64_t B) {
+    try {
+        const host::PublicPlan P0 = host::build_public(n, n_limbs, 0);
+        if (!P0.nsplit.G) return 2;
+        if (B == 0) return 0;
+        host::SplitPack M = P0.nsplit;
+        if (group > 0) {
+            M = host::build_public(n, n_limbs, group).nsplit;
+            if (M.G == 0 || M.G == 64 || M.H != P0.nsplit.H || M.rows != M.H) return 2;
+        }
+        int max_bits = 1;
+        for (uint64_t i = 0; i < B; ++i)
+            max_bits = std::max(max_bits, host::big_bits(host::big_from(exps + i * exp_limbs, exp_limbs, exp_limbs)));
+        SplitVarArgs A;
+        memset(&A, 0, sizeof A);
+        A.pair_io = 1;
+        A.mod = split_consts_of(M);
+        A.base = a;
+        A.exps = exps; A.exp_limbs = exp_limbs;
+        A.window = host::pick_window(max_bits);
+        A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);
+        A.out = out; A.batch = B;
+        DISPATCH_SPLIT(M.G, M.L, (run_var_split<GG, LL, true>(A)));
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }

@@ -142,6 +142,17 @@ class Emu:
         self._ck(rc)
         return out
 
+    def pair_powmod(self, n, a, exps, group=0):
+        """a[i]^exps[i] on pair-form rows, pair form out (phe_hip_pair_powmod_dev); None where pair_op gives None"""
+        a = np.ascontiguousarray(a, np.uint32)
+        exps = np.ascontiguousarray(exps, np.uint32)
+        out = np.zeros_like(a)
+        rc = self.L.emu_pair_powmod(P(n), n.shape[0], group, P(a), P(exps), exps.shape[1], P(out), ctypes.c_uint64(a.shape[0]))
+        if rc == 2:
+            return None
+        self._ck(rc)
+        return out
+
     def powmod_n2(self, n, base, exps):
         """base^exp mod n^2 the way phe_hip_powmod runs it (split-modulus kernel when the engine is on)"""
         out = np.zeros_like(base)

@@ -411,6 +411,23 @@ def test_pair_form_entry_points(native, c_oracle, key_bits, batch):
     for i in idx.tolist():
         av, mv = native.limbs_to_ints(a[i:i + 1])[0], native.limbs_to_ints(m[i:i + 1])[0]
         assert native.limbs_to_ints(got[i:i + 1])[0] == av * b0 % n2 * (1 + n_int * (mv % n_int)) % n2, i
+    # scalar multiplication that stays in the form: a[i]^k[i] (56-bit scalars, some 0 / 1 / 2^56 - 1) against libgmp's powmod
+    k = rs.integers(0, 1 << 32, size=(batch, 2), dtype=np.uint32)
+    k[:, 1] &= 0x00ffffff
+    k[0], k[1], k[2] = 0, (1, 0), (0xffffffff, 0x00ffffff)
+    dk = DeviceArray.from_host(ctx, k)
+    ctx.pair_powmod_dev(pa.ptr, dk.ptr, 2, 56, prod.ptr, batch)
+    ctx.from_pair_dev(prod.ptr, None, out.ptr, batch)
+    ctx.sync()
+    sc = np.zeros((len(idx), s1), np.uint32)
+    sc[:, :2] = k[idx]
+    assert np.array_equal(out.to_host()[idx], c_oracle.mul(n, a_red[idx], sc, nthreads=8))
+    plain_pow = DeviceArray(ctx, batch, s2)                            # the same through plain residues in and out
+    ctx.from_pair_dev(pa.ptr, None, out.ptr, batch)
+    ctx.powmod_dev(out.ptr, dk.ptr, 2, 56, plain_pow.ptr, batch)
+    ctx.from_pair_dev(prod.ptr, None, out.ptr, batch)
+    ctx.sync()
+    assert np.array_equal(out.to_host(), plain_pow.to_host())
     # the tree: product of all rows
     root = DeviceArray(ctx, 1, words)
     ctx.pair_reduce_dev(pb.ptr, batch, root.ptr)
@@ -459,6 +476,15 @@ def test_encrypted_vector_in_pair_form(native):
     assert priv.decrypt_batch(v) == xs.tolist()
     fresh = pub.encrypt_batch(ys[:1000], device=True)                      # from the pool (pair form) with the plaintext folded in
     assert pub.obfuscators_available() == 0 and priv.decrypt_batch(fresh) == ys[:1000].tolist()
+    # multiplication by non-negative scalars stays in the pair form (negative ones take the inverse branch on residues)
+    w = (np.arange(5000, dtype=np.int64) % 97) * 12345
+    scaled = a.to_pair() * w
+    assert scaled._pair
+    plain_scaled = a * w
+    assert scaled.ciphertexts(False) == plain_scaled.ciphertexts(False)
+    assert priv.decrypt_batch(scaled) == (xs * w).tolist()
+    signed = a.to_pair() * (w - 500)
+    assert not signed._pair and priv.decrypt_batch(signed) == (xs * (w - 500)).tolist()
 
 
 def test_integration_stub_of_section_b_runs(native, c_oracle):

@@ -93,3 +93,35 @@ def test_golden_raw_add_through_the_pair_form(emu):
     rn = [pow(H(e["r"]), n, n * n) for e in enc]
     got = ints(emu.pair_op(n_arr, 1, emu.pair_op(n_arr, 0, limbs(rn, 2 * s1)), limbs([H(e["m"]) % (1 << (32 * s1)) for e in enc], s1)))
     assert got == [H(e["c"]) for e in enc]
+
+
+@pytest.mark.parametrize("bits", [256, 1024, 2048])
+def test_scalar_multiplication_stays_in_the_pair_form(emu, bits):
+    """modexp_var_split_body<G, L, PAIR> (phe_hip_pair_powmod_dev): a[i]^k[i] on pair rows, pair rows out — _raw_mul by
+    non-negative scalars (phe/paillier.py:721-751: powmod(c, k, nsquare)) without the conversion in and the exit.  The golden
+    raw_mul vectors of the reference whose scalar takes the direct branch, then random ciphertexts with scalars 0, 1, 2, 2^56 - 1
+    and 64-bit ones; on the wider rung that shares the rows' limb count as well."""
+    g = load_golden(bits)
+    n = H(g["n"])
+    n2, s1 = n * n, (n.bit_length() + 31) // 32
+    n_arr = limbs([n], s1)[0]
+    rng = random.Random(bits + 5)
+    cs = [rng.randrange(1, n2) for _ in range(7)]
+    ks = [0, 1, 2, (1 << 56) - 1, rng.getrandbits(64), rng.getrandbits(53), 3]
+    want = [pow(c, k, n2) for c, k in zip(cs, ks)]
+    # the reference's own _raw_mul vectors whose scalar takes the direct branch (s < n - max_int: powmod(c, s, nsquare))
+    direct = [e for e in g["raw_mul"] if H(e["s"]) < n - H(g["max_int"])][:6]
+    assert direct
+    pg = emu.pair_op(n_arr, 0, limbs([H(e["c"]) for e in direct], 2 * s1))
+    outg = emu.pair_powmod(n_arr, pg, limbs([H(e["s"]) for e in direct], s1))
+    assert ints(emu.pair_op(n_arr, 1, outg)) == [H(e["out"]) for e in direct]
+    pa = emu.pair_op(n_arr, 0, limbs(cs, 2 * s1))
+    out = emu.pair_powmod(n_arr, pa, limbs(ks, 2))
+    assert out is not None and ints(emu.pair_op(n_arr, 1, out)) == want
+    # a chain that never leaves the form: (c^k) * c2, then ^3
+    pb = emu.pair_op(n_arr, 0, limbs(cs[::-1], 2 * s1))
+    chain = emu.pair_powmod(n_arr, emu.pair_op(n_arr, 2, out, pb), limbs([3] * len(cs), 1))
+    assert ints(emu.pair_op(n_arr, 1, chain)) == [pow(w * c2 % n2, 3, n2) for w, c2 in zip(want, cs[::-1])]
+    if bits == 2048:
+        out8 = emu.pair_powmod(n_arr, pa, limbs(ks, 2), group=8)
+        assert out8 is not None and ints(emu.pair_op(n_arr, 1, out8)) == want
