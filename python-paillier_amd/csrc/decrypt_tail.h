@@ -3,7 +3,7 @@
 // Reference: phe/paillier.py:346-354 (raw_decrypt), :362-364 (l_function), :366-374 (crt).
 // Input are x_p = c^(p-1) mod p^2 and x_q = c^(q-1) mod q^2 from the two half-exponentiation
 // launches (mont_core.h, kModeHalfDecrypt).  Per ciphertext:
-//     L_p = (x_p - 1) / p                      exact division -> multiply by p^-1 mod W^h, low half
+//     L_p = (x_p - 1) / p                      exact division -> multiply by p^-1 mod W^h, low half (x_p = 0: -1, tail_l_function)
 //     m_p = L_p * hp mod p                     one h-limb Montgomery product against hp*W^h mod p
 //     (same for q)
 //     u   = (m_q - m_p) * p^-1 mod q           m_p < p < q, so one conditional +q fixes the sign
@@ -67,6 +67,21 @@ PHE_DEV void tail_exact_div(const TailWs& ws, int out, int tmp, const uint32_t* 
     }
 }
 
+// l_function (phe/paillier.py:362-364: (x - 1) // p) for x = c^(p-1) mod p^2.  A ciphertext coprime to p gives x = 1 (mod p)
+// and the division is exact; one that is NOT (c = 0, a multiple of p: nothing a holder of the public key can produce without
+// knowing a factor of n, but the reference returns a value for it) gives x = 0, and the reference's floor division gives -1:
+// out = p - 1 then, which the Montgomery product by hp turns into -hp mod p like the reference's (-1 * hp) % p.
+PHE_DEV void tail_l_function(const TailWs& ws, int out, int tmp, const uint32_t* x, int x_words, const uint32_t* p,
+                             const uint32_t* pinv, int h) {
+    uint32_t any = 0;
+    for (int i = 0; i < x_words; ++i) any |= x[i];
+    if (any == 0) {
+        for (int i = 0; i < h; ++i) ws(out, i) = p[i] - (i == 0 ? 1u : 0u);  // p is odd: no borrow
+        return;
+    }
+    tail_exact_div(ws, out, tmp, x, pinv, h);
+}
+
 // out = a * b * W^-h mod n   (acc: h+2 words; a in ws, b and n in global memory; a < W^h, b < n)
 PHE_DEV void tail_montmul(const TailWs& ws, int out, int acc, int a, const uint32_t* b, const uint32_t* n,
                           uint32_t n0inv, int h) {
@@ -114,10 +129,10 @@ PHE_DEV void decrypt_tail_one(const TailArgs& A, const TailWs& ws, uint64_t item
     const uint32_t* xp = A.xp + item * (uint64_t)A.x_stride;
     const uint32_t* xq = A.xq + item * (uint64_t)A.x_stride;
     // m_p
-    tail_exact_div(ws, TA, ACC, xp, A.k.pinvw, h);
+    tail_l_function(ws, TA, ACC, xp, A.x_stride, A.k.p, A.k.pinvw, h);
     tail_montmul(ws, MP, ACC, TA, A.k.hp_r, A.k.p, A.k.p0inv, h);
     // m_q
-    tail_exact_div(ws, TA, ACC, xq, A.k.qinvw, h);
+    tail_l_function(ws, TA, ACC, xq, A.x_stride, A.k.q, A.k.qinvw, h);
     tail_montmul(ws, MQ, ACC, TA, A.k.hq_r, A.k.q, A.k.q0inv, h);
     // d = (m_q - m_p) mod q
     uint32_t borrow = 0;

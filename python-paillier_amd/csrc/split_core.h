@@ -1672,6 +1672,13 @@ PHE_DEV void decrypt_tail_wave_body(const TailWaveArgs& A, uint32_t* lds, uint64
                           const uint32_t* h_row) {
         uint32_t a[L], t[L], cst[L], hi[L];
         load_u32_as_r29<L>(a, x, A.x_stride, 0, g, rows);  // x mod R
+        load_u32_as_r29<L>(t, x, A.x_stride, rows, g, rows);  // the rest of x: only to see whether x is zero
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < L; ++k) any |= a[k] | t[k];
+        // x = 0: a ciphertext that is a multiple of this prime (decrypt_tail.h tail_l_function): the reference's floor
+        // division gives (0 - 1) // n = -1, i.e. n - 1 modulo n
+        const bool x_is_zero = wave::ballot(any != 0u) == 0ull;
 #pragma unroll
         for (int k = 0; k < L; ++k) t[k] = in[k] ? kLimbMask : 0u;
         add_normalize<G, L>(a, t, ln);  // + (R - 1): x - 1 modulo R ...
@@ -1680,6 +1687,11 @@ PHE_DEV void decrypt_tail_wave_body(const TailWaveArgs& A, uint32_t* lds, uint64
         lds_put<L>(row_a, a, g);
         load_row<L>(cst, ninv_row, g);
         mul_wide<G, L>(hi, row_a, cst, zero, row_lo, ln, rows);  // row_lo: (x - 1) * n^-1 mod R = (x - 1) / n, canonical digits
+        if (x_is_zero) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) cst[k] = n[k] - ((g == 0u && k == 0) ? 1u : 0u);  // n is odd: no borrow
+            lds_put<L>(row_lo, cst, g);
+        }
         wave::lds_fence();
         load_row<L>(cst, h_row, g);
         montmul<G, L>(out, row_lo, cst, n, n0inv, ln, rows);

@@ -349,7 +349,20 @@ def test_decrypt_tail_on_one_wave_per_ciphertext(emu, key_bits):
         for m in (0, 1, n - 1, n - 2):                                  # edge plaintexts: c = (1 + n*m) * 2^n
             cts.append((1 + n * m) * pow(2, n, N) % N)
             want.append(m)
-        assert limbs_to_ints(emu.decrypt(*key, s1, ints_to_limbs(cts, s2))) == want
+        # "ciphertexts" that share a factor with n (c^(p-1) mod p^2 = 0): the reference's l_function floors (0 - 1) // p to -1
+        p, q = H(g["p"]), H(g["q"])
+
+        def reference_value(c):                                         # phe/paillier.py:346-374 on Python integers
+            mp = (pow(c, p - 1, p * p) - 1) // p * H(g["hp"]) % p
+            mq = (pow(c, q - 1, q * q) - 1) // q * H(g["hq"]) % q
+            return mp + (mq - mp) * H(g["p_inverse"]) % q * p
+        for c in (0, p, 3 * p, q, n, 7 * n, p * p, N - p):
+            cts.append(c)
+            want.append(reference_value(c))
+        got = limbs_to_ints(emu.decrypt(*key, s1, ints_to_limbs(cts, s2)))
+        assert got == want
+        emu.set_wave_tail(False)                                        # ... and the one-ciphertext-per-thread tail agrees
+        assert limbs_to_ints(emu.decrypt(*key, s1, ints_to_limbs(cts[-8:], s2))) == want[-8:]
     finally:
         emu.set_wave_tail(False)
 

@@ -222,6 +222,9 @@ def test_crt_tail_on_one_wavefront_per_ciphertext(native, c_oracle, key_bits, mo
     cts = [H(e["c"]) for e in g["raw_decrypt"]] + [(1 + n_int * m) * pow(3, n_int, N) % N for m in edge]
     want = [H(e["m"]) for e in g["raw_decrypt"]] + edge
     cts += [rng.randrange(1, N) for _ in range(40)]                # not ciphertexts of anything: whatever libgmp's arithmetic gives
+    p_int, q_int = H(g["p"]), H(g["q"])
+    # ... and some that share a factor with n (c^(p-1) mod p^2 = 0: the reference's l_function floors (0 - 1) // p to -1)
+    cts += [0, p_int, 3 * p_int, q_int, n_int, 7 * n_int, p_int * p_int, N - p_int]
     c = native.ints_to_limbs(cts, s2)
     for batch in (1, 3, len(cts)):
         got = ctx.decrypt(c[:batch])

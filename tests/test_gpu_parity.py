@@ -133,8 +133,13 @@ def test_random_batches_vs_gmp_oracle(native, c_oracle, key_bits, batch, group):
     c = ctx.encrypt(m, r)
     assert np.array_equal(c, c_oracle.encrypt(n, m, r, nthreads=8))
     assert np.array_equal(ctx.decrypt(c), m)
-    junk = native.ints_to_limbs([rng.randrange(1, n_int * n_int) for _ in range(batch)], s2)
+    p_int, q_int = H(g["p"]), H(g["q"])
+    # not ciphertexts of anything — and a few that share a factor with n (l_function then floors (0 - 1) // p to -1)
+    junk = native.ints_to_limbs([0, p_int, 5 * q_int, n_int, n_int * n_int - q_int] +
+                                [rng.randrange(1, n_int * n_int) for _ in range(batch - 5)], s2)
     assert np.array_equal(ctx.decrypt(junk), c_oracle.decrypt(n, p, q, junk, nthreads=8))
+    big_junk = np.tile(junk, (5000 // batch + 1, 1))                 # beyond the small-batch tail: one ciphertext per thread
+    assert np.array_equal(ctx.decrypt(big_junk)[:batch], c_oracle.decrypt(n, p, q, junk, nthreads=8))
     assert np.array_equal(ctx.mulmod(c, junk), c_oracle.add(n, c, junk, nthreads=8))
     scal = native.ints_to_limbs([rng.getrandbits(rng.choice([1, 8, 27, 56, 64, 130])) for _ in range(batch)], s1)
     assert np.array_equal(ctx.powmod(c, scal), c_oracle.mul(n, c, scal, nthreads=8))
