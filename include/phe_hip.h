@@ -138,7 +138,9 @@ int phe_hip_add_plain(phe_hip_ctx* ctx, const uint32_t* c, const uint32_t* m, ui
 /* out[i] = base[i]^e[i] mod n^2             — the powmod of EncryptedNumber._raw_mul,
  * phe/paillier.py:749/:751 (= phe.util.powmod, phe/util.py:38-50).  base: (batch, ct_limbs) < n^2;
  * e: (batch, exp_limbs).  The negative-scalar branch (:745-749) is composed by the host from
- * phe_hip_invert + this function, partitioned on the same threshold n - max_int. */
+ * phe_hip_invert + this function, partitioned on the same threshold n - max_int.  A handful of numbers (the scalar
+ * EncryptedNumber.__mul__ is a batch of one) run each on a pair of wavefronts with a sliding-window schedule of its own
+ * exponent, which this entry point — it sees the exponents — makes on the host; phe_hip_powmod_dev takes fixed windows. */
 int phe_hip_powmod(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, uint32_t* out,
                    size_t batch);
 

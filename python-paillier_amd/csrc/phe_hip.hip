@@ -375,6 +375,8 @@ struct phe_hip_ctx {
     size_t table2_words = 0;
     uint32_t* lookup = nullptr;  // multi-exponentiation: the 2^w-ary tables of a whole vector (phe_hip_multiexp_csr_dev)
     size_t lookup_words = 0;
+    uint32_t* item_sched = nullptr;  // per-number exponent schedules of a small phe_hip_powmod (ops of all numbers | 4 words of meta each)
+    size_t item_sched_words = 0;
     uint32_t* partial = nullptr;  // multi-exponentiation: one product per chunk, joined in place by a k_mulmod tree
     size_t partial_words = 0;
     // encryption by the key owner (CRT lift): K*R, (q^2 - K)*R mod q^2 and p^2 as rows of d_qsq.S limbs; null = not offered
@@ -616,6 +618,7 @@ static int prepare_split(phe_hip_ctx* ctx, const DevSplit& M, const DevSchedule&
     A.out_limbs = out_limbs;
     A.table = *tbl;
     A.batch = batch;
+    A.item_meta = nullptr;
     return PHE_HIP_OK;
 }
 
@@ -668,7 +671,7 @@ static bool ab_offered(const phe_hip_ctx* ctx, const DevSplit& M, size_t batch, 
 }
 static int launch_split_ab(phe_hip_ctx* ctx, int mode, const DevSplit& Mp, const DevSchedule& Ep, const DevSplit* Mq, const DevSchedule* Eq,
                            const uint32_t* base, int base_limbs, const uint32_t* post, int post_limbs, uint32_t* out_p, uint32_t* out_q,
-                           int out_limbs, size_t batch, hipStream_t stream) {
+                           int out_limbs, size_t batch, hipStream_t stream, const uint32_t* item_meta = nullptr) {
     const int halves = Mq ? 2 : 1;
     if (Mp.q_L == 0 || (Mq && Mq->q_L != Mp.q_L)) return fail(PHE_HIP_EINVAL, "the two halves need one wave-pair geometry");
     SplitArgs Ap, Aq;
@@ -692,6 +695,7 @@ static int launch_split_ab(phe_hip_ctx* ctx, int mode, const DevSplit& Mp, const
         A.out_limbs = out_limbs;
         A.table = *tbl;
         A.batch = batch;
+        A.item_meta = item_meta;
         return PHE_HIP_OK;
     };
     int rc = fill(Ap, Mp, Ep, out_p, false);
@@ -1155,7 +1159,7 @@ void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
     std::vector<uint32_t*> bufs = {ctx->d_nsplit.blob, ctx->d_psplit.blob, ctx->d_qsplit.blob,
                         ctx->d_nsq.blob, ctx->d_psq.blob, ctx->d_qsq.blob, ctx->d_exp_n.ops, ctx->d_exp_p.ops,
                         ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->table2, ctx->scratch, ctx->partial, ctx->lookup, (uint32_t*)ctx->flags, ctx->stage[0],
-                        ctx->stage[1], ctx->stage[2], ctx->owner_blob, ctx->d_nunit.blob, ctx->unit_tmp, ctx->tail_wave_blob};
+                        ctx->stage[1], ctx->stage[2], ctx->owner_blob, ctx->d_nunit.blob, ctx->unit_tmp, ctx->tail_wave_blob, ctx->item_sched};
     for (const auto& R : ctx->pub_rungs) { bufs.push_back(R.nsq.blob); bufs.push_back(R.nsplit.blob); bufs.push_back(R.nunit.blob); }
     for (const auto& R : ctx->priv_rungs) { bufs.push_back(R.psq.blob); bufs.push_back(R.qsq.blob); bufs.push_back(R.psplit.blob); bufs.push_back(R.qsplit.blob); }
     for (uint32_t* b : bufs)
@@ -2120,8 +2124,52 @@ int phe_hip_powmod(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, in
     if (max_bits == 0) max_bits = 1;
     const size_t s2 = (size_t)ctx->pub.s2;
     int rc = stage_in(ctx, 0, base, batch * s2);
-    if (!rc) rc = stage_in(ctx, 1, e, batch * (size_t)exp_limbs);
     if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
+    if (rc) return rc;
+    // A handful of numbers (EncryptedNumber.__mul__, one at a time): the exponents are on the host here, so every number gets
+    // its OWN sliding-window schedule and runs on a pair of wavefronts like a scalar encrypt / decrypt does (the per-element
+    // kernel takes fixed windows over the longest exponent on one wave per number).  A zero exponent keeps the general path.
+    if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G == 64 && ab_offered(ctx, sp, batch, 1)) {
+        std::vector<uint32_t> blob, meta;
+        DevSchedule E;
+        E.n_ops = 0;
+        E.tbl_entries = 1;
+        bool ok = true;
+        for (size_t i = 0; i < batch && ok; ++i) {
+            const Big ei = host::big_from(e + i * (size_t)exp_limbs, exp_limbs, exp_limbs);
+            if (host::big_bits(ei) == 0) {
+                ok = false;
+                break;
+            }
+            const host::Schedule S = host::build_schedule(ei);
+            meta.push_back((uint32_t)S.ops.size());
+            meta.push_back((uint32_t)S.first_idx);
+            meta.push_back((uint32_t)S.tbl_entries);
+            meta.push_back((uint32_t)blob.size());
+            blob.insert(blob.end(), S.ops.begin(), S.ops.end());
+            E.n_ops = std::max(E.n_ops, (int)S.ops.size());
+            E.tbl_entries = std::max(E.tbl_entries, S.tbl_entries);
+        }
+        if (ok) {
+            const size_t ops_words = std::max<size_t>(1, blob.size());
+            blob.resize(ops_words);
+            blob.insert(blob.end(), meta.begin(), meta.end());
+            rc = ensure_words(&ctx->item_sched, &ctx->item_sched_words, blob.size());
+            if (rc) return rc;
+            HIP_TRY(hipMemcpy(ctx->item_sched, blob.data(), blob.size() * 4, hipMemcpyHostToDevice));
+            E.ops = ctx->item_sched;
+            E.first_idx = 0;
+            PHE_CTX_ORDER(ctx, nullptr);
+            ctx->last_path = kPathWavePairs;
+            ctx->last_geom_pub = geom_code(sp.G, sp.L);
+            rc = launch_split_ab(ctx, kModeEncrypt, sp, E, nullptr, nullptr, ctx->stage[0], ctx->pub.s2, nullptr, 0, ctx->stage[2], nullptr,
+                                 ctx->pub.s2, batch, nullptr, ctx->item_sched + ops_words);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpy(out, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));
+            return PHE_HIP_OK;
+        }
+    }
+    rc = stage_in(ctx, 1, e, batch * (size_t)exp_limbs);
     if (!rc) rc = phe_hip_powmod_dev(ctx, ctx->stage[0], ctx->stage[1], exp_limbs, max_bits, ctx->stage[2], batch, nullptr);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(out, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));

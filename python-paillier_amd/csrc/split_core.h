@@ -74,6 +74,10 @@ struct SplitArgs {
     int out_limbs;
     uint32_t* table;  // scratch: total_groups * tbl_entries * 2H words (entry = X0 row | X1 row)
     uint64_t batch;
+    // wave-pair kernels: nullptr = one schedule for the batch; else four words per number {n_ops, first_idx, tbl_entries, offset of
+    // its ops in `sched`} — per-element exponents (_raw_mul of a handful of numbers, phe/paillier.py:751), each with its own
+    // sliding-window schedule made on the host (phe_hip_powmod)
+    const uint32_t* item_meta;
 };
 
 // ---- single-word passes (used by the conversions out of the pair form) -----------------------------------------

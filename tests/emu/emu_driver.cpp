@@ -795,6 +795,28 @@ int emu_powmod_n2(const uint32_t* n, int n_limbs, const uint32_t* base, const ui
         int max_bits = 0;
         for (uint64_t i = 0; i < B; ++i)
             max_bits = std::max(max_bits, host::big_bits(host::big_from(exps + i * exp_limbs, exp_limbs, exp_limbs)));
+        if (g_engine && P.nsplit.G == 64 && g_wave_pairs && P.nquick.ok()) {
+            // phe_hip_powmod for a handful of numbers: every number on a wave pair with its OWN sliding-window schedule (the
+            // kernel wrapper's SplitArgs::item_meta); a zero exponent keeps the general path
+            bool all_positive = true;
+            for (uint64_t i = 0; i < B; ++i)
+                all_positive = all_positive && host::big_bits(host::big_from(exps + i * exp_limbs, exp_limbs, exp_limbs)) > 0;
+            if (all_positive) {
+                for (uint64_t i = 0; i < B; ++i) {
+                    const host::Schedule S = host::build_schedule(host::big_from(exps + i * exp_limbs, exp_limbs, exp_limbs));
+                    SplitArgs A;
+                    memset(&A, 0, sizeof A);
+                    quick_consts_into(A, P.nquick);
+                    A.sched = S.ops.data(); A.n_ops = (int)S.ops.size();
+                    A.first_idx = S.first_idx; A.tbl_entries = S.tbl_entries;
+                    A.base = base + i * (uint64_t)P.s2; A.base_limbs = P.s2; A.base_chunks = chunks_for(P.s2, P.nquick.scaled.rows);
+                    A.post = nullptr; A.post_limbs = P.s1; A.post_chunks = 1;
+                    A.out = out + i * (uint64_t)P.s2; A.out_limbs = P.s2; A.batch = 1;
+                    DISPATCH_AB(P.nquick.scaled.L, (run_split_ab<LL, kModeEncrypt>(A)));
+                }
+                return 0;
+            }
+        }
         if (g_engine && P.nsplit.G) {
             const host::SplitPack& M = P.nsplit;
             SplitVarArgs A;

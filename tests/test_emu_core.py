@@ -434,3 +434,29 @@ def test_wave_pair_sweeps_on_key_sizes_off_the_grid(emu, key_bits):
         emu.set_wave_pairs(False)
         emu.set_unit(True)
         emu.set_group(0)
+
+
+@pytest.mark.parametrize("key_bits", [256, 1024, 2048])
+def test_scalar_multiplication_of_a_handful_on_wave_pairs(emu, key_bits):
+    """phe_hip_powmod for a handful of numbers (EncryptedNumber.__mul__, one at a time): every number on a wave pair with its own
+    sliding-window schedule — the golden _raw_mul vectors of the direct branch and 1-, 56-, 64-bit and full-width exponents, against
+    CPython's pow; an exponent 0 in the batch keeps the general kernel."""
+    emu.set_engine(True)
+    emu.set_group(64)
+    emu.set_wave_pairs(True)
+    try:
+        g = load_golden(key_bits)
+        n = H(g["n"])
+        N, s1, s2 = n * n, key_bits // 32, key_bits // 16
+        rng = random.Random(key_bits + 11)
+        direct = [e for e in g["raw_mul"] if 0 < H(e["s"]) < n - H(g["max_int"])][:3]
+        cs = [H(e["c"]) for e in direct] + [rng.randrange(1, N) for _ in range(4)]
+        ks = [H(e["s"]) for e in direct] + [1, (1 << 56) - 1, rng.getrandbits(64), rng.randrange(n // 3)]
+        got = limbs_to_ints(emu.powmod_n2(int_to_limbs(n, s1), ints_to_limbs(cs, s2), ints_to_limbs(ks, s1)))
+        assert got == [pow(c, k, N) for c, k in zip(cs, ks)]
+        assert got[:len(direct)] == [H(e["out"]) for e in direct]
+        got = limbs_to_ints(emu.powmod_n2(int_to_limbs(n, s1), ints_to_limbs(cs[:2], s2), ints_to_limbs([0, 5], 1)))
+        assert got == [1, pow(cs[1], 5, N)]
+    finally:
+        emu.set_wave_pairs(False)
+        emu.set_group(0)

@@ -165,6 +165,35 @@ def test_a_handful_of_numbers_runs_on_wave_pairs(native, c_oracle, key_bits, mon
     assert not single.last_launch()["path"] & ctx.PATH_WAVE_PAIRS
 
 
+@pytest.mark.parametrize("key_bits", [1024, 2048, 3072])
+def test_scalar_multiplication_of_a_handful_runs_on_wave_pairs(native, c_oracle, key_bits, monkeypatch):
+    """phe_hip_powmod (host entry: EncryptedNumber.__mul__ one at a time, small lists): each number on a pair of wavefronts with its
+    OWN sliding-window schedule, made on the host where the exponents are; a zero exponent in the batch keeps the general kernel.
+    libgmp's bits, the golden _raw_mul vectors of the direct branch, and the same as the per-element kernel."""
+    g = load_golden(key_bits)
+    s1, s2 = key_bits // 32, key_bits // 16
+    n_int = H(g["n"])
+    n = native.int_to_limbs(n_int, s1)
+    ctx = make_ctx(native, g, private=False)
+    monkeypatch.setenv("PHE_HIP_NO_WAVE_PAIRS", "1")
+    plain = make_ctx(native, g, private=False)
+    rng = random.Random(key_bits + 3)
+    direct = [e for e in g["raw_mul"] if 0 < H(e["s"]) < n_int - H(g["max_int"])]
+    cs = [H(e["c"]) for e in direct] + [rng.randrange(1, n_int * n_int) for _ in range(6)]
+    ks = [H(e["s"]) for e in direct] + [1, 2, (1 << 56) - 1, rng.getrandbits(64), rng.randrange(n_int // 3), 3]
+    c, k = native.ints_to_limbs(cs, s2), native.ints_to_limbs(ks, s1)
+    for batch in (1, len(cs)):
+        got = ctx.powmod(c[:batch], k[:batch])
+        assert ctx.last_launch()["path"] & ctx.PATH_WAVE_PAIRS, batch
+        assert np.array_equal(got, c_oracle.mul(n, c[:batch], k[:batch], nthreads=4)), batch
+        assert np.array_equal(got, plain.powmod(c[:batch], k[:batch])), batch
+    assert native.limbs_to_ints(ctx.powmod(c, k))[:len(direct)] == [H(e["out"]) for e in direct]
+    k0 = k.copy()
+    k0[1] = 0                                                        # c^0 = 1: the general kernel
+    got = ctx.powmod(c, k0)
+    assert np.array_equal(got, c_oracle.mul(n, c, k0, nthreads=4)) and native.limbs_to_ints(got[1:2]) == [1]
+
+
 @pytest.mark.parametrize("key_bits", [1600, 2100, 2240])
 def test_wave_pairs_on_key_sizes_off_the_grid(native, c_oracle, key_bits):
     """Keys whose limb counts are not round (primes of tests/golden/paillier_odd_sizes_primes.json; the key derived as
