@@ -1055,6 +1055,12 @@ PHE_DEV void modexp_split_ab_body(const SplitArgs& A, uint32_t* lds, uint32_t* t
         }
     }
     // ---- left-to-right sliding window ------------------------------------------------------------------------------
+    // B reads A's word of a table entry (Y0) at the top of a window: every entry must be in place before the first one is
+    // asked for.  All but the last stored were followed by a product's barrier; this one covers the last (with a table of one
+    // entry: the only one).  On the device B is a product's worth of time behind A's store anyway; the emulator's two host
+    // threads are not (tests/test_emu_core.py::test_scalar_multiplication_of_a_handful_on_wave_pairs found it with exponents of
+    // a few bits).
+    wave::block_barrier();
     load_entry(W, A.first_idx, role);
     for (int op = 0; op < A.n_ops; ++op) {
         const uint32_t w = wave::grp_bcast0<G>(sched[op], ln);  // (wave-uniform: the loops below are scalar loops)
