@@ -1432,6 +1432,15 @@ int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t
     }
     if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G) {
         ctx->last_geom_pub = geom_code(sp.G, sp.L);
+        if (c_in != c_out && ab_offered(ctx, sp, batch, 1)) {
+            // a handful of ciphertexts: r^n of each on a pair of wavefronts (the bare power: no plaintext factor), then the product
+            ctx->last_path = kPathWavePairs;
+            int rc = launch_split_ab(ctx, kModeEncrypt, sp, ctx->d_exp_n, nullptr, nullptr, r, ctx->pub.s1, nullptr, 0, c_out, nullptr,
+                                     ctx->pub.s2, batch, (hipStream_t)stream);
+            if (rc) return rc;
+            const size_t s2 = (size_t)ctx->pub.s2;
+            return launch_mul(ctx, pick_nsq(ctx, batch), c_out, s2, c_in, s2, c_out, s2, ctx->pub.s2, batch, (hipStream_t)stream);
+        }
         if (c_in != c_out && !getenv("PHE_HIP_FUSED_OBFUSCATE")) {
             // r^n with the encrypt instantiation (no plaintext factor), then one k_mulmod by the ciphertext: the fused
             // kModeObfuscate instantiation spills more (PMC: 94 KB written per element against 20 KB,

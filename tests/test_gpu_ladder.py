@@ -142,6 +142,7 @@ def test_a_handful_of_numbers_runs_on_wave_pairs(native, c_oracle, key_bits, mon
     seen = golden_hot_path(native, ctx, g)                       # a few dozen rows per call: the wave-pair path
     assert seen["encrypt"]["path"] & ctx.PATH_WAVE_PAIRS and seen["encrypt"]["geom_pub"] // 100 == 64, seen
     assert seen["decrypt"]["path"] & ctx.PATH_WAVE_PAIRS and seen["decrypt"]["geom_priv"] // 100 == 64, seen
+    assert seen["obfuscate"]["path"] & ctx.PATH_WAVE_PAIRS, seen          # golden obfuscate vectors: r^n on wave pairs, then the product
     rng = random.Random(key_bits)
     monkeypatch.setenv("PHE_HIP_NO_WAVE_PAIRS", "1")
     single = make_ctx(native, g)
