@@ -11,6 +11,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
+
+#include <string>
 
 #include "../python-paillier_amd/csrc/wave_gfx950.h"
 #include "../python-paillier_amd/csrc/mont_core.h"
@@ -194,6 +197,44 @@ __global__ void __launch_bounds__(64) k_chain(uint32_t* out, unsigned long long*
     out[lane] = (uint32_t)(x ^ (x >> 32));
 }
 
+// The whole chip saturated (8 waves per SIMD on every CU) with one instruction kind: the s_memtime ticks a wave sees against the
+// HIP-event time of the launch = the shader clock the chip holds UNDER THAT LOAD, and ticks per wave-instruction per SIMD = the
+// issue cost of the instruction in real cycles, whatever that clock is.  KIND 0: v_mad_u64_u32, 1: v_fma_f32, 2: v_pk_fma_f32.
+template <int KIND>
+__global__ void __launch_bounds__(1024) k_saturate(uint32_t* out, unsigned long long* ticks, int iters, uint32_t seed) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t aa = seed * 2654435761u + tid, bb = (seed ^ tid) | 1u;
+    uint64_t x[8];
+    float f[8];
+    for (int i = 0; i < 8; ++i) {
+        x[i] = ((uint64_t)bb << 32) | (aa + i);
+        f[i] = (float)(aa + i) * 1e-9f;
+    }
+    const float fa = 1.0000001f, fb = 1e-7f;
+    uint64_t pa = 0x3f8000013f800001ull, pb = 0x33d6bf9533d6bf95ull;  // (1.0000001f, 1.0000001f), (1e-7f, 1e-7f)
+    asm volatile("" : "+v"(pa), "+v"(pb));
+    const unsigned long long t0 = clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 8; ++rep)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if constexpr (KIND == 0) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(x[i]) : "v"(aa), "v"(bb) : "vcc");
+                else if constexpr (KIND == 1) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[i]) : "v"(fa), "v"(fb));
+                else asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(pa), "v"(pb));  // two fp32 FMAs per lane
+            }
+    }
+    const unsigned long long t1 = clock64();
+    if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) ticks[0] = t1 - t0;
+    uint64_t r = 0;
+    float g = 0;
+    for (int i = 0; i < 8; ++i) {
+        r ^= x[i];
+        g += f[i];
+    }
+    if ((uint32_t)(r ^ (r >> 32)) == 0x12345678u || g == 1.2345f) out[tid & 1023u] = (uint32_t)r;
+}
+
 template <typename F>
 static int timed(F launch, unsigned long long* dt, double& cycles) {
     unsigned long long tk = 0;
@@ -206,7 +247,41 @@ static int timed(F launch, unsigned long long* dt, double& cycles) {
     return 0;
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc >= 3 && std::string(argv[1]) == "--burn") {
+        // keep the whole chip's VALU saturated for a few seconds with one instruction kind (tools/sample_clock_under_load.sh
+        // reads the shader clock and the power beside it): --burn mad|fma [seconds]
+        uint32_t* d = nullptr;
+        unsigned long long* dt = nullptr;
+        CK(hipMalloc((void**)&d, 1 << 16));
+        CK(hipMalloc((void**)&dt, 64));
+        hipDeviceProp_t prop;
+        CK(hipGetDeviceProperties(&prop, 0));
+        const std::string kind = argv[2];
+        const bool mad = kind == "mad";
+        const double seconds = argc >= 4 ? atof(argv[3]) : 5.0;
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        double total_ms = 0, instr = 0;
+        while (total_ms < seconds * 1e3) {
+            float ms = 0;
+            CK(hipEventRecord(e0));
+            for (int k = 0; k < 16; ++k) {
+                if (mad) k_saturate<0><<<prop.multiProcessorCount * 2, 1024>>>(d, dt, 8192, 11u);
+                else if (kind == "pkfma") k_saturate<2><<<prop.multiProcessorCount * 2, 1024>>>(d, dt, 8192, 11u);
+                else k_saturate<1><<<prop.multiProcessorCount * 2, 1024>>>(d, dt, 8192, 11u);
+            }
+            CK(hipEventRecord(e1));
+            CK(hipEventSynchronize(e1));
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            total_ms += ms;
+            instr += 16.0 * 8192 * 64 * 32.0 * prop.multiProcessorCount;
+        }
+        printf("{\"burn\": \"%s\", \"seconds\": %.2f, \"wave_instr_per_s\": %.4g, \"lane_ops_per_s\": %.4g}\n", argv[2], total_ms * 1e-3,
+               instr / (total_ms * 1e-3), 64.0 * instr / (total_ms * 1e-3));
+        return 0;
+    }
     uint32_t* d = nullptr;
     unsigned long long* dt = nullptr;
     CK(hipMalloc((void**)&d, 1 << 16));
@@ -235,6 +310,34 @@ int main() {
     SWEEP((k_second<1, true>), 1, rows1)
     SWEEP((k_second<2, true>), 2, rows2)
     printf("}, ");
+    {   // the chip saturated with one instruction kind: real cycles per wave-instruction per SIMD and the clock it holds meanwhile
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0));
+        CK(hipEventCreate(&e1));
+        hipDeviceProp_t prop;
+        CK(hipGetDeviceProperties(&prop, 0));
+        const int cus = prop.multiProcessorCount, iters = 4096;
+        const char* kinds[2] = {"v_mad_u64_u32", "v_fma_f32"};
+        printf("\"saturated_chip\": {");
+        for (int kind = 0; kind < 2; ++kind) {
+            unsigned long long tk = 0;
+            float ms = 0;
+            for (int pass = 0; pass < 2; ++pass) {
+                CK(hipEventRecord(e0));
+                if (kind == 0) k_saturate<0><<<cus * 2, 1024>>>(d, dt, iters, 11u);
+                else k_saturate<1><<<cus * 2, 1024>>>(d, dt, iters, 11u);
+                CK(hipEventRecord(e1));
+                CK(hipEventSynchronize(e1));
+            }
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            CK(hipMemcpy(&tk, dt, 8, hipMemcpyDeviceToHost));
+            const double per_wave = (double)iters * 64;  // instructions a wave issues
+            printf("%s\"%s\": {\"ticks_per_wave_instr_per_simd\": %.3f, \"ticks_per_us\": %.1f, \"kernel_ms\": %.3f, "
+                   "\"wave_instr_per_s\": %.4g}", kind ? ", " : "", kinds[kind], (double)tk / per_wave / 8.0, (double)tk / (ms * 1e3), ms,
+                   per_wave * 32.0 * cus / (ms * 1e-3));
+        }
+        printf("}, ");
+    }
     {   // the shader clock a lone wavefront really gets: s_memtime ticks of one long launch against its HIP-event time
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0));
