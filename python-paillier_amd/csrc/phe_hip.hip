@@ -1986,10 +1986,10 @@ int phe_hip_ctx_release_scratch(phe_hip_ctx* ctx) {
     if (int rc = bind_device(ctx)) return rc;
     HIP_TRY(hipDeviceSynchronize());
     uint32_t** bufs[] = {&ctx->table, &ctx->table2, &ctx->scratch, &ctx->partial, &ctx->lookup, &ctx->unit_tmp,
-                         &ctx->stage[0], &ctx->stage[1], &ctx->stage[2]};
+                         &ctx->stage[0], &ctx->stage[1], &ctx->stage[2], &ctx->item_sched};
     size_t* sizes[] = {&ctx->table_words, &ctx->table2_words, &ctx->scratch_words, &ctx->partial_words, &ctx->lookup_words,
-                       &ctx->unit_tmp_words, &ctx->stage_words[0], &ctx->stage_words[1], &ctx->stage_words[2]};
-    for (int i = 0; i < 9; ++i) {
+                       &ctx->unit_tmp_words, &ctx->stage_words[0], &ctx->stage_words[1], &ctx->stage_words[2], &ctx->item_sched_words};
+    for (int i = 0; i < 10; ++i) {
         if (*bufs[i]) HIP_TRY(hipFree(*bufs[i]));
         *bufs[i] = nullptr;
         *sizes[i] = 0;
