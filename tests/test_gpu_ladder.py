@@ -166,6 +166,44 @@ def test_a_handful_of_numbers_runs_on_wave_pairs(native, c_oracle, key_bits, mon
     assert not single.last_launch()["path"] & ctx.PATH_WAVE_PAIRS
 
 
+@pytest.mark.parametrize("key_bits", [1024, 2048])
+def test_batch_sizes_either_side_of_every_switch(native, c_oracle, key_bits):
+    """The paths change with the batch size — wave pairs up to 256 / 512 numbers, the tail on one wavefront up to 16 per CU, the
+    rungs of the ladder, the decrypt halves in one grid or two launches: every size one below, at and one above a switch gives
+    the round trip, libgmp's bits on a sample, and the same ciphertexts as the neighbouring sizes' launches for the rows they share."""
+    g = load_golden(key_bits)
+    s1, s2 = key_bits // 32, key_bits // 16
+    n_int = H(g["n"])
+    n = native.int_to_limbs(n_int, s1)
+    p, q = native.int_to_limbs(H(g["p"]), s1 // 2), native.int_to_limbs(H(g["q"]), s1 // 2)
+    ctx = make_ctx(native, g)
+    rs = np.random.Generator(np.random.PCG64(key_bits))
+    top = 4200
+    m = rs.integers(0, 1 << 32, size=(top, s1), dtype=np.uint32)
+    r = rs.integers(0, 1 << 32, size=(top, s1), dtype=np.uint32)
+    m[:, s1 - 1] = 0
+    r[:, s1 - 1] &= 0x3fffffff
+    r[:, 0] |= 1
+    full = ctx.encrypt(m, r)
+    assert np.array_equal(ctx.decrypt(full), m)
+    idx = np.arange(0, top, 97)
+    assert np.array_equal(full[idx], c_oracle.encrypt(n, m[idx], r[idx], nthreads=8))
+    seen = set()
+    for batch in (1, 2, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2048, 2049, 4095, 4096, 4097):
+        c = ctx.encrypt(m[:batch], r[:batch])
+        enc_path = ctx.last_launch()
+        assert np.array_equal(c, full[:batch]), batch
+        back = ctx.decrypt(full[:batch])
+        dec_path = ctx.last_launch()
+        assert np.array_equal(back, m[:batch]), batch
+        seen.add((enc_path["path"], enc_path["geom_pub"], dec_path["path"], dec_path["geom_priv"]))
+    assert len(seen) >= 4, seen                                        # the sizes did cross switches
+    junk = rs.integers(0, 1 << 32, size=(513, s2), dtype=np.uint32)
+    junk[:, s2 - 1] = 0
+    for batch in (256, 257, 512, 513):
+        assert np.array_equal(ctx.decrypt(junk[:batch]), c_oracle.decrypt(n, p, q, junk[:batch], nthreads=8)), batch
+
+
 @pytest.mark.parametrize("key_bits", [1024, 2048, 3072])
 def test_scalar_multiplication_of_a_handful_runs_on_wave_pairs(native, c_oracle, key_bits, monkeypatch):
     """phe_hip_powmod (host entry: EncryptedNumber.__mul__ one at a time, small lists): each number on a pair of wavefronts with its
