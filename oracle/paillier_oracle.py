@@ -9,6 +9,10 @@ Two independent restatements of the reference hot path (paths relative to /root/
 
 Both are pinned in tests/test_oracle.py against the reference's known-answer vectors and
 against tests/golden/ fixtures generated from the real reference (tests/golden/gen_golden.py).
+
+Who may import this: tests/, __graft_entry__.smoke(), bench.py (checker + cpu_baseline leg) and the measurement scripts
+under tools/ (bench_*.py, ref_cpu_baseline.py — the same role as bench.py: the checker beside a timed HIP run, or the CPU
+figure printed next to it).  Nothing under python-paillier_amd/ does, and the package has no CPU route at all.
 """
 import ctypes
 import os
