@@ -878,7 +878,7 @@ def main():
             "peak_source": "256 CUs x 4 SIMD x 64 lanes x 2.4 GHz / 4 cycles per v_mad_u64_u32 (half-rate, calibrated)",
             "peak_sustained_microbench": (sustained / 1e12) if sustained else None, "microbench": peak_src,
             "hbm_algorithmic_GBps": (2 * s1 + s2) * 4 * B / enc_kernel_s / 1e9, "hbm_peak_GBps": 8000.0,
-            "decrypt": {"kernel": "2 x %s + k_decrypt_tail" % dec_kernel,
+            "decrypt": {"kernel": "2 x %s + k_decrypt_tail_wave" % dec_kernel,
                         "achieved": rate(dec_exec, dec_kernel_s) / 1e12 if dec_exec else None, "frac": frac(dec_exec, dec_kernel_s),
                         "executed_mad_per_decrypt": dec_exec, "canonical_mac32_per_decrypt": dec_mac,
                         "canonical_frac": dec_mac * B / dec_kernel_s / peak, "launch_ms_avg": dec_kernel_s * 1e3},

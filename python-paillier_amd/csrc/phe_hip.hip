@@ -365,6 +365,7 @@ struct phe_hip_ctx {
     uint32_t* tail_wave_blob = nullptr;
     TailWaveConsts d_tail_wave{};
     int tail_wave_L = 0;
+    size_t tail_wave_per_cu = 16;  // batches of up to this many ciphertexts per CU take it (create_private; PHE_HIP_WAVE_TAIL_PER_CU)
     // grow-only device scratch
     uint32_t* table = nullptr;
     size_t table_words = 0;
@@ -1135,6 +1136,13 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
     if (!rc) rc = upload_schedule(ctx->priv.exp_q, ctx->d_exp_q);
     if (!rc) rc = upload_tail(ctx->priv.tail, ctx->d_tail);
     if (!rc && !getenv("PHE_HIP_NO_WAVE_TAIL")) rc = upload_tail_wave(ctx);
+    // Which batches take it.  The per-thread tail is bound by its LDS traffic (~9 h^2 word accesses per ciphertext, h = words
+    // of p: 8.9 ns per ciphertext at 2048-bit keys, and a 0.38 ms serial chain however small the batch); the wavefront form costs
+    // ~2 ns there and grows with h, not h^2 — measured faster at every batch size from 1024-bit keys up (decrypt at 2^13 rows
+    // +7.7 %, 2^14 +4.2 %, 2^18 +1.5 % at 2048 bits, profiles/r03p_wave_tail_every_batch_size.txt).  Narrower keys keep it for
+    // small batches only: there a wavefront per ciphertext is mostly idle lanes.
+    ctx->tail_wave_per_cu = ctx->priv.tail.h >= 16 ? ((size_t)1 << 24) : 16;
+    if (const char* d = getenv("PHE_HIP_WAVE_TAIL_PER_CU")) ctx->tail_wave_per_cu = (size_t)std::max(0, atoi(d));
     if (!rc) {
         const size_t lds = (size_t)tail_ws_words(ctx->priv.tail.h) * tail_block(ctx->priv.tail.h) * 4;
         if (lds > 160 * 1024) rc = fail(PHE_HIP_EINVAL, "p/q too wide for the CRT tail kernel");
@@ -1476,9 +1484,9 @@ int phe_hip_decrypt_dev(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t
     ctx->last_path = 0;
     rc = launch_crt_halves(ctx, ctx->d_exp_p, ctx->d_exp_q, c, ctx->pub.s2, xp, xq, S, batch, st);
     if (rc) return rc;
-    // the tail: one ciphertext per thread is a long serial chain (0.4 ms at 2048-bit keys) that a large batch hides and a small
-    // one waits for; while there are SIMDs to spare it runs one ciphertext per wavefront instead (same bits)
-    if (ctx->tail_wave_L && batch <= (size_t)ctx->n_cus * 16) {
+    // the tail: one ciphertext per wavefront on the whole-wave sweeps (same bits as the per-thread kernel below, which is a
+    // 0.4 ms serial chain through LDS at 2048-bit keys and serves narrow keys' large batches and PHE_HIP_NO_WAVE_TAIL)
+    if (ctx->tail_wave_L && batch <= (size_t)ctx->n_cus * ctx->tail_wave_per_cu && batch <= (size_t)0x7fffffff) {
         TailWaveArgs W;
         W.k = ctx->d_tail_wave;
         W.xp = xp;

@@ -273,9 +273,9 @@ def test_wave_pairs_on_key_sizes_off_the_grid(native, c_oracle, key_bits):
 
 @pytest.mark.parametrize("key_bits", [1024, 2048, 3072])
 def test_crt_tail_on_one_wavefront_per_ciphertext(native, c_oracle, key_bits, monkeypatch):
-    """Small batches take the L-function / CRT tail one ciphertext per WAVEFRONT (k_decrypt_tail_wave; the per-thread tail is
+    """The L-function / CRT tail runs one ciphertext per WAVEFRONT (k_decrypt_tail_wave; the per-thread tail is
     a 0.4 ms serial chain at 2048 bits): asserted through last_launch, same plaintexts as libgmp and as the per-thread tail
-    (PHE_HIP_NO_WAVE_TAIL) on the golden vectors, edge plaintexts and junk ciphertexts; large batches keep the per-thread tail."""
+    (PHE_HIP_NO_WAVE_TAIL) on the golden vectors, edge plaintexts and junk ciphertexts, small batches and large."""
     g = load_golden(key_bits)
     s1, s2 = key_bits // 32, key_bits // 16
     n_int = H(g["n"])
@@ -301,10 +301,20 @@ def test_crt_tail_on_one_wavefront_per_ciphertext(native, c_oracle, key_bits, mo
         assert np.array_equal(got, plain.decrypt(c[:batch])), batch
         assert not plain.last_launch()["path"] & ctx.PATH_WAVE_TAIL
     assert native.limbs_to_ints(ctx.decrypt(c))[:len(want)] == want
-    big = np.tile(c, (6000 // len(cts) + 1, 1))[:6000]                 # beyond the small-batch threshold: one ciphertext per thread
+    # large batches take it too from 1024-bit keys up (it is the faster tail at every batch size there); the per-thread kernel
+    # stays behind PHE_HIP_NO_WAVE_TAIL / PHE_HIP_WAVE_TAIL_PER_CU and must give the same rows
+    big = np.tile(c, (6000 // len(cts) + 1, 1))[:6000]
     got = ctx.decrypt(big)
-    assert not ctx.last_launch()["path"] & ctx.PATH_WAVE_TAIL
+    assert ctx.last_launch()["path"] & ctx.PATH_WAVE_TAIL
     assert np.array_equal(got[:len(cts)], ctx.decrypt(c))
+    assert np.array_equal(got, plain.decrypt(big))
+    monkeypatch.delenv("PHE_HIP_NO_WAVE_TAIL")
+    monkeypatch.setenv("PHE_HIP_WAVE_TAIL_PER_CU", "1")              # the round-3 rule of thumb, now a knob: small batches only
+    few = make_ctx(native, g)
+    assert np.array_equal(few.decrypt(big), got)
+    assert not few.last_launch()["path"] & ctx.PATH_WAVE_TAIL
+    assert np.array_equal(few.decrypt(c[:3]), got[:3])
+    assert few.last_launch()["path"] & ctx.PATH_WAVE_TAIL
 
 
 @pytest.mark.parametrize("key_bits", [2048, 3072])
