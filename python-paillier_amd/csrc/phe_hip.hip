@@ -866,11 +866,30 @@ static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, 
 // crossovers: profiles/r03*_batch_sweep*.
 struct RungShape {
     int G = 0, L = 0, rows = 0;  // G == 0: this rung has no kernel of the family asked for
+    double wide = 1.0;           // what a rung too wide for the fused sweeps costs on top of the estimate (split_shape)
 };
+// Rungs with more than kMaxFusedL limbs per lane (3072-bit keys: 4 x 27 and, for the CRT halves, 2 x 27) run every pair
+// product as two single sweeps with the quotient digits handed over through LDS, and the estimate above is too kind to them
+// — by how much depends on the kernel family.  Measured at 3072 bits against the next rung pinned for every batch size
+// (profiles/r03r_pinned_rungs_3072.txt): the fixed-exponent ladder (encrypt, obfuscate) is still 6 % FASTER on 4 x 27 than
+// on 8 x 14 once two waves per SIMD are there (factor 1.10 on the estimate), the CRT halves are 7 % slower on 2 x 27 than on
+// 4 x 14 and the per-element exponents 7 % slower on 4 x 27 than on 8 x 14 (factor 1.25); with ONE wave per SIMD those
+// kernels reach 86 % of their two-wave rate where the fused ones reach 90-95 % (factor 1.16 while w <= 1).
+enum RungFamily : int { kFamOther = 0, kFamFixedExp = 1, kFamHalves = 2, kFamVarExp = 3 };
+static double wide_rung_factor(int family) {
+    switch (family) {
+        case kFamFixedExp: return 1.10;
+        case kFamHalves:
+        case kFamVarExp: return 1.25;
+        default: return 1.0;  // not measured: the plain estimate, as before
+    }
+}
 static double rung_cost(const phe_hip_ctx* ctx, size_t batch, const RungShape& r, int concurrent) {
     const double lanes = (double)ctx->n_cus * 256.0;
     const double w = (double)batch * r.G * concurrent / lanes;
-    return (double)r.rows * (19.0 * r.L + 52.0) * std::max(1.0, w);
+    const bool wide = r.L > kMaxFusedL && r.wide > 1.0;
+    const double residencies = (wide && w <= 1.0) ? 1.16 : std::max(1.0, w);
+    return (double)r.rows * (19.0 * r.L + 52.0) * (wide ? r.wide : 1.0) * residencies;
 }
 // rung index (0 = the members of the context, k >= 1 = the k-th extra rung): least estimated time for this batch
 template <class Shape>
@@ -915,18 +934,21 @@ static const DevModulus& pick_nsq(const phe_hip_ctx* ctx, size_t batch) {
     });
     return nsq_rung(ctx, k);
 }
-static RungShape split_shape(const DevSplit& sp) {
+static RungShape split_shape(const DevSplit& sp, int family = kFamOther) {
     RungShape sh;
     sh.G = sp.G;
     sh.L = sp.L;
     sh.rows = sp.rows;
+    sh.wide = wide_rung_factor(family);
     return sh;
 }
 // the pair-form kernels modulo n
-static int pick_nsplit_rung(const phe_hip_ctx* ctx, size_t batch) {
-    return pick_rung(ctx, batch, 1 + (int)ctx->pub_rungs.size(), [&](int r) { return split_shape(nsplit_rung(ctx, r)); });
+static int pick_nsplit_rung(const phe_hip_ctx* ctx, size_t batch, int family = kFamOther) {
+    return pick_rung(ctx, batch, 1 + (int)ctx->pub_rungs.size(), [&](int r) { return split_shape(nsplit_rung(ctx, r), family); });
 }
-static const DevSplit& pick_nsplit(const phe_hip_ctx* ctx, size_t batch) { return nsplit_rung(ctx, pick_nsplit_rung(ctx, batch)); }
+static const DevSplit& pick_nsplit(const phe_hip_ctx* ctx, size_t batch, int family = kFamOther) {
+    return nsplit_rung(ctx, pick_nsplit_rung(ctx, batch, family));
+}
 static int geom_code(int G, int L) { return G * 100 + L; }
 enum : int { kPathUnit = 1, kPathOwner = 2, kPathSideBySide = 4, kPathPipelined = 8, kPathFusedObfuscate = 16, kPathWavePairs = 32, kPathWaveTail = 64 };
 
@@ -1264,7 +1286,7 @@ static int unit_rung(const phe_hip_ctx* ctx, size_t batch) {
         return u.G != 0 && nsq_rung(ctx, k).G != 0;
     };
     if (ctx->force_unit) return has(0) ? 0 : -1;
-    const int k = pick_nsplit_rung(ctx, batch);
+    const int k = pick_nsplit_rung(ctx, batch, kFamFixedExp);
     return has(k) ? k : -1;
 }
 static const DevSplit& nunit_rung(const phe_hip_ctx* ctx, int k) { return k == 0 ? ctx->d_nunit : ctx->pub_rungs[(size_t)k - 1].nunit; }
@@ -1295,7 +1317,7 @@ int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, 
         return launch_mul(ctx, nsq_rung(ctx, ur), ctx->unit_tmp, w, m, s1, c, s2, ctx->pub.s2, batch, (hipStream_t)stream, ctx->pub.s1, 0,
                           (int)w);
     }
-    if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G) {
+    if (const DevSplit& sp = pick_nsplit(ctx, batch, kFamFixedExp); ctx->use_split && sp.G) {
         ctx->last_geom_pub = geom_code(sp.G, sp.L);
         if (ab_offered(ctx, sp, batch, 1)) {
             ctx->last_path = kPathWavePairs;
@@ -1329,7 +1351,7 @@ static int launch_crt_halves(phe_hip_ctx* ctx, const DevSchedule& Ep, const DevS
     const auto qsq_of = [&](int k) -> const DevModulus& { return k == 0 ? ctx->d_qsq : ctx->priv_rungs[(size_t)k - 1].qsq; };
     const bool split_ok = ctx->use_split && ctx->d_psplit.G && ctx->d_qsplit.G;
     const auto shape = [&](int k) {
-        if (split_ok) return split_shape(qsplit_of(k));
+        if (split_ok) return split_shape(qsplit_of(k), kFamHalves);
         RungShape sh;
         sh.G = qsq_of(k).G;
         sh.L = qsq_of(k).L;
@@ -1438,7 +1460,7 @@ int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t
         return launch_mul(ctx, nsq_rung(ctx, ur), ctx->unit_tmp, w, c_in, s2, c_out, s2, ctx->pub.s2, batch, (hipStream_t)stream, 0, 0,
                           (int)w);
     }
-    if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G) {
+    if (const DevSplit& sp = pick_nsplit(ctx, batch, kFamFixedExp); ctx->use_split && sp.G) {
         ctx->last_geom_pub = geom_code(sp.G, sp.L);
         if (c_in != c_out && ab_offered(ctx, sp, batch, 1)) {
             // a handful of ciphertexts: r^n of each on a pair of wavefronts (the bare power: no plaintext factor), then the product
@@ -1691,7 +1713,7 @@ int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e
     if (max_exp_bits <= 0 || max_exp_bits > 32 * exp_limbs) max_exp_bits = 32 * exp_limbs;
     if (int rc = bind_device(ctx)) return rc;
     PHE_CTX_ORDER(ctx, stream);
-    if (const DevSplit& sp = pick_nsplit(ctx, batch); ctx->use_split && sp.G)
+    if (const DevSplit& sp = pick_nsplit(ctx, batch, kFamVarExp); ctx->use_split && sp.G)
         return launch_var_split(ctx, sp, base, ctx->pub.s2, e, exp_limbs, max_exp_bits, out, ctx->pub.s2, batch,
                                 (hipStream_t)stream);
     return launch_var(ctx, pick_nsq(ctx, batch), base, ctx->pub.s2, e, exp_limbs, max_exp_bits, out, ctx->pub.s2, batch,

@@ -36,7 +36,15 @@ def main():
     from phe import _native as native
     from oracle.paillier_oracle import COracle
     dev = torch.device("cuda", 0)
-    g = json.load(open(os.path.join(ROOT, "tests", "golden", "paillier_%d.json" % args.key_bits)))
+    gdir = os.path.join(ROOT, "tests", "golden")
+    if os.path.exists(os.path.join(gdir, "paillier_%d.json" % args.key_bits)):
+        g = json.load(open(os.path.join(gdir, "paillier_%d.json" % args.key_bits)))
+    else:                                                  # key sizes with committed primes only: the key constants from them
+        g = json.load(open(os.path.join(gdir, "paillier_%d_primes.json" % args.key_bits)))
+        p_, q_ = sorted((int(g["p"], 16), int(g["q"], 16)))
+        n_ = p_ * q_
+        h_ = lambda x: pow((pow(n_ + 1, x - 1, x * x) - 1) // x, -1, x)     # phe/paillier.py:356-360
+        g = {k: "%x" % v for k, v in dict(n=n_, p=p_, q=q_, hp=h_(p_), hq=h_(q_), p_inverse=pow(p_, -1, q_)).items()}
     H = lambda k: int(g[k], 16)
     n_int = H("n")
     s1, s2 = args.key_bits // 32, args.key_bits // 16
