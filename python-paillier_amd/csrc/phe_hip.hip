@@ -386,6 +386,12 @@ struct phe_hip_ctx {
     // staging for the host-pointer entry points
     uint32_t* stage[3] = {nullptr, nullptr, nullptr};
     size_t stage_words[3] = {0, 0, 0};
+    // ... and for a handful of rows: one pinned, device-mapped buffer of three slots that the kernels read and write across
+    // PCIe themselves (stage_in / stage_out below); cur[] = where the current call's operands are, either kind
+    uint32_t* mapped_host = nullptr;
+    uint32_t* mapped_dev = nullptr;
+    bool no_mapped = false;
+    uint32_t* cur[3] = {nullptr, nullptr, nullptr};
     // large host batches: chunks double-buffered through pinned memory, uploads / kernels / downloads on three streams
     struct HostPipe {
         hipStream_t s_in = nullptr, s_comp = nullptr, s_out = nullptr;
@@ -1194,6 +1200,7 @@ void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
     for (const auto& R : ctx->priv_rungs) { bufs.push_back(R.psq.blob); bufs.push_back(R.qsq.blob); bufs.push_back(R.psplit.blob); bufs.push_back(R.qsplit.blob); }
     for (uint32_t* b : bufs)
         if (b) (void)hipFree(b);
+    if (ctx->mapped_host) (void)hipHostFree(ctx->mapped_host);
     for (int k = 0; k < 2; ++k) {
         for (int j = 0; j < 3; ++j) {
             if (ctx->pipe.pin[k][j]) (void)hipHostFree(ctx->pipe.pin[k][j]);
@@ -1880,10 +1887,52 @@ int phe_hip_multiexp_csr_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint3
 }
 
 // ---- host-pointer entry points ------------------------------------------------------------------
-static int stage_in(phe_hip_ctx* ctx, int slot, const uint32_t* host_ptr, size_t words) {
+// A call with a handful of rows (every operand and the result within kMappedSlotWords) skips the three blocking hipMemcpy of
+// the path below — 36 of the 69 us of a one-row phe_hip_mulmod at 2048 bits (tools/scalar_op_breakdown.py,
+// profiles/r03u_scalar_breakdown_2048.txt): operands are copied by the CPU into a pinned, device-mapped buffer, the kernels
+// read them (and write the result) across PCIe, one stream synchronisation ends the call.  Scratch and tables stay in HBM.
+static const size_t kMappedSlotWords = 8192;  // 32 KiB per slot: 64 rows of a 2048-bit ciphertext
+static bool use_mapped(phe_hip_ctx* ctx, size_t w0, size_t w1, size_t w2) {
+    if (ctx->no_mapped || std::max(w0, std::max(w1, w2)) > kMappedSlotWords) return false;
+    if (!ctx->mapped_host) {
+        void *h = nullptr, *d = nullptr;
+        if (getenv("PHE_HIP_NO_MAPPED_STAGING") || hipHostMalloc(&h, 3 * kMappedSlotWords * 4, hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer(&d, h, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (h) (void)hipHostFree(h);
+            ctx->no_mapped = true;
+            return false;
+        }
+        ctx->mapped_host = (uint32_t*)h;
+        ctx->mapped_dev = (uint32_t*)d;
+    }
+    return true;
+}
+// operand `slot` of a host-pointer call: ctx->cur[slot] is where the kernels find it (host_ptr == nullptr: room for a result)
+static int stage_in(phe_hip_ctx* ctx, int slot, const uint32_t* host_ptr, size_t words, bool mapped = false) {
+    if (mapped) {
+        ctx->cur[slot] = ctx->mapped_dev + (size_t)slot * kMappedSlotWords;
+        if (host_ptr) memcpy(ctx->mapped_host + (size_t)slot * kMappedSlotWords, host_ptr, words * 4);
+        return PHE_HIP_OK;
+    }
     int rc = ensure_words(&ctx->stage[slot], &ctx->stage_words[slot], words);
     if (rc) return rc;
+    ctx->cur[slot] = ctx->stage[slot];
     if (host_ptr) HIP_TRY(hipMemcpy(ctx->stage[slot], host_ptr, words * 4, hipMemcpyHostToDevice));
+    return PHE_HIP_OK;
+}
+// the result in `slot` back to the caller (rc: what the launches returned; a mapped call is drained either way, so that
+// nothing still reads or writes the buffer when the next call fills it)
+static int stage_out(phe_hip_ctx* ctx, int rc, int slot, void* host_out, size_t bytes, bool mapped) {
+    if (mapped) {
+        const hipError_t e = hipStreamSynchronize(nullptr);
+        if (rc) return rc;
+        if (e != hipSuccess) return fail(PHE_HIP_EHIP, std::string("hipStreamSynchronize: ") + hipGetErrorString(e));
+        memcpy(host_out, ctx->mapped_host + (size_t)slot * kMappedSlotWords, bytes);
+        return PHE_HIP_OK;
+    }
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(host_out, ctx->stage[slot], bytes, hipMemcpyDeviceToHost));
     return PHE_HIP_OK;
 }
 
@@ -2046,13 +2095,12 @@ int phe_hip_encrypt(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint
                              [&](uint32_t* d0, uint32_t* d1, uint32_t* d2, size_t rows, hipStream_t st) {
                                  return phe_hip_encrypt_dev(ctx, d0, d1, d2, rows, st);
                              });
-    int rc = stage_in(ctx, 0, m, batch * s1);
-    if (!rc) rc = stage_in(ctx, 1, r, batch * s1);
-    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
-    if (!rc) rc = phe_hip_encrypt_dev(ctx, ctx->stage[0], ctx->stage[1], ctx->stage[2], batch, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(c, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));
-    return PHE_HIP_OK;
+    const bool mp = use_mapped(ctx, batch * s1, batch * s1, batch * s2);
+    int rc = stage_in(ctx, 0, m, batch * s1, mp);
+    if (!rc) rc = stage_in(ctx, 1, r, batch * s1, mp);
+    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2, mp);
+    if (!rc) rc = phe_hip_encrypt_dev(ctx, ctx->cur[0], ctx->cur[1], ctx->cur[2], batch, nullptr);
+    return stage_out(ctx, rc, 2, c, batch * s2 * 4, mp);
 }
 
 int phe_hip_encrypt_owner(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, uint32_t* c, size_t batch) {
@@ -2066,13 +2114,12 @@ int phe_hip_encrypt_owner(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r
                              [&](uint32_t* d0, uint32_t* d1, uint32_t* d2, size_t rows, hipStream_t st) {
                                  return phe_hip_encrypt_owner_dev(ctx, d0, d1, d2, rows, st);
                              });
-    int rc = stage_in(ctx, 0, m, batch * s1);
-    if (!rc) rc = stage_in(ctx, 1, r, batch * s1);
-    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
-    if (!rc) rc = phe_hip_encrypt_owner_dev(ctx, ctx->stage[0], ctx->stage[1], ctx->stage[2], batch, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(c, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));
-    return PHE_HIP_OK;
+    const bool mp = use_mapped(ctx, batch * s1, batch * s1, batch * s2);
+    int rc = stage_in(ctx, 0, m, batch * s1, mp);
+    if (!rc) rc = stage_in(ctx, 1, r, batch * s1, mp);
+    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2, mp);
+    if (!rc) rc = phe_hip_encrypt_owner_dev(ctx, ctx->cur[0], ctx->cur[1], ctx->cur[2], batch, nullptr);
+    return stage_out(ctx, rc, 2, c, batch * s2 * 4, mp);
 }
 
 int phe_hip_obfuscate(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t* r, uint32_t* c_out, size_t batch) {
@@ -2086,13 +2133,12 @@ int phe_hip_obfuscate(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t* r,
                              [&](uint32_t* d0, uint32_t* d1, uint32_t* d2, size_t rows, hipStream_t st) {
                                  return phe_hip_obfuscate_dev(ctx, d0, d1, d2, rows, st);
                              });
-    int rc = stage_in(ctx, 0, c_in, batch * s2);
-    if (!rc) rc = stage_in(ctx, 1, r, batch * s1);
-    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
-    if (!rc) rc = phe_hip_obfuscate_dev(ctx, ctx->stage[0], ctx->stage[1], ctx->stage[2], batch, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(c_out, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));
-    return PHE_HIP_OK;
+    const bool mp = use_mapped(ctx, batch * s2, batch * s1, batch * s2);
+    int rc = stage_in(ctx, 0, c_in, batch * s2, mp);
+    if (!rc) rc = stage_in(ctx, 1, r, batch * s1, mp);
+    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2, mp);
+    if (!rc) rc = phe_hip_obfuscate_dev(ctx, ctx->cur[0], ctx->cur[1], ctx->cur[2], batch, nullptr);
+    return stage_out(ctx, rc, 2, c_out, batch * s2 * 4, mp);
 }
 
 int phe_hip_decrypt(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t batch) {
@@ -2106,12 +2152,11 @@ int phe_hip_decrypt(phe_hip_ctx* ctx, const uint32_t* c, uint32_t* m, size_t bat
                              [&](uint32_t* d0, uint32_t*, uint32_t* d2, size_t rows, hipStream_t st) {
                                  return phe_hip_decrypt_dev(ctx, d0, d2, rows, st);
                              });
-    int rc = stage_in(ctx, 0, c, batch * s2);
-    if (!rc) rc = stage_in(ctx, 1, nullptr, batch * s1);
-    if (!rc) rc = phe_hip_decrypt_dev(ctx, ctx->stage[0], ctx->stage[1], batch, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(m, ctx->stage[1], batch * s1 * 4, hipMemcpyDeviceToHost));
-    return PHE_HIP_OK;
+    const bool mp = use_mapped(ctx, batch * s2, batch * s1, 0);
+    int rc = stage_in(ctx, 0, c, batch * s2, mp);
+    if (!rc) rc = stage_in(ctx, 1, nullptr, batch * s1, mp);
+    if (!rc) rc = phe_hip_decrypt_dev(ctx, ctx->cur[0], ctx->cur[1], batch, nullptr);
+    return stage_out(ctx, rc, 1, m, batch * s1 * 4, mp);
 }
 
 int phe_hip_mulmod(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, uint32_t* out, size_t batch) {
@@ -2122,13 +2167,12 @@ int phe_hip_mulmod(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, uint3
     const size_t s2 = (size_t)ctx->pub.s2;
     // (no chunked pipeline here: one product per 1.5 KB moved is PCIe-bound, and the runtime's own pageable-memory copy
     //  (24 GB/s) beats a single-threaded copy into pinned staging (19 GB/s measured, profiles/r02c_host_abi.json))
-    int rc = stage_in(ctx, 0, a, batch * s2);
-    if (!rc) rc = stage_in(ctx, 1, b, batch * s2);
-    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
-    if (!rc) rc = phe_hip_mulmod_dev(ctx, ctx->stage[0], ctx->stage[1], ctx->stage[2], batch, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(out, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));
-    return PHE_HIP_OK;
+    const bool mp = use_mapped(ctx, batch * s2, batch * s2, batch * s2);
+    int rc = stage_in(ctx, 0, a, batch * s2, mp);
+    if (!rc) rc = stage_in(ctx, 1, b, batch * s2, mp);
+    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2, mp);
+    if (!rc) rc = phe_hip_mulmod_dev(ctx, ctx->cur[0], ctx->cur[1], ctx->cur[2], batch, nullptr);
+    return stage_out(ctx, rc, 2, out, batch * s2 * 4, mp);
 }
 
 int phe_hip_add_plain(phe_hip_ctx* ctx, const uint32_t* c, const uint32_t* m, uint32_t* out, size_t batch) {
@@ -2137,13 +2181,12 @@ int phe_hip_add_plain(phe_hip_ctx* ctx, const uint32_t* c, const uint32_t* m, ui
     if (!c || !m || !out) return fail(PHE_HIP_EINVAL, "null buffer");
     if (int rc = bind_device(ctx)) return rc;
     const size_t s1 = (size_t)ctx->pub.s1, s2 = (size_t)ctx->pub.s2;
-    int rc = stage_in(ctx, 0, c, batch * s2);
-    if (!rc) rc = stage_in(ctx, 1, m, batch * s1);
-    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
-    if (!rc) rc = phe_hip_add_plain_dev(ctx, ctx->stage[0], ctx->stage[1], ctx->stage[2], batch, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(out, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));
-    return PHE_HIP_OK;
+    const bool mp = use_mapped(ctx, batch * s2, batch * s1, batch * s2);
+    int rc = stage_in(ctx, 0, c, batch * s2, mp);
+    if (!rc) rc = stage_in(ctx, 1, m, batch * s1, mp);
+    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2, mp);
+    if (!rc) rc = phe_hip_add_plain_dev(ctx, ctx->cur[0], ctx->cur[1], ctx->cur[2], batch, nullptr);
+    return stage_out(ctx, rc, 2, out, batch * s2 * 4, mp);
 }
 
 int phe_hip_powmod(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, int exp_limbs, uint32_t* out, size_t batch) {
@@ -2162,8 +2205,9 @@ int phe_hip_powmod(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, in
     }
     if (max_bits == 0) max_bits = 1;
     const size_t s2 = (size_t)ctx->pub.s2;
-    int rc = stage_in(ctx, 0, base, batch * s2);
-    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2);
+    const bool mp = use_mapped(ctx, batch * s2, batch * (size_t)exp_limbs, batch * s2);
+    int rc = stage_in(ctx, 0, base, batch * s2, mp);
+    if (!rc) rc = stage_in(ctx, 2, nullptr, batch * s2, mp);
     if (rc) return rc;
     // A handful of numbers (EncryptedNumber.__mul__, one at a time): the exponents are on the host here, so every number gets
     // its OWN sliding-window schedule and runs on a pair of wavefronts like a scalar encrypt / decrypt does (the per-element
@@ -2201,18 +2245,14 @@ int phe_hip_powmod(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e, in
             PHE_CTX_ORDER(ctx, nullptr);
             ctx->last_path = kPathWavePairs;
             ctx->last_geom_pub = geom_code(sp.G, sp.L);
-            rc = launch_split_ab(ctx, kModeEncrypt, sp, E, nullptr, nullptr, ctx->stage[0], ctx->pub.s2, nullptr, 0, ctx->stage[2], nullptr,
+            rc = launch_split_ab(ctx, kModeEncrypt, sp, E, nullptr, nullptr, ctx->cur[0], ctx->pub.s2, nullptr, 0, ctx->cur[2], nullptr,
                                  ctx->pub.s2, batch, nullptr, ctx->item_sched + ops_words);
-            if (rc) return rc;
-            HIP_TRY(hipMemcpy(out, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));
-            return PHE_HIP_OK;
+            return stage_out(ctx, rc, 2, out, batch * s2 * 4, mp);
         }
     }
-    rc = stage_in(ctx, 1, e, batch * (size_t)exp_limbs);
-    if (!rc) rc = phe_hip_powmod_dev(ctx, ctx->stage[0], ctx->stage[1], exp_limbs, max_bits, ctx->stage[2], batch, nullptr);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpy(out, ctx->stage[2], batch * s2 * 4, hipMemcpyDeviceToHost));
-    return PHE_HIP_OK;
+    rc = stage_in(ctx, 1, e, batch * (size_t)exp_limbs, mp);
+    if (!rc) rc = phe_hip_powmod_dev(ctx, ctx->cur[0], ctx->cur[1], exp_limbs, max_bits, ctx->cur[2], batch, nullptr);
+    return stage_out(ctx, rc, 2, out, batch * s2 * 4, mp);
 }
 
 static int max_exp_bits_of(const uint32_t* e, int exp_limbs, size_t batch) {

@@ -608,3 +608,46 @@ def test_integration_stub_of_section_b_runs(native, c_oracle):
         exec(compile("class _More(HipContext):\n" + more, "INTEGRATION.md:B2", "exec"), ns)
         ext = ns["_More"](Pub)
         assert ext.ciphertext_strings(cts[:5]) == [str(c) for c in cts[:5]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("key_bits", [1024, 2048])
+def test_a_handful_of_host_rows_goes_through_mapped_pinned_memory(native, c_oracle, key_bits, monkeypatch):
+    """Host-pointer calls whose operands fit the mapped staging slots (32 KiB each) let the kernels read the operands from and
+    write the result to pinned host memory; beyond that, and with PHE_HIP_NO_MAPPED_STAGING, the hipMemcpy staging runs.
+    Same bits from both, for every entry point that has the short cut, either side of the slot size, against libgmp."""
+    g = load_golden(key_bits)
+    s1, s2 = key_bits // 32, key_bits // 16
+    n_int, p_int, q_int = H(g["n"]), H(g["p"]), H(g["q"])
+    N = n_int * n_int
+    n = native.int_to_limbs(n_int, s1)
+    p, q = native.int_to_limbs(p_int, s1 // 2), native.int_to_limbs(q_int, s1 // 2)
+    fits = 8192 // s2                                       # rows of a ciphertext per slot
+    rng = random.Random(7 * key_bits)
+    rows = fits + 3
+    m = native.ints_to_limbs([rng.randrange(n_int) for _ in range(rows)], s1)
+    r = native.ints_to_limbs([rng.randrange(1, n_int) for _ in range(rows)], s1)
+    e = native.ints_to_limbs([rng.randrange(1, 1 << 56) for _ in range(rows)], 2)
+    fast = make_ctx(native, g)
+    monkeypatch.setenv("PHE_HIP_NO_MAPPED_STAGING", "1")
+    slow = make_ctx(native, g)
+    c_all = slow.encrypt(m, r)
+    assert np.array_equal(c_all, c_oracle.encrypt(n, m, r, nthreads=4))
+    for batch in (1, 2, fits - 1, fits, fits + 1, rows):
+        c = fast.encrypt(m[:batch], r[:batch])
+        assert np.array_equal(c, c_all[:batch]), batch
+        assert np.array_equal(fast.encrypt_owner(m[:batch], r[:batch]), c), batch
+        assert np.array_equal(fast.decrypt(c), m[:batch]), batch
+        assert np.array_equal(fast.obfuscate(c, r[:batch][::-1].copy()), slow.obfuscate(c, r[:batch][::-1].copy())), batch
+        prod = fast.mulmod(c, c_all[rows - batch:rows])
+        assert np.array_equal(prod, slow.mulmod(c, c_all[rows - batch:rows])), batch
+        assert np.array_equal(prod, c_oracle.add(n, c, c_all[rows - batch:rows], nthreads=4)), batch
+        assert np.array_equal(fast.add_plain(c, m[:batch][::-1].copy()), slow.add_plain(c, m[:batch][::-1].copy())), batch
+        pw = fast.powmod(c, e[:batch])
+        assert np.array_equal(pw, slow.powmod(c, e[:batch])), batch
+        want = [pow(ci, ei, N) for ci, ei in zip(native.limbs_to_ints(c), native.limbs_to_ints(e[:batch]))]
+        assert native.limbs_to_ints(pw) == want, batch
+    # a failed call (bad argument) in between leaves the next one intact
+    with pytest.raises(ValueError):
+        fast.mulmod(c_all[:2], c_all[:3])
+    assert np.array_equal(fast.mulmod(c_all[:2], c_all[1:3]), slow.mulmod(c_all[:2], c_all[1:3]))
