@@ -284,8 +284,8 @@ inline ModulusPack build_modulus(const Big& N_any, const Big* aux_src, int min_b
 // only: R = 2^(29 H) >= 16 n, H = G*L limbs.  A fused sweep adds three products per digit to a column accumulator
 // (3L * 2^58 < 2^64: L <= 21); wider lanes (L = 27) run the words of a pair product as single sweeps of two.
 static const int kS16[] = {1, 2, 3, 4, 5, 7, 9, 14, 18};
-static const int kS8[] = {5, 7, 9, 14, 18};
-static const int kS4[] = {9, 14, 18, 27};
+static const int kS8[] = {3, 5, 7, 9, 14, 18};
+static const int kS4[] = {5, 9, 14, 18, 27};
 static const int kS2[] = {9, 18, 27};
 constexpr int kMaxSplitL = 31;  // two products per digit per sweep: 2L * 2^58 < 2^64 (fused sweeps, three products: L <= 21)
 // G = 64: ONE number per wavefront (wave_gfx950.h: wave-wide DPP shifts, scalar broadcast) — the latency rung for a handful
@@ -756,7 +756,8 @@ inline bool big_invert_odd(const Big& a_in, const Big& N, Big& out) {
 // geometry of q^2
 inline bool split_part_holds(int G, int L) {
     const int* list = G == 16 ? kS16 : G == 8 ? kS8 : G == 4 ? kS4 : G == 2 ? kS2 : nullptr;
-    const int count = G == 16 ? 9 : G == 8 ? 5 : G == 4 ? 4 : G == 2 ? 3 : 0;  // (the lift has no whole-wave form: G = 64 is not asked here)
+    const auto len = [](const auto& a) { return (int)(sizeof(a) / sizeof(a[0])); };
+    const int count = G == 16 ? len(kS16) : G == 8 ? len(kS8) : G == 4 ? len(kS4) : G == 2 ? len(kS2) : 0;  // (the lift has no whole-wave form: G = 64 is not asked here)
     for (int i = 0; i < count; ++i)
         if (list[i] == L) return true;
     return false;

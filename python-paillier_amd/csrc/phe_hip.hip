@@ -95,9 +95,11 @@ PHE_DECLARE_SPLIT_PART(s2c)
 PHE_DECLARE_SPLIT_PART(s4a)
 PHE_DECLARE_SPLIT_PART(s4b)
 PHE_DECLARE_SPLIT_PART(s4c)
+PHE_DECLARE_SPLIT_PART(s4d)
 PHE_DECLARE_SPLIT_PART(s8a)
 PHE_DECLARE_SPLIT_PART(s8b)
 PHE_DECLARE_SPLIT_PART(s8c)
+PHE_DECLARE_SPLIT_PART(s8d)
 PHE_DECLARE_SPLIT_PART(s16a)
 PHE_DECLARE_SPLIT_PART(s16b)
 PHE_DECLARE_SPLIT_PART(s16c)
@@ -181,6 +183,9 @@ static const SplitPart kSplitParts[] = {
     {4, phe::s4c::occ_split, phe::s4c::launch_split, phe::s4c::occ_var_split, phe::s4c::launch_var_split,
      phe::s4c::occ_multi_split, phe::s4c::launch_multi_split, phe::s4c::launch_multi_tables,
      phe::s4c::launch_multi_lookup, phe::s4c::launch_mul_split, phe::s4c::launch_crt_lift, phe::s4c::occ_split_unit, phe::s4c::launch_split_unit, phe::s4c::launch_pair, phe::s4c::launch_split_halves, phe::s4c::launch_split_ab, phe::s4c::launch_tail_wave},
+    {4, phe::s4d::occ_split, phe::s4d::launch_split, phe::s4d::occ_var_split, phe::s4d::launch_var_split,
+     phe::s4d::occ_multi_split, phe::s4d::launch_multi_split, phe::s4d::launch_multi_tables,
+     phe::s4d::launch_multi_lookup, phe::s4d::launch_mul_split, phe::s4d::launch_crt_lift, phe::s4d::occ_split_unit, phe::s4d::launch_split_unit, phe::s4d::launch_pair, phe::s4d::launch_split_halves, phe::s4d::launch_split_ab, phe::s4d::launch_tail_wave},
     {8, phe::s8a::occ_split, phe::s8a::launch_split, phe::s8a::occ_var_split, phe::s8a::launch_var_split,
      phe::s8a::occ_multi_split, phe::s8a::launch_multi_split, phe::s8a::launch_multi_tables,
      phe::s8a::launch_multi_lookup, phe::s8a::launch_mul_split, phe::s8a::launch_crt_lift, phe::s8a::occ_split_unit, phe::s8a::launch_split_unit, phe::s8a::launch_pair, phe::s8a::launch_split_halves, phe::s8a::launch_split_ab, phe::s8a::launch_tail_wave},
@@ -190,6 +195,9 @@ static const SplitPart kSplitParts[] = {
     {8, phe::s8c::occ_split, phe::s8c::launch_split, phe::s8c::occ_var_split, phe::s8c::launch_var_split,
      phe::s8c::occ_multi_split, phe::s8c::launch_multi_split, phe::s8c::launch_multi_tables,
      phe::s8c::launch_multi_lookup, phe::s8c::launch_mul_split, phe::s8c::launch_crt_lift, phe::s8c::occ_split_unit, phe::s8c::launch_split_unit, phe::s8c::launch_pair, phe::s8c::launch_split_halves, phe::s8c::launch_split_ab, phe::s8c::launch_tail_wave},
+    {8, phe::s8d::occ_split, phe::s8d::launch_split, phe::s8d::occ_var_split, phe::s8d::launch_var_split,
+     phe::s8d::occ_multi_split, phe::s8d::launch_multi_split, phe::s8d::launch_multi_tables,
+     phe::s8d::launch_multi_lookup, phe::s8d::launch_mul_split, phe::s8d::launch_crt_lift, phe::s8d::occ_split_unit, phe::s8d::launch_split_unit, phe::s8d::launch_pair, phe::s8d::launch_split_halves, phe::s8d::launch_split_ab, phe::s8d::launch_tail_wave},
     {16, phe::s16a::occ_split, phe::s16a::launch_split, phe::s16a::occ_var_split, phe::s16a::launch_var_split,
      phe::s16a::occ_multi_split, phe::s16a::launch_multi_split, phe::s16a::launch_multi_tables,
      phe::s16a::launch_multi_lookup, phe::s16a::launch_mul_split, phe::s16a::launch_crt_lift, phe::s16a::occ_split_unit, phe::s16a::launch_split_unit, phe::s16a::launch_pair, phe::s16a::launch_split_halves, phe::s16a::launch_split_ab, phe::s16a::launch_tail_wave},

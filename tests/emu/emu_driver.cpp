@@ -167,6 +167,8 @@ static void run_mul(MulArgs A) {
         case 218: { constexpr int GG = 2, LL = 18; CALL; break; }                     \
         case 227: { constexpr int GG = 2, LL = 27; CALL; break; }                     \
         case 427: { constexpr int GG = 4, LL = 27; CALL; break; }                     \
+        case 405: { constexpr int GG = 4, LL = 5; CALL; break; }                      \
+        case 803: { constexpr int GG = 8, LL = 3; CALL; break; }                      \
         case 409: { constexpr int GG = 4, LL = 9; CALL; break; }                      \
         case 414: { constexpr int GG = 4, LL = 14; CALL; break; }                     \
         case 418: { constexpr int GG = 4, LL = 18; CALL; break; }                     \
