@@ -33,10 +33,15 @@ OPS = ["encrypt", "decrypt", "add unencrypted and encrypted", "add encrypted and
        "multiply encrypted and unencrypted"]
 
 
-def timed(fn):
-    t0 = time.perf_counter()
-    out = fn()
-    return time.perf_counter() - t0, out
+def timed(fn, best_of=1):
+    """wall time of fn() (the shorter of `best_of` calls) and its result"""
+    best = None
+    for _ in range(best_of):
+        t0 = time.perf_counter()
+        out = fn()
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+    return best, out
 
 
 def bench_key(key_size, scalar_ops, batch, rng):
@@ -76,19 +81,21 @@ def bench_key(key_size, scalar_ops, batch, rng):
         warm()
     del w1, w2
     pub.discard_obfuscators()                                  # time real encryptions: r drawn and r^n computed in the call
-    t, v1 = timed(lambda: pub.encrypt_batch(X, device=True))
+    # (batched column: the shorter of two calls each — a 1 ms call is at the mercy of whatever else the process does once, e.g.
+    #  the teardown of the previous key size's context: profiles/r03y_benchmarks_batched.txt had one 28 ms addition at 1024 bits)
+    t, v1 = timed(lambda: pub.encrypt_batch(X, device=True), best_of=2)
     res["batched"][OPS[0]] = t / batch
     v2 = pub.encrypt_batch(Y, device=True)
-    t, back = timed(lambda: priv.decrypt_batch(v1))
+    t, back = timed(lambda: priv.decrypt_batch(v1), best_of=2)
     assert back == X.tolist()
     res["batched"][OPS[1]] = t / batch
-    t, a1 = timed(lambda: (v1 + Y).limbs(False))
+    t, a1 = timed(lambda: (v1 + Y).limbs(False), best_of=2)
     res["batched"][OPS[2]] = t / batch
-    t, a2 = timed(lambda: (v1 + v2).limbs(False))
+    t, a2 = timed(lambda: (v1 + v2).limbs(False), best_of=2)
     res["batched"][OPS[3]] = t / batch
-    t, a3 = timed(lambda: (v1 + 1.0).limbs(False))
+    t, a3 = timed(lambda: (v1 + 1.0).limbs(False), best_of=2)
     res["batched"][OPS[4]] = t / batch
-    t, a4 = timed(lambda: (v1 * Y).limbs(False))
+    t, a4 = timed(lambda: (v1 * Y).limbs(False), best_of=2)
     res["batched"][OPS[5]] = t / batch
     got = priv.decrypt_batch((v1 + v2)[:64])
     assert all(abs(g - (x + y)) < 1e-9 for g, x, y in zip(got, X[:64], Y[:64]))

@@ -1047,8 +1047,9 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
     ctx->no_wave_pairs = getenv("PHE_HIP_NO_WAVE_PAIRS") != nullptr;
     if (const char* d = getenv("PHE_HIP_WAVE_PAIR_DEPTH")) ctx->wave_pair_depth = std::max(1, atoi(d));
     if (!rc && !getenv("PHE_HIP_GROUP")) {
-        // the wider rungs of the ladder: 8- and 16-lane groups where they differ from what is already there
-        for (int prefer : {8, 16, 64}) {
+        // the wider rungs of the ladder: 4-, 8- and 16-lane groups and the whole wave, where they differ from what is already
+        // there (4 lanes: keys whose narrowest geometry is 2 lanes wide — n of 1024 bits is 2 x 18 limbs)
+        for (int prefer : {4, 8, 16, 64}) {
             try {
                 phe_hip_ctx::PubRung R;
                 R.plan = host::build_public(n, n_limbs, prefer);
