@@ -460,3 +460,25 @@ def test_scalar_multiplication_of_a_handful_on_wave_pairs(emu, key_bits):
     finally:
         emu.set_wave_pairs(False)
         emu.set_group(0)
+
+
+def test_split_geometries_by_modulus_width(emu):
+    """pick_geometry_split (key_setup.h) over the compiled limb counts: the rungs a modulus of a given width gets when a group
+    width is preferred — p, q of 1024-bit keys (18 limbs) have a 4-lane and an 8-lane rung of their own (4 x 5, 8 x 3), n of a
+    1024-bit key (36 limbs) a 4-lane one (4 x 9); the 2048- and 3072-bit geometries are what the GPU sweeps were measured on."""
+    def geom(bits, group):
+        emu.set_group(group)
+        try:
+            return emu.split_geometry(int_to_limbs((1 << bits) - 159, (bits + 31) // 32))
+        finally:
+            emu.set_group(0)
+    want = {
+        512: {0: (2, 9), 4: (4, 5), 8: (8, 3), 16: (16, 2), 64: (64, 1)},        # p, q of a 1024-bit key
+        1024: {0: (2, 18), 4: (4, 9), 8: (8, 5), 16: (16, 3), 64: (64, 1)},      # n of a 1024-bit key; p, q of a 2048-bit key
+        2048: {0: (4, 18), 4: (4, 18), 8: (8, 9), 16: (16, 5), 64: (64, 2)},     # n of a 2048-bit key
+        1536: {0: (2, 27), 4: (4, 14), 8: (8, 7), 16: (16, 4), 64: (64, 1)},     # p, q of a 3072-bit key
+        3072: {0: (4, 27), 8: (8, 14), 16: (16, 7), 64: (64, 2)},                # n of a 3072-bit key
+    }
+    for bits, by_group in want.items():
+        for group, gl in by_group.items():
+            assert geom(bits, group) == gl, (bits, group)
