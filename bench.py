@@ -522,6 +522,10 @@ def main():
     for _ in range(args.warmup):
         dec_step()
     dec_dt, dec_launch_ms = timed(dec_step, args.steps)
+    try:  # the rung the timed decrypt really ran on (the ladder need not end on the context's narrowest geometry)
+        dec_geom = int(ctx.last_launch()["geom_priv"]) if hasattr(ctx, "last_launch") else 0
+    except Exception:
+        dec_geom = 0
 
     # ---- bit-exactness of what was just timed -------------------------------------------------
     roundtrip_ok = be.equal(m_back, m)
@@ -844,6 +848,13 @@ def main():
         counted, counted_src = counted_mads(args.key_bits, info)
         enc_exec = counted["encrypt"] if counted else model_enc
         dec_exec = counted["decrypt"] if counted else model_dec
+        if counted and dec_geom and dec_geom != info.get("lane_limbs_priv"):
+            by_geom = counted.get("decrypt_by_halves_geometry", {})
+            if str(dec_geom) in by_geom:
+                dec_exec = by_geom[str(dec_geom)]
+                dec_kernel = kname(dec_geom, info["engine_priv"], "half_decrypt")
+            else:
+                dec_exec = None  # no exact count for the rung that ran: rather no fraction than one for another kernel
         exec_src = ("exact: wave::mad64 calls counted by the CPU wave emulator, %s" % counted_src) if counted else \
             "model (bench.py:executed_mads): no exact count committed for this geometry"
         traffic_unit, traffic_src = measured_traffic_per_unit(enc_kernel) if args.key_bits == 2048 else (None, None)

@@ -66,9 +66,32 @@ def main():
         else:
             count()
         key = [native.int_to_limbs(v, sh) for v in (p, q, H("hp"), H("hq"), H("p_inverse"))]
-        back = emu.decrypt(*key, s1, c)
+        # the CRT tail as the device runs it: one wavefront per ciphertext from 1024-bit keys up (phe_hip.hip, create_private),
+        # one ciphertext per thread (plain C arithmetic, no wave::mad64: not counted) below
+        wave_tail = bits >= 1024
+        emu.set_wave_tail(wave_tail)
+        try:
+            back = emu.decrypt(*key, s1, c)
+        finally:
+            emu.set_wave_tail(False)
         res["decrypt"] = count() / B
+        res["decrypt_tail"] = "wavefront" if wave_tail else "thread"
         assert np.array_equal(back, m)
+        # the same per geometry of the CRT halves: the ladder may end on another rung than the narrowest (3072 bits: 4 x 14,
+        # not 2 x 27, since the wide-rung factor of rung_cost) — bench.py looks the count up by what last_launch reported
+        by_geom = {}
+        for group in (0, 4):
+            emu.set_group(group)
+            emu.set_wave_tail(wave_tail)
+            try:
+                G, L = emu.split_geometry(native.int_to_limbs(q, sh))
+                back = emu.decrypt(*key, s1, c)
+            finally:
+                emu.set_wave_tail(False)
+                emu.set_group(0)
+            by_geom[str(G * 100 + L)] = count() / B
+            assert np.array_equal(back, m)
+        res["decrypt_by_halves_geometry"] = by_geom
         emu.mulmod(nsq_arr, c, np.ascontiguousarray(c[::-1]))
         res["raw_add"] = count() / B
         emu.add_plain(n_arr, c, m)
