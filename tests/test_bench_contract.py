@@ -49,6 +49,12 @@ def test_exact_counts_back_the_model():
     assert abs(counted["encrypt"] / enc - 1) < 0.01 and abs(counted["decrypt"] / dec - 1) < 0.01
     assert counted["encrypt"] < bench.mac32_counts(2048)[0]
     assert counted["raw_add"] == 4 * 144 * 144                 # two full-width 144-limb Montgomery products
+    # the count per geometry of the CRT halves (the ladder may end on another rung than the narrowest: 3072 bits run the halves
+    # on 4 x 14): same work on 2 x 18 and 4 x 9 (both 36 limbs), more on 56 limbs than on 54
+    assert counted["decrypt_by_halves_geometry"]["218"] == counted["decrypt"] == counted["decrypt_by_halves_geometry"]["409"]
+    wide, _ = bench.counted_mads(3072, dict(info, lane_limbs_pub=427))
+    assert wide["decrypt_by_halves_geometry"]["227"] == wide["decrypt"] < wide["decrypt_by_halves_geometry"]["414"]
+    assert wide["decrypt_by_halves_geometry"]["414"] / wide["decrypt"] < (56 / 54) ** 2
     # a geometry the count was not made for falls back to the model
     assert bench.counted_mads(2048, dict(info, lane_limbs_pub=236))[0] is None
     assert bench.counted_mads(2048, dict(info, engine_pub="full"))[0] is None
