@@ -18,8 +18,9 @@ The same JSON line also carries
   ops          — configs[2]: _raw_add, _raw_mul by float-like 56-bit / int64 scalars and with 10 % negative scalars
                  (the inverse branch of phe/paillier.py:745-749), obfuscate — each over the whole batch, with its own
                  roofline entry and a strided sample checked against the libgmp oracle;
-  config4      — configs[3]: a 3072-bit key, one shard of 2^20 plaintexts per GPU (8M on 8 GPUs; at N = 1 one shard of 2^18
-                 rows), the ciphertext shards concatenated on every GPU by ONE RCCL all-gather (phe.sharding.all_gather_rows)
+  config4      — configs[3]: a 3072-bit key, one shard of 2^20 plaintexts per GPU (8M on 8 GPUs; at N = 1 that one shard;
+                 --scaling strong: the 8M job itself cut over the ranks present), the ciphertext shards concatenated on every GPU
+                 by ONE RCCL all-gather (phe.sharding.all_gather_rows)
                  and, for N > 1, once more by the library's own RCCL communicator (phe_hip_allgather_dev), bits compared;
                  shard-boundary rows + a strided sample against the oracle;
   roofline     — dominant kernel (k_modexp_split<4,18,encrypt>): `frac` = multiply-adds the kernel EXECUTES
@@ -198,7 +199,12 @@ def parse_args(argv=None):
     ap.add_argument("--no-config4", action="store_true")
     ap.add_argument("--config4-key-bits", type=int, default=3072, choices=[256, 1024, 2048, 3072])
     ap.add_argument("--config4-total", type=int, default=0,
-                    help="plaintexts of the whole configs[3] job (0 = 2^20 per GPU for N > 1; at N = 1 one shard of 2^18)")
+                    help="plaintexts of the whole configs[3] job (0 = weak: 2^20 per GPU, the per-GPU shard of the 8M job on 8 "
+                         "GPUs; strong: 2^23 at every N)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): --batch plaintexts PER GPU and a 2^20-row configs[3] shard per GPU, whatever N; "
+                         "strong: --batch is the WHOLE job, sharded contiguously over the ranks, and configs[3] is the 8M job "
+                         "(2^23 rows) at every N.  The JSON line says which one it is (`scaling`).")
     ap.add_argument("--lib-allgather", action="store_true",
                     help="N = 1: repeat the configs[3] gather through the library's own RCCL communicator (always on for N > 1)")
     ap.add_argument("--no-lib-allgather", action="store_true")
@@ -471,7 +477,15 @@ def main():
         ctx.set_blocks_per_cu(args.blocks_per_cu)
 
     # ---- synthetic inputs, generated on the device (resident in HBM before any timed region) ----
-    B = args.batch
+    strong = args.scaling == "strong"
+    if strong:                                                 # --batch is the whole job: this rank's contiguous shard of it
+        lo_b, hi_b = shard_bounds(args.batch, world, rank)
+        B = hi_b - lo_b
+        if B == 0:
+            raise SystemExit("bench.py --scaling strong: --batch %d leaves rank %d of %d without a row" % (args.batch, rank, world))
+    else:
+        B = args.batch
+    job_rows = args.batch if strong else world * B             # rows of the whole job per step
     m = be.rand(B, s1, 1234 + 2 * rank)
     r = be.rand(B, s1, 1235 + 2 * rank)
     clamp_operands(m, r, s1, n_int)
@@ -513,7 +527,7 @@ def main():
         dt, launch_ms = timed(step, args.steps)
         if rank == 0:
             print(json.dumps({"profiling_aid_not_a_bench_line": True, "only": args.only, "batch": B, "key_bits": args.key_bits,
-                              "steps": args.steps, "per_s": B * args.steps * world / dt, "launch_ms": launch_ms,
+                              "steps": args.steps, "per_s": job_rows * args.steps / dt, "launch_ms": launch_ms,
                               "decrypt_round_trip": be.equal(m_back, m) if args.only == "decrypt" else None}))
         return
     for _ in range(args.warmup):
@@ -567,7 +581,7 @@ def main():
             barrier()
             dt = max_over_ranks([time.perf_counter() - t0])[0]
             ok = check() if rank == 0 else None
-            ops[name] = {"value": world * B * reps / dt, "unit": "ops/s", "reps": reps, "ms_per_pass": dt / reps * 1e3,
+            ops[name] = {"value": job_rows * reps / dt, "unit": "ops/s", "reps": reps, "ms_per_pass": dt / reps * 1e3,
                          "launch_ms_avg": sum(be.elapsed_ms(a, b) for a, b in evs) / reps,
                          "bit_exact_strided_sample_vs_gmp_oracle": ok, "rows_checked": len(idx) if rank == 0 else None}
             if note:
@@ -725,12 +739,22 @@ def main():
         k4 = golden(args.config4_key_bits)
         t1, t2 = args.config4_key_bits // 32, args.config4_key_bits // 16
         ctx4 = be.context(k4["n"], n_limbs=t1)
-        # N > 1: the job of BASELINE configs[3] scaled to the ranks present (2^20 per GPU: 8M on 8 GPUs).  N = 1: ONE SHARD
-        # of 2^18 rows of that job (~1.6 s), so that the driver's default line carries a 3072-bit number at all
-        total = args.config4_total or (world * (1 << 20) if world > 1 else (1 << 18))
+        # weak (default): the per-GPU shard of BASELINE configs[3]'s 8M job on 8 GPUs — 2^20 rows on every GPU, whatever N
+        # (N = 1: that one shard, ~6.5 s at 3072 bits); strong: the 8M job itself (2^23 rows) cut over the ranks present
+        total = args.config4_total or ((1 << 23) if strong else world * (1 << 20))
         lo, hi = shard_bounds(total, world, rank)
         rows = hi - lo
         blk = 1 << 16
+        lib_gather_wanted = (args.lib_allgather or world > 1) and not args.no_lib_allgather and be.name == "hip" and total % world == 0
+        # what this rank is about to allocate for the leg, said BEFORE it is allocated (a first N > 1 run that dies of memory
+        # should say where): operands m, r + ciphertext shard, the gathered vector (twice with the library's gather), tables
+        budget = {"operands_m_r": 2 * rows * t1 * 4, "ciphertext_shard": rows * t2 * 4,
+                  "gathered_vector_torch": (total * t2 * 4) if use_dist else 0,
+                  "gathered_vector_library_rccl": (total * t2 * 4) if lib_gather_wanted else 0,
+                  "window_tables_and_scratch_upper_bound": 2 << 30}
+        print("bench.py rank %d/%d configs[3] memory budget: %s = %.2f GB on this GPU (resident from configs[1]: %.2f GB)"
+              % (rank, world, ", ".join("%s %.2f GB" % (k, v / 1e9) for k, v in budget.items()), sum(budget.values()) / 1e9,
+                 (2 * B * s1 + B * s2 + B * s1) * 4 / 1e9), file=sys.stderr, flush=True)
 
         def operands(first, count):
             """rows [first, first+count) of the job's (m, r): a function of the row index only (a seeded stream per 2^16-row
@@ -759,7 +783,7 @@ def main():
         t_gather = time.perf_counter() - t0
         t_enc, t_gather = max_over_ranks([t_enc, t_gather])
         lib_gather = None
-        if (args.lib_allgather or world > 1) and not args.no_lib_allgather and be.name == "hip" and total % world == 0:
+        if lib_gather_wanted:
             # the same exchange issued by the library's own RCCL communicator (include/phe_hip.h phe_hip_allgather_dev):
             # the path of a host without a process group; the id travels over the torch group here
             from phe.sharding import library_communicator
@@ -778,6 +802,14 @@ def main():
             t_lib = max_over_ranks([time.perf_counter() - t0])[0]
             lib_gather = {"seconds": t_lib, "GBps_per_gpu": total * t2 * 4 / t_lib / 1e9,
                           "same_bits_as_torch_all_gather": be.equal(full2, full)}
+            if not lib_gather["same_bits_as_torch_all_gather"]:
+                # say WHERE: the first row on which the library's gather and torch's differ (the run exits non-zero below)
+                diff = (be.as_tensor(full2) != be.as_tensor(full)).any(dim=1).nonzero()
+                first = int(diff[0]) if len(diff) else -1
+                lib_gather["first_differing_row"] = first
+                lib_gather["first_differing_row_owner_rank"] = next((k for k in range(world) if shard_bounds(total, world, k)[0] <= first < shard_bounds(total, world, k)[1]), None)
+                print("bench.py rank %d: library RCCL all-gather differs from torch's at row %d of %d (%d rows differ)"
+                      % (rank, first, total, len(diff)), file=sys.stderr, flush=True)
             cfg4_ok = cfg4_ok and lib_gather["same_bits_as_torch_all_gather"]
             comm.close()
             del full2
@@ -792,9 +824,9 @@ def main():
             cfg4 = {"workload": "configs[3]: %d-bit key, %d plaintexts sharded over %d GPU(s) (%d per GPU%s), ONE all-gather "
                                 "of the ciphertext shards (phe.sharding.all_gather_rows, backend %s)"
                                 % (args.config4_key_bits, total, world, rows,
-                                   "" if world > 1 or args.config4_total else ": one shard of 2^18 rows of the 8M job",
+                                   "" if (strong or args.config4_total) else ": weak scaling, the per-GPU shard of the 8M job on 8 GPUs",
                                    be.dist_backend if use_dist else "none: 1 rank"),
-                    "total": total, "rows_per_gpu": rows,
+                    "total": total, "rows_per_gpu": rows, "scaling": args.scaling, "memory_budget_bytes_rank0": budget,
                     "encrypt": {"seconds": t_enc, "value": total / t_enc, "unit": "encrypts/s"},
                     "all_gather": {"seconds": t_gather, "bytes_received_per_gpu": total * t2 * 4,
                                    "GBps_per_gpu": total * t2 * 4 / t_gather / 1e9 if use_dist else None},
@@ -861,7 +893,7 @@ def main():
         valu_unit, valu_src = pmc_valu_per_unit(enc_kernel) if args.key_bits == 2048 else (None, None)
         enc_kernel_s = sum(enc_launch_ms) / len(enc_launch_ms) * 1e-3
         dec_kernel_s = sum(dec_launch_ms) / len(dec_launch_ms) * 1e-3
-        value = world * B * args.steps / enc_dt
+        value = job_rows * args.steps / enc_dt
         rate = lambda per_unit, seconds: per_unit * B / seconds if per_unit else None
         frac = lambda per_unit, seconds: per_unit * B / seconds / peak if per_unit else None
         roofline = {
@@ -935,14 +967,15 @@ def main():
         out = {
             "metric": METRIC, "value": value, "unit": "encrypts/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": enc_dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u32 (29-bit limbs, v_mad_u64_u32 with 64-bit accumulate)",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "u32 (29-bit limbs, v_mad_u64_u32 with 64-bit accumulate)",
             "data": "synthetic" if be.name == "hip" else "synthetic, SELFTEST on the CPU wave emulator — not a measurement",
             "rccl_ranks": dist.get_world_size() if use_dist else 1, "backend": be.dist_backend if use_dist else "single process",
-            "config": {"workload": "configs[1]: %d-bit key, %d-plaintext batch per GPU, raw_encrypt then raw_decrypt, "
-                                   "operands resident in HBM" % (args.key_bits, B),
-                       "key_bits": args.key_bits, "batch_per_gpu": B, "parallelism": "batch-sharded x%d" % world,
+            "config": {"workload": "configs[1]: %d-bit key, %s, raw_encrypt then raw_decrypt, operands resident in HBM"
+                                   % (args.key_bits, ("%d-plaintext job cut into contiguous shards (strong scaling: %d on rank 0)" % (job_rows, B))
+                                      if strong else "%d-plaintext batch per GPU" % B),
+                       "key_bits": args.key_bits, "batch_per_gpu": B, "batch_whole_job": job_rows, "parallelism": "batch-sharded x%d" % world,
                        "geometry": info},
-            "decrypt": {"value": world * B * args.steps / dec_dt, "unit": "decrypts/s",
+            "decrypt": {"value": job_rows * args.steps / dec_dt, "unit": "decrypts/s",
                         "ms_per_step": dec_dt / args.steps * 1e3},
             "bit_exact": {"roundtrip_full_batch": roundtrip_ok, "strided_sample_vs_gmp_oracle": sample_ok,
                           "strided_sample_rows": sample_rows},

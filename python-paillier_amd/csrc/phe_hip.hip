@@ -983,24 +983,29 @@ struct CtxOrder {
     phe_hip_ctx* ctx;
     hipStream_t st;
     int rc = PHE_HIP_OK;
-    // The event is recorded lazily, on the PREVIOUS stream at the moment a call arrives on a different one (it then covers
-    // everything queued there so far, the previous call included): a run of calls on one stream costs nothing extra.
+    // Every call leaves an event behind on ITS OWN stream when it returns (everything it queued is covered); a call that
+    // arrives on another stream waits for that event.  No handle of a foreign stream is kept beyond the call that was given
+    // it: a caller may destroy its stream as soon as the call has returned (recording on a destroyed stream is undefined
+    // behaviour — round 3 recorded lazily on the PREVIOUS call's stream).
     CtxOrder(phe_hip_ctx* c, void* stream) : ctx(c), st((hipStream_t)stream) {
         if (!ctx->busy_valid || ctx->busy_stream == st) return;
-        hipError_t e = hipSuccess;
-        if (!ctx->ev_busy) e = hipEventCreateWithFlags(&ctx->ev_busy, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventRecord(ctx->ev_busy, ctx->busy_stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(st, ctx->ev_busy, 0);
+        hipError_t e = hipStreamWaitEvent(st, ctx->ev_busy, 0);
         if (e != hipSuccess) {
-            // e.g. the previous stream no longer exists (its owner destroyed it): whatever ran there is ordered by a full drain
             (void)hipGetLastError();
-            e = hipDeviceSynchronize();
+            e = hipDeviceSynchronize();  // whatever ran before is ordered by a full drain
             if (e != hipSuccess) rc = fail(PHE_HIP_EHIP, std::string("stream order of the context: ") + hipGetErrorString(e));
         }
     }
     ~CtxOrder() {
-        ctx->busy_stream = st;
-        ctx->busy_valid = true;
+        hipError_t e = hipSuccess;
+        if (!ctx->ev_busy) e = hipEventCreateWithFlags(&ctx->ev_busy, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(ctx->ev_busy, st);
+        if (e != hipSuccess) {  // no event: the next call on another stream must not run beside this one
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(st);
+        }
+        ctx->busy_stream = st;  // (compared only, never used as a handle again)
+        ctx->busy_valid = e == hipSuccess;
     }
 };
 #define PHE_CTX_ORDER(ctx, stream)   \
@@ -1621,6 +1626,7 @@ static int pair_launch(phe_hip_ctx* ctx, int op, const uint32_t* a, const uint32
     A.chunks = chunks_for(ctx->pub.s2, sp.rows);
     A.b_limbs = b_limbs;
     A.batch = batch;
+    ctx->last_path = 0;  // (phe_hip_ctx_last_launch describes THIS call: no path bit of an earlier encrypt / decrypt survives)
     ctx->last_geom_pub = geom_code(sp.G, sp.L);
     const int blocks = grid_blocks(ctx, batch, sp.G, 2);
     if (PHE_SPLIT_BY_GROUP(sp.G, launch_pair(sp.L, op, blocks, st, A)) < 0) return fail(PHE_HIP_EINVAL, "unsupported split geometry");
@@ -1676,6 +1682,7 @@ int phe_hip_pair_powmod_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t*
     if (!(ctx->use_split && ctx->d_nsplit.G)) return fail(PHE_HIP_EINVAL, "the pair form needs the split-modulus engine");
     PHE_CTX_ORDER(ctx, stream);
     const DevSplit& sp = pick_pair_split(ctx, batch);
+    ctx->last_path = 0;
     ctx->last_geom_pub = geom_code(sp.G, sp.L);
     return launch_var_split(ctx, sp, a, 0, e, exp_limbs, max_exp_bits, out, 0, batch, (hipStream_t)stream, true);
 }

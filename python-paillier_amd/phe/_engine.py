@@ -568,25 +568,39 @@ class Engine:
     def obfuscators_available(self):
         return self._obf.available()
 
-    def _take_pool_rows(self, count):
-        """`count` unused pool rows as ONE DeviceArray in the pool's form (a view where possible), or None; consumed"""
+    def take_pool_rows(self, count):
+        """`count` unused pool rows as ONE DeviceArray (a view where possible), or None; consumed.  The rows come in the form
+        the engine works in NOW (pair_form(): pair rows, else ciphertext words): a block filled through another engine of the
+        key pair, or under another PHE_HIP_PAIR_FORM setting, may be in the other form — every part is brought to one form
+        BEFORE the parts are joined (a copy at the wrong row stride would corrupt the obfuscators)."""
         parts = self._obf.take(count)
         if parts is None:
             return None
+        want = self.pair_form() or self.ct_limbs
+        if want not in {part.cols for part in parts}:     # (an emulated / full-width engine never sees pair blocks)
+            want = parts[0].cols
+
+        def normal(part):
+            if part.cols == want:
+                return part
+            return self.from_pair_dev(part) if want == self.ct_limbs else self.to_pair_dev(part)
+        parts = [normal(part) for part in parts]
         if len(parts) == 1:
             return parts[0]
-        out = DeviceArray(self.ctx, count, parts[0].cols)
+        out = DeviceArray(self.ctx, count, want)
         lo = 0
         for part in parts:
-            self.ctx.d2d(out.ptr + lo * part.cols * 4, part.ptr, part.nbytes)
+            self.ctx.d2d(out.ptr + lo * want * 4, part.ptr, part.nbytes)
             lo += part.rows
         self.ctx.sync()
         return out
 
+    _take_pool_rows = take_pool_rows
+
     def take_obfuscators(self, count):
         """`count` unused obfuscators r^n mod n^2 as plain ciphertext rows (DeviceArray of ct_limbs words), or None if
         the pool is short; they are consumed: nothing is handed out twice"""
-        rows = self._take_pool_rows(count)
+        rows = self.take_pool_rows(count)
         if rows is None or rows.cols == self.ct_limbs:
             return rows
         return self.from_pair_dev(rows)
@@ -596,7 +610,7 @@ class Engine:
         if the pool is short.  plaintexts: (count, n_limbs) limb rows or Python ints."""
         if not isinstance(plaintexts, np.ndarray):
             plaintexts = self.plain_limbs([v % self.n for v in plaintexts])
-        rows = self._take_pool_rows(plaintexts.shape[0])
+        rows = self.take_pool_rows(plaintexts.shape[0])
         if rows is None:
             return None
         if rows.cols == self.ct_limbs:
@@ -843,6 +857,28 @@ class Engine:
         if stream is None:
             self.ctx.sync()
         return out
+
+    def montmul_tree_dev(self, store, debt):
+        """The pairwise product tree of EncryptedVector.sum over resident rows that hold x * R^-debt: ONE Montgomery product
+        per node (a level turns debt d into 2d + 1; an unpaired last row is taken to the new debt by a product with a constant,
+        written into the level's spare row), every level queued on the engine's launch stream, settled once at the root.
+        Returns the root as a one-row DeviceArray of plain residues.  A public method: the whole tree runs under the engine's
+        lock (stream creation and the constant-row cache are check-then-set)."""
+        st = self._launch_stream() or None
+        keep = [store]                                       # operands stay alive until the final synchronisation
+        while store.rows > 1:
+            half, odd = store.rows // 2, store.rows % 2
+            merged = DeviceArray(self.ctx, half + odd, store.cols)
+            self.ctx.montmul_dev(store.rows_view(0, half).ptr, store.rows_view(half, 2 * half).ptr, False, merged.ptr, half, st or 0)
+            if odd:                                           # the row left over is taken to the new debt: * R^-(debt+1)
+                const = self._mont_const_row(-(debt + 1) + 1)
+                self.ctx.montmul_dev(store.rows_view(2 * half, 2 * half + 1).ptr, const.ptr, True,
+                                     merged.rows_view(half, half + 1).ptr, 1, st or 0)
+            keep.append(merged)
+            store, debt = merged, 2 * debt + 1
+        root = self.scale_dev(store, debt, stream=st) if debt else store
+        self.ctx.sync(st or 0)
+        return root
 
     def add_plain_dev(self, c, plaintexts):
         m = self.upload_plain([v % self.n for v in plaintexts] if not isinstance(plaintexts, np.ndarray) else plaintexts)

@@ -199,9 +199,18 @@ class EncryptedVector(object):
             return vec
         return EncryptedVector(self.public_key, eng.to_pair_dev(vec._limbs), vec._exps, vec._obfuscated.copy(), _pair=True)
 
+    def _plain_rows(self):
+        """the rows as plain ciphertext words WITHOUT touching the vector: the non-mutating readers (alignment inside `a + b`
+        must not convert an operand out of the form its owner put it in, nor change `_store` under another thread's read)"""
+        if self._pair:
+            return self.public_key._get_engine().from_pair_dev(self._store)
+        if self._debt:
+            return self.public_key._get_engine().scale_dev(self._store, self._debt)
+        return self._store
+
     def _pair_store(self):
         """the rows in pair form (converted if need be; the vector itself is left as it is)"""
-        return self._store if self._pair else self.public_key._get_engine().to_pair_dev(self._limbs)
+        return self._store if self._pair else self.public_key._get_engine().to_pair_dev(self._plain_rows())
 
     @property
     def exponents(self):
@@ -319,7 +328,7 @@ class EncryptedVector(object):
             pooled = None
             if self.on_device and len(rows) == len(self):
                 from . import keys
-                take = eng._take_pool_rows if (self._pair and eng.pair_form()) else eng.take_obfuscators
+                take = eng.take_pool_rows if (self._pair and eng.pair_form()) else eng.take_obfuscators
                 pooled = take(len(self))
                 if pooled is None and len(self) <= keys.SCALAR_POOL_REFILL // 4:
                     eng.fill_obfuscator_pool(keys.SCALAR_POOL_REFILL)
@@ -386,7 +395,7 @@ class EncryptedVector(object):
             if self.on_device:
                 shifts = (old - new) * log2b                       # 0 for untouched rows: c^1 = c, still canonical
                 e = eng.shifted_limbs(np.ones(len(old), dtype=np.uint64), shifts)
-                return self._like(eng.powmod_dev(self._limbs, e), new, flags)
+                return self._like(eng.powmod_dev(self._plain_rows(), e), new, flags)
             e, _ = eng.shifted_limbs(np.ones(len(rows), dtype=np.uint64), delta * log2b)
             limbs = self._limbs.copy()
             limbs[rows] = eng.ctx.powmod(np.ascontiguousarray(limbs[rows]), e)
@@ -397,7 +406,7 @@ class EncryptedVector(object):
             exps = [1] * len(self)
             for i, sc in zip(rows.tolist(), scal):
                 exps[i] = sc
-            return self._like(eng.raw_mul_dev(self._limbs, exps), new, flags)   # both branches of _raw_mul
+            return self._like(eng.raw_mul_dev(self._plain_rows(), exps), new, flags)   # both branches of _raw_mul
         limbs = self._limbs.copy()
         limbs[rows] = eng.raw_mul(np.ascontiguousarray(limbs[rows]), scal)
         return self._like(limbs, new, flags)
@@ -535,21 +544,8 @@ class EncryptedVector(object):
             # (an odd row out is taken to the same debt by a product with a constant); settled once, at the root
             # every level is queued on the engine's launch stream, nothing is waited for until the root is there: a level's
             # output block holds one spare row, so that an unpaired last row joins it by ONE product written in place
-            store, debt, exp = cur._store, cur._debt, int(cur._exps[0])
-            st = eng._launch_stream() or None
-            keep = [store]                                       # operands stay alive until the final synchronisation
-            while store.rows > 1:
-                half, odd = store.rows // 2, store.rows % 2
-                merged = DeviceArray(eng.ctx, half + odd, store.cols)
-                eng.ctx.montmul_dev(store.rows_view(0, half).ptr, store.rows_view(half, 2 * half).ptr, False, merged.ptr, half, st or 0)
-                if odd:                                           # the row left over is taken to the new debt: * R^-(debt+1)
-                    const = eng._mont_const_row(-(debt + 1) + 1)
-                    eng.ctx.montmul_dev(store.rows_view(2 * half, 2 * half + 1).ptr, const.ptr, True,
-                                        merged.rows_view(half, half + 1).ptr, 1, st or 0)
-                keep.append(merged)
-                store, debt = merged, 2 * debt + 1
-            root = eng.scale_dev(store, debt, stream=st) if debt else store
-            eng.ctx.sync(st or 0)
+            exp = int(cur._exps[0])
+            root = eng.montmul_tree_dev(cur._store, cur._debt)   # (one serialised engine call: the tree and its settling product)
             return EncryptedNumber(pk, eng.to_ints(root.to_host())[0], exp)
         limbs, exp = cur._limbs, int(cur._exps[0])
         if self.on_device:

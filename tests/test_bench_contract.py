@@ -109,6 +109,23 @@ def test_bench_under_torchrun_is_a_rank():
     _check_two_rank_line(_run_bench(cmd))
 
 
+def test_bench_strong_scaling_shards_one_job_over_the_ranks():
+    """--scaling strong: --batch is the WHOLE job (7 rows over two ranks: 4 + 3), configs[3] keeps its total at every N, and the
+    line says which kind of scaling it is"""
+    args = [a for a in SELFTEST]
+    args[args.index("--batch") + 1] = "7"
+    out = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--scaling", "strong"] + args)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["batch_whole_job"] == 7 and out["config"]["batch_per_gpu"] == 4
+    assert out["bit_exact"]["roundtrip_full_batch"] is True
+    cfg4 = out["config4"]
+    assert cfg4["scaling"] == "strong" and cfg4["total"] == 9 and cfg4["rows_per_gpu"] == 5
+    assert cfg4["bit_exact_boundaries_and_sample_vs_gmp_oracle"] is True
+    assert cfg4["memory_budget_bytes_rank0"]["ciphertext_shard"] == 5 * 16 * 4
+    weak = _run_bench([sys.executable, "bench.py", "--gpus", "2"] + SELFTEST)
+    assert weak["scaling"] == "weak" and weak["config"]["batch_whole_job"] == 12 and weak["config4"]["scaling"] == "weak"
+
+
 def test_bench_single_process_line():
     out = _run_bench([sys.executable, "bench.py"] + SELFTEST + ["--config4"])
     assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1
