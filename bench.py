@@ -99,6 +99,31 @@ def executed_mads(key_bits, info):
     return enc, dec
 
 
+def current_csrc_hash():
+    """hash of the device sources in the tree (tools/csrc_hash.py): committed counts made from other sources are STALE"""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from csrc_hash import csrc_hash
+        return csrc_hash()
+    except Exception:
+        return None
+    finally:
+        if sys.path and sys.path[0] == os.path.join(ROOT, "tools"):
+            sys.path.pop(0)
+
+
+def committed_count_is_stale(basename):
+    """True when profiles/<basename> was made from other device sources than the tree holds (or does not say which)"""
+    if not basename:
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", basename)) as f:
+            made_from = json.load(f).get("csrc_sha256")
+    except Exception:
+        return True
+    return made_from is None or made_from != current_csrc_hash()
+
+
 def counted_mads(key_bits, info=None):
     """EXACT executed multiply-adds per element from the newest profiles/executed_mads_r*.json (tools/count_executed_mads.py:
     every wave::mad64 call of the device headers counted by the CPU wave emulator on full wavefronts) -> (dict, file),
@@ -913,6 +938,11 @@ def main():
             "pmc_valu_lane_ops_per_encrypt": valu_unit * 64 if valu_unit else None,
             "mad_share_of_valu_instructions": (enc_exec / (valu_unit * 64)) if (valu_unit and enc_exec) else None,
             "pmc_source": valu_src,
+            # committed measurements (rocprofv3 / the emulator count cannot run inside this script): stale = made from other
+            # device sources than this tree's (tools/csrc_hash.py) — the figure then describes an OLDER kernel
+            "stale": bool(committed_count_is_stale(counted_src) or committed_count_is_stale(traffic_src) or committed_count_is_stale(valu_src)),
+            "stale_sources": [f for f in sorted({counted_src, traffic_src, valu_src} - {None}) if committed_count_is_stale(f)],
+            "csrc_sha256": current_csrc_hash(),
             "traffic": (traffic_unit * B) if traffic_unit else None,
             "traffic_note": ("HBM+MALL bytes per launch = %.0f B/encrypt (PMC FETCH_SIZE x2 + WRITE_SIZE, %s) x batch; "
                              "algorithmic bytes are %d B/encrypt" % (traffic_unit, traffic_src, (2 * s1 + s2) * 4))

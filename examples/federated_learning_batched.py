@@ -9,6 +9,11 @@ is exact fixed-point arithmetic, the resulting models — and the printed test e
 reference's scalar loops produce (3775.50 for every hospital at the default settings).
 
     python examples/federated_learning_batched.py [key_length]
+
+On a multi-GPU node one process can use all devices: PHE_HIP_DEVICES=all (phe/fleet.py) makes every key hold one engine per
+GPU and cuts large batches contiguously over them.  This example's batches (11 gradient entries) stay on the first device —
+a launch of 11 rows is latency-bound — so its output is the same with or without the variable; what does fan out here is the
+offline half: `precompute=True` fills every device's obfuscator pool with its share.
 """
 import os
 import sys

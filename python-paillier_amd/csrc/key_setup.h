@@ -339,14 +339,16 @@ struct SplitPack {
 };
 
 // max_input_bits: widest number that will be converted into the pair representation (a ciphertext).
-// whole_L / whole_rows (both or none): a whole-wave pack (G = 64) with exactly that lane width and that many limbs per number
-inline SplitPack build_split(const Big& n_any, int max_input_bits, int prefer_group = 0, int whole_L = 0, int whole_rows = 0) {
+// whole_L / whole_rows (both or none): a pack with exactly that lane width and that many limbs per number on groups of whole_G
+// lanes (the whole wave, or 16-lane groups: the geometries whose row count is a run-time value, split_core.h SplitLane::rows)
+inline SplitPack build_split(const Big& n_any, int max_input_bits, int prefer_group = 0, int whole_L = 0, int whole_rows = 0,
+                             int whole_G = 64) {
     SplitPack P;
     P.bits = big_bits(n_any);
     const int w = (P.bits + 31) / 32;
     Geometry geo = pick_geometry_split(P.bits, prefer_group);
     if (whole_L) {
-        geo.G = 64;
+        geo.G = whole_G;
         geo.L = whole_L;
     }
     if (geo.G == 0) return P;  // caller falls back to the full-width kernels
@@ -355,7 +357,7 @@ inline SplitPack build_split(const Big& n_any, int max_input_bits, int prefer_gr
     P.H = geo.S();
     P.rows = P.H;
     if (whole_L) {
-        if (whole_rows % whole_L || whole_rows > P.H || kRadixBits * whole_rows < P.bits + 4) throw std::invalid_argument("bad whole-wave rows");
+        if (whole_rows % whole_L || whole_rows > P.H || kRadixBits * whole_rows < P.bits + 4) throw std::invalid_argument("bad row count for the pack");
         P.rows = whole_rows;
     } else if (P.G == 64) {
         // a multiple of the digits a whole-wave sweep takes per trip (split_core.h Trip<64, L>: 4, 4, 6, 10)
@@ -409,13 +411,16 @@ inline SplitPack build_split(const Big& n_any, int max_input_bits, int prefer_gr
 // pair form inside is the one modulo n~^2 (n^2 divides it), and the way out works modulo the true n with the same
 // R = 2^(29 rows): X0 - n~*X1 = X0 - n*(k*X1), so split_exit multiplies X1 by k*(n-1) where it multiplies by n-1 otherwise.
 // rows covers n~ with the 4 bits of slack the lazy bounds need: one limb more than n's own, no rounding to a trip length.
+// Round 4: the same constants serve the single-wave kernels on the late sweeps (split_core.h pair_late / modexp_split_late_body)
+// on the whole wave AND on 16-lane groups (G = 16: the rung's own lane width, rows = the least multiple of it that covers n~).
 struct QuickPack {
-    SplitPack scaled;            // constants modulo n~ (G = 64)
-    SplitPack exit;              // constants modulo n, same L and rows
+    SplitPack scaled;            // constants modulo n~ (G = 64 or 16)
+    SplitPack exit;              // constants modulo n, same G, L and rows
     std::vector<uint32_t> nbar;  // (n~ + 1) / 2^29, H limbs
     std::vector<uint32_t> kx;    // k*(n - 1) mod n, H limbs
-    bool ok() const { return scaled.G == 64; }
+    bool ok() const { return scaled.G != 0; }
 };
+constexpr int kMaxLateL = 9;  // lane widths the late single-wave kernels are instantiated for (split_kernels.inc)
 
 // lane width a QuickPack of this modulus needs (0: wider than the whole-wave kernels go)
 inline int quick_lane_width(const Big& n_any) {
@@ -425,7 +430,7 @@ inline int quick_lane_width(const Big& n_any) {
     return 0;
 }
 
-inline QuickPack build_quick(const Big& n_any, int max_input_bits, int L) {
+inline QuickPack build_quick(const Big& n_any, int max_input_bits, int L, int G = 64) {
     QuickPack Q;
     if (L == 0) return Q;
     const int bits = big_bits(n_any), w = (bits + 31) / 32;
@@ -437,16 +442,17 @@ inline QuickPack build_quick(const Big& n_any, int max_input_bits, int L) {
     nk = big_resize(nk, (kbits + 31) / 32);
     const int need = (kbits + 4 + kRadixBits - 1) / kRadixBits;
     const int rows = (need + L - 1) / L * L;
-    // a sweep is at least two trips (split_core.h AbTrip), and word `rows` of a digit row is used (the quotient row has rows + 1 words)
-    if (rows + 1 > 64 * L || rows < (L == 1 ? 4 : 2) * L) return Q;
-    Q.scaled = build_split(nk, max_input_bits, 64, L, rows);
-    Q.exit = build_split(n, max_input_bits, 64, L, rows);
+    // the whole wave: a sweep of the wave-pair kernels is at least two trips (split_core.h AbTrip), and word `rows` of a digit row
+    // is used (the quotient row has rows + 1 words); 16-lane groups (late single-wave kernels only): the lanes must hold n~
+    if (G == 64 ? (rows + 1 > 64 * L || rows < (L == 1 ? 4 : 2) * L) : (G != 16 || rows > 16 * L || L > kMaxLateL)) return Q;
+    Q.scaled = build_split(nk, max_input_bits, G, L, rows, G);
+    Q.exit = build_split(n, max_input_bits, G, L, rows, G);
     if (Q.scaled.n0inv != 1u) throw std::logic_error("scaled modulus is not -1 modulo the radix");
     {   // (n~ + 1) / 2^29: limb 0 of n~ + 1 is zero
         Big one(nk.size() + 1, 0u), up = big_resize(nk, (int)nk.size() + 1);
         one[0] = 1;
         big_add_inplace(up, one);
-        const std::vector<uint32_t> all = to_r29(up, 64 * L + 1);
+        const std::vector<uint32_t> all = to_r29(up, G * L + 1);
         if (all[0] != 0u) throw std::logic_error("scaled modulus + 1 is not a multiple of the radix");
         Q.nbar.assign(all.begin() + 1, all.end());
     }
@@ -455,7 +461,7 @@ inline QuickPack build_quick(const Big& n_any, int max_input_bits, int L) {
         one[0] = 1;
         big_sub_inplace(nm1, one);
         big_divmod(big_mul(nm1, Big(1, k)), n, quo, rem);
-        Q.kx = to_r29(big_resize(rem, w), 64 * L);
+        Q.kx = to_r29(big_resize(rem, w), G * L);
     }
     return Q;
 }
@@ -654,6 +660,7 @@ inline PublicPlan build_public(const uint32_t* n, int n_limbs, int prefer_group 
     }
     P.exp_n = build_schedule(P.n);
     if (P.nsplit.G == 64) P.nquick = build_quick(P.n, 32 * P.s2, quick_lane_width(P.n));
+    else if (P.nsplit.G == 16) P.nquick = build_quick(P.n, 32 * P.s2, P.nsplit.L, 16);
     if (P.nsplit.G && P.nsq.G) {
         Big k(1, P.nsplit.n0inv);                       // -n^-1 mod 2^29
         Big nk = big_mul(P.n, k);                       // n' = k*n = -1 (mod 2^29)
@@ -702,6 +709,10 @@ inline PrivatePlan build_private(const uint32_t* p, const uint32_t* q, const uin
             P.pquick = build_quick(bp, 32 * P.s2, Lw);
             P.qquick = build_quick(bq, 32 * P.s2, Lw);
         }
+    } else if (P.psplit.G == 16 && P.qsplit.G == 16 && P.psplit.L == P.qsplit.L) {
+        P.pquick = build_quick(bp, 32 * P.s2, P.psplit.L, 16);
+        P.qquick = build_quick(bq, 32 * P.s2, P.psplit.L, 16);
+        if (!(P.pquick.ok() && P.qquick.ok() && P.pquick.scaled.rows == P.qquick.scaled.rows)) P.pquick = P.qquick = QuickPack();
     }
     Big one((size_t)pq_limbs, 0u);
     one[0] = 1;

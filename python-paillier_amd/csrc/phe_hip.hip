@@ -88,6 +88,12 @@ PHE_DECLARE_PART(g16b)
     int launch_split_halves(int L, int blocks, hipStream_t st, const SplitArgs& Ap, const SplitArgs& Aq); \
     int launch_split_ab(int L, int mode, int numbers, int halves, hipStream_t st, const SplitArgs& Ap, const SplitArgs& Aq); \
     int launch_tail_wave(int L, int numbers, hipStream_t st, const TailWaveArgs& A);              \
+    int occ_split_late(int L, int mode);                                                          \
+    int launch_split_late(int L, int mode, int blocks, hipStream_t st, const SplitArgs& A);       \
+    int launch_split_late_halves(int L, int blocks, hipStream_t st, const SplitArgs& Ap, const SplitArgs& Aq); \
+    int occ_split_quick(int L, int mode);                                                         \
+    int launch_split_quick(int L, int mode, int blocks, hipStream_t st, const SplitArgs& A);      \
+    int launch_split_quick_halves(int L, int blocks, hipStream_t st, const SplitArgs& Ap, const SplitArgs& Aq); \
     }
 PHE_DECLARE_SPLIT_PART(s2a)
 PHE_DECLARE_SPLIT_PART(s2b)
@@ -163,57 +169,39 @@ struct SplitPart {
     int (*launch_split_halves)(int, int, hipStream_t, const SplitArgs&, const SplitArgs&);
     int (*launch_split_ab)(int, int, int, int, hipStream_t, const SplitArgs&, const SplitArgs&);
     int (*launch_tail_wave)(int, int, hipStream_t, const TailWaveArgs&);
+    int (*occ_split_late)(int, int);
+    int (*launch_split_late)(int, int, int, hipStream_t, const SplitArgs&);
+    int (*launch_split_late_halves)(int, int, hipStream_t, const SplitArgs&, const SplitArgs&);
+    int (*occ_split_quick)(int, int);
+    int (*launch_split_quick)(int, int, int, hipStream_t, const SplitArgs&);
+    int (*launch_split_quick_halves)(int, int, hipStream_t, const SplitArgs&, const SplitArgs&);
 };
+#define PHE_SPLIT_PART(NS, G_)                                                                                                   \
+    {G_, phe::NS::occ_split, phe::NS::launch_split, phe::NS::occ_var_split, phe::NS::launch_var_split, phe::NS::occ_multi_split,  \
+     phe::NS::launch_multi_split, phe::NS::launch_multi_tables, phe::NS::launch_multi_lookup, phe::NS::launch_mul_split,        \
+     phe::NS::launch_crt_lift, phe::NS::occ_split_unit, phe::NS::launch_split_unit, phe::NS::launch_pair,                       \
+     phe::NS::launch_split_halves, phe::NS::launch_split_ab, phe::NS::launch_tail_wave, phe::NS::occ_split_late,               \
+     phe::NS::launch_split_late, phe::NS::launch_split_late_halves, phe::NS::occ_split_quick, phe::NS::launch_split_quick,      \
+     phe::NS::launch_split_quick_halves}
 static const SplitPart kSplitParts[] = {
-    {2, phe::s2a::occ_split, phe::s2a::launch_split, phe::s2a::occ_var_split, phe::s2a::launch_var_split,
-     phe::s2a::occ_multi_split, phe::s2a::launch_multi_split, phe::s2a::launch_multi_tables,
-     phe::s2a::launch_multi_lookup, phe::s2a::launch_mul_split, phe::s2a::launch_crt_lift, phe::s2a::occ_split_unit, phe::s2a::launch_split_unit, phe::s2a::launch_pair, phe::s2a::launch_split_halves, phe::s2a::launch_split_ab, phe::s2a::launch_tail_wave},
-    {2, phe::s2b::occ_split, phe::s2b::launch_split, phe::s2b::occ_var_split, phe::s2b::launch_var_split,
-     phe::s2b::occ_multi_split, phe::s2b::launch_multi_split, phe::s2b::launch_multi_tables,
-     phe::s2b::launch_multi_lookup, phe::s2b::launch_mul_split, phe::s2b::launch_crt_lift, phe::s2b::occ_split_unit, phe::s2b::launch_split_unit, phe::s2b::launch_pair, phe::s2b::launch_split_halves, phe::s2b::launch_split_ab, phe::s2b::launch_tail_wave},
-    {2, phe::s2c::occ_split, phe::s2c::launch_split, phe::s2c::occ_var_split, phe::s2c::launch_var_split,
-     phe::s2c::occ_multi_split, phe::s2c::launch_multi_split, phe::s2c::launch_multi_tables,
-     phe::s2c::launch_multi_lookup, phe::s2c::launch_mul_split, phe::s2c::launch_crt_lift, phe::s2c::occ_split_unit, phe::s2c::launch_split_unit, phe::s2c::launch_pair, phe::s2c::launch_split_halves, phe::s2c::launch_split_ab, phe::s2c::launch_tail_wave},
-    {4, phe::s4a::occ_split, phe::s4a::launch_split, phe::s4a::occ_var_split, phe::s4a::launch_var_split,
-     phe::s4a::occ_multi_split, phe::s4a::launch_multi_split, phe::s4a::launch_multi_tables,
-     phe::s4a::launch_multi_lookup, phe::s4a::launch_mul_split, phe::s4a::launch_crt_lift, phe::s4a::occ_split_unit, phe::s4a::launch_split_unit, phe::s4a::launch_pair, phe::s4a::launch_split_halves, phe::s4a::launch_split_ab, phe::s4a::launch_tail_wave},
-    {4, phe::s4b::occ_split, phe::s4b::launch_split, phe::s4b::occ_var_split, phe::s4b::launch_var_split,
-     phe::s4b::occ_multi_split, phe::s4b::launch_multi_split, phe::s4b::launch_multi_tables,
-     phe::s4b::launch_multi_lookup, phe::s4b::launch_mul_split, phe::s4b::launch_crt_lift, phe::s4b::occ_split_unit, phe::s4b::launch_split_unit, phe::s4b::launch_pair, phe::s4b::launch_split_halves, phe::s4b::launch_split_ab, phe::s4b::launch_tail_wave},
-    {4, phe::s4c::occ_split, phe::s4c::launch_split, phe::s4c::occ_var_split, phe::s4c::launch_var_split,
-     phe::s4c::occ_multi_split, phe::s4c::launch_multi_split, phe::s4c::launch_multi_tables,
-     phe::s4c::launch_multi_lookup, phe::s4c::launch_mul_split, phe::s4c::launch_crt_lift, phe::s4c::occ_split_unit, phe::s4c::launch_split_unit, phe::s4c::launch_pair, phe::s4c::launch_split_halves, phe::s4c::launch_split_ab, phe::s4c::launch_tail_wave},
-    {4, phe::s4d::occ_split, phe::s4d::launch_split, phe::s4d::occ_var_split, phe::s4d::launch_var_split,
-     phe::s4d::occ_multi_split, phe::s4d::launch_multi_split, phe::s4d::launch_multi_tables,
-     phe::s4d::launch_multi_lookup, phe::s4d::launch_mul_split, phe::s4d::launch_crt_lift, phe::s4d::occ_split_unit, phe::s4d::launch_split_unit, phe::s4d::launch_pair, phe::s4d::launch_split_halves, phe::s4d::launch_split_ab, phe::s4d::launch_tail_wave},
-    {8, phe::s8a::occ_split, phe::s8a::launch_split, phe::s8a::occ_var_split, phe::s8a::launch_var_split,
-     phe::s8a::occ_multi_split, phe::s8a::launch_multi_split, phe::s8a::launch_multi_tables,
-     phe::s8a::launch_multi_lookup, phe::s8a::launch_mul_split, phe::s8a::launch_crt_lift, phe::s8a::occ_split_unit, phe::s8a::launch_split_unit, phe::s8a::launch_pair, phe::s8a::launch_split_halves, phe::s8a::launch_split_ab, phe::s8a::launch_tail_wave},
-    {8, phe::s8b::occ_split, phe::s8b::launch_split, phe::s8b::occ_var_split, phe::s8b::launch_var_split,
-     phe::s8b::occ_multi_split, phe::s8b::launch_multi_split, phe::s8b::launch_multi_tables,
-     phe::s8b::launch_multi_lookup, phe::s8b::launch_mul_split, phe::s8b::launch_crt_lift, phe::s8b::occ_split_unit, phe::s8b::launch_split_unit, phe::s8b::launch_pair, phe::s8b::launch_split_halves, phe::s8b::launch_split_ab, phe::s8b::launch_tail_wave},
-    {8, phe::s8c::occ_split, phe::s8c::launch_split, phe::s8c::occ_var_split, phe::s8c::launch_var_split,
-     phe::s8c::occ_multi_split, phe::s8c::launch_multi_split, phe::s8c::launch_multi_tables,
-     phe::s8c::launch_multi_lookup, phe::s8c::launch_mul_split, phe::s8c::launch_crt_lift, phe::s8c::occ_split_unit, phe::s8c::launch_split_unit, phe::s8c::launch_pair, phe::s8c::launch_split_halves, phe::s8c::launch_split_ab, phe::s8c::launch_tail_wave},
-    {8, phe::s8d::occ_split, phe::s8d::launch_split, phe::s8d::occ_var_split, phe::s8d::launch_var_split,
-     phe::s8d::occ_multi_split, phe::s8d::launch_multi_split, phe::s8d::launch_multi_tables,
-     phe::s8d::launch_multi_lookup, phe::s8d::launch_mul_split, phe::s8d::launch_crt_lift, phe::s8d::occ_split_unit, phe::s8d::launch_split_unit, phe::s8d::launch_pair, phe::s8d::launch_split_halves, phe::s8d::launch_split_ab, phe::s8d::launch_tail_wave},
-    {16, phe::s16a::occ_split, phe::s16a::launch_split, phe::s16a::occ_var_split, phe::s16a::launch_var_split,
-     phe::s16a::occ_multi_split, phe::s16a::launch_multi_split, phe::s16a::launch_multi_tables,
-     phe::s16a::launch_multi_lookup, phe::s16a::launch_mul_split, phe::s16a::launch_crt_lift, phe::s16a::occ_split_unit, phe::s16a::launch_split_unit, phe::s16a::launch_pair, phe::s16a::launch_split_halves, phe::s16a::launch_split_ab, phe::s16a::launch_tail_wave},
-    {16, phe::s16b::occ_split, phe::s16b::launch_split, phe::s16b::occ_var_split, phe::s16b::launch_var_split,
-     phe::s16b::occ_multi_split, phe::s16b::launch_multi_split, phe::s16b::launch_multi_tables,
-     phe::s16b::launch_multi_lookup, phe::s16b::launch_mul_split, phe::s16b::launch_crt_lift, phe::s16b::occ_split_unit, phe::s16b::launch_split_unit, phe::s16b::launch_pair, phe::s16b::launch_split_halves, phe::s16b::launch_split_ab, phe::s16b::launch_tail_wave},
-    {16, phe::s16c::occ_split, phe::s16c::launch_split, phe::s16c::occ_var_split, phe::s16c::launch_var_split,
-     phe::s16c::occ_multi_split, phe::s16c::launch_multi_split, phe::s16c::launch_multi_tables,
-     phe::s16c::launch_multi_lookup, phe::s16c::launch_mul_split, phe::s16c::launch_crt_lift, phe::s16c::occ_split_unit, phe::s16c::launch_split_unit, phe::s16c::launch_pair, phe::s16c::launch_split_halves, phe::s16c::launch_split_ab, phe::s16c::launch_tail_wave},
-    {64, phe::s64a::occ_split, phe::s64a::launch_split, phe::s64a::occ_var_split, phe::s64a::launch_var_split,
-     phe::s64a::occ_multi_split, phe::s64a::launch_multi_split, phe::s64a::launch_multi_tables,
-     phe::s64a::launch_multi_lookup, phe::s64a::launch_mul_split, phe::s64a::launch_crt_lift, phe::s64a::occ_split_unit, phe::s64a::launch_split_unit, phe::s64a::launch_pair, phe::s64a::launch_split_halves, phe::s64a::launch_split_ab, phe::s64a::launch_tail_wave},
-    {64, phe::s64b::occ_split, phe::s64b::launch_split, phe::s64b::occ_var_split, phe::s64b::launch_var_split,
-     phe::s64b::occ_multi_split, phe::s64b::launch_multi_split, phe::s64b::launch_multi_tables,
-     phe::s64b::launch_multi_lookup, phe::s64b::launch_mul_split, phe::s64b::launch_crt_lift, phe::s64b::occ_split_unit, phe::s64b::launch_split_unit, phe::s64b::launch_pair, phe::s64b::launch_split_halves, phe::s64b::launch_split_ab, phe::s64b::launch_tail_wave},
+    PHE_SPLIT_PART(s2a, 2),
+    PHE_SPLIT_PART(s2b, 2),
+    PHE_SPLIT_PART(s2c, 2),
+    PHE_SPLIT_PART(s4a, 4),
+    PHE_SPLIT_PART(s4b, 4),
+    PHE_SPLIT_PART(s4c, 4),
+    PHE_SPLIT_PART(s4d, 4),
+    PHE_SPLIT_PART(s8a, 8),
+    PHE_SPLIT_PART(s8b, 8),
+    PHE_SPLIT_PART(s8c, 8),
+    PHE_SPLIT_PART(s8d, 8),
+    PHE_SPLIT_PART(s16a, 16),
+    PHE_SPLIT_PART(s16b, 16),
+    PHE_SPLIT_PART(s16c, 16),
+    PHE_SPLIT_PART(s64a, 64),
+    PHE_SPLIT_PART(s64b, 64),
 };
+#undef PHE_SPLIT_PART
 #define PHE_SPLIT_BY_GROUP(G_, CALL2)                 \
     [&]() -> int {                                    \
         for (const SplitPart& part_ : kSplitParts) {  \
@@ -357,6 +345,7 @@ struct phe_hip_ctx {
     std::vector<PrivRung> priv_rungs;  // rungs 1.. of the private side
     int wave_pair_depth = 1;           // waves per SIMD up to which a batch stays on the wave-pair kernels (PHE_HIP_WAVE_PAIR_DEPTH)
     bool no_wave_pairs = false;        // PHE_HIP_NO_WAVE_PAIRS=1: a handful of numbers stays on the single-wave kernels (A/B measurements, tests)
+    bool no_late = false;              // PHE_HIP_NO_LATE=1: the small-batch rungs stay on the round-3 kernels (textbook row order; A/B measurements, tests)
     bool force_unit = false;           // PHE_HIP_FORCE_UNIT=1: r^n through the scaled modulus whatever the batch size (tests)
     int force_group = 0;               // phe_hip_ctx_set_group: 0 = pick by batch size; G = the rung whose groups are G lanes wide
     // what the last launch on this context took (phe_hip_ctx_last_launch): tests assert the path they meant to exercise
@@ -438,7 +427,7 @@ static int upload_split(const host::SplitPack& m, DevSplit& d, const host::Quick
     d.rows = m.rows;
     if (m.G == 0) return PHE_HIP_OK;
     std::vector<uint32_t> h;
-    const bool q = quick && quick->ok() && m.G == 64;
+    const bool q = quick && quick->ok() && m.G >= 16 && quick->scaled.G == m.G;
     const std::vector<uint32_t>* parts[15] = {&m.n, &m.r1, &m.e, &m.nsq, &m.conv};
     int n_parts = 5;
     if (q) {
@@ -669,6 +658,78 @@ static int launch_split_halves(phe_hip_ctx* ctx, const DevSplit& Mp, const DevSc
     if (!rc) rc = prepare_split(ctx, Mq, Eq, base, base_limbs, nullptr, 0, out_q, out_limbs, batch, half_cu, true, Aq, bq);
     if (rc) return rc;
     if (PHE_SPLIT_BY_GROUP(Mp.G, launch_split_halves(Mp.L, bp, stream, Ap, Aq)) < 0) return fail(PHE_HIP_EINVAL, "unsupported split geometry");
+    HIP_TRY(hipGetLastError());
+    return PHE_HIP_OK;
+}
+
+// ---- the late single-wave kernels (split_core.h modexp_split_late_body): rungs of 16 lanes and of the whole wave ---------------
+// offered where the rung carries the two constant sets (key_setup.h QuickPack: the scaled modulus and, for the way out, the true
+// one) and a part holds the kernel for its lane width; PHE_HIP_NO_LATE=1 keeps the round-3 kernels (A/B measurements, tests)
+// Two kernels behind the same constants: the whole wave runs the late sweeps (k_modexp_split_late), 16-lane groups the textbook
+// order on the scaled modulus with the quick way out (k_modexp_split<..., unit> with A.exit_mod set: "quick").
+static int occ_small_rung(const DevSplit& M, int mode) {
+    return M.G == 64 ? PHE_SPLIT_BY_GROUP(64, occ_split_late(M.q_L, mode)) : PHE_SPLIT_BY_GROUP(M.G, occ_split_quick(M.q_L, mode));
+}
+static bool late_offered(const phe_hip_ctx* ctx, const DevSplit& M) {
+    return !ctx->no_late && ctx->use_split && (M.G == 16 || M.G == 64) && M.q_L != 0 && M.q_L <= host::kMaxLateL &&
+           occ_small_rung(M, kModeEncrypt) > 0;
+}
+static int prepare_late(phe_hip_ctx* ctx, const DevSplit& M, const DevSchedule& E, const uint32_t* base, int base_limbs,
+                        const uint32_t* post, int post_limbs, uint32_t* out, int out_limbs, size_t batch, int per_cu, bool second_table,
+                        SplitArgs& A, int& blocks) {
+    if (per_cu < 0) return fail(PHE_HIP_EINVAL, "no late kernel for this geometry");
+    blocks = grid_blocks(ctx, batch, M.G, per_cu);
+    const size_t rows = (size_t)blocks * (size_t)(kBlock / M.G);
+    uint32_t** tbl = second_table ? &ctx->table2 : &ctx->table;
+    int rc = ensure_words(tbl, second_table ? &ctx->table2_words : &ctx->table_words, rows * (size_t)E.tbl_entries * 2 * M.q_H);
+    if (rc) return rc;
+    A.mod = M.q_scaled;
+    A.exit_mod = M.q_exit;
+    A.sched = E.ops;
+    A.n_ops = E.n_ops;
+    A.first_idx = E.first_idx;
+    A.tbl_entries = E.tbl_entries;
+    A.base = base;
+    A.base_limbs = base_limbs;
+    A.base_chunks = chunks_for(base_limbs, M.q_rows);
+    A.post = post;
+    A.post_limbs = post_limbs;
+    A.post_chunks = chunks_for(post_limbs, M.q_rows);
+    A.out = out;
+    A.out_limbs = out_limbs;
+    A.table = *tbl;
+    A.batch = batch;
+    A.item_meta = nullptr;
+    return PHE_HIP_OK;
+}
+static int launch_late(phe_hip_ctx* ctx, int mode, const DevSplit& M, const DevSchedule& E, const uint32_t* base, int base_limbs,
+                       const uint32_t* post, int post_limbs, uint32_t* out, int out_limbs, size_t batch, hipStream_t stream) {
+    int per_cu = ctx->blocks_per_cu;
+    if (per_cu == 0) per_cu = occ_small_rung(M, mode);
+    SplitArgs A;
+    int blocks = 0;
+    if (int rc = prepare_late(ctx, M, E, base, base_limbs, post, post_limbs, out, out_limbs, batch, per_cu, false, A, blocks)) return rc;
+    if ((M.G == 64 ? PHE_SPLIT_BY_GROUP(64, launch_split_late(M.q_L, mode, blocks, stream, A))
+                   : PHE_SPLIT_BY_GROUP(M.G, launch_split_quick(M.q_L, mode, blocks, stream, A))) < 0)
+        return fail(PHE_HIP_EINVAL, "no late kernel for this geometry");
+    HIP_TRY(hipGetLastError());
+    return PHE_HIP_OK;
+}
+static int launch_late_halves(phe_hip_ctx* ctx, const DevSplit& Mp, const DevSchedule& Ep, const DevSplit& Mq, const DevSchedule& Eq,
+                              const uint32_t* base, int base_limbs, uint32_t* out_p, uint32_t* out_q, int out_limbs, size_t batch,
+                              hipStream_t stream) {
+    if (Mp.G != Mq.G || Mp.q_L != Mq.q_L) return fail(PHE_HIP_EINVAL, "the two halves need one geometry");
+    int per_cu = ctx->blocks_per_cu;
+    if (per_cu == 0) per_cu = occ_small_rung(Mp, kModeHalfDecrypt);
+    SplitArgs Ap, Aq;
+    int bp = 0, bq = 0;
+    const int half_cu = per_cu > 1 ? per_cu / 2 : per_cu;  // together the halves are one kernel's worth of resident workgroups
+    int rc = prepare_late(ctx, Mp, Ep, base, base_limbs, nullptr, 0, out_p, out_limbs, batch, half_cu, false, Ap, bp);
+    if (!rc) rc = prepare_late(ctx, Mq, Eq, base, base_limbs, nullptr, 0, out_q, out_limbs, batch, half_cu, true, Aq, bq);
+    if (rc) return rc;
+    if ((Mp.G == 64 ? PHE_SPLIT_BY_GROUP(64, launch_split_late_halves(Mp.q_L, bp, stream, Ap, Aq))
+                    : PHE_SPLIT_BY_GROUP(Mp.G, launch_split_quick_halves(Mp.q_L, bp, stream, Ap, Aq))) < 0)
+        return fail(PHE_HIP_EINVAL, "no late kernel for this geometry");
     HIP_TRY(hipGetLastError());
     return PHE_HIP_OK;
 }
@@ -948,23 +1009,30 @@ static const DevModulus& pick_nsq(const phe_hip_ctx* ctx, size_t batch) {
     });
     return nsq_rung(ctx, k);
 }
-static RungShape split_shape(const DevSplit& sp, int family = kFamOther) {
+// late: the rung runs this family on the late sweeps (late_offered): rows = the limbs the scaled modulus really needs + 1, not
+// the G*L the lanes could hold — e.g. 40 instead of 48 for the CRT halves of a 2048-bit key on 16 lanes x 3 limbs
+static RungShape split_shape(const DevSplit& sp, int family = kFamOther, bool late = false) {
     RungShape sh;
     sh.G = sp.G;
-    sh.L = sp.L;
-    sh.rows = sp.rows;
+    sh.L = late ? sp.q_L : sp.L;
+    sh.rows = late ? sp.q_rows + (sp.G == 64 ? 1 : 0) : sp.rows;
     sh.wide = wide_rung_factor(family);
     return sh;
 }
 // the pair-form kernels modulo n
+static bool late_offered(const phe_hip_ctx* ctx, const DevSplit& M);
 static int pick_nsplit_rung(const phe_hip_ctx* ctx, size_t batch, int family = kFamOther) {
-    return pick_rung(ctx, batch, 1 + (int)ctx->pub_rungs.size(), [&](int r) { return split_shape(nsplit_rung(ctx, r), family); });
+    return pick_rung(ctx, batch, 1 + (int)ctx->pub_rungs.size(), [&](int r) {
+        const DevSplit& sp = nsplit_rung(ctx, r);
+        return split_shape(sp, family, family == kFamFixedExp && late_offered(ctx, sp));
+    });
 }
 static const DevSplit& pick_nsplit(const phe_hip_ctx* ctx, size_t batch, int family = kFamOther) {
     return nsplit_rung(ctx, pick_nsplit_rung(ctx, batch, family));
 }
 static int geom_code(int G, int L) { return G * 100 + L; }
-enum : int { kPathUnit = 1, kPathOwner = 2, kPathSideBySide = 4, kPathPipelined = 8, kPathFusedObfuscate = 16, kPathWavePairs = 32, kPathWaveTail = 64 };
+enum : int { kPathUnit = 1, kPathOwner = 2, kPathSideBySide = 4, kPathPipelined = 8, kPathFusedObfuscate = 16, kPathWavePairs = 32, kPathWaveTail = 64,
+             kPathLate = 128 };
 
 static int check_ctx(const phe_hip_ctx* ctx) {
     if (!ctx) return fail(PHE_HIP_EINVAL, "null context");
@@ -1050,6 +1118,7 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
     if (!rc) rc = upload_schedule(ctx->pub.exp_n, ctx->d_exp_n);
     ctx->force_unit = getenv("PHE_HIP_FORCE_UNIT") != nullptr;
     ctx->no_wave_pairs = getenv("PHE_HIP_NO_WAVE_PAIRS") != nullptr;
+    ctx->no_late = getenv("PHE_HIP_NO_LATE") != nullptr;
     if (const char* d = getenv("PHE_HIP_WAVE_PAIR_DEPTH")) ctx->wave_pair_depth = std::max(1, atoi(d));
     if (!rc && !getenv("PHE_HIP_GROUP")) {
         // the wider rungs of the ladder: 4-, 8- and 16-lane groups and the whole wave, where they differ from what is already
@@ -1327,7 +1396,14 @@ int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, 
     if (int rc = bind_device(ctx)) return rc;
     PHE_CTX_ORDER(ctx, stream);
     ctx->last_path = 0;
-    if (const int ur = unit_rung(ctx, batch); ur >= 0) {
+    if (const DevSplit& sp = pick_nsplit(ctx, batch, kFamFixedExp); !ctx->force_unit && late_offered(ctx, sp) && !ab_offered(ctx, sp, batch, 1)) {
+        // a small batch on a rung of 16 lanes or of the whole wave: the late sweeps (scaled modulus, the way out modulo n with the
+        // plaintext factor folded in: one launch, no wide scratch rows, no product pass)
+        ctx->last_path = kPathLate;
+        ctx->last_geom_pub = geom_code(sp.G, sp.q_L);
+        return launch_late(ctx, kModeEncrypt, sp, ctx->d_exp_n, r, ctx->pub.s1, m, ctx->pub.s1, c, ctx->pub.s2, batch, (hipStream_t)stream);
+    }
+    if (const int ur = unit_rung(ctx, batch); ur >= 0 && !(late_offered(ctx, nsplit_rung(ctx, ur)) && !ctx->force_unit)) {
         ctx->last_path = kPathUnit;
         ctx->last_geom_pub = geom_code(nunit_rung(ctx, ur).G, nunit_rung(ctx, ur).L);
         // r^n modulo the scaled modulus n'^2 (no multiply per quotient digit), then ONE pass of the product kernel takes
@@ -1371,8 +1447,11 @@ static int launch_crt_halves(phe_hip_ctx* ctx, const DevSchedule& Ep, const DevS
     const auto psq_of = [&](int k) -> const DevModulus& { return k == 0 ? ctx->d_psq : ctx->priv_rungs[(size_t)k - 1].psq; };
     const auto qsq_of = [&](int k) -> const DevModulus& { return k == 0 ? ctx->d_qsq : ctx->priv_rungs[(size_t)k - 1].qsq; };
     const bool split_ok = ctx->use_split && ctx->d_psplit.G && ctx->d_qsplit.G;
+    const auto late_rung = [&](int k) {
+        return split_ok && late_offered(ctx, psplit_of(k)) && late_offered(ctx, qsplit_of(k)) && psplit_of(k).q_L == qsplit_of(k).q_L;
+    };
     const auto shape = [&](int k) {
-        if (split_ok) return split_shape(qsplit_of(k), kFamHalves);
+        if (split_ok) return split_shape(qsplit_of(k), kFamHalves, late_rung(k));
         RungShape sh;
         sh.G = qsq_of(k).G;
         sh.L = qsq_of(k).L;
@@ -1385,17 +1464,29 @@ static int launch_crt_halves(phe_hip_ctx* ctx, const DevSchedule& Ep, const DevS
     const DevSplit& sp_q = qsplit_of(rung);
     // side by side (one grid, k_modexp_split_halves) while both halves together fit one residency of workgroups; beyond that
     // each half fills the GPU on its own and they run one after the other
+    const bool late = late_rung(rung);
     int occ = ctx->blocks_per_cu;
-    if (occ == 0 && split_ok) occ = PHE_SPLIT_BY_GROUP(sp_p.G, occ_split(sp_p.L, kModeHalfDecrypt));
+    if (occ == 0 && split_ok)
+        occ = late ? occ_small_rung(sp_p, kModeHalfDecrypt) : PHE_SPLIT_BY_GROUP(sp_p.G, occ_split(sp_p.L, kModeHalfDecrypt));
     const size_t wg_per_half = (batch + (size_t)(kBlock / std::max(1, sp_p.G)) - 1) / (size_t)(kBlock / std::max(1, sp_p.G));
     const bool side_by_side = split_ok && sp_p.G == sp_q.G && sp_p.L == sp_q.L &&
                               2 * wg_per_half <= (size_t)ctx->n_cus * (size_t)std::max(1, occ);
-    ctx->last_geom_priv = split_ok ? geom_code(sp_p.G, sp_p.L) : geom_code(psq_of(rung).G, psq_of(rung).L);
+    ctx->last_geom_priv = split_ok ? geom_code(sp_p.G, late ? sp_p.q_L : sp_p.L) : geom_code(psq_of(rung).G, psq_of(rung).L);
     ctx->last_path |= side_by_side ? kPathSideBySide : 0;
     if (split_ok && sp_p.G == sp_q.G && sp_p.L == sp_q.L && ab_offered(ctx, sp_p, batch, 2)) {
         // a handful of ciphertexts: every half-exponentiation on a PAIR of wavefronts (about half the time per product)
         ctx->last_path |= kPathSideBySide | kPathWavePairs;
         rc = launch_split_ab(ctx, kModeHalfDecrypt, sp_p, Ep, &sp_q, &Eq, base, base_limbs, nullptr, 0, xp, xq, S, batch, st);
+        if (rc) return rc;
+    } else if (late) {
+        // the small-batch rungs on the late sweeps: one grid for both halves while they fit one residency together
+        ctx->last_path |= kPathLate;
+        if (side_by_side) {
+            rc = launch_late_halves(ctx, sp_p, Ep, sp_q, Eq, base, base_limbs, xp, xq, S, batch, st);
+        } else {
+            rc = launch_late(ctx, kModeHalfDecrypt, sp_p, Ep, base, base_limbs, nullptr, 0, xp, S, batch, st);
+            if (!rc) rc = launch_late(ctx, kModeHalfDecrypt, sp_q, Eq, base, base_limbs, nullptr, 0, xq, S, batch, st);
+        }
         if (rc) return rc;
     } else if (side_by_side) {
         rc = launch_split_halves(ctx, sp_p, Ep, sp_q, Eq, base, base_limbs, xp, xq, S, batch, st);
@@ -1470,7 +1561,18 @@ int phe_hip_obfuscate_dev(phe_hip_ctx* ctx, const uint32_t* c_in, const uint32_t
     if (int rc = bind_device(ctx)) return rc;
     PHE_CTX_ORDER(ctx, stream);
     ctx->last_path = 0;
-    if (const int ur = unit_rung(ctx, batch); ur >= 0 && !getenv("PHE_HIP_FUSED_OBFUSCATE")) {
+    if (const DevSplit& sp = pick_nsplit(ctx, batch, kFamFixedExp);
+        c_in != c_out && !ctx->force_unit && late_offered(ctx, sp) && !ab_offered(ctx, sp, batch, 1) && !getenv("PHE_HIP_FUSED_OBFUSCATE")) {
+        // r^n (the bare power) by the late sweeps, then the product with the ciphertext
+        ctx->last_path = kPathLate;
+        ctx->last_geom_pub = geom_code(sp.G, sp.q_L);
+        int rc = launch_late(ctx, kModeEncrypt, sp, ctx->d_exp_n, r, ctx->pub.s1, nullptr, 0, c_out, ctx->pub.s2, batch, (hipStream_t)stream);
+        if (rc) return rc;
+        const size_t s2 = (size_t)ctx->pub.s2;
+        return launch_mul(ctx, pick_nsq(ctx, batch), c_out, s2, c_in, s2, c_out, s2, ctx->pub.s2, batch, (hipStream_t)stream);
+    }
+    if (const int ur = unit_rung(ctx, batch); ur >= 0 && !getenv("PHE_HIP_FUSED_OBFUSCATE") &&
+                                                !(late_offered(ctx, nsplit_rung(ctx, ur)) && !ctx->force_unit && c_in != c_out)) {
         ctx->last_path = kPathUnit;
         ctx->last_geom_pub = geom_code(nunit_rung(ctx, ur).G, nunit_rung(ctx, ur).L);
         // r^n modulo the scaled modulus, then the product with the ciphertext brings it to n^2 (in-place calls included:

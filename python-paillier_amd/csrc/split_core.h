@@ -32,6 +32,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "mont_core.h"
 
 namespace phe {
@@ -389,9 +391,9 @@ struct SplitLane {  // what every pass needs, loaded once per kernel (U: the mod
     uint32_t n0inv;
     uint32_t* row_a;  // H words: digits of X0 (or of a plain multiplier)
     uint32_t* row_c;  // H words: digits of X1 (quotient digits in split_exit)
-    int rows_;        // G = 64 only: limbs the numbers really have (R = 2^(29 rows)); every other geometry fills its G*L limbs
+    int rows_;        // G >= 16 only: limbs the numbers really have (R = 2^(29 rows), a multiple of L); narrower groups fill their G*L limbs
     PHE_DEV int rows() const {
-        if constexpr (G == 64) return rows_;
+        if constexpr (G >= 16) return rows_;
         else return G * L;
     }
 };
@@ -593,7 +595,7 @@ PHE_DEV void split_exit(uint32_t* out, int out_limbs, uint32_t (&X0)[L], uint32_
     mul_wide<G, L>(hi, K.row_a, K.n, u, K.row_c, ln, K.rows());
     wave::lds_fence();
     load_row<L>(lo, K.row_c, g);
-    if constexpr (G == 64) {  // the sweep wrote `rows` digits: what lies beyond in the row is not part of the number
+    if constexpr (G >= 16) {  // the sweep wrote `rows` digits: what lies beyond in the row is not part of the number
 #pragma unroll
         for (int k = 0; k < L; ++k) lo[k] = ((int)g * L + k < K.rows()) ? lo[k] : 0u;
     }
@@ -664,7 +666,338 @@ PHE_DEV void modexp_split_body(const SplitArgs& A, uint32_t* lds_row, uint32_t s
             split_conv<G, L>(Y0, Y1, A.post + item * (uint64_t)A.post_limbs, A.post_limbs, A.post_chunks, A.mod, K, ln);
             split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
         }
-        split_exit<G, L>(A.out + item * (uint64_t)A.out_limbs, A.out_limbs, X0, X1, mp, A.post_limbs, A.mod, K, ln, live);
+        if (U && A.exit_mod.n != nullptr) {
+            // "quick" rungs (16-lane groups on the scaled modulus with R = 2^(29 rows), rows = the limbs it needs: key_setup.h
+            // QuickPack): the way out works modulo the TRUE modulus with the same R — X0 - n~*X1 = X0 - n*(k*X1), one constant row
+            // k*(n-1) where split_exit uses n-1 otherwise (see modexp_split_ab_body) — straight to the canonical residue, the
+            // plaintext factor folded in: no wide scratch row, no product pass
+            SplitLane<G, L, false> KE;
+            load_row<L>(KE.n, A.exit_mod.n, g);
+            KE.n0inv = A.exit_mod.n0inv;
+            KE.rows_ = K.rows_;
+            KE.row_a = K.row_a;
+            KE.row_c = K.row_c;
+            split_exit<G, L>(A.out + item * (uint64_t)A.out_limbs, A.out_limbs, X0, X1, mp, A.post_limbs, A.exit_mod, KE, ln, live,
+                             A.exit_mod.kx);
+        } else {
+            split_exit<G, L>(A.out + item * (uint64_t)A.out_limbs, A.out_limbs, X0, X1, mp, A.post_limbs, A.mod, K, ln, live);
+        }
+    }
+}
+
+// ---- the wave pair's row order on ONE wavefront: both words of a pair product in one sweep ("late" sweeps) -------------------
+// The rungs that serve small batches (groups of 16 lanes, the whole wave) run one wave per SIMD or little more, where nothing
+// hides a dependent chain, and their numbers have few limbs per lane, where every instruction that is not a multiply-add
+// counts.  Round 3 gave the wave-pair kernels (below) a row order for exactly that situation; these sweeps bring it to the
+// single-wave kernels: the modulus is the SCALED one n~ = k*n = -1 (mod 2^29) (key_setup.h QuickPack, R = 2^(29 rows) with rows
+// = the limbs n~ really needs, a multiple of L — not the G*L the lanes could hold), so a quotient digit is the accumulator's
+// low digit as it is, and its product enters AFTER the shift:
+//      q_s     = S_s mod 2^29
+//      S_(s+1) = (S_s - q_s) / 2^29  +  a_s * b  +  q_s * nbar              nbar = (n~ + 1) / 2^29,   s = 0 ... rows, S_0 = 0
+// i.e. S * R = a*b + Q*n~ with Q = sum q_(s+1) 2^(29 s): the digit travels to the other lanes while they shift and take a_s*b
+// in, and ONE multiply-add per limb closes the row.  The second word adds digit s of Q at ITS step s — the digit the first word
+// forms at step s + 1 — so the fused sweep runs the first word one step ahead: iteration i = first word's step i + 1 and second
+// word's step i, a prologue (the first word's step 0: a_0*b0 alone) and an epilogue (the second word's step `rows`: no digit).
+// Same algebra as ab_first_steps / ab_second_steps below (whose tests pin it), the same values at the end of the sweep.
+template <int G, int L>
+struct LateShape {
+    // iterations per trip: a multiple of L (the accumulators rotate by renaming with period L)
+    static constexpr int kIter = (G == 64 ? (L == 1 ? 4 : (L == 2 ? 2 : 1)) : 1) * L;
+};
+
+// products a column takes per step -> may its carry be taken as a 32-bit number (at most 7 products of < 2^58 between two shifts)?
+template <int G, int L>
+constexpr bool late_narrow(int products_per_step) {
+    return products_per_step * L <= 7 && (L == 1 || G == 64);
+}
+
+// masks of a late sweep, plain VGPR data (see pair_pass2)
+template <int G>
+struct LateMasks {
+    uint32_t lane0, dmask, vmask;
+    PHE_DEV explicit LateMasks(const Lanes<G>& ln) {
+        lane0 = kLimbMask & ~ln.not_low;
+        dmask = kLimbMask & ln.not_top;
+        vmask = kLimbMask & (ln.not_top | ln.not_low);
+    }
+};
+
+// One quotient step of a column-accumulator set: the low digit of the lowest column (index jl) is, in lane 0, the quotient
+// digit — broadcast as the return value —, the set moves down by one column, `extra` (lane 0: a digit of the other word's
+// quotient; 0 elsewhere) joins the carry.  lane0_digit: the low digit in lane 0, 0 in the other lanes (WANT_DIGIT only).
+// NARROW: the column holds at most 7 products between two shifts (< 2^61): its carry is a 32-bit number (ab_shift_narrow).
+template <int G, int L, bool NARROW, bool WANT_DIGIT>
+PHE_DEV uint32_t late_quotient_step(uint64_t (&acc)[L], int jl, uint32_t extra, uint32_t& lane0_digit, const LateMasks<G>& mk,
+                                    const Lanes<G>& ln) {
+    uint32_t m, recv;
+    if constexpr (G == 64) {
+        const uint32_t t = wave::reread((uint32_t)acc[jl] & kLimbMask);  // (kept on the vector side: the lane shift takes it there)
+        m = wave::grp_bcast0<G>(t, ln);  // through an SGPR: no mask to apply afterwards
+        recv = wave::grp_down1<G>(t, ln);
+        if constexpr (WANT_DIGIT) lane0_digit = t & mk.lane0;
+    } else {
+        const uint32_t low = (uint32_t)acc[jl];
+        m = wave::grp_bcast0<G>(low, ln) & mk.vmask;          // one v_and_b32_dpp each
+        recv = wave::grp_down1_raw<G>(low) & mk.dmask;
+        if constexpr (WANT_DIGIT) lane0_digit = low & mk.lane0;
+    }
+    if constexpr (NARROW) {
+        const uint32_t carry = (uint32_t)(acc[jl] >> kRadixBits);
+        if constexpr (L > 1) {
+            acc[(jl + 1) % L] += (uint64_t)(carry + extra);
+            acc[jl] = (uint64_t)recv;
+        } else {
+            acc[0] = (uint64_t)(recv + carry + extra);
+        }
+    } else {
+        const uint64_t carry = acc[jl] >> kRadixBits;
+        if constexpr (L > 1) {
+            acc[(jl + 1) % L] += carry + (uint64_t)extra;
+            acc[jl] = (uint64_t)recv;
+        } else {
+            acc[0] = carry + (uint64_t)recv + (uint64_t)extra;
+        }
+    }
+    return m;
+}
+
+// iteration T (mod L) of a trip: the first word's step i + 1 (digit an = a_(i+1)) and the second word's step i (ai = a_i, ci = c_i)
+template <int G, int L, bool MUL, int T>
+PHE_DEV void late_iteration(uint64_t (&p)[L], uint64_t (&q)[L], uint32_t an, uint32_t ai, uint32_t ci, const uint32_t (&b0)[L],
+                            const uint32_t (&b1)[L], const uint32_t (&nbar)[L], const LateMasks<G>& mk, const Lanes<G>& ln) {
+    constexpr int jl = T % L, j = (T + 1) % L;         // first word: lowest column before / after the shift of its step
+    constexpr int jlq = (T + L - 1) % L, jq = T % L;   // second word
+    // narrow (32-bit) carries: one limb per lane always (the whole shift is 32-bit arithmetic); with more limbs only on the whole
+    // wave, where a lone wavefront waits for the 64-bit shift's latency — on 16-lane groups the zero-extensions the narrow form
+    // needs for its 64-bit additions cost 3-4 more instructions per row than they save (code object, round 4)
+    constexpr bool kNarrowP = late_narrow<G, L>(2), kNarrowQ = late_narrow<G, L>(MUL ? 3 : 2);
+    uint32_t dq = 0, unused = 0;
+    const uint32_t m = late_quotient_step<G, L, kNarrowP, true>(p, jl, 0u, dq, mk, ln);    // dq: digit i of Q (lane 0)
+    const uint32_t m2 = late_quotient_step<G, L, kNarrowQ, false>(q, jlq, dq, unused, mk, ln);
+#pragma unroll
+    for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(an, b0[k], p[(k + j) % L]);
+#pragma unroll
+    for (int k = 0; k < L; ++k) q[(k + jq) % L] = wave::mad64(ai, b1[k], q[(k + jq) % L]);
+    if constexpr (MUL) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) q[(k + jq) % L] = wave::mad64(ci, b0[k], q[(k + jq) % L]);
+    }
+    if constexpr (L == 1) {  // (the digits' products first: the quotient digits are still on their way)
+        p[0] = wave::reread64(p[0]);
+        q[0] = wave::reread64(q[0]);
+    }
+#pragma unroll
+    for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(m, nbar[k], p[(k + j) % L]);
+#pragma unroll
+    for (int k = 0; k < L; ++k) q[(k + jq) % L] = wave::mad64(m2, nbar[k], q[(k + jq) % L]);
+}
+
+template <int G, int L, bool MUL, int N, int T = 0>
+PHE_DEV void late_trip(uint64_t (&p)[L], uint64_t (&q)[L], const uint32_t (&da)[N + 1], const uint32_t (&dc)[N], const uint32_t (&b0)[L],
+                       const uint32_t (&b1)[L], const uint32_t (&nbar)[L], const LateMasks<G>& mk, const Lanes<G>& ln) {
+    if constexpr (T < N) {
+        late_iteration<G, L, MUL, T % L>(p, q, da[T + 1], da[T], dc[T], b0, b1, nbar, mk, ln);
+        late_trip<G, L, MUL, N, T + 1>(p, q, da, dc, b0, b1, nbar, mk, ln);
+    }
+}
+
+// z0 = (a*b0 + Q*n~) / R,   z1 = (Q + a*b1 [+ c*b0] + Q2*n~) / R;   a (and c): digit rows in LDS, `rows` digits each (a multiple of L);
+// word `rows` of a must be 0 (see `load` below).   MUL: the product (a, c) * (b0, b1); else a squaring / a conversion.
+template <int G, int L, bool MUL>
+PHE_DEV void pair_late(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a, const uint32_t* c, const uint32_t (&b0)[L],
+                       const uint32_t (&b1)[L], const uint32_t (&nbar)[L], const Lanes<G>& ln, int rows) {
+    constexpr int kI = LateShape<G, L>::kIter;
+    const LateMasks<G> mk(ln);
+    uint64_t p[L], q[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) p[k] = q[k] = 0;
+    // digits a_i .. a_(i+N) and c_i .. c_(i+N-1) of a trip of N iterations starting at i.  a_rows, the digit the first word's last
+    // step "takes", must read as 0: it does — the word after the number's last limb is a zero limb where the lanes hold more
+    // than `rows` limbs, and the row's zeroed pad word where they do not (LateLane: the caller keeps a[G*L] zero)
+    const auto load = [&](auto& da, auto& dc, int i, auto n_tag) {
+        constexpr int N = decltype(n_tag)::value;
+#pragma unroll
+        for (int t = 0; t <= N; ++t) da[t] = a[i + t];
+#pragma unroll
+        for (int t = 0; t < N; ++t) dc[t] = MUL ? c[i + t] : 0u;
+    };
+    using TagI = std::integral_constant<int, kI>;
+    using TagL = std::integral_constant<int, L>;
+    // prologue: the first word's step 0
+    {
+        const uint32_t a0 = a[0];
+#pragma unroll
+        for (int k = 0; k < L; ++k) p[k] = wave::mad64(a0, b0[k], p[k]);
+    }
+    int i = 0;
+    if constexpr (G == 64) {
+        // a lone wave per SIMD hides nothing: two digit sets that change roles, each fetched a trip ahead of its use (no copies)
+        uint32_t da_a[kI + 1], dc_a[kI], da_b[kI + 1], dc_b[kI];
+        if (rows >= kI) load(da_a, dc_a, 0, TagI());
+#pragma unroll 1
+        for (; i + 2 * kI <= rows; i += 2 * kI) {
+            load(da_b, dc_b, i + kI, TagI());
+            late_trip<G, L, MUL, kI>(p, q, da_a, dc_a, b0, b1, nbar, mk, ln);
+            if (i + 3 * kI <= rows) load(da_a, dc_a, i + 2 * kI, TagI());
+            late_trip<G, L, MUL, kI>(p, q, da_b, dc_b, b0, b1, nbar, mk, ln);
+        }
+        if (i + kI <= rows) {  // (set a holds this trip: fetched before the loop, or by its last pass)
+            late_trip<G, L, MUL, kI>(p, q, da_a, dc_a, b0, b1, nbar, mk, ln);
+            i += kI;
+        }
+    } else {
+#pragma unroll 1
+        for (; i + kI <= rows; i += kI) {
+            uint32_t da[kI + 1], dc[kI];
+            load(da, dc, i, TagI());
+            late_trip<G, L, MUL, kI>(p, q, da, dc, b0, b1, nbar, mk, ln);
+        }
+    }
+#pragma unroll 1
+    for (; i < rows; i += L) {  // what whole trips did not cover: L iterations at a time
+        uint32_t da[L + 1], dc[L];
+        load(da, dc, i, TagL());
+        late_trip<G, L, MUL, L>(p, q, da, dc, b0, b1, nbar, mk, ln);
+    }
+    // epilogue: the second word's step `rows` (no digit, and Q has no digit `rows`)
+    {
+        constexpr bool kNarrowQ = late_narrow<G, L>(MUL ? 3 : 2);
+        uint32_t unused = 0;
+        const uint32_t m2 = late_quotient_step<G, L, kNarrowQ, false>(q, L - 1, 0u, unused, mk, ln);
+#pragma unroll
+        for (int k = 0; k < L; ++k) q[k] = wave::mad64(m2, nbar[k], q[k]);
+    }
+    normalize_partial<G, L>(z0, p, ln);
+    normalize_partial<G, L>(z1, q, ln);
+}
+
+// what the late sweeps need, loaded once per kernel.  LDS of a limb group (2*G*L + kLdsPad words): row_a = [0, H), then the pad
+// words, then row_c = [H + kLdsPad, 2H + kLdsPad) — so that word H of row_a is a pad word that late_zero_pad keeps at zero
+// (the digit "a_rows" of a sweep whose numbers fill all H limbs of the lanes).
+template <int G, int L>
+struct LateLane {
+    uint32_t nbar[L];
+    uint32_t* row_a;
+    uint32_t* row_c;
+    int rows;
+};
+template <int G, int L>
+PHE_DEV void late_zero_pad(const LateLane<G, L>& K, const Lanes<G>& ln) {
+    if (ln.g == 0u) K.row_a[G * L] = 0u;  // (ordered before the sweeps' reads by the fences of the next lds_put)
+}
+
+template <int G, int L>
+PHE_DEV void late_square(uint32_t (&X0)[L], uint32_t (&X1)[L], const LateLane<G, L>& K, const Lanes<G>& ln) {
+    uint32_t d[L];
+    lds_put<L>(K.row_a, X0, ln.g);
+#pragma unroll
+    for (int k = 0; k < L; ++k) d[k] = X1[k];
+    add_normalize<G, L>(d, X1, ln);  // 2*X1
+    pair_late<G, L, false>(X0, X1, K.row_a, nullptr, X0, d, K.nbar, ln, K.rows);
+}
+
+template <int G, int L>
+PHE_DEV void late_mul(uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t (&Y0)[L], const uint32_t (&Y1)[L], const LateLane<G, L>& K,
+                      const Lanes<G>& ln) {
+    wave::lds_fence();
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        K.row_a[ln.g * L + k] = X0[k];
+        K.row_c[ln.g * L + k] = X1[k];
+    }
+    wave::lds_fence();
+    pair_late<G, L, true>(X0, X1, K.row_a, K.row_c, Y0, Y1, K.nbar, ln, K.rows);
+}
+
+// the number in the 32-bit-word row src -> the pair form modulo the scaled modulus (split_conv on the late sweeps)
+template <int G, int L>
+PHE_DEV void late_conv(uint32_t (&X0)[L], uint32_t (&X1)[L], const uint32_t* src, int limbs32, int chunks, const SplitConsts& C,
+                       const LateLane<G, L>& K, const Lanes<G>& ln) {
+    constexpr int H = G * L;
+    uint32_t tmp[L], d0[L], d1[L], u[L], t[L];
+    for (int j = 0; j < chunks; ++j) {
+        load_u32_as_r29<L>(tmp, src, limbs32, j * K.rows, ln.g, K.rows);
+        lds_put<L>(K.row_a, tmp, ln.g);
+        load_row<L>(d0, wave::reread_ptr(C.conv) + (size_t)(2 * j) * H, ln.g);
+        load_row<L>(d1, wave::reread_ptr(C.conv) + (size_t)(2 * j + 1) * H, ln.g);
+        if (j == 0) {
+            pair_late<G, L, false>(X0, X1, K.row_a, nullptr, d0, d1, K.nbar, ln, K.rows);
+        } else {
+            pair_late<G, L, false>(u, t, K.row_a, nullptr, d0, d1, K.nbar, ln, K.rows);
+            add_normalize<G, L>(X0, u, ln);
+            add_normalize<G, L>(X1, t, ln);
+        }
+    }
+    if (chunks > 1) {  // the sums exceed the lazy bounds: one product with the pair of 1 restores them
+        load_row<L>(d0, wave::reread_ptr(C.e), ln.g);
+        load_row<L>(d1, wave::reread_ptr(C.e) + H, ln.g);
+        late_mul<G, L>(X0, X1, d0, d1, K, ln);
+    }
+}
+
+// modexp_split_body on the late sweeps: A.mod = constants modulo the scaled modulus n~ (with nbar), A.exit_mod = modulo the true n
+// with the same R (with kx): the way out is the ordinary split_exit modulo n, fed X0 - n~*X1 = X0 - n*(k*X1) (see
+// modexp_split_ab_body).  MODE: kModeEncrypt (A.post: plaintexts or nullptr for the bare power) or kModeHalfDecrypt.
+template <int G, int L, int MODE>
+PHE_DEV void modexp_split_late_body(const SplitArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots, uint32_t lane) {
+    constexpr int H = G * L, S2 = 2 * H;
+    const Lanes<G> ln(lane);
+    const uint32_t g = ln.g;
+    LateLane<G, L> K;
+    load_row<L>(K.nbar, A.mod.nbar, g);
+    K.rows = A.mod.rows;
+    K.row_a = lds_row;
+    K.row_c = lds_row + H + kLdsPad;
+    uint32_t* tbl = A.table + (size_t)slot * (size_t)A.tbl_entries * S2;
+    const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
+    for (uint64_t it = 0; it < n_iter; ++it) {
+        uint64_t item = slot + it * (uint64_t)total_slots;
+        const bool live = item < A.batch;
+        if (!live) item = A.batch - 1;
+        uint32_t X0[L], X1[L], Y0[L], Y1[L];
+        late_zero_pad<G, L>(K, ln);  // (the way out of the previous item wrote across the pad words)
+        late_conv<G, L>(X0, X1, A.base + item * (uint64_t)A.base_limbs, A.base_limbs, A.base_chunks, A.mod, K, ln);
+        // ---- odd powers base^1, base^3, ... ---------------------------------------------------------------
+        store_row<L>(tbl, X0, g);
+        store_row<L>(tbl + H, X1, g);
+        if (A.tbl_entries > 1) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                Y0[k] = X0[k];
+                Y1[k] = X1[k];
+            }
+            late_square<G, L>(Y0, Y1, K, ln);  // base^2
+            for (int j = 1; j < A.tbl_entries; ++j) {
+                late_mul<G, L>(X0, X1, Y0, Y1, K, ln);
+                store_row<L>(tbl + (size_t)j * S2, X0, g);
+                store_row<L>(tbl + (size_t)j * S2 + H, X1, g);
+            }
+        }
+        // ---- left-to-right sliding window ------------------------------------------------------------------
+        load_row<L>(X0, tbl + (size_t)A.first_idx * S2, g);
+        load_row<L>(X1, tbl + (size_t)A.first_idx * S2 + H, g);
+        for (int op = 0; op < A.n_ops; ++op) {
+            const uint32_t w = A.sched[op];
+            const int nsq = (int)(w >> 8);
+            const int sel = (int)(w & 0xffu);
+            if (sel) {  // the factor is fetched before the squarings: it arrives under them
+                load_row<L>(Y0, tbl + (size_t)(sel - 1) * S2, g);
+                load_row<L>(Y1, tbl + (size_t)(sel - 1) * S2 + H, g);
+            }
+            for (int s = 0; s < nsq; ++s) late_square<G, L>(X0, X1, K, ln);
+            if (sel) late_mul<G, L>(X0, X1, Y0, Y1, K, ln);
+        }
+        // ---- the way out: modulo the true n -------------------------------------------------------------------------
+        SplitLane<G, L, false> KE;
+        load_row<L>(KE.n, A.exit_mod.n, g);
+        KE.n0inv = A.exit_mod.n0inv;
+        KE.rows_ = K.rows;
+        KE.row_a = lds_row;      // (the way out uses the group's block as two adjacent rows of H words: store_pair_as_u32)
+        KE.row_c = lds_row + H;
+        const uint32_t* mp = nullptr;
+        if (MODE == kModeEncrypt) mp = A.post ? A.post + item * (uint64_t)A.post_limbs : nullptr;
+        split_exit<G, L>(A.out + item * (uint64_t)A.out_limbs, A.out_limbs, X0, X1, mp, A.post_limbs, A.exit_mod, KE, ln, live,
+                         A.exit_mod.kx);
     }
 }
 

@@ -22,11 +22,18 @@ from ._device import DeviceArray
 
 
 def default_device():
-    """One process per GPU: LOCAL_RANK picks the device unless PHE_HIP_DEVICE overrides it."""
-    for var in ("PHE_HIP_DEVICE", "LOCAL_RANK"):
-        v = os.environ.get(var)
-        if v is not None and v.strip() != "":
-            return int(v)
+    """One process per GPU: LOCAL_RANK picks the device unless PHE_HIP_DEVICE overrides it.  A single process that fans out
+    over several devices (PHE_HIP_DEVICES, phe/fleet.py) keeps its ordinary engine on the first of them."""
+    v = os.environ.get("PHE_HIP_DEVICE")
+    if v is not None and v.strip() != "":
+        return int(v)
+    from . import fleet
+    devices = fleet.configured_devices()
+    if devices:
+        return devices[0]
+    v = os.environ.get("LOCAL_RANK")
+    if v is not None and v.strip() != "":
+        return int(v)
     return 0
 
 

@@ -277,6 +277,7 @@ class Context:
         _check(lib().phe_hip_ctx_set_group(self._h, int(group)))
 
     PATH_UNIT, PATH_OWNER, PATH_SIDE_BY_SIDE, PATH_PIPELINED, PATH_FUSED_OBFUSCATE, PATH_WAVE_PAIRS, PATH_WAVE_TAIL = 1, 2, 4, 8, 16, 32, 64
+    PATH_LATE = 128
 
     def last_launch(self):
         """what the last encrypt / obfuscate / decrypt / pair call took: {"path": PATH_* bits, "geom_pub", "geom_priv"}"""

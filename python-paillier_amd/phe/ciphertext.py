@@ -146,6 +146,11 @@ class EncryptedNumber(object):
         return eng.to_ints(eng.raw_mul([self.ciphertext(False) % pk.nsquare], [plaintext]))[0]
 
 
+def _fleet_min_rows():
+    from . import fleet
+    return fleet.MIN_ROWS_PER_DEVICE
+
+
 class EncryptedVector(object):
     """A batch of Paillier ciphertexts under one public key, stored as little-endian uint32 limbs — either a
     host numpy array or a device-resident DeviceArray (`device=True` / `.to_device()`), in which case every
@@ -175,13 +180,18 @@ class EncryptedVector(object):
         flags = obfuscated if isinstance(obfuscated, np.ndarray) else np.full(len(self._exps), bool(obfuscated))
         self._obfuscated = flags.astype(bool)
 
+    def _eng(self):
+        """the engine this vector's rows are worked on by: the key's ordinary engine, or — for a resident vector that lives on
+        another device of a fleet (PaillierPublicKey.encrypt_batch_sharded, phe/fleet.py) — the engine of that device"""
+        return self.public_key._engine_for(self._store) if self.on_device else self.public_key._get_engine()
+
     @property
     def _limbs(self):
         if self._pair:
-            self._store = self.public_key._get_engine().from_pair_dev(self._store)
+            self._store = self._eng().from_pair_dev(self._store)
             self._pair = False
         elif self._debt:
-            self._store = self.public_key._get_engine().scale_dev(self._store, self._debt)
+            self._store = self._eng().scale_dev(self._store, self._debt)
             self._debt = 0
         return self._store
 
@@ -194,7 +204,7 @@ class EncryptedVector(object):
         it for rows that will be added to several times — `+` between two resident vectors then costs one pair product, and
         sum() one call.  Everything else (download, decrypt, `*`, obfuscate, indexing) converts back by itself."""
         vec = self if self.on_device else self.to_device()
-        eng = self.public_key._get_engine()
+        eng = self._eng()
         if vec._pair or not eng.pair_form():
             return vec
         return EncryptedVector(self.public_key, eng.to_pair_dev(vec._limbs), vec._exps, vec._obfuscated.copy(), _pair=True)
@@ -203,14 +213,14 @@ class EncryptedVector(object):
         """the rows as plain ciphertext words WITHOUT touching the vector: the non-mutating readers (alignment inside `a + b`
         must not convert an operand out of the form its owner put it in, nor change `_store` under another thread's read)"""
         if self._pair:
-            return self.public_key._get_engine().from_pair_dev(self._store)
+            return self._eng().from_pair_dev(self._store)
         if self._debt:
-            return self.public_key._get_engine().scale_dev(self._store, self._debt)
+            return self._eng().scale_dev(self._store, self._debt)
         return self._store
 
     def _pair_store(self):
         """the rows in pair form (converted if need be; the vector itself is left as it is)"""
-        return self._store if self._pair else self.public_key._get_engine().to_pair_dev(self._plain_rows())
+        return self._store if self._pair else self._eng().to_pair_dev(self._plain_rows())
 
     @property
     def exponents(self):
@@ -306,7 +316,7 @@ class EncryptedVector(object):
             return self._like(host[i], self._exps[i], self._obfuscated[i])
         i = range(len(self))[i]
         row = self._limbs.rows_view(i, i + 1).to_host() if self.on_device else self._limbs[i:i + 1]
-        eng = self.public_key._get_engine()
+        eng = self._eng()
         x = EncryptedNumber(self.public_key, eng.to_ints(row)[0], int(self._exps[i]))
         x._EncryptedNumber__is_obfuscated = bool(self._obfuscated[i])
         return x
@@ -319,7 +329,7 @@ class EncryptedVector(object):
     def obfuscate(self, r_values=None):
         """c_i <- c_i * r_i^n mod n^2 for the rows not yet obfuscated (all rows if r_values is given)."""
         pk = self.public_key
-        eng = pk._get_engine()
+        eng = self._eng()
         rows = np.arange(len(self)) if r_values is not None else np.nonzero(~self._obfuscated)[0]
         if len(rows) == 0:
             return self
@@ -364,7 +374,7 @@ class EncryptedVector(object):
 
     def ciphertexts(self, be_secure=True):
         limbs = self.limbs(be_secure)
-        return self.public_key._get_engine().to_ints(limbs.to_host() if self.on_device else limbs)
+        return self._eng().to_ints(limbs.to_host() if self.on_device else limbs)
 
     def decrease_exponent_to(self, new_exps):
         """Per-element EncryptedNumber.decrease_exponent_to: rows whose exponent is above the target are
@@ -387,7 +397,7 @@ class EncryptedVector(object):
         powers = {int(d): pow(EncodedNumber.BASE, int(d)) for d in np.unique(delta).tolist()}
         _check_alignment_factor(pk, max(powers.values()))
         flags[rows] = False
-        eng = pk._get_engine()
+        eng = self._eng()
         log2b = int(round(EncodedNumber.LOG2_BASE))
         if (1 << log2b) == EncodedNumber.BASE and max(powers.values()) < pk.n - pk.max_int:
             # BASE^delta = 1 << (log2b * delta): the exponents as limb rows, no Python integer per row
@@ -417,11 +427,16 @@ class EncryptedVector(object):
         return self.decrease_exponent_to(target), target
 
     def _raw_add(self, a_limbs, b):
-        eng = self.public_key._get_engine()
+        eng = self._eng()
         if self.on_device:
             b_dev = b if isinstance(b, DeviceArray) else eng.upload_cipher(b)
             return eng.raw_add_dev(a_limbs, b_dev)
-        return eng.raw_add(a_limbs, b.to_host() if isinstance(b, DeviceArray) else b)
+        b = b.to_host() if isinstance(b, DeviceArray) else b
+        fl = self.public_key._get_fleet()
+        if fl is not None and len(fl.shards(len(a_limbs), 8 * _fleet_min_rows())) > 1:
+            # host rows over the devices of a fleet (phe/fleet.py): contiguous shards, one array back
+            return np.concatenate(fl.run(len(a_limbs), lambda e, lo, hi: e.raw_add(a_limbs[lo:hi], b[lo:hi]), 8 * _fleet_min_rows()))
+        return eng.raw_add(a_limbs, b)
 
     def __add__(self, other):
         pk = self.public_key
@@ -432,9 +447,13 @@ class EncryptedVector(object):
                 raise ValueError("vector lengths differ")
             if other.on_device != self.on_device:
                 other = other.to_device() if self.on_device else other.to_host()
+            if self.on_device and other.on_device and other._store.ctx is not self._store.ctx:
+                # two resident vectors of a fleet that live on different devices: the other one comes over (through the host)
+                host = other.to_host()
+                other = EncryptedVector(pk, self._eng().upload_cipher(host._limbs), host._exps, host._obfuscated.copy())
             a, target = self._aligned(other._exps)
             b = other.decrease_exponent_to(target)
-            eng = pk._get_engine()
+            eng = self._eng()
             if self.on_device and (a._pair or b._pair) and eng.pair_form():
                 # one pair product (the operand that is not in pair form yet is converted: it pays once, the sum stays)
                 return EncryptedVector(pk, eng.pair_mul_dev(a._pair_store(), b._pair_store()), target, _pair=True)
@@ -446,7 +465,7 @@ class EncryptedVector(object):
         values = other if isinstance(other, (list, tuple, np.ndarray)) else [other] * len(self)
         if len(values) != len(self):
             raise ValueError("vector lengths differ")
-        eng = pk._get_engine()
+        eng = self._eng()
         signed = EncodedNumber.encode_signed(values) if eng.n_limbs >= 4 else None
         if signed is not None:
             # array form of the loop below: encode(v, max_exponent=e) = the natural encoding with its mantissa
@@ -492,7 +511,7 @@ class EncryptedVector(object):
         values = other if isinstance(other, (list, tuple, np.ndarray)) else [other] * len(self)
         if len(values) != len(self):
             raise ValueError("vector lengths differ")
-        eng = pk._get_engine()
+        eng = self._eng()
         signed = EncodedNumber.encode_signed(values) if eng.n_limbs >= 4 else None
         if signed is not None:
             mag, neg, exps = signed
@@ -500,7 +519,12 @@ class EncryptedVector(object):
                 # rows in the engine's pair form and no negative scalar (those take invert(c), phe/paillier.py:745-749, which
                 # wants residues): the powers stay in the pair form — no conversion in, no exit
                 return EncryptedVector(pk, eng.pair_mul_scalars_dev(self._store, mag), self._exps + exps, _pair=True)
-            limbs = eng.raw_mul_signed_dev(self._limbs, mag, neg) if self.on_device else eng.raw_mul_signed(self._limbs, mag, neg)
+            fl = None if self.on_device else self.public_key._get_fleet()
+            if fl is not None and len(fl.shards(len(self))) > 1:
+                rows = self._limbs
+                limbs = np.concatenate(fl.run(len(self), lambda e, lo, hi: e.raw_mul_signed(rows[lo:hi], mag[lo:hi], neg[lo:hi])))
+            else:
+                limbs = eng.raw_mul_signed_dev(self._limbs, mag, neg) if self.on_device else eng.raw_mul_signed(self._limbs, mag, neg)
             return self._like(limbs, self._exps + exps)
         if isinstance(values, np.ndarray) or not any(isinstance(v, EncodedNumber) for v in values):
             encs, exps = EncodedNumber.encode_many(pk, values)
@@ -533,7 +557,7 @@ class EncryptedVector(object):
         if len(self) == 0:
             raise ValueError("empty vector")
         pk = self.public_key
-        eng = pk._get_engine()
+        eng = self._eng()
         cur = self.decrease_exponent_to(int(self._exps.min()))
         if self.on_device and cur._pair and eng.pair_form():
             # rows already in pair form: the whole pairwise tree is one call (log2 launches queued back to back), one exit
@@ -572,7 +596,7 @@ class EncryptedVector(object):
         vector format; like EncryptedNumber.ciphertext() the rows are obfuscated first unless be_secure=False
         (one launch over the vector instead of one modexp per element).  The decimal strings come from the device
         (Engine.decimal_strings: the batch form of str(int)); the text is what json.dumps would write."""
-        eng = self.public_key._get_engine()
+        eng = self._eng()
         strings = eng.decimal_strings(self.limbs(be_secure))
         body = ", ".join('["%s", %d]' % (c, e) for c, e in zip(strings, self._exps.tolist()))
         return '{"public_key": {"n": %d}, "values": [%s]}' % (self.public_key.n, body)
@@ -605,7 +629,7 @@ class EncryptedVector(object):
             raise ValueError("empty vector")
         if any(isinstance(v, (EncryptedNumber, EncryptedVector)) for v in (values if not isinstance(values, np.ndarray) else ())):
             raise NotImplementedError('Good luck with that...')
-        eng = pk._get_engine()
+        eng = self._eng()
         signed = EncodedNumber.encode_signed(values) if eng.n_limbs >= 4 else None
         if signed is not None:
             mag, neg, kexp = signed
@@ -676,7 +700,7 @@ class EncryptedVector(object):
         few dense rows over a long vector through the chunked form (Engine.raw_matvec).  Negative-branch inverses are
         formed once for the whole vector.  A row without entries is the ciphertext 1 (an encryption of 0)."""
         pk = self.public_key
-        eng = pk._get_engine()
+        eng = self._eng()
         if len(self) == 0:
             raise ValueError("empty vector")
         log2b = int(round(EncodedNumber.LOG2_BASE))

@@ -19,6 +19,7 @@ import numpy as np
 from . import util
 from ._engine import Engine, random_lt_n, random_lt_n_limbs
 from .codec import EncodedNumber
+from .sharding import shard_bounds
 
 DEFAULT_KEYSIZE = 3072
 # scalar encrypt() / obfuscate() refill the obfuscator pool with this many r^n per launch when it runs dry (0 = one
@@ -72,6 +73,8 @@ class PaillierPublicKey(object):
         self.max_int = n // 3 - 1
         self._engine = None
         self._engine_lock = threading.Lock()
+        self._fleet = None
+        self._fleet_factory = None               # device -> Engine for the further devices of a fleet (a key pair installs its own)
 
     # one GPU context per key, created on first use (a private key shares its context with its public key); the creation
     # is guarded so that two threads never build two contexts — and two obfuscator pools — for one key
@@ -83,6 +86,34 @@ class PaillierPublicKey(object):
                     self._engine = Engine(self.n)
                 eng = self._engine
         return eng
+
+    def _get_fleet(self):
+        """One engine per device of PHE_HIP_DEVICES (phe/fleet.py), the key's ordinary engine first — or None when no
+        single-process fan-out is asked for.  A key pair shares one fleet, as it shares one engine."""
+        fl = self._fleet
+        if fl is not None:
+            return fl
+        from . import fleet
+        devices = fleet.configured_devices()
+        if devices is None:
+            return None
+        primary = self._get_engine()
+        with self._engine_lock:
+            if self._fleet is None or self._fleet.engine(0) is not self._engine:
+                make = self._fleet_factory or (lambda device: Engine(self.n, device=device))
+                self._fleet = fleet.Fleet(self._engine or primary, make, devices)
+            return self._fleet
+
+    def _engine_for(self, store):
+        """the engine that owns a resident array (a vector made by encrypt_batch_sharded lives on ITS device), else the
+        key's ordinary engine"""
+        fl = self._fleet
+        ctx = getattr(store, "ctx", None)
+        if fl is not None and ctx is not None:
+            eng = fl.engine_of(ctx)
+            if eng is not None:
+                return eng
+        return self._get_engine()
 
     def __repr__(self):
         return "<PaillierPublicKey {}>".format(hex(hash(self))[2:][:10])
@@ -147,14 +178,25 @@ class PaillierPublicKey(object):
         encrypt_batch without r_values and EncryptedVector.obfuscate() then consume them — one product per element
         instead of a modular exponentiation — and fall back to drawing on the spot when the pool is short.  Every
         obfuscator is used once.  Returns the number available."""
-        return self._get_engine().fill_obfuscator_pool(int(count))
+        fl = self._get_fleet()
+        count = int(count)
+        if fl is not None and count >= 2 * len(fl):
+            # every device fills ITS pool with its contiguous share (a pool is never shared across devices)
+            fl.each(lambda eng, k: eng.fill_obfuscator_pool(shard_bounds(count, len(fl), k)[1] - shard_bounds(count, len(fl), k)[0]))
+            return self.obfuscators_available()
+        return self._get_engine().fill_obfuscator_pool(count)
 
     def obfuscators_available(self):
+        fl = self._fleet
+        if fl is not None:
+            return sum(eng.obfuscators_available() for eng in fl.made())
         return self._get_engine().obfuscators_available()
 
     def discard_obfuscators(self):
         """forget the obfuscators made ahead of time: the next encryptions draw and exponentiate on the spot again"""
-        self._get_engine().clear_obfuscator_pool()
+        fl = self._fleet
+        for eng in (fl.made() if fl is not None else [self._get_engine()]):
+            eng.clear_obfuscator_pool()
 
     # ---- batched API ------------------------------------------------------------------------------
     def raw_encrypt_batch(self, plaintexts, r_values=None):
@@ -183,6 +225,19 @@ class PaillierPublicKey(object):
             m, exps = EncodedNumber.encode_many(self, values, precision)
         count = len(exps)
         limbs = None
+        fl = self._get_fleet() if (not device and isinstance(m, np.ndarray)) else None
+        if fl is not None and len(fl.shards(count)) > 1:
+            # single-process fan-out (phe/fleet.py): contiguous shards, one device each, results into ONE host array
+            if fresh:
+                def shard(e, lo, hi):
+                    if not hasattr(e.ctx, "encrypt_dev"):           # (a backend without resident rows: draw, then one call)
+                        return e.raw_encrypt(m[lo:hi], random_lt_n_limbs(self.n, hi - lo, e.n_limbs))
+                    got = e.encrypt_from_obfuscators(m[lo:hi])      # the device's own pool first (each obfuscator used once)
+                    return got.to_host() if got is not None else e.raw_encrypt_fresh(m[lo:hi], False)
+            else:
+                r_all = r_values if isinstance(r_values, np.ndarray) else eng.plain_limbs(list(r_values))
+                shard = lambda e, lo, hi: e.raw_encrypt(m[lo:hi], r_all[lo:hi])
+            return EncryptedVector(self, np.concatenate(fl.run(count, shard)), exps, obfuscated=fresh)
         if fresh and isinstance(m, np.ndarray) and hasattr(eng.ctx, "encrypt_dev"):
             # online part only: (1 + n m) * r^n with r^n from the pool made by precompute_obfuscators (each used once)
             limbs = eng.encrypt_from_obfuscators(m)
@@ -198,6 +253,31 @@ class PaillierPublicKey(object):
             r = random_lt_n_limbs(self.n, count, eng.n_limbs) if fresh else list(r_values)
             limbs = eng.raw_encrypt_dev(m, r) if device else eng.raw_encrypt(m, r)
         return EncryptedVector(self, limbs, exps, obfuscated=fresh)
+
+    def encrypt_batch_sharded(self, values, precision=None):
+        """encrypt_batch with the ciphertexts left RESIDENT, one EncryptedVector per device of the fleet (contiguous shards in
+        order; a single vector on the ordinary device when no fleet is configured): the per-device list form of the fan-out.
+        Each vector is operated on by the engine of its own device; `PaillierPrivateKey.decrypt_batch` takes the list."""
+        from .ciphertext import EncryptedVector
+        eng = self._get_engine()
+        fl = self._get_fleet()
+        if fl is None or not hasattr(eng.ctx, "encrypt_dev"):
+            return [self.encrypt_batch(values, precision, device=hasattr(eng.ctx, "encrypt_dev"))]
+        signed = EncodedNumber.encode_signed(values, precision) if eng.n_limbs >= 4 else None
+        if signed is not None:
+            mag, neg, exps = signed
+            m = EncodedNumber.signed_to_limbs(self, mag, neg, eng.n_limbs)
+        else:
+            m, exps = EncodedNumber.encode_many(self, values, precision)
+            m = m if isinstance(m, np.ndarray) else eng.plain_limbs([v % self.n for v in m])
+        exps = np.asarray(exps, dtype=np.int64)
+
+        def shard(e, lo, hi):
+            got = e.encrypt_from_obfuscators(m[lo:hi])
+            return got if got is not None else e.raw_encrypt_fresh(m[lo:hi], True)
+        bounds = fl.shards(len(exps), min_rows=1)
+        parts = fl.run(len(exps), shard, min_rows=1)
+        return [EncryptedVector(self, part, exps[lo:hi], obfuscated=True) for part, (lo, hi) in zip(parts, bounds)]
 
 
 class PaillierPrivateKey(object):
@@ -251,8 +331,17 @@ class PaillierPrivateKey(object):
                     if old is not None and old is not fresh:
                         fresh._obf = old._obf
                     pub._engine = fresh
+                    # the further devices of a fleet get key-pair engines too (built on first use), each with a pool of its own
+                    n, p, q, hp, hq, pinv = pub.n, self.p, self.q, self.hp, self.hq, self.p_inverse
+                    pub._fleet_factory = lambda device: Engine(n, p, q, hp, hq, pinv, device=device)
+                    pub._fleet = None
                 self._engine = fresh
             return self._engine
+
+    def _get_fleet(self):
+        """the key pair's fleet (PaillierPublicKey._get_fleet): every engine of it holds the private key"""
+        self._get_engine()
+        return self.public_key._get_fleet()
 
     def __repr__(self):
         return "<PaillierPrivateKey for {}>".format(repr(self.public_key))
@@ -313,12 +402,33 @@ class PaillierPrivateKey(object):
     def decrypt_batch(self, vector, Encoding=None):
         """EncryptedVector (or list of EncryptedNumber) -> list of decoded ints/floats."""
         from .ciphertext import EncryptedVector
+        if isinstance(vector, (list, tuple)) and vector and all(isinstance(v, EncryptedVector) for v in vector):
+            # the per-device list of encrypt_batch_sharded: every part on the engine of its own device, concurrently
+            fl = self._get_fleet()
+            if fl is None or len(vector) == 1:
+                return [x for v in vector for x in self.decrypt_batch(v, Encoding)]
+            import concurrent.futures as cf
+            with cf.ThreadPoolExecutor(len(vector)) as pool:
+                return [x for part in pool.map(lambda v: self.decrypt_batch(v, Encoding), vector) for x in part]
         if not isinstance(vector, EncryptedVector):
             vector = EncryptedVector.from_numbers(self.public_key, vector)
         if self.public_key != vector.public_key:
             raise ValueError('encrypted_number was encrypted against a different key!')
         eng = self._get_engine()
         plain_decode = Encoding is None or Encoding is EncodedNumber
+        fl = self._get_fleet()
+        if vector.on_device and fl is not None:
+            eng = self.public_key._engine_for(vector._store)       # a resident vector is decrypted where it lives
+        if not vector.on_device and fl is not None and len(fl.shards(len(vector))) > 1:
+            # single-process fan-out: contiguous shards of the host vector, one device each, decoded in shard order
+            limbs, exps = vector.limbs(be_secure=False), vector.exponent_array
+
+            def shard(e, lo, hi):
+                plain = e.raw_decrypt(limbs[lo:hi])
+                if plain_decode:
+                    return EncodedNumber.decode_limbs(self.public_key, plain, exps[lo:hi])
+                return Encoding.decode_many(self.public_key, e.to_ints(plain), exps[lo:hi].tolist())
+            return [x for part in fl.run(len(vector), shard) for x in part]
         if vector.on_device or hasattr(eng.ctx, "decrypt_dev"):
             # chunks: the download and decoding of one chunk (and, for a host vector, the upload of the next) overlap
             # the kernels; device pointers are valid across contexts of the same GPU

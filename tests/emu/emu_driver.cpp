@@ -212,6 +212,27 @@ static void run_split(SplitArgs A) {
     }
 }
 
+// k_modexp_split_late: the single-wave kernels of the small-batch rungs on the late sweeps (split_core.h modexp_split_late_body)
+template <int G, int L, int MODE>
+static void run_split_late(SplitArgs A) {
+    constexpr int S2 = 2 * G * L, kPer = 64 / G;
+    if constexpr (G == 64 && L <= 9) {
+        const int n_waves = waves_for(A.batch, G);
+        const uint32_t total = (uint32_t)(kPer * n_waves);
+        std::vector<uint32_t> table((size_t)total * (size_t)A.tbl_entries * S2);
+        A.table = table.data();
+        for (int w = 0; w < n_waves; ++w) {
+            std::vector<uint32_t> lds(kPer * (S2 + kLdsPad), 0xdeadbeefu);   // LDS is not zero on the device either
+            wave::run_wave([&](uint32_t lane) {
+                const uint32_t grp = lane / G;
+                modexp_split_late_body<G, L, MODE>(A, lds.data() + grp * (S2 + kLdsPad), (uint32_t)w * kPer + grp, total, lane);
+            });
+        }
+    } else {
+        throw std::invalid_argument("no late kernel for this geometry");
+    }
+}
+
 // k_modexp_split_ab: one number on a PAIR of waves (role 0 = first words, 1 = second words), the two waves in two host
 // threads joined by wave::block_barrier; one table of (tbl_entries + 1) pairs per number.  G = 64 only.
 template <int L, int MODE>
@@ -236,6 +257,7 @@ static void run_split_ab(SplitArgs A) {
     }
 static int g_wave_tail = 0;   // 1: the CRT tail of a decrypt runs one ciphertext per wavefront (the library's choice for small batches)
 static int g_wave_pairs = 0;  // 1: whole-wave geometry runs every exponentiation on a wave pair (the library's choice for a handful of numbers)
+static int g_late = 0;        // 1: rungs of 16 lanes / the whole wave run encrypt and the decrypt halves on the late sweeps (the library's choice for small batches)
 
 template <int G, int L, bool PAIR = false>
 static void run_var_split(SplitVarArgs A) {
@@ -375,6 +397,7 @@ void emu_set_mul_io(int e) { g_mul_io = e ? 1 : 0; }
 void emu_set_unit(int e) { g_unit = e ? 1 : 0; }
 void emu_set_wave_pairs(int e) { g_wave_pairs = e ? 1 : 0; }
 void emu_set_wave_tail(int e) { g_wave_tail = e ? 1 : 0; }
+void emu_set_late(int e) { g_late = e ? 1 : 0; }
 int emu_unit_offered(const uint32_t* n, int n_limbs) {
     try { return host::build_public(n, n_limbs, g_prefer_group).nunit.G ? 1 : 0; } catch (...) { return 0; }
 }
@@ -421,6 +444,34 @@ int emu_encrypt(const uint32_t* n, int n_limbs, const uint32_t* m, const uint32_
     try {
         if (B == 0) return 0;
         host::PublicPlan P = host::build_public(n, n_limbs, g_prefer_group);
+        if (g_engine && g_late && !(P.nsplit.G == 64 && g_wave_pairs)) {
+            // the library's path for small batches on the rungs of 16 lanes / the whole wave: late sweeps, the plaintext factor
+            // folded into the way out (obfuscate: the bare power, then the product kernel)
+            if (!(P.nsplit.G >= 16 && P.nquick.ok() && P.nquick.scaled.L <= 9)) throw std::invalid_argument("no late kernel for this key / group");
+            const host::QuickPack& Q = P.nquick;
+            std::vector<uint32_t> power;
+            SplitArgs A;
+            memset(&A, 0, sizeof A);
+            quick_consts_into(A, Q);
+            A.sched = P.exp_n.ops.data(); A.n_ops = (int)P.exp_n.ops.size();
+            A.first_idx = P.exp_n.first_idx; A.tbl_entries = P.exp_n.tbl_entries;
+            A.base = r; A.base_limbs = P.s1; A.base_chunks = chunks_for(P.s1, Q.scaled.rows);
+            A.post = c_in ? nullptr : m; A.post_limbs = P.s1; A.post_chunks = 1;
+            if (c_in) power.resize((size_t)B * P.s2);
+            A.out = c_in ? power.data() : c_out; A.out_limbs = P.s2; A.batch = B;
+            if (Q.scaled.G == 64) { DISPATCH_SPLIT(Q.scaled.G, Q.scaled.L, (run_split_late<GG, LL, kModeEncrypt>(A))); }
+            else { DISPATCH_SPLIT(Q.scaled.G, Q.scaled.L, (run_split<GG, LL, kModeEncrypt, true>(A))); }   // 16 lanes: the quick form
+            if (c_in) {
+                MulArgs Mu;
+                memset(&Mu, 0, sizeof Mu);
+                Mu.mod = consts_of(P.nsq); Mu.a = power.data(); Mu.a_stride = (size_t)P.s2;
+                Mu.b = c_in; Mu.b_stride = (size_t)P.s2; Mu.out = c_out; Mu.out_stride = (size_t)P.s2; Mu.limbs = P.s2; Mu.batch = B;
+                int MG, ML;
+                light_geometry_of(P.nsq, MG, ML);
+                DISPATCH_GL(MG, ML, (run_mul<GG, LL>(Mu)));
+            }
+            return 0;
+        }
         if (g_engine && g_unit && P.nunit.G) {
             // the library's large-batch path: r^n modulo the scaled modulus n'^2 (quotient digits without a multiply), then
             // one pass of the product kernel takes that residue to (1 + n*m) * r^n mod n^2 (or c_in * r^n)
@@ -508,6 +559,14 @@ int emu_encrypt_owner(const uint32_t* n, const uint32_t* p, const uint32_t* q, c
             A.first_idx = PUB.exp_n.first_idx; A.tbl_entries = PUB.exp_n.tbl_entries;
             A.base = r; A.base_limbs = P.s1; A.base_chunks = chunks_for(P.s1, SP.rows);
             A.out = half ? yq.data() : yp.data(); A.out_limbs = S; A.batch = B;
+            const host::QuickPack& QP = half ? P.qquick : P.pquick;
+            if (g_late && SP.G >= 16 && QP.ok() && QP.scaled.L <= 9) {
+                quick_consts_into(A, QP);
+                A.base_chunks = chunks_for(P.s1, QP.scaled.rows);
+                if (QP.scaled.G == 64) { DISPATCH_SPLIT(QP.scaled.G, QP.scaled.L, (run_split_late<GG, LL, kModeHalfDecrypt>(A))); }
+                else { DISPATCH_SPLIT(QP.scaled.G, QP.scaled.L, (run_split<GG, LL, kModeHalfDecrypt, true>(A))); }
+                continue;
+            }
             DISPATCH_SPLIT(SP.G, SP.L, (run_split<GG, LL, kModeHalfDecrypt>(A)));
         }
         CrtLiftArgs A;
@@ -554,6 +613,14 @@ int emu_decrypt(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const 
                     quick_consts_into(A, QP);
                     A.base_chunks = chunks_for(P.s2, QP.scaled.rows);
                     DISPATCH_AB(QP.scaled.L, (run_split_ab<LL, kModeHalfDecrypt>(A)));
+                    continue;
+                }
+                if (g_late) {
+                    if (!(SP.G >= 16 && QP.ok() && QP.scaled.L <= 9)) throw std::invalid_argument("no late kernel for this key / group");
+                    quick_consts_into(A, QP);
+                    A.base_chunks = chunks_for(P.s2, QP.scaled.rows);
+                    if (QP.scaled.G == 64) { DISPATCH_SPLIT(QP.scaled.G, QP.scaled.L, (run_split_late<GG, LL, kModeHalfDecrypt>(A))); }
+                    else { DISPATCH_SPLIT(QP.scaled.G, QP.scaled.L, (run_split<GG, LL, kModeHalfDecrypt, true>(A))); }
                     continue;
                 }
                 DISPATCH_SPLIT(SP.G, SP.L, (run_split<GG, LL, kModeHalfDecrypt>(A)));

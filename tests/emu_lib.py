@@ -32,6 +32,11 @@ class Emu:
         """True: on the whole-wave geometry (set_group(64)) encrypt / decrypt run every number on a PAIR of waves"""
         self.L.emu_set_wave_pairs(1 if on else 0)
 
+    def set_late(self, on):
+        """True: on the rungs of 16 lanes / the whole wave (set_group(16 | 64)) encrypt, obfuscate and the decrypt halves run on
+        the late sweeps (split_core.h modexp_split_late_body: the library's choice for small batches)"""
+        self.L.emu_set_late(1 if on else 0)
+
     def set_wave_tail(self, on):
         """True: the CRT tail of decrypt runs one ciphertext per wavefront (the library's choice for small batches)"""
         self.L.emu_set_wave_tail(1 if on else 0)

@@ -331,6 +331,40 @@ def test_one_number_on_a_wave_pair(emu, key_bits, count):
         emu.set_group(0)
 
 
+@pytest.mark.parametrize("group,key_bits,count", [(16, 256, None), (64, 256, None), (16, 1024, 3), (64, 1024, 2), (16, 2048, 3), (64, 2048, 2),
+                                                  (16, 3072, 1), (64, 3072, 1)])
+def test_small_batch_rungs_on_the_late_sweeps(emu, group, key_bits, count):
+    """split_core.h pair_late / modexp_split_late_body (round 4): the single-wave kernels of the 16-lane and whole-wave rungs
+    in the wave pair's row order — scaled modulus, quotient product after the shift, both words in one sweep with the first
+    word one step ahead, rows = the limbs the scaled modulus needs (75 of 80 for a 2048-bit n on 16 x 5, 39 of 48 for its p on
+    16 x 3), the way out modulo the true modulus.  encrypt (edge plaintexts m = 0, 1, ... and r = 1, n - 1 included at 256 bits),
+    obfuscate and both decrypt halves must give the golden bits."""
+    emu.set_engine(True)
+    emu.set_group(group)
+    emu.set_late(True)
+    try:
+        g = load_golden(key_bits)
+        s1, s2, h = key_bits // 32, key_bits // 16, key_bits // 64
+        n = int_to_limbs(H(g["n"]), s1)
+        enc = g["raw_encrypt"]
+        if count:
+            enc = enc[:2] + enc[7:7 + count] + enc[-2:]
+        c = emu.encrypt(n, ints_to_limbs([H(e["m"]) % H(g["n"]) for e in enc], s1), ints_to_limbs([H(e["r"]) for e in enc], s1))
+        assert limbs_to_ints(c) == [H(e["c"]) for e in enc]
+        dec = g["raw_decrypt"]
+        if count:
+            dec = dec[-count:] + dec[:1]
+        key = [int_to_limbs(H(g[k]), h) for k in ("p", "q", "hp", "hq", "p_inverse")]
+        m = emu.decrypt(*key, s1, ints_to_limbs([H(e["c"]) for e in dec], s2))
+        assert limbs_to_ints(m) == [H(e["m"]) for e in dec]
+        obf = g["obfuscate"][:count or None]
+        out = emu.obfuscate(n, ints_to_limbs([H(e["c_in"]) for e in obf], s2), ints_to_limbs([H(e["r"]) for e in obf], s1))
+        assert limbs_to_ints(out) == [H(e["c_out"]) for e in obf]
+    finally:
+        emu.set_late(False)
+        emu.set_group(0)
+
+
 @pytest.mark.parametrize("key_bits", [256, 1024, 2048, 3072])
 def test_decrypt_tail_on_one_wave_per_ciphertext(emu, key_bits):
     """split_core.h decrypt_tail_wave_body (the tail the library takes for small batches): L-function, * hp, CRT on the

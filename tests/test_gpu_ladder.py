@@ -129,6 +129,56 @@ def test_the_rung_follows_the_batch_size(native, c_oracle):
 
 
 @pytest.mark.parametrize("key_bits", [1024, 2048, 3072])
+def test_small_batch_rungs_run_the_late_sweeps(native, c_oracle, key_bits, monkeypatch):
+    """Round 4: the rungs of 16 lanes and of the whole wave run encrypt / obfuscate / the decrypt halves
+    on the LATE sweeps (k_modexp_split_late: scaled modulus, quotient product after the shift, rows = the limbs the modulus
+    needs) — the path asserted through last_launch, every golden vector on both rungs, random batches of 100 ... 5000 rows
+    against libgmp, the full round trip, and against what the round-3 kernels give (PHE_HIP_NO_LATE)."""
+    g = load_golden(key_bits)
+    s1, s2 = key_bits // 32, key_bits // 16
+    n_int = H(g["n"])
+    n = native.int_to_limbs(n_int, s1)
+    monkeypatch.setenv("PHE_HIP_NO_WAVE_PAIRS", "1")             # the whole-wave rung on its SINGLE-wave kernels for a handful too
+    ctx = make_ctx(native, g)
+    for width in (16, 64):
+        ctx.set_group(width)
+        seen = golden_hot_path(native, ctx, g)
+        for op in ("encrypt", "decrypt", "obfuscate"):
+            assert seen[op]["path"] & ctx.PATH_LATE, (width, op, seen)
+        assert seen["encrypt"]["geom_pub"] // 100 >= width and seen["decrypt"]["geom_priv"] // 100 >= width, (width, seen)   # (the next wider rung where the key has none of this width)
+    ctx.set_group(0)
+    monkeypatch.setenv("PHE_HIP_NO_LATE", "1")
+    plain = make_ctx(native, g)
+    monkeypatch.delenv("PHE_HIP_NO_LATE")
+    rs = np.random.Generator(np.random.PCG64(key_bits + 4))
+    took_late = 0
+    for batch in (100, 700, 1100, 2500, 5000):
+        m = rs.integers(0, 1 << 32, size=(batch, s1), dtype=np.uint32)
+        r = rs.integers(0, 1 << 32, size=(batch, s1), dtype=np.uint32)
+        m[:, s1 - 1] = 0
+        r[:, s1 - 1] &= 0x3fffffff
+        r[:, 0] |= 1
+        c = ctx.encrypt(m, r)
+        enc_info = ctx.last_launch()
+        back = ctx.decrypt(c)
+        dec_info = ctx.last_launch()
+        took_late += bool(enc_info["path"] & ctx.PATH_LATE) + bool(dec_info["path"] & ctx.PATH_LATE)
+        if enc_info["geom_pub"] // 100 >= 16:
+            assert enc_info["path"] & ctx.PATH_LATE, (batch, enc_info)
+        if dec_info["geom_priv"] // 100 >= 16:
+            assert dec_info["path"] & ctx.PATH_LATE, (batch, dec_info)
+        assert np.array_equal(back, m), batch
+        assert np.array_equal(c, plain.encrypt(m, r)), batch
+        assert not plain.last_launch()["path"] & ctx.PATH_LATE
+        assert np.array_equal(plain.decrypt(c), m), batch
+        idx = np.arange(0, batch, max(1, batch // 29))
+        assert np.array_equal(c[idx], c_oracle.encrypt(n, m[idx], r[idx], nthreads=8)), batch
+        c2 = ctx.obfuscate(c, r[::-1].copy())
+        assert np.array_equal(c2[idx], c_oracle.obfuscate(n, c[idx], r[::-1][idx].copy(), nthreads=8)), batch
+    assert took_late >= 6, took_late
+
+
+@pytest.mark.parametrize("key_bits", [1024, 2048, 3072])
 def test_a_handful_of_numbers_runs_on_wave_pairs(native, c_oracle, key_bits, monkeypatch):
     """1 ... 60 numbers: every exponentiation on a PAIR of wavefronts (k_modexp_split_ab: first words on one wave, second words
     one product behind on the other) — asserted through last_launch, bit-exact against the golden vectors and libgmp, and

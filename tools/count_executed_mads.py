@@ -36,8 +36,11 @@ def main():
     emu = Emu()
     emu.L.emu_mad_count.restype = ctypes.c_uint64
     count = lambda: int(emu.L.emu_mad_count(1))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from csrc_hash import csrc_hash
     out = {"unit": "v_mad_u64_u32 lane-operations per element (wave::mad64 calls counted by the CPU wave emulator on "
-                   "full wavefronts; 29-bit limbs)", "elements_per_run": args.elements, "keys": {}}
+                   "full wavefronts; 29-bit limbs)", "elements_per_run": args.elements,
+           "csrc_sha256": csrc_hash(), "keys": {}}
     for bits in args.key_bits:
         g = json.load(open(os.path.join(ROOT, "tests", "golden", "paillier_%d.json" % bits)))
         H = lambda k: int(g[k], 16)

@@ -1,0 +1,17 @@
+#!/bin/bash
+# TAG=<name> bash tools/gpu_pmc_traffic.sh (through gpurun): the PMC passes behind bench.py's roofline.traffic / pmc_valu figures on the
+# CURRENT tree -> gpurun_out/$TAG/hbm_traffic.json (copy to profiles/hbm_traffic_rNN.json).  Own runs, counters only (no tracing).
+cd "$GRAFT_REPO_ROOT" || exit 1
+T=${TAG:-r04}; O=gpurun_out/$T; mkdir -p $O; R=$PWD; B=${BATCH:-131072}
+cd /tmp && export TMPDIR=/tmp
+for leg in encrypt decrypt; do
+  timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_LDS -d $R/$O/pmc_${leg}_valu -- python $R/bench.py --batch $B --steps 1 --warmup 0 --only $leg > $R/$O/pmc_${leg}_valu.log 2>&1; echo "$leg valu rc=$?"
+  timeout 300 rocprofv3 --pmc FETCH_SIZE -d $R/$O/pmc_${leg}_fetch -- python $R/bench.py --batch $B --steps 1 --warmup 0 --only $leg > $R/$O/pmc_${leg}_fetch.log 2>&1; echo "$leg fetch rc=$?"
+  timeout 300 rocprofv3 --pmc WRITE_SIZE -d $R/$O/pmc_${leg}_write -- python $R/bench.py --batch $B --steps 1 --warmup 0 --only $leg > $R/$O/pmc_${leg}_write.log 2>&1; echo "$leg write rc=$?"
+done
+cd $R
+python tools/pmc_traffic_json.py --batch $B --source "rocprofv3 --pmc on the tree of $T (tools/gpu_pmc_traffic.sh: bench.py --only <leg> --batch $B --steps 1 --warmup 0)" \
+  --leg encrypt $O/pmc_encrypt_valu $O/pmc_encrypt_fetch $O/pmc_encrypt_write --leg decrypt $O/pmc_decrypt_valu $O/pmc_decrypt_fetch $O/pmc_decrypt_write > $O/hbm_traffic.json
+python tools/rocprof_summarize.py $O/pmc_encrypt_valu $O/pmc_encrypt_fetch $O/pmc_encrypt_write $O/pmc_decrypt_valu $O/pmc_decrypt_fetch $O/pmc_decrypt_write > $O/rocprofv3_pmc.txt 2>&1
+rm -rf $O/pmc_encrypt_valu $O/pmc_encrypt_fetch $O/pmc_encrypt_write $O/pmc_decrypt_valu $O/pmc_decrypt_fetch $O/pmc_decrypt_write
+cat $O/hbm_traffic.json | head -40

