@@ -607,6 +607,7 @@ static int prepare_split(phe_hip_ctx* ctx, const DevSplit& M, const DevSchedule&
     uint32_t** tbl = second_table ? &ctx->table2 : &ctx->table;
     int rc = ensure_words(tbl, second_table ? &ctx->table2_words : &ctx->table_words, rows * (size_t)E.tbl_entries * 2 * M.H);
     if (rc) return rc;
+    A = SplitArgs{};  // (exit_mod stays null: modexp_split_body takes the quick way out only where a caller sets it)
     A.mod = M.c;
     A.sched = E.ops;
     A.n_ops = E.n_ops;
@@ -683,6 +684,7 @@ static int prepare_late(phe_hip_ctx* ctx, const DevSplit& M, const DevSchedule& 
     uint32_t** tbl = second_table ? &ctx->table2 : &ctx->table;
     int rc = ensure_words(tbl, second_table ? &ctx->table2_words : &ctx->table_words, rows * (size_t)E.tbl_entries * 2 * M.q_H);
     if (rc) return rc;
+    A = SplitArgs{};
     A.mod = M.q_scaled;
     A.exit_mod = M.q_exit;
     A.sched = E.ops;
