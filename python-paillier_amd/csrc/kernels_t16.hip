@@ -1,0 +1,67 @@
+// kernels_t16.hip — a*b mod N as one plain product + one fold against a per-key table in LDS (mul_table.h): 512-thread workgroups
+// (8 wavefronts = 32 limb groups of 16 lanes), one per CU, the whole LDS of the CU to itself.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// clang-format off
+#include "wave_gfx950.h"
+#include "mont_core.h"
+#include "mul_io.h"
+#include "split_core.h"
+#include "mul_table.h"
+// clang-format on
+
+namespace phe {
+
+constexpr int kTableBlock = 512;
+
+template <int L>
+__global__ void __launch_bounds__(kTableBlock, 1) k_mulmod_table(TableMulArgs A) {
+    constexpr int S = 16 * L, kRowT = S + kTableRowSlack, kGroups = kTableBlock / 16;
+    using IO = RowIO<16, L>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_t[];
+    uint32_t* tbl = lds_t;
+    uint32_t* cst = tbl + (size_t)A.digits * S;
+    uint32_t* rows = cst + 3 * S;
+    uint32_t* stage = rows + kGroups * kRowT;
+    // the table and the constant rows: global (L2) -> LDS once per workgroup, 16 bytes per thread and trip
+    {
+        const int n4 = A.digits * S / 4;  // (S is a multiple of 16)
+        const Words4* src = reinterpret_cast<const Words4*>(A.table);
+        Words4* dst = reinterpret_cast<Words4*>(tbl);
+        for (int i = (int)threadIdx.x; i < n4; i += kTableBlock) dst[i] = src[i];
+        for (int i = (int)threadIdx.x; i < S; i += kTableBlock) {
+            cst[i] = A.n[i];
+            cst[S + i] = A.ncomp[i];
+            cst[2 * S + i] = A.ncomp1[i];
+        }
+    }
+    __syncthreads();
+    const uint32_t grp = threadIdx.x / 16, wv = threadIdx.x / 64u;
+    mul_table_body<L>(A, rows + grp * kRowT, stage + wv * 2 * IO::kStageWave, tbl, cst, blockIdx.x * kGroups + grp, gridDim.x * kGroups,
+                      threadIdx.x & 63u);
+}
+
+namespace t16 {
+
+template <int L>
+static int launch_L(int blocks, size_t lds_bytes, hipStream_t st, const TableMulArgs& A) {
+    static size_t allowed = 0;  // (one attribute call per size: the default cap of dynamic LDS is 64 KB)
+    if (lds_bytes > allowed) {
+        if (hipFuncSetAttribute((const void*)k_mulmod_table<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
+        allowed = lds_bytes;
+    }
+    k_mulmod_table<L><<<dim3(blocks), dim3(kTableBlock), lds_bytes, st>>>(A);
+    return 0;
+}
+// -1: no kernel for this lane width; -2: the device refused the LDS size
+int launch_mul_table(int L, int blocks, size_t lds_bytes, hipStream_t st, const TableMulArgs& A) {
+    switch (L) {
+        case 5: return launch_L<5>(blocks, lds_bytes, st, A);
+        case 9: return launch_L<9>(blocks, lds_bytes, st, A);
+        default: return -1;
+    }
+}
+
+}  // namespace t16
+}  // namespace phe

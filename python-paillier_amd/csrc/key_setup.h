@@ -724,6 +724,95 @@ inline PrivatePlan build_private(const uint32_t* p, const uint32_t* q, const uin
     return P;
 }
 
+// ---- a*b mod N as one plain product + one fold against a table (csrc/mul_table.h) ---------------------------------------------
+// G = 16 lanes x L limbs, S = 16 L >= (bits(N) + 38) / 29 limbs; P = ceil(bits(N) / 29): the limbs of T = a*b at and above P are
+// the D fold digits, row i of the table is W^(P+i) mod N (W = 2^29).  Offered while the table fits the LDS of a CU beside the
+// kernel's other areas (keys up to ~2700 bits: L = 5 or 9) — ok() false otherwise, mul_io.h's kernels serve.
+struct TableMulPack {
+    int L = 0, S = 0;
+    int split = 0, digits = 0, base = 0;
+    double inv = 0.0;                          // W^base / N
+    std::vector<uint32_t> n, ncomp, ncomp1;    // S limbs each: N, W^S - N, (W^S - N) * W mod W^S
+    std::vector<uint32_t> table;               // digits rows of S words, device layout (mul_table.h table_row_limbs)
+    size_t lds_words = 0;
+    bool ok() const { return L != 0; }
+};
+// lane widths offered: 9 (n^2 of ~1850 ... 2048-bit keys).  5 limbs per lane (1024-bit keys) was built and measured SLOWER than
+// the Montgomery kernels there (818 M against 1024 M products/s: 80 limbs for a number of 71, and 5 multiply-adds per table read
+// and per shift) — kept compiled for the emulator tests, not offered by the library (build_table_mul's `offer_narrow`)
+static const int kTableL[] = {5, 9};
+constexpr size_t kTableLdsLimitBytes = 158 * 1024;  // of the 160 KB of a CU
+
+inline TableMulPack build_table_mul(const Big& N_any, int word_limbs, bool offer_narrow = true) {
+    TableMulPack T;
+    const int bits = big_bits(N_any);
+    if (bits < 64 || bits > 32 * word_limbs) return T;
+    const int need = (bits + 38 + kRadixBits - 1) / kRadixBits;
+    int L = 0;
+    for (int cand : kTableL)
+        if (16 * cand >= need) {
+            L = cand;
+            break;
+        }
+    if (!L || (!offer_narrow && (L < 9 || 16 * L - need >= 16))) return T;  // (the library: only where the lanes are well filled)
+    const int S = 16 * L, P = (bits + kRadixBits - 1) / kRadixBits, n_lo = S - P;
+    // limbs the high half of a product of two `word_limbs`-word numbers can have, on top of the S low ones
+    const int hi_limbs = std::max(0, (2 * 32 * word_limbs + kRadixBits - 1) / kRadixBits - S);
+    const int D = n_lo + hi_limbs;
+    if (n_lo < 2 || n_lo > 16 || hi_limbs > S) return T;
+    // LDS of the 512-thread workgroup (mul_table.h table_lds_words): table | 3 constant rows | 32 digit rows | 8 x 2 staging areas
+    const int k_words = (S * kRadixBits + 31) / 32, k_vec = (k_words + 1 + 63) / 64;
+    const size_t lds_words = (size_t)D * S + 3 * (size_t)S + 32 * (size_t)(S + 16) + 8 * 2 * (size_t)(256 * k_vec);
+    if (lds_words * 4 > kTableLdsLimitBytes) return T;
+    const int w32 = (kRadixBits * S + 31) / 32 + 1;  // words that hold W^S
+    const Big N = big_resize(N_any, w32);
+    if ((N[0] & 1u) == 0u) return T;
+    T.n = to_r29(N, S);
+    {
+        Big top((size_t)w32, 0u);  // W^S
+        top[(size_t)((kRadixBits * S) >> 5)] = 1u << ((kRadixBits * S) & 31);
+        Big nc = top;
+        big_sub_inplace(nc, N);
+        T.ncomp = to_r29(nc, S);
+        T.ncomp1.assign((size_t)S, 0u);
+        for (int k = 1; k < S; ++k) T.ncomp1[(size_t)k] = T.ncomp[(size_t)k - 1];  // * W, the limb shifted out of W^S dropped
+    }
+    // rows W^(P+i) mod N
+    Big one((size_t)w32, 0u);
+    one[0] = 1;
+    Big c = big_shift_mod(one, kRadixBits * P, N);
+    constexpr int kFullMax = 16;
+    const int full = L / 4, rem = L % 4;
+    (void)kFullMax;
+    T.table.assign((size_t)D * S, 0u);
+    for (int i = 0; i < D; ++i) {
+        const std::vector<uint32_t> limbs = to_r29(c, S);
+        uint32_t* row = T.table.data() + (size_t)i * S;
+        for (int g = 0; g < 16; ++g) {
+            for (int q = 0; q < full; ++q)
+                for (int e = 0; e < 4; ++e) row[q * 64 + 4 * g + e] = limbs[(size_t)(g * L + 4 * q + e)];
+            for (int r = 0; r < rem; ++r) row[full * 64 + g * rem + r] = limbs[(size_t)(g * L + 4 * full + r)];
+        }
+        c = big_shift_mod(c, kRadixBits, N);
+    }
+    // W^base / N as a double: N = top64 * 2^(bits - 64) up to 2^-63 relative
+    {
+        uint64_t top64 = 0;
+        for (int b = 0; b < 64; ++b) {
+            const int bit = bits - 1 - b;
+            top64 = (top64 << 1) | ((N[(size_t)(bit >> 5)] >> (bit & 31)) & 1u);
+        }
+        T.base = P - 2;
+        T.inv = __builtin_ldexp(1.0 / (double)top64, kRadixBits * T.base - (bits - 64));
+    }
+    T.L = L;
+    T.S = S;
+    T.split = P;
+    T.digits = D;
+    T.lds_words = lds_words;
+    return T;
+}
+
 // scalar inverse of a residue modulo an odd N (binary extended Euclid); false if gcd != 1
 inline bool big_invert_odd(const Big& a_in, const Big& N, Big& out) {
     const size_t w = N.size();

@@ -147,6 +147,19 @@ PHE_DEV void mul_table_body(const TableMulArgs& A, uint32_t* row, uint32_t* stag
             }
         }
         wave::lds_fence();
+        {   // the low halves were written across a's staging area: the chunks a copy never touches (words at or beyond the row
+            // length) must read as zero again before the next row is sliced out of it
+            const uint32_t gi = wave::reread(g);
+#pragma unroll
+            for (int t = 0; t < IO::kVec; ++t) {
+                if (4 * (t * G + (int)gi) >= A.limbs) {
+                    Words4 z;
+                    z.x = z.y = z.z = z.w = 0u;
+                    *reinterpret_cast<Words4*>(stage_a + t * 256 + 4 * (int)lane) = z;
+                }
+            }
+        }
+        wave::lds_fence();
         if (it + 1 < n_iter) {  // the next element's rows: copied while this one is folded (both staging halves are free now)
             uint64_t nxt = slot + (it + 1) * (uint64_t)total_slots;
             if (nxt >= A.batch) nxt = A.batch - 1;
@@ -157,7 +170,7 @@ PHE_DEV void mul_table_body(const TableMulArgs& A, uint32_t* row, uint32_t* stag
         // ---- y = lo_kept + sum_i f_i * C_i: chain-free; 48 products of < 2^58.01 per column between two renormalisations ----
         {
             const uint32_t gi = wave::reread(g);
-            int i = 0;
+            int i = 0, since = 0;  // digits folded since the accumulators were last brought below 2^29 + carries
 #pragma unroll 1
             for (; i + 4 <= D; i += 4) {
                 const Words4 dg = *reinterpret_cast<const Words4*>(row + i);
@@ -169,7 +182,11 @@ PHE_DEV void mul_table_body(const TableMulArgs& A, uint32_t* row, uint32_t* stag
 #pragma unroll
                     for (int k = 0; k < L; ++k) acc[k] = wave::mad64(d4[u], t[k], acc[k]);
                 }
-                if ((i & 63) == 44) table_renormalize<L>(acc, ln);  // after 48, 112, 176 ... digits (i + 4 of them done)
+                since += 4;
+                if (since == 48) {  // 48 products of < 2^58.01 on top of < 2^37: below 2^64 whatever the operands
+                    table_renormalize<L>(acc, ln);
+                    since = 0;
+                }
             }
             for (; i < D; ++i) {
                 uint32_t t[L];

@@ -28,6 +28,8 @@
 #include "wave_gfx950.h"
 #include "mont_core.h"
 #include "split_core.h"
+#include "mul_io.h"
+#include "mul_table.h"
 #include "decrypt_tail.h"
 #include "key_setup.h"
 #include "radix_conv.h"
@@ -112,6 +114,12 @@ PHE_DECLARE_SPLIT_PART(s16c)
 PHE_DECLARE_SPLIT_PART(s64a)
 PHE_DECLARE_SPLIT_PART(s64b)
 #undef PHE_DECLARE_SPLIT_PART
+}  // namespace phe
+
+namespace phe {
+namespace t16 {  // kernels_t16.hip
+int launch_mul_table(int L, int blocks, size_t lds_bytes, hipStream_t st, const TableMulArgs& A);
+}  // namespace t16
 }  // namespace phe
 
 namespace phe {
@@ -275,6 +283,9 @@ __global__ void k_selftest_prims(uint32_t* out) {
 // ------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------
+// what phe_hip_ctx_last_launch reports (include/phe_hip.h)
+enum : int { kPathUnit = 1, kPathOwner = 2, kPathSideBySide = 4, kPathPipelined = 8, kPathFusedObfuscate = 16, kPathWavePairs = 32, kPathWaveTail = 64,
+             kPathLate = 128, kPathTableMul = 256 };
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -345,6 +356,10 @@ struct phe_hip_ctx {
     std::vector<PrivRung> priv_rungs;  // rungs 1.. of the private side
     int wave_pair_depth = 1;           // waves per SIMD up to which a batch stays on the wave-pair kernels (PHE_HIP_WAVE_PAIR_DEPTH)
     bool no_wave_pairs = false;        // PHE_HIP_NO_WAVE_PAIRS=1: a handful of numbers stays on the single-wave kernels (A/B measurements, tests)
+    // a*b mod n^2 as one plain product + one fold against a table in LDS (csrc/mul_table.h): constants n | W^S - n^2 | its shift |
+    // table on the device; null = not offered for this key width (the table does not fit a CU's LDS) or PHE_HIP_NO_TABLE_MUL=1
+    host::TableMulPack tmul;
+    uint32_t* tmul_blob = nullptr;
     bool no_late = false;              // PHE_HIP_NO_LATE=1: the small-batch rungs stay on the round-3 kernels (textbook row order; A/B measurements, tests)
     bool force_unit = false;           // PHE_HIP_FORCE_UNIT=1: r^n through the scaled modulus whatever the batch size (tests)
     int force_group = 0;               // phe_hip_ctx_set_group: 0 = pick by batch size; G = the rung whose groups are G lanes wide
@@ -883,9 +898,46 @@ static int launch_var(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* bas
     return PHE_HIP_OK;
 }
 
+// batches from this many rows on take the table kernel: one 512-thread workgroup per CU (32 limb groups) copies the 80 KB table
+// into LDS before its first product — measured against the Montgomery kernels on one box (profiles/r04g_*): 2^11 rows 71 M against
+// 87 M/s, 2^12 140 against 171, 2^13 276 against 212, 2^20 368 against 313
+static const size_t kTableMulMinRows = 8192;
 static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, size_t a_stride, const uint32_t* b,
                       size_t b_stride, uint32_t* out, size_t out_stride, int limbs, size_t batch,
-                      hipStream_t stream, int b_plain_limbs = 0, int one_product = 0, int a_limbs = 0) {
+                      hipStream_t stream, int b_plain_limbs = 0, int one_product = 0, int a_limbs = 0, bool plain_mulmod = false) {
+    if (plain_mulmod && ctx->tmul_blob && !b_plain_limbs && !one_product && !a_limbs && batch >= kTableMulMinRows && limbs == ctx->pub.s2 &&
+        limbs % 4 == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15u) == 0) && a_stride % 4 == 0 && b_stride % 4 == 0 &&
+        out_stride % 4 == 0 && b_stride != 0) {
+        // _raw_add on plain residues (phe/paillier.py:705-719): one plain product + one fold against the key's table
+        // (mul_table.h) instead of two Montgomery products
+        const host::TableMulPack& T = ctx->tmul;
+        TableMulArgs B;
+        B.n = ctx->tmul_blob;
+        B.ncomp = ctx->tmul_blob + T.S;
+        B.ncomp1 = ctx->tmul_blob + 2 * T.S;
+        B.table = ctx->tmul_blob + 3 * T.S;
+        B.inv = T.inv;
+        B.split = T.split;
+        B.digits = T.digits;
+        B.base = T.base;
+        B.a = a;
+        B.b = b;
+        B.out = out;
+        B.a_stride = a_stride;
+        B.b_stride = b_stride;
+        B.out_stride = out_stride;
+        B.limbs = limbs;
+        B.batch = batch;
+        const size_t per_block = 32;  // limb groups of a 512-thread workgroup
+        const int blocks = (int)std::max<size_t>(1, std::min((batch + per_block - 1) / per_block, (size_t)ctx->n_cus));
+        const int rc = phe::t16::launch_mul_table(T.L, blocks, T.lds_words * 4, stream, B);
+        if (rc == 0) {
+            HIP_TRY(hipGetLastError());
+            ctx->last_path |= kPathTableMul;
+            return PHE_HIP_OK;
+        }
+        (void)hipGetLastError();  // (-1 / -2: no kernel for the width, or the LDS size refused: the Montgomery kernels serve)
+    }
     MulArgs A;
     A.b_plain_limbs = b_plain_limbs;
     A.one_product = one_product;
@@ -1033,8 +1085,6 @@ static const DevSplit& pick_nsplit(const phe_hip_ctx* ctx, size_t batch, int fam
     return nsplit_rung(ctx, pick_nsplit_rung(ctx, batch, family));
 }
 static int geom_code(int G, int L) { return G * 100 + L; }
-enum : int { kPathUnit = 1, kPathOwner = 2, kPathSideBySide = 4, kPathPipelined = 8, kPathFusedObfuscate = 16, kPathWavePairs = 32, kPathWaveTail = 64,
-             kPathLate = 128 };
 
 static int check_ctx(const phe_hip_ctx* ctx) {
     if (!ctx) return fail(PHE_HIP_EINVAL, "null context");
@@ -1118,6 +1168,22 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
     if (!rc) rc = upload_split(ctx->pub.nsplit, ctx->d_nsplit, &ctx->pub.nquick);
     if (!rc && !getenv("PHE_HIP_NO_UNIT")) rc = upload_split(ctx->pub.nunit, ctx->d_nunit);
     if (!rc) rc = upload_schedule(ctx->pub.exp_n, ctx->d_exp_n);
+    if (!rc && !getenv("PHE_HIP_NO_TABLE_MUL")) {
+        try {
+            ctx->tmul = host::build_table_mul(ctx->pub.nsq32, ctx->pub.s2, getenv("PHE_HIP_TABLE_MUL_ANY_WIDTH") != nullptr);
+        } catch (const std::exception&) {
+            ctx->tmul = host::TableMulPack();
+        }
+        if (ctx->tmul.ok()) {
+            const host::TableMulPack& T = ctx->tmul;
+            std::vector<uint32_t> h(T.n);
+            h.insert(h.end(), T.ncomp.begin(), T.ncomp.end());
+            h.insert(h.end(), T.ncomp1.begin(), T.ncomp1.end());
+            h.insert(h.end(), T.table.begin(), T.table.end());
+            HIP_TRY(hipMalloc((void**)&ctx->tmul_blob, h.size() * 4));
+            HIP_TRY(hipMemcpy(ctx->tmul_blob, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+        }
+    }
     ctx->force_unit = getenv("PHE_HIP_FORCE_UNIT") != nullptr;
     ctx->no_wave_pairs = getenv("PHE_HIP_NO_WAVE_PAIRS") != nullptr;
     ctx->no_late = getenv("PHE_HIP_NO_LATE") != nullptr;
@@ -1280,7 +1346,8 @@ void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
     std::vector<uint32_t*> bufs = {ctx->d_nsplit.blob, ctx->d_psplit.blob, ctx->d_qsplit.blob,
                         ctx->d_nsq.blob, ctx->d_psq.blob, ctx->d_qsq.blob, ctx->d_exp_n.ops, ctx->d_exp_p.ops,
                         ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->table2, ctx->scratch, ctx->partial, ctx->lookup, (uint32_t*)ctx->flags, ctx->stage[0],
-                        ctx->stage[1], ctx->stage[2], ctx->owner_blob, ctx->d_nunit.blob, ctx->unit_tmp, ctx->tail_wave_blob, ctx->item_sched};
+                        ctx->stage[1], ctx->stage[2], ctx->owner_blob, ctx->d_nunit.blob, ctx->unit_tmp, ctx->tail_wave_blob, ctx->item_sched,
+                        ctx->tmul_blob};
     for (const auto& R : ctx->pub_rungs) { bufs.push_back(R.nsq.blob); bufs.push_back(R.nsplit.blob); bufs.push_back(R.nunit.blob); }
     for (const auto& R : ctx->priv_rungs) { bufs.push_back(R.psq.blob); bufs.push_back(R.qsq.blob); bufs.push_back(R.psplit.blob); bufs.push_back(R.qsplit.blob); }
     for (uint32_t* b : bufs)
@@ -1671,7 +1738,8 @@ int phe_hip_mulmod_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, u
     if (int rc = bind_device(ctx)) return rc;
     PHE_CTX_ORDER(ctx, stream);
     const size_t s2 = (size_t)ctx->pub.s2;
-    return launch_mul(ctx, pick_nsq(ctx, batch), a, s2, b, s2, out, s2, ctx->pub.s2, batch, (hipStream_t)stream);
+    ctx->last_path = 0;
+    return launch_mul(ctx, pick_nsq(ctx, batch), a, s2, b, s2, out, s2, ctx->pub.s2, batch, (hipStream_t)stream, 0, 0, 0, true);
 }
 
 int phe_hip_montmul_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, int b_is_row, uint32_t* out, size_t batch,

@@ -9,6 +9,7 @@
 #include "../../python-paillier_amd/csrc/mont_core.h"
 #include "../../python-paillier_amd/csrc/mul_io.h"
 #include "../../python-paillier_amd/csrc/split_core.h"
+#include "../../python-paillier_amd/csrc/mul_table.h"
 #include "../../python-paillier_amd/csrc/decrypt_tail.h"
 #include "../../python-paillier_amd/csrc/key_setup.h"
 #include "../../python-paillier_amd/csrc/radix_conv.h"
@@ -390,6 +391,31 @@ static void light_geometry_of(const host::ModulusPack& M, int& G, int& L) {
     else if (G == 2 && L == 36) { G = 4; L = 18; }
 }
 
+// k_mulmod_table (mul_table.h): a*b mod N as one plain product + one fold against the key's table; one emulated wave (4 limb
+// groups) at a time with its own copy of the workgroup's LDS areas.  rc 2: not offered for this modulus (the table does not fit)
+template <int L>
+static void run_mul_table(TableMulArgs A, const host::TableMulPack& T) {
+    constexpr int G = 16, S = G * L, kRowT = S + kTableRowSlack, kPer = 64 / G;
+    using IO = RowIO<G, L>;
+    const int n_waves = waves_for(A.batch, G, 8);
+    const uint32_t total = (uint32_t)(kPer * n_waves);
+    std::vector<Words4> tbl4(T.table.size() / 4 + 1), cst4(3 * S / 4 + 1);
+    uint32_t* tbl = (uint32_t*)tbl4.data();
+    uint32_t* cst = (uint32_t*)cst4.data();
+    memcpy(tbl, T.table.data(), T.table.size() * 4);
+    memcpy(cst, T.n.data(), S * 4);
+    memcpy(cst + S, T.ncomp.data(), S * 4);
+    memcpy(cst + 2 * S, T.ncomp1.data(), S * 4);
+    for (int w = 0; w < n_waves; ++w) {
+        std::vector<Words4> lds((size_t)(kPer * kRowT + 2 * IO::kStageWave) / 4 + 1);
+        uint32_t* base = (uint32_t*)lds.data();
+        for (size_t i = 0; i < lds.size() * 4; ++i) base[i] = 0xdeadbeefu;   // LDS is not zero on the device either
+        wave::run_wave([&](uint32_t lane) {
+            const uint32_t grp = lane / G;
+            mul_table_body<L>(A, base + grp * kRowT, base + kPer * kRowT, tbl, cst, (uint32_t)w * kPer + grp, total, lane);
+        });
+    }
+}
 extern "C" {
 
 void emu_set_engine(int e) { g_engine = e ? 1 : 0; }
@@ -663,6 +689,29 @@ int emu_decrypt(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const 
             TailWs ws{wsbuf.data(), 1};
             decrypt_tail_one(T, ws, i);
         }
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
+int emu_mulmod_table(const uint32_t* N, int limbs, const uint32_t* a, const uint32_t* b, uint32_t* out, uint64_t B) {
+    try {
+        if (B == 0) return 0;
+        const host::TableMulPack T = host::build_table_mul(host::big_from(N, limbs, limbs), limbs);
+        if (!T.ok()) return 2;
+        std::vector<Words4> a4((size_t)B * limbs / 4 + 1), b4((size_t)B * limbs / 4 + 1), o4((size_t)B * limbs / 4 + 1);   // 16-byte aligned rows
+        memcpy(a4.data(), a, (size_t)B * limbs * 4);
+        memcpy(b4.data(), b, (size_t)B * limbs * 4);
+        TableMulArgs A;
+        memset(&A, 0, sizeof A);
+        A.n = T.n.data(); A.ncomp = T.ncomp.data(); A.ncomp1 = T.ncomp1.data(); A.table = T.table.data();
+        A.inv = T.inv; A.split = T.split; A.digits = T.digits; A.base = T.base;
+        A.a = (const uint32_t*)a4.data(); A.b = (const uint32_t*)b4.data(); A.out = (uint32_t*)o4.data();
+        A.a_stride = A.b_stride = A.out_stride = (size_t)limbs; A.limbs = limbs; A.batch = B;
+        if (limbs % 4) return 2;
+        if (T.L == 5) run_mul_table<5>(A, T);
+        else if (T.L == 9) run_mul_table<9>(A, T);
+        else return 2;
+        memcpy(out, o4.data(), (size_t)B * limbs * 4);
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }

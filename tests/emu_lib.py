@@ -93,6 +93,16 @@ class Emu:
         self._ck(self.L.emu_mulmod(P(N), N.shape[0], P(a), P(b), P(out), ctypes.c_uint64(a.shape[0])))
         return out
 
+    def mulmod_table(self, N, a, b):
+        """a*b mod N by the table kernel's body (csrc/mul_table.h: one plain product + one fold against the key's table); None
+        where the library would not offer it (the table does not fit a CU's LDS)"""
+        out = np.zeros_like(a)
+        rc = self.L.emu_mulmod_table(P(N), N.shape[0], P(a), P(b), P(out), ctypes.c_uint64(a.shape[0]))
+        if rc == 2:
+            return None
+        self._ck(rc)
+        return out
+
     def add_plain(self, n, c, m):
         out = np.zeros_like(c)
         self._ck(self.L.emu_add_plain(P(n), n.shape[0], P(c), P(m), P(out), ctypes.c_uint64(c.shape[0])))

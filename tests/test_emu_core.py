@@ -1,6 +1,7 @@
 """CPU tests of the code the GPU runs: csrc/mont_core.h, csrc/decrypt_tail.h and csrc/key_setup.h are
 compiled for the host on a fiber-based wavefront emulator (tests/emu/) and compared, limb for limb,
 with the golden fixtures (real reference) and the libgmp oracle."""
+import ctypes
 import random
 
 import numpy as np
@@ -363,6 +364,46 @@ def test_small_batch_rungs_on_the_late_sweeps(emu, group, key_bits, count):
     finally:
         emu.set_late(False)
         emu.set_group(0)
+
+
+@pytest.mark.parametrize("key_bits", [1024, 2048])
+def test_product_by_one_plain_product_and_one_table_fold(emu, key_bits):
+    """csrc/mul_table.h (round 4): a*b mod n^2 — phe/util.py:53-64 mulmod, phe/paillier.py:705-719
+    _raw_add — as ONE plain product and ONE fold of the limbs above n^2's width against the key's table W^(P+i) mod n^2, one
+    double-precision quotient estimate, r = y - q n^2 < 3 n^2, conditional subtractions: no Montgomery factor to repair, half
+    the multiply-adds of the two-product form.  Every golden raw_add vector, operands 0 / 1 / n^2 - 1 / all-ones rows (any
+    value of the row's width is a legal operand: the result is the canonical residue of the product), random rows."""
+    g = load_golden(key_bits)
+    s2 = key_bits // 16
+    n = H(g["n"])
+    N = n * n
+    rng = random.Random(key_bits + 7)
+    top = (1 << (32 * s2)) - 1
+    pairs = [(H(e["a"]), H(e["b"])) for e in g["raw_add"]]
+    pairs += [(0, 5), (1, N - 1), (N - 1, N - 1), (top, top), (top, 1), (N, 7), (N + 1, N + 1), (1 << (32 * s2 - 1), 3)]
+    pairs += [(rng.randrange(N), rng.randrange(N)) for _ in range(9)]
+    pairs += [(rng.randrange(top), rng.randrange(top)) for _ in range(3)]
+    pairs += [(rng.randrange(N), rng.randrange(N)) for _ in range(70)]     # > 32 rows: every limb group of the 8 emulated waves
+    pairs += [(top, top), (N - 1, 2)]                                      # works on a second, third ... row (staging reused)
+    a = ints_to_limbs([x for x, _ in pairs], s2)
+    b = ints_to_limbs([y for _, y in pairs], s2)
+    out = emu.mulmod_table(int_to_limbs(N, s2), a, b)
+    assert out is not None
+    assert limbs_to_ints(out) == [x * y % N for x, y in pairs]
+    emu.L.emu_mad_count.restype = ctypes.c_uint64
+    emu.L.emu_mad_count(1)
+    emu.mulmod_table(int_to_limbs(N, s2), a[:8], b[:8])                      # two full waves' worth of groups
+    table_mads = int(emu.L.emu_mad_count(1)) // 8
+    emu.mulmod(int_to_limbs(N, s2), a[:8], b[:8])
+    two_products = int(emu.L.emu_mad_count(1)) // 8
+    assert table_mads * 1.9 < two_products, (table_mads, two_products)        # about half the multiply-adds per product
+
+
+def test_table_product_is_not_offered_where_the_table_does_not_fit(emu):
+    g = load_golden(3072)
+    N = H(g["n"]) ** 2
+    a = ints_to_limbs([5, 6], 192)
+    assert emu.mulmod_table(int_to_limbs(N, 192), a, a) is None
 
 
 @pytest.mark.parametrize("key_bits", [256, 1024, 2048, 3072])

@@ -325,6 +325,70 @@ def test_one_product_entry_and_debt_constants(native, key_bits, batch, group):
     assert native.limbs_to_ints(out.to_host()) == [x * y % N for x, y in zip(a, b)]
 
 
+@pytest.mark.parametrize("key_bits", [1024, 2048])
+def test_raw_add_by_one_plain_product_and_one_table_fold(native, c_oracle, key_bits, monkeypatch):
+    """Round 4: phe_hip_mulmod / _raw_add (phe/paillier.py:705-719 -> phe/util.py:53-64) as ONE plain
+    product + ONE fold against the key's table in LDS (csrc/mul_table.h, k_mulmod_table) — the path asserted, every row of
+    batches either side of the switch against libgmp, the golden raw_add vectors and edge operands padded to a full batch,
+    in place, and equal to what the two-Montgomery-product kernels give (PHE_HIP_NO_TABLE_MUL); rows off a 16-byte boundary
+    and small batches keep those kernels.  (1024-bit keys: the 5-limb form is compiled but not offered by default — slower than
+    the Montgomery kernels there — PHE_HIP_TABLE_MUL_ANY_WIDTH offers it.)"""
+    from phe._device import DeviceArray
+    monkeypatch.setenv("PHE_HIP_TABLE_MUL_ANY_WIDTH", "1")
+    g = load_golden(key_bits)
+    s1, s2 = key_bits // 32, key_bits // 16
+    n_int = H(g["n"])
+    N = n_int * n_int
+    n = native.int_to_limbs(n_int, s1)
+    ctx = make_ctx(native, g, private=False)
+    monkeypatch.setenv("PHE_HIP_NO_TABLE_MUL", "1")
+    plain = make_ctx(native, g, private=False)
+    monkeypatch.delenv("PHE_HIP_NO_TABLE_MUL")
+    rs = np.random.Generator(np.random.PCG64(key_bits + 11))
+    top = (1 << (32 * s2)) - 1
+    edge = [(H(e["a"]), H(e["b"])) for e in g["raw_add"]] + [(0, 5), (1, N - 1), (N - 1, N - 1), (top, top), (top, 1), (N, 7), (N + 1, N + 1)]
+    for batch in (8191, 8192, 20000, 70000):
+        a = rs.integers(0, 1 << 32, size=(batch, s2), dtype=np.uint32)
+        b = rs.integers(0, 1 << 32, size=(batch, s2), dtype=np.uint32)
+        a[:, s2 - 1] &= 0x3fffffff                                    # residues below n^2 (what the reference passes); the edge rows
+        b[:, s2 - 1] &= 0x3fffffff                                    # below also hold wider operands
+        a[:len(edge)] = native.ints_to_limbs([x for x, _ in edge], s2)
+        b[:len(edge)] = native.ints_to_limbs([y for _, y in edge], s2)
+        da, db = DeviceArray.from_host(ctx, a), DeviceArray.from_host(ctx, b)
+        out = DeviceArray(ctx, batch, s2)
+        ctx.mulmod_dev(da.ptr, db.ptr, out.ptr, batch)
+        ctx.sync()
+        took_table = bool(ctx.last_launch()["path"] & ctx.PATH_TABLE_MUL)
+        assert took_table == (batch >= 8192), (batch, ctx.last_launch())
+        got = out.to_host()
+        assert native.limbs_to_ints(got[:len(edge)]) == [x * y % N for x, y in edge], batch
+        if batch <= 20000:
+            want = plain.mulmod(a[len(edge):], b[len(edge):])                                        # two Montgomery products
+            assert not plain.last_launch()["path"] & ctx.PATH_TABLE_MUL
+            assert np.array_equal(got[len(edge):], want), batch
+        idx = np.arange(len(edge), batch, max(1, batch // 300))
+        res = [int(x) * int(y) % N for x, y in zip(native.limbs_to_ints(a[idx]), native.limbs_to_ints(b[idx]))]
+        assert native.limbs_to_ints(got[idx]) == res, batch
+        ctx.mulmod_dev(da.ptr, db.ptr, da.ptr, batch)                                                  # in place: out = a
+        ctx.sync()
+        assert np.array_equal(da.to_host(), got), batch
+    # host-pointer entry point: same path, same bits
+    a = rs.integers(0, 1 << 32, size=(9000, s2), dtype=np.uint32)
+    b = rs.integers(0, 1 << 32, size=(9000, s2), dtype=np.uint32)
+    got = ctx.mulmod(a, b)
+    assert ctx.last_launch()["path"] & ctx.PATH_TABLE_MUL
+    assert native.limbs_to_ints(got[:200]) == [int(x) * int(y) % N for x, y in zip(native.limbs_to_ints(a[:200]), native.limbs_to_ints(b[:200]))]
+    # rows 4 bytes off a 16-byte boundary: the plain Montgomery body
+    flat = lambda v: np.concatenate([np.zeros(1, np.uint32), v.reshape(-1)])
+    da = DeviceArray.from_host(ctx, flat(a).reshape(-1, 1))
+    db = DeviceArray.from_host(ctx, flat(b).reshape(-1, 1))
+    out = DeviceArray(ctx, 9000 * s2 + 1, 1)
+    ctx.mulmod_dev(da.ptr + 4, db.ptr + 4, out.ptr + 4, 9000)
+    ctx.sync()
+    assert not ctx.last_launch()["path"] & ctx.PATH_TABLE_MUL
+    assert np.array_equal(out.to_host().reshape(-1)[1:].reshape(9000, s2), got)
+
+
 def test_products_on_rows_that_are_not_16_byte_aligned(native, c_oracle):
     """rows that start 4 bytes off a 16-byte boundary take the plain body (no 16-byte chunks): same results"""
     from phe._device import DeviceArray
