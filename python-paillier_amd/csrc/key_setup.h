@@ -287,6 +287,9 @@ static const int kS16[] = {1, 2, 3, 4, 5, 7, 9, 14, 18};
 static const int kS8[] = {3, 5, 7, 9, 14, 18};
 static const int kS4[] = {5, 9, 14, 18, 27};
 static const int kS2[] = {9, 18, 27};
+// ONE lane per number (G = 1): no cross-lane step at all — the natural throughput geometry of the CRT halves of 1024-bit keys
+// (p, q of 512 bits = 18 limbs).  Asked for with prefer_group = 1 (the private side's rung 0 only).
+static const int kS1[] = {18};
 constexpr int kMaxSplitL = 31;  // two products per digit per sweep: 2L * 2^58 < 2^64 (fused sweeps, three products: L <= 21)
 // G = 64: ONE number per wavefront (wave_gfx950.h: wave-wide DPP shifts, scalar broadcast) — the latency rung for a handful
 // of numbers.  Its numbers need not fill the 64*L limbs: SplitPack::rows (a multiple of L) is what a sweep runs over.
@@ -314,6 +317,8 @@ inline Geometry pick_geometry_split(int n_bits, int prefer_group) {
     };
     if (prefer_group != 16) {
         const int narrowest = prefer_group == 0 ? 2 : prefer_group;
+        if (narrowest <= 1)
+            for (int L : kS1) consider(1, L);
         if (narrowest <= 2)
             for (int L : kS2) consider(2, L);
         if (narrowest <= 4)
@@ -701,8 +706,13 @@ inline PrivatePlan build_private(const uint32_t* p, const uint32_t* q, const uin
     P.psq = build_modulus(psq, nullptr, min_bits, prefer_group);
     P.qsq = build_modulus(qsq, nullptr, min_bits, prefer_group);
     if (P.psq.L != P.qsq.L || P.psq.G != P.qsq.G) throw std::invalid_argument("p and q too unbalanced");
-    P.psplit = build_split(bp, 32 * P.s2, prefer_group);
-    P.qsplit = build_split(bq, 32 * P.s2, prefer_group);
+    // (prefer_group 0 = automatic: the halves may take one lane per number where p, q are that short)
+    P.psplit = build_split(bp, 32 * P.s2, prefer_group == 0 ? 1 : prefer_group);
+    P.qsplit = build_split(bq, 32 * P.s2, prefer_group == 0 ? 1 : prefer_group);
+    if (P.psplit.G != P.qsplit.G || P.psplit.L != P.qsplit.L) {  // (the halves run as one geometry: the narrowest both have)
+        P.psplit = build_split(bp, 32 * P.s2, prefer_group);
+        P.qsplit = build_split(bq, 32 * P.s2, prefer_group);
+    }
     if (P.psplit.G == 64 && P.qsplit.G == 64) {
         const int Lp = quick_lane_width(bp), Lq = quick_lane_width(bq), Lw = std::max(Lp, Lq);
         if (Lp && Lq) {
@@ -855,7 +865,7 @@ inline bool big_invert_odd(const Big& a_in, const Big& N, Big& out) {
 // which (G, L) the split translation units instantiate (kernels_s*.hip): the CRT lift runs there on the full-width
 // geometry of q^2
 inline bool split_part_holds(int G, int L) {
-    const int* list = G == 16 ? kS16 : G == 8 ? kS8 : G == 4 ? kS4 : G == 2 ? kS2 : nullptr;
+    const int* list = G == 16 ? kS16 : G == 8 ? kS8 : G == 4 ? kS4 : G == 2 ? kS2 : nullptr;  // (no lift on one lane: q^2 never fits)
     const auto len = [](const auto& a) { return (int)(sizeof(a) / sizeof(a[0])); };
     const int count = G == 16 ? len(kS16) : G == 8 ? len(kS8) : G == 4 ? len(kS4) : G == 2 ? len(kS2) : 0;  // (the lift has no whole-wave form: G = 64 is not asked here)
     for (int i = 0; i < count; ++i)

@@ -52,11 +52,20 @@ struct GroupMasks {
                                       : (G == 16) ? 0x0001000100010001ull
                                       : (G == 8) ? 0x0101010101010101ull
                                       : (G == 4) ? 0x1111111111111111ull
-                                                 : 0x5555555555555555ull;
+                                      : (G == 2) ? 0x5555555555555555ull
+                                                 : 0xffffffffffffffffull;
     static constexpr uint64_t top = lane0 << (G - 1);
 };
 
 PHE_DEV uint32_t lane_bit(uint64_t mask, uint32_t lane) { return (uint32_t)(mask >> lane) & 1u; }
+// kLimbMask in every lane, as plain VGPR data (so that "dpp(x) & mask" becomes one v_and_b32_dpp instead of v_and with a literal
+// + v_mov_b32_dpp): no lane of a group of two or more is both its top and its low lane; a group of ONE lane (G = 1: one number
+// per lane, no cross-lane step at all) is both
+template <int G>
+PHE_DEV uint32_t digit_mask(const Lanes<G>& ln) {
+    if constexpr (G == 1) return wave::reread(kLimbMask);
+    else return kLimbMask & (ln.not_top | ln.not_low);
+}
 template <int G>
 PHE_DEV uint32_t group_top_bit(uint64_t mask, uint32_t lane) { return (uint32_t)(mask >> (lane | (G - 1))) & 1u; }
 
@@ -182,7 +191,7 @@ PHE_DEV void montmul(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[
     const int S = rows;
     const uint32_t dmask = kLimbMask & ln.not_top;  // digit mask + "the top lane receives 0" as one v_and
     // kLimbMask as plain VGPR data (no lane of a group is both top and low): lets "dpp(x) & mask" be one v_and_b32_dpp
-    const uint32_t vmask = kLimbMask & (ln.not_top | ln.not_low);
+    const uint32_t vmask = digit_mask<G>(ln);
     uint64_t acc[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) acc[k] = 0;

@@ -97,6 +97,7 @@ PHE_DECLARE_PART(g16b)
     int launch_split_quick(int L, int mode, int blocks, hipStream_t st, const SplitArgs& A);      \
     int launch_split_quick_halves(int L, int blocks, hipStream_t st, const SplitArgs& Ap, const SplitArgs& Aq); \
     }
+PHE_DECLARE_SPLIT_PART(s1a)
 PHE_DECLARE_SPLIT_PART(s2a)
 PHE_DECLARE_SPLIT_PART(s2b)
 PHE_DECLARE_SPLIT_PART(s2c)
@@ -192,6 +193,7 @@ struct SplitPart {
      phe::NS::launch_split_late, phe::NS::launch_split_late_halves, phe::NS::occ_split_quick, phe::NS::launch_split_quick,      \
      phe::NS::launch_split_quick_halves}
 static const SplitPart kSplitParts[] = {
+    PHE_SPLIT_PART(s1a, 1),
     PHE_SPLIT_PART(s2a, 2),
     PHE_SPLIT_PART(s2b, 2),
     PHE_SPLIT_PART(s2c, 2),
@@ -1058,6 +1060,9 @@ static const DevModulus& pick_nsq(const phe_hip_ctx* ctx, size_t batch) {
         if (M.G) {
             light_geometry(M, sh.G, sh.L);
             sh.rows = M.S;
+            // lanes of more than 18 limbs take the plain product body (no LDS-DMA staging: mul_io.h RowIO::kUse) — measured at 3072
+            // bits: 8 x 27 limbs 117 M products/s, 16 x 14 (staged) 138 M/s at every batch size (profiles/r04e_*)
+            sh.wide = 1.5;
         }
         return sh;
     });
@@ -1285,7 +1290,7 @@ int phe_hip_ctx_create_private(const uint32_t* n, int n_limbs, const uint32_t* p
     if (!rc) rc = upload_split(ctx->priv.psplit, ctx->d_psplit, &ctx->priv.pquick);
     if (!rc) rc = upload_split(ctx->priv.qsplit, ctx->d_qsplit, &ctx->priv.qquick);
     if (!rc && !getenv("PHE_HIP_GROUP")) {
-        for (int prefer : {4, 8, 16, 64}) {
+        for (int prefer : {2, 4, 8, 16, 64}) {  // (2: only where rung 0 is the one-lane geometry of 1024-bit keys' p, q)
             try {
                 phe_hip_ctx::PrivRung R;
                 R.plan = host::build_private(p, q, hp, hq, p_inverse, pq_limbs, n_limbs, prefer);
@@ -1403,8 +1408,8 @@ int phe_hip_ctx_set_blocks_per_cu(phe_hip_ctx* ctx, int blocks_per_cu) {
 
 int phe_hip_ctx_set_group(phe_hip_ctx* ctx, int group) {
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
-    if (group != 0 && group != 2 && group != 4 && group != 8 && group != 16 && group != 64)
-        return fail(PHE_HIP_EINVAL, "group must be 0 (by batch size), 2, 4, 8, 16 or 64");
+    if (group != 0 && group != 1 && group != 2 && group != 4 && group != 8 && group != 16 && group != 64)
+        return fail(PHE_HIP_EINVAL, "group must be 0 (by batch size), 1, 2, 4, 8, 16 or 64");
     ctx->force_group = group;
     return PHE_HIP_OK;
 }

@@ -158,7 +158,7 @@ template <int G, int L, bool U = false>
 PHE_DEV void montmul_addend(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[L], const uint32_t* addend_row,
                             const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln, int rows = G * L) {
     const uint32_t dmask = kLimbMask & ln.not_top;
-    const uint32_t vmask = kLimbMask & (ln.not_top | ln.not_low);
+    const uint32_t vmask = digit_mask<G>(ln);
     uint64_t acc[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) acc[k] = addend_row[ln.g * L + k];
@@ -283,7 +283,7 @@ PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
     const uint32_t dmask = kLimbMask & ln.not_top;
     // = kLimbMask in every lane (no lane of a group of >= 2 is both top and low), but plain VGPR data to the compiler,
     // so that "dpp(x) & mask" becomes one v_and_b32_dpp instead of v_and (literal) + v_mov_b32_dpp
-    const uint32_t vmask = kLimbMask & (ln.not_top | ln.not_low);
+    const uint32_t vmask = digit_mask<G>(ln);
     uint64_t p[L], q[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) p[k] = q[k] = 0;
@@ -334,7 +334,7 @@ PHE_DEV void pair_pass3(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
                         const Lanes<G>& ln, int rows = G * L) {
     const uint32_t lane0 = kLimbMask & ~ln.not_low;
     const uint32_t dmask = kLimbMask & ln.not_top;
-    const uint32_t vmask = kLimbMask & (ln.not_top | ln.not_low);
+    const uint32_t vmask = digit_mask<G>(ln);
     uint64_t p[L], q[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) p[k] = q[k] = 0;
@@ -718,7 +718,7 @@ struct LateMasks {
     PHE_DEV explicit LateMasks(const Lanes<G>& ln) {
         lane0 = kLimbMask & ~ln.not_low;
         dmask = kLimbMask & ln.not_top;
-        vmask = kLimbMask & (ln.not_top | ln.not_low);
+        vmask = digit_mask<G>(ln);
     }
 };
 

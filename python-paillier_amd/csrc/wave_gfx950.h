@@ -55,9 +55,11 @@ PHE_DEV uint32_t dpp_row_shr1(uint32_t x) {  // lane i <- lane i-1 in the 16-lan
 }
 
 // lane g <- lane g+1 of its group; the group's top lane receives 0
+// (G = 1, one number per lane: there is no neighbour — "the lane above" hands down 0, lane 0 of the group is the lane itself)
 template <int G>
 PHE_DEV uint32_t grp_down1(uint32_t x, const Lanes<G>& l) {
-    if constexpr (G == 64) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
+    if constexpr (G == 1) return 0u;
+    else if constexpr (G == 64) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
     else if constexpr (G == 16) return dpp_row_shl1(x);
     else if constexpr (G == 8) return dpp_row_shl1(x) & l.not_top;
     else if constexpr (G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9 /*quad_perm:[1,2,3,3]*/, 0xf, 0xf, true) & l.not_top;
@@ -67,7 +69,8 @@ PHE_DEV uint32_t grp_down1(uint32_t x, const Lanes<G>& l) {
 // fold "& not_top" into a mask they apply anyway
 template <int G>
 PHE_DEV uint32_t grp_down1_raw(uint32_t x) {
-    if constexpr (G == 64) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
+    if constexpr (G == 1) return x;  // (the caller's mask, 0 in a group's top lane, clears it)
+    else if constexpr (G == 64) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
     else if constexpr (G >= 8) return dpp_row_shl1(x);
     else if constexpr (G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF9 /*quad_perm:[1,2,3,3]*/, 0xf, 0xf, true);
     else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xF5 /*quad_perm:[1,1,3,3]*/, 0xf, 0xf, true);
@@ -75,7 +78,8 @@ PHE_DEV uint32_t grp_down1_raw(uint32_t x) {
 // lane g <- lane g-1 of its group; the group's lane 0 receives 0
 template <int G>
 PHE_DEV uint32_t grp_up1(uint32_t x, const Lanes<G>& l) {
-    if constexpr (G == 64) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+    if constexpr (G == 1) return 0u;
+    else if constexpr (G == 64) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
     else if constexpr (G == 16) return dpp_row_shr1(x);
     else if constexpr (G == 8) return dpp_row_shr1(x) & l.not_low;
     else if constexpr (G == 4) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x90 /*quad_perm:[0,0,1,2]*/, 0xf, 0xf, true) & l.not_low;
@@ -84,7 +88,9 @@ PHE_DEV uint32_t grp_up1(uint32_t x, const Lanes<G>& l) {
 // every lane <- lane 0 of its group
 template <int G>
 PHE_DEV uint32_t grp_bcast0(uint32_t x, const Lanes<G>&) {
-    if constexpr (G == 64) {
+    if constexpr (G == 1) {
+        return x;
+    } else if constexpr (G == 64) {
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);  // all 64 lanes are active in these kernels
     } else if constexpr (G == 16) {
         return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x150 /*row_newbcast:0*/, 0xf, 0xf, true);

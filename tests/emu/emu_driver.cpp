@@ -164,6 +164,7 @@ static void run_mul(MulArgs A) {
         case 1609: { constexpr int GG = 16, LL = 9; CALL; break; }                    \
         case 1614: { constexpr int GG = 16, LL = 14; CALL; break; }                   \
         case 1618: { constexpr int GG = 16, LL = 18; CALL; break; }                   \
+        case 118: { constexpr int GG = 1, LL = 18; CALL; break; }                     \
         case 209: { constexpr int GG = 2, LL = 9; CALL; break; }                      \
         case 218: { constexpr int GG = 2, LL = 18; CALL; break; }                     \
         case 227: { constexpr int GG = 2, LL = 27; CALL; break; }                     \
@@ -438,7 +439,7 @@ uint64_t emu_mad_count(int reset) {
 
 const char* emu_last_error() { return g_err.c_str(); }
 
-void emu_set_group(int g) { g_prefer_group = (g == 2 || g == 4 || g == 8 || g == 16 || g == 64) ? g : 0; }
+void emu_set_group(int g) { g_prefer_group = (g == 1 || g == 2 || g == 4 || g == 8 || g == 16 || g == 64) ? g : 0; }
 
 // 64/G independent products a[r]*b[r]*R^-1 (mod N), one per limb group.  All arrays hold 29-bit limbs,
 // G*L words per number; a < R, b < 2N; the result is < 2N, almost-normalised (limbs < 2^29 + 2^8).
@@ -1062,6 +1063,17 @@ int emu_from_decimal(const char* digits, int width, uint32_t* limbs, int words, 
 }
 
 // geometry of the split-modulus kernels for modulus n (given as `limbs` words): GL_out = {G, L}; G = 0 if none
+// the geometry the CRT halves of this key run on (rung 0 of the private side: one lane per number where p, q are short enough)
+int emu_private_split_geometry(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const uint32_t* hq, const uint32_t* p_inverse,
+                               int pq_limbs, int n_limbs, int* GL_out) {
+    try {
+        host::PrivatePlan P = host::build_private(p, q, hp, hq, p_inverse, pq_limbs, n_limbs, g_prefer_group);
+        GL_out[0] = P.psplit.G;
+        GL_out[1] = P.psplit.L;
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return 1; }
+}
+
 int emu_split_geometry(const uint32_t* n, int limbs, int* GL_out) {
     try {
         const host::Geometry geo = host::pick_geometry_split(host::big_bits(host::big_from(n, limbs, limbs)), g_prefer_group);

@@ -54,6 +54,12 @@ class Emu:
         self._ck(self.L.emu_split_geometry(P(n), len(n), gl))
         return gl[0], gl[1]
 
+    def private_split_geometry(self, p, q, hp, hq, pinv, n_limbs):
+        """(G, L) of the CRT halves' kernels for this key (rung 0 of the private side)"""
+        gl = (ctypes.c_int * 2)()
+        self._ck(self.L.emu_private_split_geometry(P(p), P(q), P(hp), P(hq), P(pinv), p.shape[0], n_limbs, gl))
+        return gl[0], gl[1]
+
     def montmul(self, G, L, a, b, n, n0inv):
         """a, b: (64/G, G*L) arrays of 29-bit limbs; n: (G*L,) limbs."""
         out = np.zeros((64 // G, G * L), np.uint32)

@@ -366,6 +366,42 @@ def test_small_batch_rungs_on_the_late_sweeps(emu, group, key_bits, count):
         emu.set_group(0)
 
 
+def test_crt_halves_of_1024_bit_keys_run_one_lane_per_number(emu):
+    """p, q of 512 bits are 18 limbs — ONE lane per number (G = 1, L = 18: no cross-lane step in any
+    sweep, key_setup.h kS1) is rung 0 of the private side; the public side (n: 36 limbs) keeps 2 x 18.  Golden decrypts, junk
+    ciphertexts that share a factor with n, and the key owner's encryption (same kernel, exponent n) give the reference's bits;
+    wider keys are untouched."""
+    emu.set_engine(True)
+    emu.set_group(0)
+    g = load_golden(1024)
+    key = [int_to_limbs(H(g[k]), 16) for k in ("p", "q", "hp", "hq", "p_inverse")]
+    assert emu.private_split_geometry(*key, 32) == (1, 18)
+    emu.set_group(2)
+    assert emu.private_split_geometry(*key, 32) == (2, 9)                    # the next rung of the ladder
+    emu.set_group(0)
+    g2 = load_golden(2048)
+    key2 = [int_to_limbs(H(g2[k]), 32) for k in ("p", "q", "hp", "hq", "p_inverse")]
+    assert emu.private_split_geometry(*key2, 64) == (2, 18)
+    n, p, q = H(g["n"]), H(g["p"]), H(g["q"])
+    dec = g["raw_decrypt"]
+    junk = [0, p, 3 * p, q, n, 7 * n, p * p, n * n - p]
+    cs = [H(e["c"]) for e in dec] + junk
+    for wave_tail in (False, True):
+        emu.set_wave_tail(wave_tail)
+        try:
+            m = emu.decrypt(*key, 32, ints_to_limbs(cs, 64))
+        finally:
+            emu.set_wave_tail(False)
+        got = limbs_to_ints(m)
+        assert got[:len(dec)] == [H(e["m"]) for e in dec]
+        ref = lambda c: ((((pow(c, p - 1, p * p) - 1) // p) * H(g["hp"]) % p), (((pow(c, q - 1, q * q) - 1) // q) * H(g["hq"]) % q))
+        want = [mp + ((mq - mp) * H(g["p_inverse"]) % q) * p for mp, mq in map(ref, junk)]
+        assert got[len(dec):] == want
+    enc = g["raw_encrypt"][:6]
+    out = emu.encrypt_owner(int_to_limbs(n, 32), *key, ints_to_limbs([H(e["m"]) % n for e in enc], 32), ints_to_limbs([H(e["r"]) for e in enc], 32))
+    assert out is not None and limbs_to_ints(out) == [H(e["c"]) for e in enc]
+
+
 @pytest.mark.parametrize("key_bits", [1024, 2048])
 def test_product_by_one_plain_product_and_one_table_fold(emu, key_bits):
     """csrc/mul_table.h (round 4): a*b mod n^2 — phe/util.py:53-64 mulmod, phe/paillier.py:705-719
@@ -548,7 +584,9 @@ def test_split_geometries_by_modulus_width(emu):
         finally:
             emu.set_group(0)
     want = {
-        512: {0: (2, 9), 4: (4, 5), 8: (8, 3), 16: (16, 2), 64: (64, 1)},        # p, q of a 1024-bit key
+        512: {1: (1, 18), 0: (2, 9), 4: (4, 5), 8: (8, 3), 16: (16, 2), 64: (64, 1)},   # p, q of a 1024-bit key (1: one lane per
+                                                                                 # number, what the private side's rung 0 asks for)
+        1023: {1: (2, 18)},                                                      # no one-lane geometry above 18 limbs
         1024: {0: (2, 18), 4: (4, 9), 8: (8, 5), 16: (16, 3), 64: (64, 1)},      # n of a 1024-bit key; p, q of a 2048-bit key
         2048: {0: (4, 18), 4: (4, 18), 8: (8, 9), 16: (16, 5), 64: (64, 2)},     # n of a 2048-bit key
         1536: {0: (2, 27), 4: (4, 14), 8: (8, 7), 16: (16, 4), 64: (64, 1)},     # p, q of a 3072-bit key
