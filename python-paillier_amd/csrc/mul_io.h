@@ -50,6 +50,7 @@ PHE_DEV uint32_t stage_word(const uint32_t* stage, uint32_t gw, int q) {
 // start the copies of one row (limbs32 words, 16-byte aligned, limbs32 % 4 == 0) into the wave's staging area
 template <int G, int L>
 PHE_DEV void stage_row_async(uint32_t* stage, const uint32_t* p, int limbs32, uint32_t g) {
+    PHE_BOUNDS(limbs32 <= RowIO<G, L>::kVec * 4 * G);  // every word of the row has a chunk to land in
 #pragma unroll
     for (int t = 0; t < RowIO<G, L>::kVec; ++t) {
         const int w = 4 * (t * G + (int)g);
@@ -63,6 +64,7 @@ PHE_DEV void limbs_from_stage(uint32_t (&x)[L], const uint32_t* stage, uint32_t 
     for (int k = 0; k < L; ++k) {
         const int bit = kRadixBits * ((int)g * L + k);
         const int q = bit >> 5, o = bit & 31;
+        PHE_BOUNDS(q + 1 < RowIO<G, L>::kVec * 4 * G && (int)gw < 64 / G);  // both words lie in the chunks the staging area holds
         const uint64_t v = ((uint64_t)stage_word<G>(stage, gw, q + 1) << 32) | stage_word<G>(stage, gw, q);
         x[k] = (uint32_t)(v >> o) & kLimbMask;
     }
@@ -74,6 +76,7 @@ PHE_DEV void digits_from_stage(uint32_t* row, const uint32_t* stage, uint32_t gw
     for (int k = 0; k < L; ++k) {
         const int bit = kRadixBits * ((int)g * L + k);
         const int q = bit >> 5, o = bit & 31;
+        PHE_BOUNDS(q + 1 < RowIO<G, L>::kVec * 4 * G && (int)g * L + k < RowIO<G, L>::kRow);
         const uint64_t v = ((uint64_t)stage_word<G>(stage, gw, q + 1) << 32) | stage_word<G>(stage, gw, q);
         row[(int)g * L + k] = (uint32_t)(v >> o) & kLimbMask;
     }

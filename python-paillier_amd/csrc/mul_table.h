@@ -104,6 +104,7 @@ PHE_DEV void mul_table_body(const TableMulArgs& A, uint32_t* row, uint32_t* stag
     uint32_t n[L];
     load_row<L>(n, cst, g);
     const int P = A.split, D = A.digits, n_lo = S - P;
+    PHE_BOUNDS(n_lo >= 2 && n_lo <= kTableRowSlack && D <= n_lo + S && A.base >= 0 && A.base + 3 < S && (int)gw < 4);
 #pragma unroll
     for (int t = 0; t < 2 * IO::kVec; ++t) {  // chunks at or beyond the row length are never copied: they must read as zero
         Words4 z;

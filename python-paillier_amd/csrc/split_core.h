@@ -823,6 +823,7 @@ PHE_DEV void pair_late(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a, 
     };
     using TagI = std::integral_constant<int, kI>;
     using TagL = std::integral_constant<int, L>;
+    PHE_BOUNDS(rows >= L && rows % L == 0 && rows <= G * L);  // a_rows is the last word `load` touches: inside the row or its pad
     // prologue: the first word's step 0
     {
         const uint32_t a0 = a[0];
@@ -1132,6 +1133,7 @@ PHE_DEV void ab_first_word(uint32_t (&z0)[L], const uint32_t* a, const uint32_t 
     for (int k = 0; k < L; ++k) p[k] = 0;
     wave::lds_u32* const w = wave::as_lds(ln.g == 0u ? m_row : dump + 4 * ln.g + 8);
     const int trips = (rows + kT) / kT;  // ceil((rows + 1) / kT) >= 2 (key_setup.h build_quick)
+    PHE_BOUNDS(trips >= 2 && (trips + 1) * kT <= G * L + 48);  // digit blocks are fetched up to two trips ahead: still inside the slot
     uint32_t blk_a[kT], blk_b[kT], held[kT - 1];
 #pragma unroll
     for (int i = 0; i + 1 < kT; ++i) held[i] = 0u;

@@ -23,6 +23,17 @@
 
 #define PHE_DEV __device__ __forceinline__
 #define PHE_LDS_PTR(T) T*
+// -DPHE_DEBUG_BOUNDS (tools/build_sanitizer.sh: the debug build of the sanitizer pass): an index into an LDS area that leaves
+// the area traps the wavefront (the process dies with a GPU fault: a test run over such a build fails loudly).  Off in the
+// product build: the conditions are wave-uniform compares in the hottest loops.
+#if defined(PHE_DEBUG_BOUNDS)
+#define PHE_BOUNDS(...)                      \
+    do {                                     \
+        if (!(__VA_ARGS__)) __builtin_trap(); \
+    } while (0)
+#else
+#define PHE_BOUNDS(...) ((void)0)
+#endif
 
 namespace wave {
 

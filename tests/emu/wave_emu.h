@@ -16,6 +16,11 @@
 #include <vector>
 
 #define PHE_DEV inline
+// the device's LDS-bounds assertions (wave_gfx950.h PHE_BOUNDS) are ALWAYS on in the emulator: an index out of its area aborts the test
+#define PHE_BOUNDS(...)               \
+    do {                              \
+        if (!(__VA_ARGS__)) abort();  \
+    } while (0)
 
 namespace wave {
 
