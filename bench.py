@@ -363,6 +363,19 @@ class HipBackend:
     def select_rows(self, ctx, a, b, mask, out, rows):
         ctx.select_rows_dev(a.data_ptr(), b.data_ptr(), mask.data_ptr(), out.data_ptr(), a.shape[1], rows, self.stream)
 
+    def index_every(self, rows, step):
+        """row indices 0, step, 2 step ... < rows as a device array of 32-bit words"""
+        return self.torch.arange(0, rows, step, dtype=self.torch.int32, device=self.dev)
+
+    def gather_rows(self, ctx, src, idx, dst, count):
+        ctx.gather_rows_dev(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), src.shape[1], count, self.stream)
+
+    def scatter_rows(self, ctx, src, idx, dst, count):
+        ctx.scatter_rows_dev(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), src.shape[1], count, self.stream)
+
+    def copy_rows(self, dst, src, rows):
+        dst[:rows].copy_(src[:rows])
+
 
 class EmuSelftestBackend:
     """CPU contract test only (--selftest-emu): numpy operands, the wave emulator of tests/emu behind the same method
@@ -721,9 +734,22 @@ def main():
         neg = be.mask_every(B, 10)
         inv, base = be.empty(B, s2), be.empty(B, s2)
 
+        subset = hasattr(be, "gather_rows") and hasattr(ctx, "gather_rows_dev")
+        neg_idx = be.index_every(B, 10) if subset else None
+        sub = be.empty((B + 9) // 10, s2) if subset else None
+
         def neg_mul(k):
-            be.invert(ctx, c, inv, k)
-            be.select_rows(ctx, c, inv, neg, base, k)
+            if subset:
+                # what Engine._inverted_where does for few negative rows: only THOSE are inverted (gather, the simultaneous
+                # inversion of the subset, scatter into a copy of the vector)
+                cnt = (k + 9) // 10
+                be.gather_rows(ctx, c, neg_idx, sub, cnt)
+                be.invert(ctx, sub, inv, cnt)
+                be.copy_rows(base, c, k)
+                be.scatter_rows(ctx, inv, neg_idx, base, cnt)
+            else:
+                be.invert(ctx, c, inv, k)
+                be.select_rows(ctx, c, inv, neg, base, k)
             be.powmod(ctx, base, e, 56, out, k)
 
         def check_neg():
@@ -732,6 +758,8 @@ def main():
             got = be.np(be.take(out, idx))
             return bool(np.array_equal(got, orc.mul(n_arr, ca_s(), native.ints_to_limbs(sc, s1), nthreads=cores)))
         ops_ok &= run_op("raw_mul_float56_neg10pct", neg_mul, 2 if be.name == "hip" else 1, check_neg,
+                         "the 10 % negative rows gathered, inverted as a batch of their own (3 modmuls per row + 1 host inversion), "
+                         "scattered into a copy of the vector, then one powmod over all rows" if subset else
                          "simultaneous inversion of the whole vector (3 modmuls per row + 1 host inversion) + select + powmod")
         ops_ok &= run_op("obfuscate", lambda k: be.obfuscate(ctx, c, r, out, k), 1,
                          lambda: bool(np.array_equal(be.np(be.take(out, idx)),

@@ -237,6 +237,11 @@ int phe_hip_pair_mul_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b,
 int phe_hip_from_pair_dev(phe_hip_ctx* ctx, const uint32_t* pair, const uint32_t* m, uint32_t* c, size_t batch, void* stream);
 int phe_hip_pair_powmod_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* e, int exp_limbs, int max_exp_bits, uint32_t* out,
                             size_t batch, void* stream);
+/* rows dot products  out[r] = prod_i a_i ^ e[r][i]  over a resident vector in the pair form (phe_hip_multiexp_rows_dev without
+ * the conversion of every ciphertext into the form; non-negative scalars only: the negative branch of _raw_mul inverts
+ * residues).  e: (rows, batch, exp_limbs); out: (rows, ct_limbs) canonical residues. */
+int phe_hip_pair_multiexp_rows_dev(phe_hip_ctx* ctx, const uint32_t* pair_base, const uint32_t* e, int exp_limbs, int max_exp_bits,
+                                   uint32_t* out, size_t batch, size_t rows, void* stream);
 /* out (ONE pair row) = the product of all `batch` pair rows: the homomorphic sum of a resident vector — sum(enc_list) in
  * the reference is a chain of _raw_add (phe/paillier.py:705-719); the product of residues is independent of the order —
  * as a pairwise tree of log2(batch) launches queued back to back on `stream`, no host round trip between the levels. */
@@ -284,6 +289,14 @@ int phe_hip_invert_dev(phe_hip_ctx* ctx, const uint32_t* a, uint32_t* out, size_
  * branch select of _raw_mul (phe/paillier.py:745-751: inverted base for scalars >= n - max_int) on the device. */
 int phe_hip_select_rows_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t* b, const uint8_t* mask, uint32_t* out,
                             int limbs, size_t batch, void* stream);
+/* Rows of `limbs` words moved by an index list (device, `count` 32-bit row indices): gather dst[j] = src[idx[j]], scatter
+ * dst[idx[j]] = src[j].  With them the negative-scalar branch of _raw_mul (phe/paillier.py:745-749: powmod(invert(c), n - s))
+ * inverts only the rows that take it — gather, phe_hip_invert_dev on the subset, scatter into a copy of the vector — instead of
+ * inverting the whole vector and selecting. */
+int phe_hip_gather_rows_dev(phe_hip_ctx* ctx, const uint32_t* src, const uint32_t* idx, uint32_t* dst, int limbs, size_t count,
+                            void* stream);
+int phe_hip_scatter_rows_dev(phe_hip_ctx* ctx, const uint32_t* src, const uint32_t* idx, uint32_t* dst, int limbs, size_t count,
+                             void* stream);
 
 /* ---- device memory helpers for hosts without a tensor library ------------------------------- */
 int phe_hip_malloc(phe_hip_ctx* ctx, size_t bytes, void** dptr);

@@ -255,6 +255,19 @@ __global__ void __launch_bounds__(256) k_select_rows(const uint32_t* a, const ui
     }
 }
 
+// rows of `limbs` words moved by an index list: gather dst[j] = src[idx[j]], scatter dst[idx[j]] = src[j] (j < count) — the
+// negative-scalar branch of _raw_mul inverts only the rows that take it (phe/paillier.py:745-749)
+template <bool SCATTER>
+__global__ void __launch_bounds__(256) k_move_rows(const uint32_t* src, const uint32_t* idx, uint32_t* dst, int limbs, uint64_t count) {
+    const uint64_t total = count * (uint64_t)limbs;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t j = i / (uint64_t)limbs, w = i - j * (uint64_t)limbs;
+        const uint64_t far = (uint64_t)idx[j] * (uint64_t)limbs + w;
+        if (SCATTER) dst[far] = src[i];
+        else dst[i] = src[far];
+    }
+}
+
 __global__ void k_selftest_prims(uint32_t* out) {
     const uint32_t lane = threadIdx.x & 63u;
     const wave::Lanes<16> l16(lane);
@@ -836,8 +849,10 @@ static int launch_var_split(phe_hip_ctx* ctx, const DevSplit& M, const uint32_t*
 
 static int launch_multi_split(phe_hip_ctx* ctx, const DevSplit& M, const uint32_t* base, const uint32_t* base_inv,
                               int base_limbs, const uint32_t* e, const uint8_t* neg, int exp_limbs, int max_bits, int chunk,
-                              int row_block, uint32_t* out, int out_limbs, size_t batch, size_t rows, hipStream_t stream) {
+                              int row_block, uint32_t* out, int out_limbs, size_t batch, size_t rows, hipStream_t stream,
+                              bool pair_in = false) {
     SplitMultiArgs A;
+    A.pair_in = pair_in ? 1 : 0;
     A.mod = M.c;
     A.base = base;
     A.base_inv = base_inv;
@@ -1925,9 +1940,10 @@ int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e
 // k_multiexp_split — tables built once per task, one shared square-and-multiply ladder per row — and the chunk products
 // of every row are joined in place by a pairwise k_mulmod tree over the chunk index.  Without a split geometry (or
 // PHE_HIP_ENGINE=full) a single row without negative entries takes the powmod kernel (chunk = 1) and the same tree.
+static const DevSplit& pick_pair_split(const phe_hip_ctx* ctx, size_t batch);
 static int multiexp_rows_impl(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* base_inv, const uint32_t* e,
                               const uint8_t* neg, int exp_limbs, int max_exp_bits, uint32_t* out, size_t batch, size_t rows,
-                              hipStream_t st) {
+                              hipStream_t st, bool pair_in = false) {
     const size_t s2 = (size_t)ctx->pub.s2;
     if (rows == 0) return PHE_HIP_OK;
     if (batch == 0) {  // empty products
@@ -1970,8 +1986,10 @@ static int multiexp_rows_impl(phe_hip_ctx* ctx, const uint32_t* base, const uint
     uint32_t* P = ctx->partial;
     if (split) {
         const size_t tasks = cur * ((rows + row_block - 1) / row_block);
-        rc = launch_multi_split(ctx, pick_nsplit(ctx, tasks), base, base_inv, ctx->pub.s2, e, neg, exp_limbs, max_exp_bits,
-                                (int)chunk, (int)row_block, P, ctx->pub.s2, batch, rows, st);
+        // pair_in: the rows are 2H limbs of rung 0's pair geometry — a wider rung with the same H may serve a small job
+        const DevSplit& rung = pair_in ? pick_pair_split(ctx, tasks) : pick_nsplit(ctx, tasks);
+        rc = launch_multi_split(ctx, rung, base, base_inv, pair_in ? 2 * rung.H : ctx->pub.s2, e, neg, exp_limbs, max_exp_bits,
+                                (int)chunk, (int)row_block, P, ctx->pub.s2, batch, rows, st, pair_in);
     } else {
         rc = launch_var(ctx, pick_nsq(ctx, batch), base, ctx->pub.s2, e, exp_limbs, max_exp_bits, P, ctx->pub.s2, batch, st);
     }
@@ -1999,6 +2017,19 @@ int phe_hip_multiexp_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t*
     if (int rc = bind_device(ctx)) return rc;
     PHE_CTX_ORDER(ctx, stream);
     return multiexp_rows_impl(ctx, base, nullptr, e, nullptr, exp_limbs, max_exp_bits, out, batch, 1, (hipStream_t)stream);
+}
+
+// the same on resident rows in the pair form (phe_hip_to_pair_dev): no conversion into the form per ciphertext; no negative
+// entries (those take invert(c), which wants residues).  out: canonical residues, as ever.
+int phe_hip_pair_multiexp_rows_dev(phe_hip_ctx* ctx, const uint32_t* pair_base, const uint32_t* e, int exp_limbs, int max_exp_bits,
+                                   uint32_t* out, size_t batch, size_t rows, void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (!out) return fail(PHE_HIP_EINVAL, "null buffer");
+    if (!(ctx->use_split && ctx->d_nsplit.G)) return fail(PHE_HIP_EINVAL, "the pair form needs the split-modulus engine");
+    if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
+    ctx->last_path = 0;
+    return multiexp_rows_impl(ctx, pair_base, nullptr, e, nullptr, exp_limbs, max_exp_bits, out, batch, rows, (hipStream_t)stream, true);
 }
 
 int phe_hip_multiexp_rows_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* base_inv, const uint32_t* e,
@@ -2575,6 +2606,28 @@ int phe_hip_select_rows_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t*
     k_select_rows<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(a, b, mask, out, limbs, (uint64_t)batch);
     HIP_TRY(hipGetLastError());
     return PHE_HIP_OK;
+}
+
+static int move_rows(phe_hip_ctx* ctx, bool scatter, const uint32_t* src, const uint32_t* idx, uint32_t* dst, int limbs, size_t count,
+                     void* stream) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (count == 0) return PHE_HIP_OK;
+    if (!src || !idx || !dst || limbs < 1) return fail(PHE_HIP_EINVAL, "null buffer / limbs");
+    if (int rc = bind_device(ctx)) return rc;
+    const size_t total = count * (size_t)limbs;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)ctx->n_cus * 8);
+    if (scatter) k_move_rows<true><<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(src, idx, dst, limbs, (uint64_t)count);
+    else k_move_rows<false><<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(src, idx, dst, limbs, (uint64_t)count);
+    HIP_TRY(hipGetLastError());
+    return PHE_HIP_OK;
+}
+int phe_hip_gather_rows_dev(phe_hip_ctx* ctx, const uint32_t* src, const uint32_t* idx, uint32_t* dst, int limbs, size_t count,
+                            void* stream) {
+    return move_rows(ctx, false, src, idx, dst, limbs, count, stream);
+}
+int phe_hip_scatter_rows_dev(phe_hip_ctx* ctx, const uint32_t* src, const uint32_t* idx, uint32_t* dst, int limbs, size_t count,
+                             void* stream) {
+    return move_rows(ctx, true, src, idx, dst, limbs, count, stream);
 }
 
 // ---- decimal wire format (csrc/radix_conv.h, kernels_radix.hip) -------------------------------------------------

@@ -1758,6 +1758,8 @@ struct SplitMultiArgs {
     uint64_t rows;
     uint64_t n_chunks;      // ceil(batch / chunk)
     uint64_t n_row_blocks;  // ceil(rows / row_block)
+    int pair_in;            // 1: base (and base_inv) are resident rows in the pair form (2H limbs each, base_limbs = 2H): no conversion
+                            // in — 13 H^2 of the ~170 H^2 multiply-adds an element of a 56-bit dot product costs
 };
 
 template <int G, int L>
@@ -1792,7 +1794,12 @@ PHE_DEV void multiexp_split_body(const SplitMultiArgs& A, uint32_t* lds_row, uin
             for (int el = 0; el < A.chunk; ++el) {
                 uint64_t item = first + (uint64_t)el;
                 if (item >= A.batch) item = A.batch - 1;
-                split_conv<G, L>(Y0, Y1, src + item * (uint64_t)A.base_limbs, A.base_limbs, A.base_chunks, A.mod, K, ln);
+                if (A.pair_in) {
+                    load_row<L>(Y0, src + item * (uint64_t)A.base_limbs, g);
+                    load_row<L>(Y1, src + item * (uint64_t)A.base_limbs + H, g);
+                } else {
+                    split_conv<G, L>(Y0, Y1, src + item * (uint64_t)A.base_limbs, A.base_limbs, A.base_chunks, A.mod, K, ln);
+                }
                 uint32_t* t = tbl + ((size_t)sg * (size_t)A.chunk + (size_t)el) * (size_t)per * S2;
                 store_row<L>(t, Y0, g);
                 store_row<L>(t + H, Y1, g);

@@ -284,16 +284,42 @@ class Engine:
             base[idx] = self.ctx.invert(np.ascontiguousarray(c[idx]))
         return self.ctx.powmod(base, exps)
 
+    def _inverted_where(self, c, neg):
+        """a vector equal to c with the rows where `neg` holds replaced by invert(c_i, n^2): the base of the negative-scalar branch
+        of _raw_mul (phe/paillier.py:745-749).  Few negative rows (under a quarter): only those are inverted — gathered, inverted
+        as a batch of their own (the simultaneous-inversion tree costs 3 products per row it is given), scattered into a copy;
+        otherwise the whole vector is inverted and selected per row.  ZeroDivisionError carries the row's index in c."""
+        neg = np.asarray(neg, dtype=bool)
+        count = int(neg.sum())
+        if count * 4 < c.rows and hasattr(self.ctx, "gather_rows_dev"):
+            idx = np.nonzero(neg)[0].astype(np.uint32)
+            idx_d = DeviceArray.from_host(self.ctx, idx)
+            sub = DeviceArray(self.ctx, count, self.ct_limbs)
+            self.ctx.gather_rows_dev(c.ptr, idx_d.ptr, sub.ptr, self.ct_limbs, count)
+            inv = DeviceArray(self.ctx, count, self.ct_limbs)
+            try:
+                self.ctx.invert_dev(sub.ptr, inv.ptr, count)
+            except ZeroDivisionError as e:
+                if getattr(e, "bad_index", None) is not None and e.bad_index < count:
+                    e.bad_index = int(idx[e.bad_index])
+                raise
+            base = c.copy()
+            self.ctx.scatter_rows_dev(inv.ptr, idx_d.ptr, base.ptr, self.ct_limbs, count)
+            self.ctx.sync()
+            return base
+        inv = DeviceArray(self.ctx, c.rows, self.ct_limbs)
+        self.ctx.invert_dev(c.ptr, inv.ptr, c.rows)
+        mask = DeviceArray.from_host(self.ctx, neg.astype(np.uint8), dtype=np.uint8)
+        base = DeviceArray(self.ctx, c.rows, self.ct_limbs)
+        self.ctx.select_rows_dev(c.ptr, inv.ptr, mask.ptr, base.ptr, self.ct_limbs, c.rows)
+        self.ctx.sync()
+        return base
+
     def raw_mul_signed_dev(self, c, mag, neg):
         exps, bits = self._mag_limbs(mag)
         base = c
         if neg.any():
-            inv = DeviceArray(self.ctx, c.rows, self.ct_limbs)
-            self.ctx.invert_dev(c.ptr, inv.ptr, c.rows)
-            mask = DeviceArray.from_host(self.ctx, neg.astype(np.uint8), dtype=np.uint8)
-            base = DeviceArray(self.ctx, c.rows, self.ct_limbs)
-            self.ctx.select_rows_dev(c.ptr, inv.ptr, mask.ptr, base.ptr, self.ct_limbs, c.rows)
-            self.ctx.sync()
+            base = self._inverted_where(c, neg)
         e = DeviceArray.from_host(self.ctx, exps)
         out = DeviceArray(self.ctx, base.rows, self.ct_limbs)
         self.ctx.powmod_dev(base.ptr, e.ptr, exps.shape[1], bits, out.ptr, base.rows)
@@ -361,6 +387,16 @@ class Engine:
         products (include/phe_hip.h phe_hip_multiexp).  c: host limb array or DeviceArray.  Returns a Python int."""
         limbs, bits = exps if isinstance(exps, tuple) else self._exp_limbs(exps)
         neg = np.asarray(neg, dtype=bool)
+        if isinstance(c, DeviceArray) and self.pair_form() and c.cols == self.pair_form() != self.ct_limbs:
+            # rows resident in the pair form, no negative scalar (the caller checked): the multi-exponentiation reads them as they
+            # are — no conversion of every ciphertext into the form (include/phe_hip.h phe_hip_pair_multiexp_rows_dev)
+            if neg.any():
+                raise ValueError("pair-form rows take non-negative scalars only")
+            e = DeviceArray.from_host(self.ctx, limbs)
+            out = DeviceArray(self.ctx, 1, self.ct_limbs)
+            self.ctx.pair_multiexp_rows_dev(c.ptr, e.ptr, limbs.shape[1], bits, out.ptr, c.rows, 1)
+            self.ctx.sync()
+            return self.to_ints(out.to_host())[0]
         if isinstance(c, DeviceArray):
             base = c
             if neg.any():
@@ -402,6 +438,14 @@ class Engine:
         bits = max(bits, 1)
         on_dev = isinstance(c, DeviceArray)
         any_neg = bool(neg.any())
+        if on_dev and self.pair_form() and c.cols == self.pair_form() != self.ct_limbs:
+            if any_neg:
+                raise ValueError("pair-form rows take non-negative scalars only")
+            e = DeviceArray.from_host(self.ctx, limbs.reshape(rows * batch, -1))
+            out = DeviceArray(self.ctx, rows, self.ct_limbs)
+            self.ctx.pair_multiexp_rows_dev(c.ptr, e.ptr, limbs.shape[2], bits, out.ptr, batch, rows)
+            self.ctx.sync()
+            return out
         info = self.ctx.info()
         if not (info.get("emulated") or info.get("engine_pub") == "split"):
             # keys without a split geometry: row by row on the single-row entry point
@@ -915,12 +959,5 @@ class Engine:
         n, threshold = self.n, self.n - self.max_int
         neg = np.fromiter((s >= threshold for s in scalars), dtype=np.uint8, count=len(scalars))
         exps = [n - s if s >= threshold else s for s in scalars]
-        base = c
-        if neg.any():
-            inv = DeviceArray(self.ctx, c.rows, self.ct_limbs)
-            self.ctx.invert_dev(c.ptr, inv.ptr, c.rows)
-            mask = DeviceArray.from_host(self.ctx, neg, dtype=np.uint8)
-            base = DeviceArray(self.ctx, c.rows, self.ct_limbs)
-            self.ctx.select_rows_dev(c.ptr, inv.ptr, mask.ptr, base.ptr, self.ct_limbs, c.rows)
-            self.ctx.sync()
+        base = self._inverted_where(c, neg) if neg.any() else c
         return self.powmod_dev(base, exps)

@@ -83,6 +83,8 @@ def lib():
         L.phe_hip_memcpy_d2d.argtypes = [vp, vp, vp, sz, vp]
         L.phe_hip_invert_dev.argtypes = [vp, vp, vp, sz, ctypes.POINTER(sz), vp]
         L.phe_hip_select_rows_dev.argtypes = [vp, vp, vp, vp, vp, ci, sz, vp]
+        L.phe_hip_gather_rows_dev.argtypes = [vp, vp, vp, vp, ci, sz, vp]
+        L.phe_hip_scatter_rows_dev.argtypes = [vp, vp, vp, vp, ci, sz, vp]
         L.phe_hip_selftest_prims.argtypes = [ci, vp]
         L.phe_hip_comm_unique_id.argtypes = [vp]
         L.phe_hip_comm_create.argtypes = [vp, vp, ci, ci, ctypes.POINTER(vp)]
@@ -99,6 +101,7 @@ def lib():
         L.phe_hip_from_pair_dev.argtypes = [vp, vp, vp, vp, sz, vp]
         L.phe_hip_pair_reduce_dev.argtypes = [vp, vp, sz, vp, vp]
         L.phe_hip_pair_powmod_dev.argtypes = [vp, vp, vp, ci, ci, vp, sz, vp]
+        L.phe_hip_pair_multiexp_rows_dev.argtypes = [vp, vp, vp, ci, ci, vp, sz, sz, vp]
         _lib = L
     return _lib
 
@@ -110,7 +113,7 @@ EXPORTED_SYMBOLS = [
     "phe_hip_encrypt_dev", "phe_hip_obfuscate_dev", "phe_hip_decrypt_dev", "phe_hip_mulmod_dev",
     "phe_hip_powmod_dev", "phe_hip_malloc", "phe_hip_free", "phe_hip_memcpy_h2d", "phe_hip_memcpy_d2h",
     "phe_hip_stream_sync", "phe_hip_selftest_prims", "phe_hip_memcpy_d2d", "phe_hip_invert_dev",
-    "phe_hip_select_rows_dev", "phe_hip_add_plain", "phe_hip_add_plain_dev", "phe_hip_ctx_engine",
+    "phe_hip_select_rows_dev", "phe_hip_gather_rows_dev", "phe_hip_scatter_rows_dev", "phe_hip_add_plain", "phe_hip_add_plain_dev", "phe_hip_ctx_engine",
     "phe_hip_multiexp", "phe_hip_multiexp_dev", "phe_hip_multiexp_rows_dev", "phe_hip_multiexp_csr_dev", "phe_hip_decimal_width", "phe_hip_to_decimal",
     "phe_hip_from_decimal", "phe_hip_to_decimal_dev", "phe_hip_from_decimal_dev", "phe_hip_stream_create",
     "phe_hip_stream_destroy", "phe_hip_miller_rabin", "phe_hip_montmul_dev", "phe_hip_mont_radix_bits",
@@ -118,7 +121,7 @@ EXPORTED_SYMBOLS = [
     "phe_hip_encrypt_owner", "phe_hip_encrypt_owner_dev", "phe_hip_ctx_owner_encrypt",
     "phe_hip_ctx_ladder", "phe_hip_ctx_set_group", "phe_hip_ctx_last_launch", "phe_hip_ctx_release_scratch",
     "phe_hip_pair_words", "phe_hip_to_pair_dev", "phe_hip_pair_mul_dev", "phe_hip_from_pair_dev", "phe_hip_pair_reduce_dev",
-    "phe_hip_pair_powmod_dev",
+    "phe_hip_pair_powmod_dev", "phe_hip_pair_multiexp_rows_dev",
 ]
 
 
@@ -307,6 +310,10 @@ class Context:
 
     def pair_powmod_dev(self, a_ptr, e_ptr, exp_limbs, max_exp_bits, out_ptr, batch, stream=0):
         _check(lib().phe_hip_pair_powmod_dev(self._h, a_ptr, e_ptr, exp_limbs, max_exp_bits, out_ptr, batch, stream))
+
+    def pair_multiexp_rows_dev(self, pair_ptr, exp_ptr, exp_limbs, max_exp_bits, out_ptr, batch, rows, stream=0):
+        """rows dot products over a resident vector in the pair form (non-negative scalars): canonical residues out"""
+        _check(lib().phe_hip_pair_multiexp_rows_dev(self._h, pair_ptr, exp_ptr, exp_limbs, max_exp_bits, out_ptr, batch, rows, stream))
 
     def pair_reduce_dev(self, pair_ptr, batch, out_ptr, stream=0):
         _check(lib().phe_hip_pair_reduce_dev(self._h, pair_ptr, batch, out_ptr, stream))
@@ -559,6 +566,14 @@ class Context:
 
     def select_rows_dev(self, a_ptr, b_ptr, mask_ptr, out_ptr, limbs, batch, stream=0):
         _check(lib().phe_hip_select_rows_dev(self._h, a_ptr, b_ptr, mask_ptr, out_ptr, limbs, batch, stream))
+
+    def gather_rows_dev(self, src_ptr, idx_ptr, dst_ptr, limbs, count, stream=0):
+        """dst[j] = src[idx[j]] for `count` rows of `limbs` words (idx: uint32 row indices on the device)"""
+        _check(lib().phe_hip_gather_rows_dev(self._h, src_ptr, idx_ptr, dst_ptr, limbs, count, stream))
+
+    def scatter_rows_dev(self, src_ptr, idx_ptr, dst_ptr, limbs, count, stream=0):
+        """dst[idx[j]] = src[j]"""
+        _check(lib().phe_hip_scatter_rows_dev(self._h, src_ptr, idx_ptr, dst_ptr, limbs, count, stream))
 
     def stream_create(self):
         """a stream whose launches overlap the blocking h2d / d2h copies (they are ordered on the NULL stream)"""

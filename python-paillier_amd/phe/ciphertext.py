@@ -663,7 +663,9 @@ class EncryptedVector(object):
             mags = mag.tolist() if isinstance(mag, np.ndarray) else mag
             powers = {d: pow(EncodedNumber.BASE, d) for d in np.unique(delta).tolist()}
             exps = [m * powers[d] for m, d in zip(mags, delta.tolist())]
-        return EncryptedNumber(pk, eng.raw_dot(self._limbs, exps, neg), target)
+        # rows resident in the pair form and no scalar on the negative branch: the multi-exponentiation takes them as they are
+        in_form = self.on_device and self._pair and eng.pair_form() and hasattr(eng.ctx, "pair_multiexp_rows_dev") and not np.asarray(neg).any()
+        return EncryptedNumber(pk, eng.raw_dot(self._store if in_form else self._limbs, exps, neg), target)
 
     # numpy must not try to broadcast over the rows of a vector: `W @ vec`, `w @ vec`, `vec @ w` come here
     __array_ufunc__ = None
@@ -771,5 +773,6 @@ class EncryptedVector(object):
             exps = mag
         else:                                                    # k * BASE^delta as limb rows, no Python ints
             exps = eng.shifted_limbs(mag.reshape(-1), (delta * log2b).reshape(-1))
-        limbs = eng.raw_matvec(self._limbs, exps, neg)
+        in_form = self.on_device and self._pair and eng.pair_form() and hasattr(eng.ctx, "pair_multiexp_rows_dev") and not np.asarray(neg).any()
+        limbs = eng.raw_matvec(self._store if in_form else self._limbs, exps, neg)
         return EncryptedVector(pk, limbs, target)

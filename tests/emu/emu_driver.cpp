@@ -963,6 +963,8 @@ int emu_powmod_n2(const uint32_t* n, int n_limbs, const uint32_t* base, const ui
 // k_multiexp_split alone: out[(j * rows + r)] = prod over the chunk [j*chunk, (j+1)*chunk) of b[i]^exps[r][i], b = base or
 // base_inv where neg[r][i] (base_inv / neg may be null).  Returns 2 when the key has no split geometry (the product
 // then takes powmod + the mulmod tree).
+static int g_multi_pair_in = 0;  // 1: emu_multiexp_n2's bases are rows in the pair form (2H limbs each)
+void emu_set_multiexp_pair_in(int e) { g_multi_pair_in = e ? 1 : 0; }
 int emu_multiexp_n2(const uint32_t* n, int n_limbs, const uint32_t* base, const uint32_t* base_inv, const uint32_t* exps,
                     const uint8_t* neg, int exp_limbs, int chunk, int row_block, uint32_t* out, uint64_t rows, uint64_t B) {
     try {
@@ -977,6 +979,7 @@ int emu_multiexp_n2(const uint32_t* n, int n_limbs, const uint32_t* base, const 
         memset(&A, 0, sizeof A);
         A.mod = split_consts_of(M);
         A.base = base; A.base_inv = base_inv; A.base_limbs = P.s2; A.base_chunks = chunks_for(P.s2, M.rows);
+        if (g_multi_pair_in) { A.pair_in = 1; A.base_limbs = 2 * M.H; }
         A.exps = exps; A.neg = neg; A.exp_limbs = exp_limbs;
         A.window = host::pick_multi_window(max_bits);
         A.n_windows = std::max(1, (max_bits + A.window - 1) / A.window);

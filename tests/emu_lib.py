@@ -181,18 +181,21 @@ class Emu:
                                       ctypes.c_uint64(base.shape[0])))
         return out
 
-    def multiexp_n2(self, n, base, exps, chunk, base_inv=None, neg=None, row_block=1):
+    def multiexp_n2(self, n, base, exps, chunk, base_inv=None, neg=None, row_block=1, pair_in=False):
         """per-chunk products the way k_multiexp_split forms them -> (n_chunks, rows, ct_limbs); exps: (batch, exp_limbs)
-        for one row or (rows, batch, exp_limbs); neg: (rows, batch) bytes selecting base_inv.  None without a split geometry"""
+        for one row or (rows, batch, exp_limbs); neg: (rows, batch) bytes selecting base_inv.  None without a split geometry.
+        pair_in: `base` holds rows in the pair form (pair_op(..., 0, ...)): no conversion in."""
         B = base.shape[0]
         exps = np.ascontiguousarray(exps.reshape((-1, B, exps.shape[-1])))
         rows = exps.shape[0]
         n_chunks = -(-B // chunk)
-        out = np.zeros((n_chunks, rows, base.shape[1]), dtype=np.uint32)
+        out = np.zeros((n_chunks, rows, 2 * n.shape[0]), dtype=np.uint32)
+        self.L.emu_set_multiexp_pair_in(1 if pair_in else 0)
         inv_p = P(np.ascontiguousarray(base_inv)) if base_inv is not None else None
         neg_arr = np.ascontiguousarray(neg, dtype=np.uint8).reshape(rows, B) if neg is not None else None
         rc = self.L.emu_multiexp_n2(P(n), n.shape[0], P(base), inv_p, P(exps), P(neg_arr) if neg_arr is not None else None,
                                     exps.shape[-1], chunk, row_block, P(out), ctypes.c_uint64(rows), ctypes.c_uint64(B))
+        self.L.emu_set_multiexp_pair_in(0)
         if rc == 2:
             return None
         self._ck(rc)

@@ -389,6 +389,55 @@ def test_raw_add_by_one_plain_product_and_one_table_fold(native, c_oracle, key_b
     assert np.array_equal(out.to_host().reshape(-1)[1:].reshape(9000, s2), got)
 
 
+def test_negative_scalars_invert_only_the_rows_that_take_the_branch(native, c_oracle):
+    """_raw_mul's negative branch (phe/paillier.py:745-749: powmod(invert(c), n - s)) on a resident vector with few negative
+    scalars: only those rows are inverted — phe_hip_gather_rows_dev, the simultaneous inversion of the subset,
+    phe_hip_scatter_rows_dev into a copy (Engine._inverted_where) — same bits as the whole-vector form and as libgmp; a row
+    without an inverse is reported by its index in the VECTOR."""
+    from phe._device import DeviceArray
+    from phe._engine import Engine
+    g = load_golden(2048)
+    n_int, s1, s2 = H(g["n"]), 64, 128
+    N = n_int * n_int
+    eng = Engine(n_int)
+    rng = random.Random(77)
+    rows = 3000
+    cs = [rng.randrange(1, N) for _ in range(rows)]
+    mag = np.array([rng.randrange(1, 1 << 50) for _ in range(rows)], dtype=np.uint64)
+    neg = np.zeros(rows, dtype=bool)
+    neg[rng.sample(range(rows), 211)] = True                       # 7 %: the subset form
+    c_dev = eng.upload_cipher(cs)
+    src = c_dev.to_host().copy()
+    out = eng.raw_mul_signed_dev(c_dev, mag, neg).to_host()
+    assert np.array_equal(c_dev.to_host(), src)                    # the operand is left alone (the inverses land in a copy)
+    want = [pow(pow(c, -1, N) if ng else c, int(k), N) for c, k, ng in zip(cs, mag.tolist(), neg.tolist())]
+    assert native.limbs_to_ints(out) == want
+    dense = neg.copy()
+    dense[::2] = True                                              # more than a quarter negative: whole-vector inversion + select
+    out2 = eng.raw_mul_signed_dev(c_dev, mag, dense).to_host()
+    pick = np.nonzero(neg)[0][:40]
+    assert np.array_equal(out2[pick], out[pick])
+    # the two data movements on their own
+    idx = np.array([5, 2999, 0, 77], dtype=np.uint32)
+    idx_d = DeviceArray.from_host(eng.ctx, idx)
+    sub = DeviceArray(eng.ctx, 4, s2)
+    eng.ctx.gather_rows_dev(c_dev.ptr, idx_d.ptr, sub.ptr, s2, 4)
+    eng.ctx.sync()
+    assert np.array_equal(sub.to_host(), src[idx.astype(np.int64)])
+    dst = DeviceArray.from_host(eng.ctx, np.zeros((rows, s2), np.uint32))
+    eng.ctx.scatter_rows_dev(sub.ptr, idx_d.ptr, dst.ptr, s2, 4)
+    eng.ctx.sync()
+    back = dst.to_host()
+    assert np.array_equal(back[idx.astype(np.int64)], src[idx.astype(np.int64)]) and int(np.count_nonzero(back.any(axis=1))) == 4
+    # no inverse: the index is the row's place in the vector, not in the subset
+    bad = list(cs)
+    where = int(np.nonzero(neg)[0][17])
+    bad[where] = H(g["p"]) * 12345
+    with pytest.raises(ZeroDivisionError) as info:
+        eng.raw_mul_signed_dev(eng.upload_cipher(bad), mag, neg)
+    assert info.value.bad_index == where
+
+
 def test_products_on_rows_that_are_not_16_byte_aligned(native, c_oracle):
     """rows that start 4 bytes off a 16-byte boundary take the plain body (no 16-byte chunks): same results"""
     from phe._device import DeviceArray

@@ -85,6 +85,37 @@ def test_chunk_products_through_emulator(emu, key_bits, group):
     emu.set_group(0)
 
 
+@pytest.mark.parametrize("key_bits", [256, 1024])
+def test_chunk_products_on_pair_form_input(emu, key_bits):
+    """multiexp_split_body with pair_in (round 4): the bases are resident rows in the pair form
+    (to_pair_body's output) — no conversion in; same chunk products as on plain residues, one row and the matrix form"""
+    emu.set_engine(True)
+    emu.set_group(0)
+    g = load_golden(key_bits)
+    n_int = H(g["n"])
+    nsq = n_int * n_int
+    s1, s2 = key_bits // 32, key_bits // 16
+    rng = random.Random(key_bits + 99)
+    n_arr = int_to_limbs(n_int, s1)
+    for batch, chunk, ebits in [(7, 3, 64), (5, 1, 20), (6, 4, 3)]:
+        bases = [rng.randrange(1, nsq) for _ in range(batch)]
+        exps = [rng.getrandbits(ebits) for _ in range(batch)]
+        exps[0], bases[1], bases[2] = 0, 1, nsq - 1
+        width = max(1, -(-ebits // 32))
+        plain = emu.multiexp_n2(n_arr, ints_to_limbs(bases, s2), ints_to_limbs(exps, width), chunk)
+        pairs = emu.pair_op(n_arr, 0, ints_to_limbs(bases, s2))
+        assert pairs is not None and pairs.shape[1] != s2
+        got = emu.multiexp_n2(n_arr, pairs, ints_to_limbs(exps, width), chunk, pair_in=True)
+        assert np.array_equal(got, plain), (batch, chunk, ebits)
+    batch, rows, chunk, row_block = 7, 5, 3, 2
+    bases = [rng.randrange(1, nsq) for _ in range(batch)]
+    ex = [[rng.getrandbits(40) for _ in range(batch)] for _ in range(rows)]
+    e_arr = np.stack([ints_to_limbs(row, 2) for row in ex])
+    plain = emu.multiexp_n2(n_arr, ints_to_limbs(bases, s2), e_arr, chunk, row_block=row_block)
+    got = emu.multiexp_n2(n_arr, emu.pair_op(n_arr, 0, ints_to_limbs(bases, s2)), e_arr, chunk, row_block=row_block, pair_in=True)
+    assert np.array_equal(got, plain)
+
+
 def _chain(pub_oracle, cts, exps_c, encodings, exps_k):
     """the reference's left-to-right chain on integers: _raw_mul per term, then _add_encrypted's alignment + _raw_add"""
     nsq = pub_oracle.nsquare
@@ -353,6 +384,38 @@ def test_dot_large_batch_properties(native, c_oracle):
     want = functools.reduce(lambda a, b: a * b % nsq, terms, 1)
     assert head.dot(w_int[:k]).ciphertext(False) == want
     assert isinstance(got, phe.EncryptedNumber)
+
+
+@pytest.mark.gpu
+def test_dot_and_matvec_on_vectors_in_the_pair_form(native, c_oracle):
+    """`vec.to_pair().dot(w)` / `.matvec(W)` with non-negative weights read the resident pair rows as they are
+    (phe_hip_pair_multiexp_rows_dev): the ciphertext bits of the plain-residue path, the vector left in its form; a negative
+    weight falls back to the residues (the inverse branch of _raw_mul), same bits again; forced chunk sizes as well"""
+    from phe import paillier
+    g = load_golden(2048)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    rs = np.random.Generator(np.random.PCG64(41))
+    B = 5000
+    vals = rs.integers(-10 ** 6, 10 ** 6, B)
+    vec = pub.encrypt_batch(vals, device=True)
+    pv = vec.to_pair()
+    assert pv._pair and pv._store.cols != vec._store.cols
+    w = rs.integers(0, 2 ** 56, B)                                   # non-negative: stays in the form
+    got = pv.dot(w)
+    assert pv._pair                                                  # not converted back
+    assert got.ciphertext(False) == vec.dot(w).ciphertext(False)
+    assert priv.decrypt(got) == int(np.dot(vals.astype(object), w.astype(object)))
+    wf = np.abs(rs.standard_normal(B))
+    assert pv.dot(wf).ciphertext(False) == vec.dot(wf).ciphertext(False)
+    w_neg = w.copy()
+    w_neg[7] = -5
+    assert pv.dot(w_neg).ciphertext(False) == vec.dot(w_neg).ciphertext(False)
+    W = rs.integers(0, 2 ** 40, (6, B))
+    rows_pair = pv.matvec(W)
+    rows_plain = vec.matvec(W)
+    assert rows_pair.ciphertexts(False) == rows_plain.ciphertexts(False)
+    assert priv.decrypt_batch(rows_pair) == [int(np.dot(vals.astype(object), r.astype(object))) for r in W]
 
 
 @pytest.mark.gpu

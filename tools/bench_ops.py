@@ -119,6 +119,17 @@ def main():
         ok = native.limbs_to_ints(to_np(one_row))[0] == want
         res[name] = {"elements_per_s": B / t, "ms": t * 1e3, "composed_powmod_plus_tree_ms": t_old * 1e3,
                      "speedup_vs_composed": t_old / t, "same_bits_as_composed": same, "bit_exact_prefix_vs_oracle": bool(ok)}
+        # the same dot product over the vector resident in the pair form (phe_hip_pair_multiexp_rows_dev: no conversion in)
+        pw = ctx.pair_words()
+        if pw:
+            pa = torch.empty((B, pw), dtype=torch.int32, device=dev)
+            ctx.to_pair_dev(ca.data_ptr(), pa.data_ptr(), B, st)
+            ctx.multiexp_dev(ca.data_ptr(), e.data_ptr(), 2, bits, one_row.data_ptr(), B, st)
+            pair_row = torch.empty_like(one_row)
+            tp = timed(lambda: ctx.pair_multiexp_rows_dev(pa.data_ptr(), e.data_ptr(), 2, bits, pair_row.data_ptr(), B, 1, st))
+            res[name + "_pair_in"] = {"elements_per_s": B / tp, "ms": tp * 1e3, "speedup_vs_plain_input": t / tp,
+                                      "same_bits_as_plain_input": bool(torch.equal(pair_row, one_row))}
+            del pa
     # ---- matrix form: a (rows x features) plaintext matrix times an encrypted feature vector (the shape of
     #      examples/logistic_regression_encrypted_model.py:170-177 with the roles of weights and samples swapped) ----
     feat, nrows = 128, 8192
