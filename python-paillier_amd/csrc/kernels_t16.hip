@@ -9,6 +9,7 @@
 #include "mul_io.h"
 #include "split_core.h"
 #include "mul_table.h"
+#include "mul_tile.h"
 // clang-format on
 
 namespace phe {
@@ -42,7 +43,52 @@ __global__ void __launch_bounds__(kTableBlock, 1) k_mulmod_table(TableMulArgs A)
                       threadIdx.x & 63u);
 }
 
+// mul_tile.h: the same product with the fold on lane = element and the table on the scalar path; the workgroup owns tiles of 64
+// products and meets at barriers between the phases
+template <int L>
+__global__ void __launch_bounds__(kTableBlock, 1) k_mulmod_tile(TableMulArgs A) {
+    constexpr int S = 16 * L, kRowT = S + kTableRowSlack, kGroups = kTableBlock / 16;
+    using IO = RowIO<16, L>;
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_t[];
+    uint32_t* tile = lds_t;
+    uint32_t* top = tile + 2 * S * kTile;
+    uint32_t* carries = top + kTile * kTableRowSlack;
+    uint32_t* cst = carries + kTile * kTileWaves * 2;
+    uint32_t* rows = cst + 3 * S;
+    uint32_t* stage = rows + kGroups * kRowT;
+    static_assert(kTableBlock == 64 * kTileWaves, "one wave per column block");
+    for (int i = (int)threadIdx.x; i < S; i += kTableBlock) {
+        cst[i] = A.n[i];
+        cst[S + i] = A.ncomp[i];
+        cst[2 * S + i] = A.ncomp1[i];
+    }
+    __syncthreads();
+    const uint32_t grp = threadIdx.x / 16, wv = wave::uniform(threadIdx.x / 64u);
+    mul_tile_body<L>(A, tile, top, carries, rows + grp * kRowT, stage + wv * 2 * IO::kStageWave, cst, wv, blockIdx.x, gridDim.x,
+                     threadIdx.x & 63u);
+}
+
 namespace t16 {
+
+template <int L>
+static int launch_tile_L(int blocks, hipStream_t st, const TableMulArgs& A) {
+    constexpr size_t lds_bytes = (size_t)tile_lds_words<L>() * 4;
+    static bool allowed = false;
+    if (!allowed) {
+        if (hipFuncSetAttribute((const void*)k_mulmod_tile<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
+        allowed = true;
+    }
+    k_mulmod_tile<L><<<dim3(blocks), dim3(kTableBlock), lds_bytes, st>>>(A);
+    return 0;
+}
+// (A.table: the column-block layout)  -1: no kernel for this lane width; -2: the device refused the LDS size
+int launch_mul_tile(int L, int blocks, hipStream_t st, const TableMulArgs& A) {
+    switch (L) {
+        case 5: return launch_tile_L<5>(blocks, st, A);
+        case 9: return launch_tile_L<9>(blocks, st, A);
+        default: return -1;
+    }
+}
 
 template <int L>
 static int launch_L(int blocks, size_t lds_bytes, hipStream_t st, const TableMulArgs& A) {

@@ -740,11 +740,13 @@ inline PrivatePlan build_private(const uint32_t* p, const uint32_t* q, const uin
 // kernel's other areas (keys up to ~2700 bits: L = 5 or 9) — ok() false otherwise, mul_io.h's kernels serve.
 struct TableMulPack {
     int L = 0, S = 0;
-    int split = 0, digits = 0, base = 0;
+    int split = 0, digits = 0, base = 0, digits_padded = 0;
     double inv = 0.0;                          // W^base / N
     std::vector<uint32_t> n, ncomp, ncomp1;    // S limbs each: N, W^S - N, (W^S - N) * W mod W^S
     std::vector<uint32_t> table;               // digits rows of S words, device layout (mul_table.h table_row_limbs)
+    std::vector<uint32_t> table_cols;          // the same rows in the column-block layout [wave][digit][2L words] (mul_tile.h)
     size_t lds_words = 0;
+    size_t tile_lds_words = 0;                 // LDS of mul_tile.h's workgroup (no table in it)
     bool ok() const { return L != 0; }
 };
 // lane widths offered: 9 (n^2 of ~1850 ... 2048-bit keys).  5 limbs per lane (1024-bit keys) was built and measured SLOWER than
@@ -795,8 +797,14 @@ inline TableMulPack build_table_mul(const Big& N_any, int word_limbs, bool offer
     const int full = L / 4, rem = L % 4;
     (void)kFullMax;
     T.table.assign((size_t)D * S, 0u);
+    const int cw = 2 * L;  // columns of one wave of mul_tile.h's fold: 8 waves x 2L = S
+    T.digits_padded = (D + 3) & ~3;
+    const int d_rows = T.digits_padded + 4;  // (mul_tile.h kFoldPadRows: zero rows for the fold's look-ahead)
+    T.table_cols.assign((size_t)8 * d_rows * cw, 0u);
     for (int i = 0; i < D; ++i) {
         const std::vector<uint32_t> limbs = to_r29(c, S);
+        for (int w = 0; w < 8; ++w)
+            for (int k = 0; k < cw; ++k) T.table_cols[((size_t)w * d_rows + (size_t)i) * cw + k] = limbs[(size_t)(w * cw + k)];
         uint32_t* row = T.table.data() + (size_t)i * S;
         for (int g = 0; g < 16; ++g) {
             for (int q = 0; q < full; ++q)
@@ -820,6 +828,9 @@ inline TableMulPack build_table_mul(const Big& N_any, int word_limbs, bool offer
     T.split = P;
     T.digits = D;
     T.lds_words = lds_words;
+    // mul_tile.h tile_lds_words<L>(): tile buffer | top columns | block carries | 3 constant rows | 32 digit rows | 8 x 2 staging areas
+    T.tile_lds_words = 2 * (size_t)S * 64 + 64 * 16 + 64 * 8 * 2 + 3 * (size_t)S + 32 * (size_t)(S + 16) + 8 * 2 * (size_t)(256 * k_vec);
+    if (T.tile_lds_words * 4 > kTableLdsLimitBytes) T.tile_lds_words = 0;
     return T;
 }
 

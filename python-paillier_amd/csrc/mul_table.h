@@ -36,6 +36,7 @@ struct TableMulArgs {
     double inv;              // W^base / N
     int split;               // P: limbs of T below it are kept, the ones above are folded
     int digits;              // D: fold digits = (S - P) top limbs of the low half + the limbs the high half can have
+    int digits_padded;       // mul_tile.h: D rounded up to a multiple of 4 (the column-block table has zero rows from D on)
     int base;                // limb index the quotient estimate reads y from (4 limbs: base ... base + 3)
     const uint32_t* a;
     const uint32_t* b;
@@ -43,6 +44,9 @@ struct TableMulArgs {
     size_t a_stride, b_stride, out_stride;  // 32-bit words between consecutive rows (16-byte aligned rows)
     int limbs;                              // 32-bit words per number (a multiple of 4)
     uint64_t batch;
+#if defined(PHE_TILE_PROFILE)
+    uint64_t* profile;  // measurement-only build: 8 sums of shader clocks (mul_tile.h PHE_TILE_MARK)
+#endif
 };
 
 constexpr int kTableRowSlack = 16;  // a group's digit row holds S + this many words (the fold digits are S - P more than S)

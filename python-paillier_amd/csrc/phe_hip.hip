@@ -120,6 +120,7 @@ PHE_DECLARE_SPLIT_PART(s64b)
 namespace phe {
 namespace t16 {  // kernels_t16.hip
 int launch_mul_table(int L, int blocks, size_t lds_bytes, hipStream_t st, const TableMulArgs& A);
+int launch_mul_tile(int L, int blocks, hipStream_t st, const TableMulArgs& A);
 }  // namespace t16
 }  // namespace phe
 
@@ -300,7 +301,7 @@ __global__ void k_selftest_prims(uint32_t* out) {
 // ------------------------------------------------------------------------------------------------
 // what phe_hip_ctx_last_launch reports (include/phe_hip.h)
 enum : int { kPathUnit = 1, kPathOwner = 2, kPathSideBySide = 4, kPathPipelined = 8, kPathFusedObfuscate = 16, kPathWavePairs = 32, kPathWaveTail = 64,
-             kPathLate = 128, kPathTableMul = 256 };
+             kPathLate = 128, kPathTableMul = 256, kPathTileMul = 512 };
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
     g_err = msg;
@@ -375,6 +376,7 @@ struct phe_hip_ctx {
     // table on the device; null = not offered for this key width (the table does not fit a CU's LDS) or PHE_HIP_NO_TABLE_MUL=1
     host::TableMulPack tmul;
     uint32_t* tmul_blob = nullptr;
+    uint32_t* tmul_cols = nullptr;  // the table in mul_tile.h's column-block layout (nullptr: that kernel is not offered)
     bool no_late = false;              // PHE_HIP_NO_LATE=1: the small-batch rungs stay on the round-3 kernels (textbook row order; A/B measurements, tests)
     bool force_unit = false;           // PHE_HIP_FORCE_UNIT=1: r^n through the scaled modulus whatever the batch size (tests)
     int force_group = 0;               // phe_hip_ctx_set_group: 0 = pick by batch size; G = the rung whose groups are G lanes wide
@@ -922,7 +924,11 @@ static const size_t kTableMulMinRows = 8192;
 static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, size_t a_stride, const uint32_t* b,
                       size_t b_stride, uint32_t* out, size_t out_stride, int limbs, size_t batch,
                       hipStream_t stream, int b_plain_limbs = 0, int one_product = 0, int a_limbs = 0, bool plain_mulmod = false) {
-    if (plain_mulmod && ctx->tmul_blob && !b_plain_limbs && !one_product && !a_limbs && batch >= kTableMulMinRows && limbs == ctx->pub.s2 &&
+    static const size_t min_rows = [] {  // (PHE_HIP_TABLE_MUL_MIN_ROWS: measurements of the crossover)
+        const char* e = getenv("PHE_HIP_TABLE_MUL_MIN_ROWS");
+        return e ? (size_t)std::max(1, atoi(e)) : kTableMulMinRows;
+    }();
+    if (plain_mulmod && ctx->tmul_blob && !b_plain_limbs && !one_product && !a_limbs && batch >= min_rows && limbs == ctx->pub.s2 &&
         limbs % 4 == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15u) == 0) && a_stride % 4 == 0 && b_stride % 4 == 0 &&
         out_stride % 4 == 0 && b_stride != 0) {
         // _raw_add on plain residues (phe/paillier.py:705-719): one plain product + one fold against the key's table
@@ -945,9 +951,23 @@ static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, 
         B.out_stride = out_stride;
         B.limbs = limbs;
         B.batch = batch;
-        const size_t per_block = 32;  // limb groups of a 512-thread workgroup
-        const int blocks = (int)std::max<size_t>(1, std::min((batch + per_block - 1) / per_block, (size_t)ctx->n_cus));
-        const int rc = phe::t16::launch_mul_table(T.L, blocks, T.lds_words * 4, stream, B);
+        B.digits_padded = T.digits_padded;
+        int rc = -1;
+        if (ctx->tmul_cols) {
+            // by tiles of 64 products per workgroup, the fold on one element per lane with the table words on the scalar path
+            // (mul_tile.h); PHE_HIP_NO_TILE_MUL=1 keeps the kernel with the table in LDS
+            TableMulArgs C = B;
+            C.table = ctx->tmul_cols;
+            const size_t tiles = (batch + 63) / 64;
+            rc = phe::t16::launch_mul_tile(T.L, (int)std::max<size_t>(1, std::min(tiles, (size_t)ctx->n_cus)), stream, C);
+            if (rc == 0) ctx->last_path |= kPathTileMul;
+        }
+        if (rc != 0) {
+            (void)hipGetLastError();
+            const size_t per_block = 32;  // limb groups of a 512-thread workgroup
+            const int blocks = (int)std::max<size_t>(1, std::min((batch + per_block - 1) / per_block, (size_t)ctx->n_cus));
+            rc = phe::t16::launch_mul_table(T.L, blocks, T.lds_words * 4, stream, B);
+        }
         if (rc == 0) {
             HIP_TRY(hipGetLastError());
             ctx->last_path |= kPathTableMul;
@@ -1202,6 +1222,10 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
             h.insert(h.end(), T.table.begin(), T.table.end());
             HIP_TRY(hipMalloc((void**)&ctx->tmul_blob, h.size() * 4));
             HIP_TRY(hipMemcpy(ctx->tmul_blob, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+            if (T.tile_lds_words && !getenv("PHE_HIP_NO_TILE_MUL")) {
+                HIP_TRY(hipMalloc((void**)&ctx->tmul_cols, T.table_cols.size() * 4));
+                HIP_TRY(hipMemcpy(ctx->tmul_cols, T.table_cols.data(), T.table_cols.size() * 4, hipMemcpyHostToDevice));
+            }
         }
     }
     ctx->force_unit = getenv("PHE_HIP_FORCE_UNIT") != nullptr;
@@ -1367,7 +1391,7 @@ void phe_hip_ctx_destroy(phe_hip_ctx* ctx) {
                         ctx->d_nsq.blob, ctx->d_psq.blob, ctx->d_qsq.blob, ctx->d_exp_n.ops, ctx->d_exp_p.ops,
                         ctx->d_exp_q.ops, ctx->d_tail.blob, ctx->table, ctx->table2, ctx->scratch, ctx->partial, ctx->lookup, (uint32_t*)ctx->flags, ctx->stage[0],
                         ctx->stage[1], ctx->stage[2], ctx->owner_blob, ctx->d_nunit.blob, ctx->unit_tmp, ctx->tail_wave_blob, ctx->item_sched,
-                        ctx->tmul_blob};
+                        ctx->tmul_blob, ctx->tmul_cols};
     for (const auto& R : ctx->pub_rungs) { bufs.push_back(R.nsq.blob); bufs.push_back(R.nsplit.blob); bufs.push_back(R.nunit.blob); }
     for (const auto& R : ctx->priv_rungs) { bufs.push_back(R.psq.blob); bufs.push_back(R.qsq.blob); bufs.push_back(R.psplit.blob); bufs.push_back(R.qsplit.blob); }
     for (uint32_t* b : bufs)

@@ -185,11 +185,11 @@ PHE_DEV void montmul_addend(uint32_t (&out)[L], const uint32_t* a, const uint32_
     normalize_partial<G, L>(out, acc, ln);
 }
 
-// plain product: a*b + addend = hi*R + lo.  a: H digits in LDS; lo: H canonical digits stored to lo_row (LDS);
-// hi: almost-normalised.
+// plain product: a*b + addend = hi*R + lo.  a: H digits in LDS; lo: H canonical digits stored to lo_row (LDS; digit d at
+// lo_row[d * lo_stride]: mul_tile.h keeps the digits of 64 numbers side by side); hi: almost-normalised.
 template <int G, int L>
 PHE_DEV void mul_wide(uint32_t (&hi)[L], const uint32_t* a, const uint32_t (&b)[L], const uint32_t (&addend)[L],
-                      uint32_t* lo_row, const Lanes<G>& ln, int rows = G * L) {
+                      uint32_t* lo_row, const Lanes<G>& ln, int rows = G * L, int lo_stride = 1) {
     uint64_t acc[L];
 #pragma unroll
     for (int k = 0; k < L; ++k) acc[k] = addend[k];
@@ -214,7 +214,7 @@ PHE_DEV void mul_wide(uint32_t (&hi)[L], const uint32_t* a, const uint32_t (&b)[
         }
         if (ln.g == 0u) {
 #pragma unroll
-            for (int j = 0; j < L; ++j) lo_row[i + j] = dq[j];
+            for (int j = 0; j < L; ++j) lo_row[(i + j) * lo_stride] = dq[j];
         }
     }
     normalize_partial<G, L>(hi, acc, ln);

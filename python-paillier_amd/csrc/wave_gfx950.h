@@ -194,6 +194,67 @@ PHE_DEV void lds_store4(lds_u32* p, uint32_t a, uint32_t b, uint32_t c, uint32_t
     *(__attribute__((address_space(3))) u32x4*)p = (u32x4){a, b, c, d};
 }
 
+// A wave-uniform value as the compiler should see it (an SGPR): v_readfirstlane
+PHE_DEV uint32_t uniform(uint32_t x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// N consecutive words of batch-constant data at a WAVE-UNIFORM address, through the scalar data cache (s_load_dwordx*) into
+// SGPRs: a multiply-add then takes the word as its scalar operand — one 4-byte read feeds all 64 lanes, no LDS or VGPR traffic
+// (mul_tile.h: lane = element, the fold table word is the same for every lane).  The constant address space tells the
+// compiler the memory is never written by this kernel, which is what lets it use the scalar path next to the kernel's stores.
+template <int N>
+PHE_DEV void scalar_words(uint32_t (&c)[N], const uint32_t* p) {
+    typedef const uint32_t __attribute__((address_space(4))) const_u32;
+    const_u32* q = (const_u32*)(uintptr_t)p;
+#pragma unroll
+    for (int k = 0; k < N; ++k) c[k] = q[k];
+}
+
+// ---- table words on the scalar path, requested ahead of their use (mul_tile.h) -------------------------------------------------
+// ScalarRow<N>: N (= 16 + 2 or 8 + 2) consecutive words at a wave-uniform address, in SGPRs.  request() issues the s_load and
+// returns at once; the words may be read after arrived() — the s_waitcnt is written by hand because the compiler, left to
+// place the loads itself, sinks them to their first use and waits there (scalar loads return out of order: the only wait
+// there is waits for every outstanding one, so a wait in front of a use must come BEFORE the next requests are issued).
+typedef uint32_t __attribute__((ext_vector_type(16))) u32x16;
+typedef uint32_t __attribute__((ext_vector_type(8))) u32x8;
+typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+template <int N>
+struct ScalarRow;
+template <>
+struct ScalarRow<18> {
+    u32x16 lo;
+    u32x2 hi;
+    PHE_DEV void request(const uint32_t* p) {
+        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x40" : "=&s"(lo), "=&s"(hi) : "s"(p) : "memory");
+    }
+    PHE_DEV uint32_t word(int k) const { return k < 16 ? lo[k] : hi[k - 16]; }
+};
+template <>
+struct ScalarRow<10> {
+    u32x8 lo;
+    u32x2 hi;
+    PHE_DEV void request(const uint32_t* p) {
+        asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20" : "=&s"(lo), "=&s"(hi) : "s"(p) : "memory");
+    }
+    PHE_DEV uint32_t word(int k) const { return k < 8 ? lo[k] : hi[k - 8]; }
+};
+// every request issued so far has landed (and every LDS read: the counter is shared); the rows named are the ones read next
+// Two LDS words 64 rows of 4 bytes apart (rows ROW and ROW + 1 of a [row][64 lanes] buffer, this lane's column), requested the
+// same way: were the read left to the compiler, its own wait for it — the counter is shared with the scalar loads — would sit
+// in front of the first use and wait for the requests issued since.
+struct DigitPair {
+    u32x2 v;
+    template <int ROW>
+    PHE_DEV void request(const uint32_t* lds_column) {
+        const uint32_t addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t*)lds_column;
+        asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=&v"(v) : "v"(addr), "n"(ROW), "n"(ROW + 1) : "memory");
+    }
+    PHE_DEV uint32_t word(int u) const { return v[u]; }
+};
+template <int N>
+PHE_DEV void arrived(ScalarRow<N>& a, ScalarRow<N>& b, DigitPair& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a.lo), "+s"(a.hi), "+s"(b.lo), "+s"(b.hi), "+v"(d.v)::"memory");
+}
+
 // 32x32+64 -> 64 multiply-accumulate: v_mad_u64_u32 with a full 64-bit addend.  The radix-2^29 core
 // keeps every accumulator below 2^64 by construction, so the carry-out is never needed.
 PHE_DEV uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) { return (uint64_t)a * b + c; }

@@ -282,6 +282,7 @@ class Context:
     PATH_UNIT, PATH_OWNER, PATH_SIDE_BY_SIDE, PATH_PIPELINED, PATH_FUSED_OBFUSCATE, PATH_WAVE_PAIRS, PATH_WAVE_TAIL = 1, 2, 4, 8, 16, 32, 64
     PATH_LATE = 128
     PATH_TABLE_MUL = 256
+    PATH_TILE_MUL = 512
 
     def last_launch(self):
         """what the last encrypt / obfuscate / decrypt / pair call took: {"path": PATH_* bits, "geom_pub", "geom_priv"}"""

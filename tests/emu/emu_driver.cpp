@@ -10,6 +10,7 @@
 #include "../../python-paillier_amd/csrc/mul_io.h"
 #include "../../python-paillier_amd/csrc/split_core.h"
 #include "../../python-paillier_amd/csrc/mul_table.h"
+#include "../../python-paillier_amd/csrc/mul_tile.h"
 #include "../../python-paillier_amd/csrc/decrypt_tail.h"
 #include "../../python-paillier_amd/csrc/key_setup.h"
 #include "../../python-paillier_amd/csrc/radix_conv.h"
@@ -417,8 +418,37 @@ static void run_mul_table(TableMulArgs A, const host::TableMulPack& T) {
         });
     }
 }
+// k_mulmod_tile (mul_tile.h): the same product by tiles of 64 with the fold on lane = element; one emulated workgroup of 8
+// waves (one host thread each, joined by the barriers) per block
+template <int L>
+static void run_mul_tile(TableMulArgs A, const host::TableMulPack& T, int n_blocks) {
+    constexpr int G = 16, S = G * L, kRowT = S + kTableRowSlack;
+    using IO = RowIO<G, L>;
+    A.table = T.table_cols.data();
+    A.digits_padded = T.digits_padded;
+    for (int b = 0; b < n_blocks; ++b) {
+        std::vector<Words4> lds((size_t)tile_lds_words<L>() / 4 + 1);
+        uint32_t* tile = (uint32_t*)lds.data();
+        for (size_t i = 0; i < lds.size() * 4; ++i) tile[i] = 0xdeadbeefu;   // LDS is not zero on the device either
+        uint32_t* top = tile + 2 * S * kTile;
+        uint32_t* carries = top + kTile * kTableRowSlack;
+        uint32_t* cst = carries + kTile * kTileWaves * 2;
+        uint32_t* rows = cst + 3 * S;
+        uint32_t* stage = rows + 32 * kRowT;
+        memcpy(cst, T.n.data(), S * 4);
+        memcpy(cst + S, T.ncomp.data(), S * 4);
+        memcpy(cst + 2 * S, T.ncomp1.data(), S * 4);
+        wave::run_block(kTileWaves, [&](uint32_t wv, uint32_t lane) {
+            const uint32_t grp = wv * 4 + lane / G;
+            mul_tile_body<L>(A, tile, top, carries, rows + grp * kRowT, stage + wv * 2 * IO::kStageWave, cst, wv, (uint32_t)b,
+                             (uint32_t)n_blocks, lane);
+        });
+    }
+}
+static int g_tile_mul = 0, g_tile_blocks = 2;
 extern "C" {
 
+void emu_set_tile_mul(int e, int blocks) { g_tile_mul = e ? 1 : 0; g_tile_blocks = blocks > 0 ? blocks : 2; }
 void emu_set_engine(int e) { g_engine = e ? 1 : 0; }
 void emu_set_mul_io(int e) { g_mul_io = e ? 1 : 0; }
 void emu_set_unit(int e) { g_unit = e ? 1 : 0; }
@@ -709,7 +739,12 @@ int emu_mulmod_table(const uint32_t* N, int limbs, const uint32_t* a, const uint
         A.a = (const uint32_t*)a4.data(); A.b = (const uint32_t*)b4.data(); A.out = (uint32_t*)o4.data();
         A.a_stride = A.b_stride = A.out_stride = (size_t)limbs; A.limbs = limbs; A.batch = B;
         if (limbs % 4) return 2;
-        if (T.L == 5) run_mul_table<5>(A, T);
+        if (g_tile_mul) {
+            if (!T.tile_lds_words) return 2;
+            if (T.L == 5) run_mul_tile<5>(A, T, g_tile_blocks);
+            else if (T.L == 9) run_mul_tile<9>(A, T, g_tile_blocks);
+            else return 2;
+        } else if (T.L == 5) run_mul_table<5>(A, T);
         else if (T.L == 9) run_mul_table<9>(A, T);
         else return 2;
         memcpy(out, o4.data(), (size_t)B * limbs * 4);

@@ -251,6 +251,30 @@ inline void async_copy16_to_lds(const uint32_t* gsrc, uint32_t* lds_wave_base, b
 }
 inline void wait_async_copies() { lds_fence(); }
 
+template <int N>
+struct ScalarRow {
+    uint32_t w[N];
+    void request(const uint32_t* p) {
+        for (int k = 0; k < N; ++k) w[k] = p[k];
+    }
+    uint32_t word(int k) const { return w[k]; }
+};
+struct DigitPair {
+    uint32_t w[2];
+    template <int ROW>
+    void request(const uint32_t* lds_column) {
+        w[0] = lds_column[ROW * 64];
+        w[1] = lds_column[(ROW + 1) * 64];
+    }
+    uint32_t word(int u) const { return w[u]; }
+};
+template <int N>
+inline void arrived(ScalarRow<N>&, ScalarRow<N>&, DigitPair&) {}
+inline uint32_t uniform(uint32_t x) { return x; }
+template <int N>
+inline void scalar_words(uint32_t (&c)[N], const uint32_t* p) {
+    for (int k = 0; k < N; ++k) c[k] = p[k];
+}
 inline const uint32_t* reread_ptr(const uint32_t* p) { return p; }
 template <class T>
 inline T* reread_vptr(T* p) { return p; }

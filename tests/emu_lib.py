@@ -99,11 +99,16 @@ class Emu:
         self._ck(self.L.emu_mulmod(P(N), N.shape[0], P(a), P(b), P(out), ctypes.c_uint64(a.shape[0])))
         return out
 
-    def mulmod_table(self, N, a, b):
+    def mulmod_table(self, N, a, b, tiles=False, blocks=2):
         """a*b mod N by the table kernel's body (csrc/mul_table.h: one plain product + one fold against the key's table); None
-        where the library would not offer it (the table does not fit a CU's LDS)"""
+        where the library would not offer it (the table does not fit a CU's LDS).  tiles: by csrc/mul_tile.h instead (tiles of
+        64 products per workgroup of 8 waves, the fold on lane = element), `blocks` emulated workgroups"""
         out = np.zeros_like(a)
-        rc = self.L.emu_mulmod_table(P(N), N.shape[0], P(a), P(b), P(out), ctypes.c_uint64(a.shape[0]))
+        self.L.emu_set_tile_mul(1 if tiles else 0, blocks)
+        try:
+            rc = self.L.emu_mulmod_table(P(N), N.shape[0], P(a), P(b), P(out), ctypes.c_uint64(a.shape[0]))
+        finally:
+            self.L.emu_set_tile_mul(0, 0)
         if rc == 2:
             return None
         self._ck(rc)

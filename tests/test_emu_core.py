@@ -435,6 +435,35 @@ def test_product_by_one_plain_product_and_one_table_fold(emu, key_bits):
     assert table_mads * 1.9 < two_products, (table_mads, two_products)        # about half the multiply-adds per product
 
 
+@pytest.mark.parametrize("key_bits", [1024, 2048])
+def test_product_by_tiles_with_the_fold_on_one_element_per_lane(emu, key_bits):
+    """csrc/mul_tile.h (round 4): the arithmetic of mul_table.h by tiles of 64 products per workgroup — the product on 16-lane
+    groups, the fold on lane = element against the column-block table (the scalar-path words), the settle back on the groups;
+    8 emulated waves joined by the barriers.  Same canonical residues on the golden raw_add vectors, the edge operands, and
+    batches that are not a multiple of the tile (ragged last tile, more tiles than workgroups, fewer tiles than workgroups)."""
+    g = load_golden(key_bits)
+    s2 = key_bits // 16
+    n = H(g["n"])
+    N = n * n
+    rng = random.Random(key_bits + 11)
+    top = (1 << (32 * s2)) - 1
+    pairs = [(H(e["a"]), H(e["b"])) for e in g["raw_add"]]
+    pairs += [(0, 5), (1, N - 1), (N - 1, N - 1), (top, top), (top, 1), (N, 7), (N + 1, N + 1), (1 << (32 * s2 - 1), 3)]
+    pairs += [(rng.randrange(top), rng.randrange(top)) for _ in range(6)]
+    pairs += [(rng.randrange(N), rng.randrange(N)) for _ in range(200 - len(pairs))]
+    pairs += [(top, top), (N - 1, 2), (3, 0)]                              # 203 rows: 4 tiles, the last one with 11 live rows
+    a = ints_to_limbs([x for x, _ in pairs], s2)
+    b = ints_to_limbs([y for _, y in pairs], s2)
+    want = [x * y % N for x, y in pairs]
+    Nl = int_to_limbs(N, s2)
+    out = emu.mulmod_table(Nl, a, b, tiles=True, blocks=2)                 # 2 workgroups x 2 tiles each
+    assert out is not None
+    assert limbs_to_ints(out) == want
+    assert limbs_to_ints(emu.mulmod_table(Nl, a[:70], b[:70], tiles=True, blocks=3)) == want[:70]   # a workgroup without a tile
+    assert limbs_to_ints(emu.mulmod_table(Nl, a[:5], b[:5], tiles=True, blocks=1)) == want[:5]
+    assert np.array_equal(out, emu.mulmod_table(Nl, a, b))                 # ... and the bits of mul_table.h
+
+
 def test_table_product_is_not_offered_where_the_table_does_not_fit(emu):
     g = load_golden(3072)
     N = H(g["n"]) ** 2

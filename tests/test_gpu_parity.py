@@ -344,6 +344,9 @@ def test_raw_add_by_one_plain_product_and_one_table_fold(native, c_oracle, key_b
     monkeypatch.setenv("PHE_HIP_NO_TABLE_MUL", "1")
     plain = make_ctx(native, g, private=False)
     monkeypatch.delenv("PHE_HIP_NO_TABLE_MUL")
+    monkeypatch.setenv("PHE_HIP_NO_TILE_MUL", "1")                    # the round-4 first form: the table in LDS (mul_table.h)
+    in_lds = make_ctx(native, g, private=False)
+    monkeypatch.delenv("PHE_HIP_NO_TILE_MUL")
     rs = np.random.Generator(np.random.PCG64(key_bits + 11))
     top = (1 << (32 * s2)) - 1
     edge = [(H(e["a"]), H(e["b"])) for e in g["raw_add"]] + [(0, 5), (1, N - 1), (N - 1, N - 1), (top, top), (top, 1), (N, 7), (N + 1, N + 1)]
@@ -360,7 +363,12 @@ def test_raw_add_by_one_plain_product_and_one_table_fold(native, c_oracle, key_b
         ctx.sync()
         took_table = bool(ctx.last_launch()["path"] & ctx.PATH_TABLE_MUL)
         assert took_table == (batch >= 8192), (batch, ctx.last_launch())
+        assert bool(ctx.last_launch()["path"] & ctx.PATH_TILE_MUL) == took_table      # by tiles, the fold on lane = element (mul_tile.h)
         got = out.to_host()
+        if took_table:
+            other = in_lds.mulmod(a, b)
+            assert in_lds.last_launch()["path"] & (ctx.PATH_TABLE_MUL | ctx.PATH_TILE_MUL) == ctx.PATH_TABLE_MUL
+            assert np.array_equal(got, other), batch
         assert native.limbs_to_ints(got[:len(edge)]) == [x * y % N for x, y in edge], batch
         if batch <= 20000:
             want = plain.mulmod(a[len(edge):], b[len(edge):])                                        # two Montgomery products
