@@ -43,29 +43,27 @@ __global__ void __launch_bounds__(kTableBlock, 1) k_mulmod_table(TableMulArgs A)
                       threadIdx.x & 63u);
 }
 
-// mul_tile.h: the same product with the fold on lane = element and the table on the scalar path; the workgroup owns tiles of 64
-// products and meets at barriers between the phases
+// mul_tile.h: the same product with one element per lane: the workgroup owns tiles of 64 products, its eight waves split the
+// columns and meet at barriers between the phases; the fold's table words come through the scalar cache
 template <int L>
 __global__ void __launch_bounds__(kTableBlock, 1) k_mulmod_tile(TableMulArgs A) {
-    constexpr int S = 16 * L, kRowT = S + kTableRowSlack, kGroups = kTableBlock / 16;
-    using IO = RowIO<16, L>;
+    using T = TileShape<L>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_t[];
     uint32_t* tile = lds_t;
-    uint32_t* top = tile + 2 * S * kTile;
-    uint32_t* carries = top + kTile * kTableRowSlack;
-    uint32_t* cst = carries + kTile * kTileWaves * 2;
-    uint32_t* rows = cst + 3 * S;
-    uint32_t* stage = rows + kGroups * kRowT;
+    uint32_t* prod_carry = tile + T::kRows * kTile;
+    uint32_t* top = prod_carry + 2 * 2 * kTileWaves * kTile;
+    uint32_t* fold_carry = top + kTile * kTableRowSlack;
+    uint32_t* cst = fold_carry + 2 * kTileWaves * kTile;
+    uint32_t* rows = cst + 3 * T::S;
     static_assert(kTableBlock == 64 * kTileWaves, "one wave per column block");
-    for (int i = (int)threadIdx.x; i < S; i += kTableBlock) {
+    for (int i = (int)threadIdx.x; i < T::S; i += kTableBlock) {
         cst[i] = A.n[i];
-        cst[S + i] = A.ncomp[i];
-        cst[2 * S + i] = A.ncomp1[i];
+        cst[T::S + i] = A.ncomp[i];
+        cst[2 * T::S + i] = A.ncomp1[i];
     }
     __syncthreads();
-    const uint32_t grp = threadIdx.x / 16, wv = wave::uniform(threadIdx.x / 64u);
-    mul_tile_body<L>(A, tile, top, carries, rows + grp * kRowT, stage + wv * 2 * IO::kStageWave, cst, wv, blockIdx.x, gridDim.x,
-                     threadIdx.x & 63u);
+    const uint32_t wv = wave::uniform(threadIdx.x / 64u);
+    mul_tile_body<L>(A, tile, prod_carry, top, fold_carry, cst, rows, wv, blockIdx.x, gridDim.x, threadIdx.x & 63u);
 }
 
 namespace t16 {

@@ -828,8 +828,8 @@ inline TableMulPack build_table_mul(const Big& N_any, int word_limbs, bool offer
     T.split = P;
     T.digits = D;
     T.lds_words = lds_words;
-    // mul_tile.h tile_lds_words<L>(): tile buffer | top columns | block carries | 3 constant rows | 32 digit rows | 8 x 2 staging areas
-    T.tile_lds_words = 2 * (size_t)S * 64 + 64 * 16 + 64 * 8 * 2 + 3 * (size_t)S + 32 * (size_t)(S + 16) + 8 * 2 * (size_t)(256 * k_vec);
+    // mul_tile.h TileShape<L>::kLdsWords: tile buffer | product carries | top columns | fold carries | 3 constant rows | 32 digit rows
+    T.tile_lds_words = (2 * (size_t)S + 1) * 64 + 2 * 2 * 8 * 64 + 64 * 16 + 2 * 8 * 64 + 3 * (size_t)S + 32 * (size_t)(S + 4);
     if (T.tile_lds_words * 4 > kTableLdsLimitBytes) T.tile_lds_words = 0;
     return T;
 }

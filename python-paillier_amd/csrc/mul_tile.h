@@ -1,21 +1,30 @@
 // mul_tile.h — a*b mod N (phe/util.py:53-64 mulmod; phe/paillier.py:705-719 _raw_add) as one plain product and one fold
-// against the key's table (the arithmetic of mul_table.h), with the fold turned by 90 degrees: LANE = ELEMENT.
+// against the key's table (the arithmetic of mul_table.h) with LANE = ELEMENT: a 512-thread workgroup takes a tile of 64
+// products, every lane of every wave works on "its" element, and the eight waves split the COLUMNS of the numbers.
 //
-// mul_table.h folds inside the 16-lane limb group of the product: every lane reads its 9 table words per fold digit from LDS
-// — 4 bytes of LDS per multiply-add, 256 B/clk asked of a CU whose LDS delivers 128 — and the 84 KB table sits in LDS next to
-// everything else.  Measured (profiles/r04g): the fold half of the kernel runs at about a quarter of the multiply-add peak.
+// Why: in the limb-group form (16 lanes per number) a row of the product is 9 multiply-adds against 13 other instructions
+// (digit broadcast, shift across lanes, carries, masks), and the fold reads every table word from LDS once per lane — 4 bytes
+// of LDS per multiply-add, twice what a CU's LDS delivers.  Measured (tools/exp/tile_phases.hip, profiles/r04l): the product
+// ran at 40 % multiply-add density, the LDS-fed fold at a quarter of the multiply-add peak.  With one element per lane
+//   * nothing crosses lanes: the digits of 64 numbers lie side by side in LDS (buffer[row r][lane e]: every read and write of
+//     a wave is 256 consecutive bytes), a step of the product is ONE digit of a (LDS) times a sliding window of 2L digits of b
+//     held in registers — 2L multiply-adds, two LDS words, no shift (the window "moves" by register renaming in the unrolled
+//     code), no mask, no broadcast;
+//   * a table word of the fold is the same for all 64 lanes: it comes through the scalar data cache into an SGPR and enters
+//     v_mad_u64_u32 as its scalar operand (wave::ScalarRow): no LDS, no VGPR, 4 bytes per 64 multiply-adds.  The 84 KB table
+//     ([wave][digit][2L words]) streams from L2; the requests run two fold digits ahead of the multiply-adds.
 //
-// Here a 512-thread workgroup takes a TILE of 64 elements through three phases:
-//   1. product   (16-lane groups, mul_wide as before): T = a*b of element e leaves as 2S digits in column e of the tile
-//                buffer  tile[row r][element e]  (r < S: the canonical low digits, r >= S: the high limbs);
-//   2. fold      wave w owns the columns [2L w, 2L (w + 1)) of ALL 64 elements, one element per lane:
-//                    y_c = lo_c + sum_i f_i * C_i[c]        f_i = tile[P + i][lane]   (one conflict-free LDS word per 2L products)
-//                the table word C_i[c] is the same for every lane: it comes through the SCALAR data cache into an SGPR
-//                (wave::scalar_words) and enters v_mad_u64_u32 as its scalar operand — no LDS, no VGPR, 4 bytes per 64
-//                multiply-adds; the table (84 KB, [wave][digit][2L words]) stays in L2;
-//   3. settle    (16-lane groups again) the column sums come back through LDS, then the quotient estimate, r = y - q^ N and the
-//                conditional subtractions of mul_table.h.
-// Between the phases the waves of the group meet at a barrier (4 per tile of 64 products, ~60 k clocks of work each).
+// Phases of a tile (S = 16 L columns; wave w owns the column blocks named; `|` = workgroup barrier):
+//   load     wave w: digits [2L w, 2L w + 2L) of a and b of all 64 elements: 16-byte global loads of the lane's own row
+//            (issued one tile ahead), re-sliced to 29 bits in registers, to A[digit][e], B[digit][e]                        |
+//   product  wave w: columns [2L w, +2L) and [2L (w + 8), +2L) of T = a*b — 9 * 2L steps of 2L multiply-adds, the same for
+//            every wave; 64-bit column sums, carries inside the lane, the block's carry-out to LDS                          |
+//            the carry-out of the block below enters the block's two lowest digits; T[row][e] over A and B                  |
+//   fold     wave w: columns [2L w, +2L) of y = T_low + sum_i T[P + i] * C_i     (the accumulators open from the wave's own
+//            low block of the product: the same columns)
+//            carries inside the lane, y to LDS as [element][column], the block's carry-out beside it                        |
+//   settle   16 lanes per element (two elements per limb group, one after the other): y canonical, q^ = floor(y / N) - 1 or - 2 from four limbs,
+//            r = y - q^ N < 3 N, conditional subtractions, 16-byte stores                                                   |
 // Same bits as mul_table.h, mul_io.h and gmpy2.mod(gmpy2.mul(a, b), c).
 #pragma once
 #include <stddef.h>
@@ -28,11 +37,11 @@
 
 // measurement-only build (tools/exp/tile_phases.hip): shader-clock time per phase, summed over the tiles of a wave
 #if defined(PHE_TILE_PROFILE)
-#define PHE_TILE_MARK(i)                                   \
-    {                                                      \
+#define PHE_TILE_MARK(i)                                    \
+    {                                                       \
         const uint64_t now_ = __builtin_readcyclecounter(); \
-        prof_[i] += now_ - last_;                          \
-        last_ = now_;                                      \
+        prof_[i] += now_ - last_;                           \
+        last_ = now_;                                       \
     }
 #else
 #define PHE_TILE_MARK(i) ((void)0)
@@ -40,108 +49,266 @@
 
 namespace phe {
 
-constexpr int kTile = 64;       // elements of a tile = lanes of a wave
-constexpr int kTileWaves = 8;   // waves of the workgroup = column blocks of the fold
-constexpr int kFoldPadRows = 4; // zero rows the column-block table carries past its last digit (the fold's look-ahead)
-constexpr int kFoldChunk = 48;  // fold digits between two hand-overs of the accumulators' upper halves (48 * 2^58.01 + 2^32 < 2^64)
+constexpr int kTile = 64;        // elements of a tile = lanes of a wave
+constexpr int kTileWaves = 8;    // waves of the workgroup; 2 * kTileWaves column blocks of 2L columns make the product
+constexpr int kFoldPadRows = 4;  // zero rows the column-block table carries past its last digit (the fold's look-ahead)
+constexpr int kFoldChunk = 48;   // fold digits between two hand-overs of the accumulators' upper halves (48 * 2^58.01 + 2^32 < 2^64)
 
-// LDS words of the workgroup: tile buffer | top columns | block carries | n, ncomp, ncomp1 | 32 digit rows | 8 waves x (stage a | b)
+template <int L>
+struct TileShape {
+    static constexpr int S = 16 * L;    // columns of the fold and of the settle; digit rows of an operand (the ones past its
+                                        // last digit hold zeros)
+    static constexpr int CW = 2 * L;    // columns of a block: what one wave folds, what one lane of the settle holds
+    static constexpr int kRows = 2 * S + 1;  // rows of the tile buffer: A (S rows + one zero row) | B (S rows); T (2S rows) over both
+    // 32-bit words wave w must see to cut its digits [CW w, CW w + CW): from the 16-byte piece that holds bit 29 CW w on
+    // (rows are whole 16-byte pieces: a piece is either inside the row or beyond it)
+    static constexpr int first_word(int w) { return ((kRadixBits * CW * w) >> 5) & ~3; }
+    static constexpr int word_skip(int w) { return ((kRadixBits * CW * w) >> 5) & 3; }
+    static constexpr int max_chunks() {
+        int m = 0;
+        for (int w = 0; w < kTileWaves; ++w) {
+            const int c = (word_skip(w) + ((kRadixBits * (CW - 1)) >> 5) + 3 + 3) / 4;
+            m = c > m ? c : m;
+        }
+        return m;
+    }
+    static constexpr int kChunks = max_chunks();
+    static constexpr int kRowT = S + kLdsPad;  // a settle group's digit row
+    // LDS words: tile buffer | product carries (2 words x 16 blocks x 64) | top columns | fold carries | n, ncomp, ncomp1 | 32 digit rows
+    static constexpr int kLdsWords = kRows * kTile + 2 * 2 * kTileWaves * kTile + kTile * kTableRowSlack + 2 * kTileWaves * kTile +
+                                     3 * S + 32 * kRowT;
+};
 template <int L>
 constexpr int tile_lds_words() {
-    return 2 * 16 * L * kTile + kTile * kTableRowSlack + kTile * kTileWaves * 2 + 3 * 16 * L + 32 * (16 * L + kTableRowSlack) +
-           kTileWaves * 2 * RowIO<16, L>::kStageWave;
+    return TileShape<L>::kLdsWords;
 }
 
-// A.table: the fold table in the COLUMN-BLOCK layout [wave w][digit i][2L words]: limbs [2L w, 2L (w + 1)) of W^(P+i) mod N
-// (key_setup.h:build_table_mul writes both layouts).  tile: 2 S kTile words; top: kTile * kTableRowSlack; carries: kTile *
-// kTileWaves * 2; row: the group's digit row (S + kTableRowSlack); stage: the wave's staging area; cst: n | ncomp | ncomp1.
-// `wv` must be wave-uniform.  Every wave of the workgroup runs the same number of tiles (the barriers).
-template <int L>
-PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* top, uint32_t* carries, uint32_t* row, uint32_t* stage,
-                           const uint32_t* cst, uint32_t wv, uint32_t block, uint32_t n_blocks, uint32_t lane) {
-    constexpr int G = 16, S = G * L, CW = 2 * L;
-    using IO = RowIO<G, L>;
-    const Lanes<G> ln(lane);
-    const uint32_t g = ln.g, gw = lane / G;
-    uint32_t* stage_a = stage;
-    uint32_t* stage_b = stage + IO::kStageWave;
-    const int P = A.split, D = A.digits, n_lo = S - P;
-    PHE_BOUNDS(n_lo >= 2 && n_lo <= kTableRowSlack && P + D <= 2 * S && A.base >= 0 && A.base + 3 < S && wv < (uint32_t)kTileWaves);
+// 64-bit column sums of one lane -> digits below 2^29 and the carry that leaves the block (sum = acc + upper * 2^32)
+template <int CW>
+PHE_DEV uint64_t tile_block_carries(uint32_t (&digit)[CW], const uint64_t (&acc)[CW], const uint64_t (&upper)[CW]) {
+    uint64_t carry = 0;
 #pragma unroll
-    for (int t = 0; t < 2 * IO::kVec; ++t) {  // chunks at or beyond the row length are never copied: they must read as zero
+    for (int k = 0; k < CW; ++k) {
+        const uint64_t v = (acc[k] & 0xffffffffull) + carry;
+        digit[k] = (uint32_t)v & kLimbMask;
+        carry = (v >> kRadixBits) + ((upper[k] + (acc[k] >> 32)) << (32 - kRadixBits));
+    }
+    return carry;
+}
+// the upper halves of the accumulators to their own sums (D * 2^58 can pass 2^65: they need more than 32 bits)
+template <int CW>
+PHE_DEV void tile_hand_over(uint64_t (&acc)[CW], uint64_t (&upper)[CW]) {
+#pragma unroll
+    for (int k = 0; k < CW; ++k) {
+        upper[k] += acc[k] >> 32;
+        acc[k] &= 0xffffffffull;
+    }
+}
+
+// CW steps of a column block of the product.  Before: win[j] = b[q0 + j] (q0 = the block's lowest column minus the step
+// index i; digits outside b read as zero), a_col = &A[i][e], b_col = &B[q0 - 1][e].  After: the same for i + CW (q0 - CW).
+// Step u multiplies a[i + u] into every column: column c takes b[q0 + c - u], which is win[(c - u) mod CW] once the digits
+// b[q0 - 1 ... q0 - u] have replaced win[CW - 1 ... CW - u] — the window slides by renaming, not by moving.  LOADS = false:
+// the digits that would enter lie below b[0] (the last CW steps of a low block).
+template <int CW, bool LOADS>
+PHE_DEV void tile_product_steps(uint64_t (&acc)[CW], uint32_t (&win)[CW], const uint32_t* a_col, const uint32_t* b_col) {
+    // the 2 CW digits of the block first, then CW * CW multiply-adds with nothing to wait for (left to place the reads itself
+    // the compiler puts each one in front of its first use, with the wait for it)
+    uint32_t ad[CW], bd[CW];
+    const uint32_t* b_low = b_col - (CW - 1) * kTile;
+#pragma unroll
+    for (int u = 0; u < CW; ++u) {
+        ad[u] = a_col[u * kTile];
+        bd[u] = LOADS ? b_low[(CW - 1 - u) * kTile] : 0u;  // (offsets from the block's lowest row: immediates of the LDS reads)
+    }
+    wave::order_fence();
+#pragma unroll
+    for (int u = 0; u < CW; ++u) {
+#pragma unroll
+        for (int c = 0; c < CW; ++c) acc[c] = wave::mad64(ad[u], win[(c - u + CW) % CW], acc[c]);
+        win[CW - 1 - u] = bd[u];
+    }
+}
+
+// digits [CW wv, CW wv + CW) of the number whose 32-bit words from TileShape::first_word(wv) on are in `w` (4 per piece); SKIP =
+// TileShape::word_skip(wv) words lie before the one that holds the first digit's lowest bit.  One funnel shift by the
+// wave-uniform bit offset of that digit, then every digit sits at a compile-time position.
+template <int L, int SKIP>
+PHE_DEV void tile_cut_digits(uint32_t* column, const Words4 (&w)[TileShape<L>::kChunks], uint32_t wv) {
+    using T = TileShape<L>;
+    constexpr int kWords = 4 * T::kChunks;
+    uint32_t v[kWords + 1];
+#pragma unroll
+    for (int c = 0; c < T::kChunks; ++c) {
+        v[4 * c] = w[c].x;
+        v[4 * c + 1] = w[c].y;
+        v[4 * c + 2] = w[c].z;
+        v[4 * c + 3] = w[c].w;
+    }
+    v[kWords] = 0u;
+    const uint32_t shift = (kRadixBits * T::CW * wv) & 31u;
+    uint32_t* out = column + (size_t)(T::CW * wv) * kTile;
+#pragma unroll
+    for (int j = 0; j < T::CW; ++j) {
+        constexpr int kLast = SKIP + ((kRadixBits * (T::CW - 1)) >> 5) + 2;
+        static_assert(kLast <= kWords, "a wave's digits lie in the pieces it loads");
+        const int bit = kRadixBits * j, q = SKIP + (bit >> 5), o = bit & 31;
+        const uint32_t lo = (uint32_t)((((uint64_t)v[q + 1] << 32) | v[q]) >> shift);
+        const uint32_t hi = (uint32_t)((((uint64_t)v[q + 2] << 32) | v[q + 1]) >> shift);
+        out[j * kTile] = (uint32_t)((((uint64_t)hi << 32) | lo) >> o) & kLimbMask;
+    }
+}
+
+// a lane's row of the batch from word w0 (a multiple of 4) on, as the 16-byte pieces its wave cuts its digits from (pieces at
+// or beyond the row read as zero)
+template <int L>
+PHE_DEV void tile_request_row(Words4 (&raw)[TileShape<L>::kChunks], const uint32_t* p, int w0, int limbs) {
+#pragma unroll
+    for (int c = 0; c < TileShape<L>::kChunks; ++c) {
         Words4 z;
         z.x = z.y = z.z = z.w = 0u;
-        *reinterpret_cast<Words4*>(stage + t * 256 + 4 * (int)lane) = z;
+        raw[c] = z;
+        if (w0 + 4 * c < limbs) raw[c] = *reinterpret_cast<const Words4*>(p + 4 * c);
     }
-    wave::lds_fence();
+}
+
+// A.table: the fold table in the COLUMN-BLOCK layout [wave w][digit i][2L words]: limbs [2L w, 2L (w + 1)) of W^(P+i) mod N,
+// A.digits_padded + kFoldPadRows rows per wave (key_setup.h:build_table_mul writes both layouts).
+// tile: TileShape::kRows * 64 words; prod_carry: 2 * 16 * 64; top: 64 * kTableRowSlack; fold_carry: 2 * 8 * 64; cst: n | ncomp |
+// ncomp1 (S limbs each); rows: 32 digit rows of kRowT words.  `wv` must be wave-uniform; every wave of the workgroup runs the
+// same number of tiles (the barriers).  Rows of a, b, out: A.limbs words (a multiple of 4), 16-byte aligned.
+template <int L>
+PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod_carry, uint32_t* top, uint32_t* fold_carry,
+                           const uint32_t* cst, uint32_t* rows, uint32_t wv, uint32_t block, uint32_t n_blocks, uint32_t lane) {
+    using T = TileShape<L>;
+    constexpr int S = T::S, CW = T::CW, GS = 16;  // (GS: lanes per element of the settle)
+    const int P = A.split, D = A.digits_padded;
+    PHE_BOUNDS(S - P >= 2 && S - P <= kTableRowSlack && P + D + kFoldPadRows + 2 <= T::kRows + kTableRowSlack && A.base >= 0 &&
+               A.base + 3 < S && wv < (uint32_t)kTileWaves && A.limbs % 4 == 0 && 32 * A.limbs <= kRadixBits * S);
+    uint32_t* const buf_a = tile;                    // A[digit][e]: rows 0 .. S - 1, row S zero
+    uint32_t* const buf_b = tile + (S + 1) * kTile;  // B[digit][e]: rows 0 .. S - 1 (B[-1] is A's zero row)
     const uint64_t n_tiles = (A.batch + kTile - 1) / kTile;
-    // element of the tile this limb group works on in half `it` of phases 1 and 3, and its row of the batch (clamped)
-    auto element = [&](int it) { return wv * 8u + (uint32_t)it * 4u + wave::reread(gw); };
-    auto item_of = [&](uint64_t tile_i, int it) {
-        const uint64_t item = tile_i * kTile + element(it);
-        return item < A.batch ? item : A.batch - 1;
+    const int w0 = ((kRadixBits * CW * (int)wv) >> 5) & ~3;  // (wave-uniform) the 16-byte piece with the lowest bit of this wave's first digit
+    Words4 raw_a[T::kChunks], raw_b[T::kChunks];
+    auto request_rows = [&](uint64_t tile_i) __attribute__((always_inline)) {
+        uint64_t item = tile_i * kTile + wave::reread(lane);
+        if (item >= A.batch) item = A.batch - 1;
+        tile_request_row<L>(raw_a, A.a + item * A.a_stride + w0, w0, A.limbs);
+        tile_request_row<L>(raw_b, A.b + item * A.b_stride + w0, w0, A.limbs);
     };
-    if (block < n_tiles) {
-        const uint64_t first = item_of(block, 0);
-        stage_row_async<G, L>(stage_a, A.a + first * A.a_stride, A.limbs, g);
-        stage_row_async<G, L>(stage_b, A.b + first * A.b_stride, A.limbs, g);
-    }
+    if (block < n_tiles) request_rows(block);
 #if defined(PHE_TILE_PROFILE)
     uint64_t prof_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
 #endif
     for (uint64_t tile_i = block; tile_i < n_tiles; tile_i += n_blocks) {
-        // ---- phase 1: T = a*b, 2S digits into column e of the tile buffer ---------------------------------------------------------
-#pragma unroll 1
-        for (int it = 0; it < 2; ++it) {
-            const uint32_t e = element(it);
-            uint32_t y[L], hi[L], zero[L];
-            wave::wait_async_copies();
+        const uint32_t e = wave::reread(lane);
+        // ---- load: this wave's digits of a and b, all 64 elements ------------------------------------------------------------------
+        switch (((kRadixBits * CW * wv) >> 5) & 3u) {  // (wave-uniform: words of the first piece before the first digit)
+#define PHE_TILE_CUT(SKIP)                                \
+    case SKIP:                                            \
+        tile_cut_digits<L, SKIP>(buf_a + e, raw_a, wv);   \
+        tile_cut_digits<L, SKIP>(buf_b + e, raw_b, wv);   \
+        break;
+            PHE_TILE_CUT(0) PHE_TILE_CUT(1) PHE_TILE_CUT(2) PHE_TILE_CUT(3)
+#undef PHE_TILE_CUT
+            default: break;
+        }
+        if (wv == 0u) buf_a[S * kTile + e] = 0u;
+        wave::block_barrier();
+        PHE_TILE_MARK(0);  // load
+        // ---- product: column blocks wv (low) and wv + 8 (high) of T = a*b ---------------------------------------------------------
+        uint32_t t_low[CW], t_high[CW];
+        uint64_t out_low, out_high;
+        {
+            uint64_t acc[CW], upper[CW];
+            uint32_t win[CW];
+            // low block: columns p0 = CW wv ...; steps i = 0 .. p0 + CW - 1, the last CW of them with nothing left of b to enter
             {
-                const uint32_t gi = wave::reread(g), gwi = wave::reread(gw);
-                limbs_from_stage<G, L>(y, stage_b, gwi, gi);
-                digits_from_stage<G, L>(row, stage_a, gwi, gi);
-            }
-            wave::lds_fence();
-            {   // the next rows of this group: copied while this product runs (and, after the second half, under phases 2 and 3)
-                const bool more = it == 0 || tile_i + n_blocks < n_tiles;
-                if (more) {
-                    const uint64_t nxt = it == 0 ? item_of(tile_i, 1) : item_of(tile_i + n_blocks, 0);
-                    const uint32_t gi = wave::reread(g);
-                    stage_row_async<G, L>(stage_a, A.a + nxt * A.a_stride, A.limbs, gi);
-                    stage_row_async<G, L>(stage_b, A.b + nxt * A.b_stride, A.limbs, gi);
+                const wave::lds_u32* b_open = wave::reread_lds(buf_b + (size_t)(wv * CW) * kTile + e);  // (one address, CW immediates)
+#pragma unroll
+                for (int c = 0; c < CW; ++c) {
+                    acc[c] = 0;
+                    upper[c] = 0;
+                    win[c] = b_open[c * kTile];
                 }
             }
-#pragma unroll
-            for (int k = 0; k < L; ++k) zero[k] = 0u;
-            mul_wide<G, L>(hi, row, y, zero, tile + e, ln, S, kTile);
             {
-                const uint32_t gi = wave::reread(g);
-#pragma unroll
-                for (int k = 0; k < L; ++k) tile[(S + (int)gi * L + k) * kTile + (int)e] = hi[k];
+                const uint32_t* a_col = buf_a + e;
+                const uint32_t* b_col = buf_b + ((int)wv * CW - 1) * kTile + e;
+#pragma unroll 1
+                for (uint32_t t = 0; t < wv; ++t) {
+                    tile_product_steps<CW, true>(acc, win, a_col, b_col);
+                    a_col += CW * kTile;
+                    b_col -= CW * kTile;
+                    if (t & 1u) tile_hand_over<CW>(acc, upper);  // (2 CW products of < 2^58.01 between two hand-overs)
+                }
+                tile_product_steps<CW, false>(acc, win, a_col, b_col);
             }
+            out_low = tile_block_carries<CW>(t_low, acc, upper);
+            // high block: columns p0 = CW (wv + 8) ...; steps i = p0 - (S - 1) ... : the window opens on b[S - 1] alone
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                acc[c] = 0;
+                upper[c] = 0;
+                win[c] = 0u;
+            }
+            win[0] = buf_b[(S - 1) * kTile + (int)e];
+            {
+                const int i0 = CW * (int)wv + 1;  // (the last of the CW (8 - wv) steps reads a[S]: the zero row)
+                const uint32_t* a_col = buf_a + i0 * kTile + e;
+                const uint32_t* b_col = buf_b + (S - 2) * kTile + e;
+#pragma unroll 1
+                for (uint32_t t = 0; t < (uint32_t)kTileWaves - wv; ++t) {
+                    tile_product_steps<CW, true>(acc, win, a_col, b_col);
+                    a_col += CW * kTile;
+                    b_col -= CW * kTile;
+                    if (t & 1u) tile_hand_over<CW>(acc, upper);
+                }
+            }
+            out_high = tile_block_carries<CW>(t_high, acc, upper);
         }
-        PHE_TILE_MARK(0);  // product
-        wave::block_barrier();
-        PHE_TILE_MARK(1);  // barrier
-        // ---- phase 2: lane = element; this wave's 2L columns of y = lo_kept + sum_i f_i * C_i ------------------------------------
+        prod_carry[(wv * kTile + e) * 2u] = (uint32_t)out_low;
+        prod_carry[(wv * kTile + e) * 2u + 1u] = (uint32_t)(out_low >> 32);
+        prod_carry[((wv + 8u) * kTile + e) * 2u] = (uint32_t)out_high;
+        prod_carry[((wv + 8u) * kTile + e) * 2u + 1u] = (uint32_t)(out_high >> 32);
+        PHE_TILE_MARK(1);  // product
+        wave::block_barrier();  // every wave is through with A and B, every carry-out is in LDS
         {
-            const uint32_t e = wave::reread(lane);
+            // what left the block below enters the two lowest digits (digit 1 stays below 2^29 + 2^10: almost-normalised, as
+            // the fold's bound wants it); T over A and B
+            auto enter = [&](uint32_t (&t)[CW], uint32_t blk) {
+                const uint64_t c = ((uint64_t)prod_carry[((blk - 1u) * kTile + e) * 2u + 1u] << 32) | prod_carry[((blk - 1u) * kTile + e) * 2u];
+                const uint32_t d0 = t[0] + ((uint32_t)c & kLimbMask);
+                t[0] = d0 & kLimbMask;
+                t[1] += (uint32_t)(c >> kRadixBits) + (d0 >> kRadixBits);
+            };
+            if (wv != 0u) enter(t_low, wv);
+            enter(t_high, wv + 8u);
+            // (the low block's columns below P never reach LDS: they open this wave's own fold accumulators — same columns)
+            wave::lds_u32* t_rows = wave::reread_lds(tile + (size_t)(wv * CW) * kTile + e);
+#pragma unroll
+            for (int c = 0; c < CW; ++c) {
+                if ((int)wv * CW + c >= P) t_rows[c * kTile] = t_low[c];
+                t_rows[(8 * CW + c) * kTile] = t_high[c];
+            }
+            if (wv == 0u) tile[2 * S * kTile + e] = 0u;  // (row 2S: the fold's look-ahead reads it)
+        }
+        wave::block_barrier();
+        PHE_TILE_MARK(2);  // carries in, T written
+        // ---- fold: this wave's 2L columns of y = T_low + sum_i T[P + i] * C_i -----------------------------------------------------
+        {
             const int c0 = (int)wv * CW;
-            uint64_t acc[CW];
-            uint64_t upper[CW];  // what the accumulators' upper halves held at the hand-overs: column = acc + upper * 2^32
-                                 // (D * 2^58 can pass 2^65: the sum of the upper halves does not fit 32 bits)
+            uint64_t acc[CW], upper[CW];
 #pragma unroll
             for (int k = 0; k < CW; ++k) {
-                acc[k] = (c0 + k < P) ? tile[(c0 + k) * kTile + (int)e] : 0u;
+                acc[k] = (c0 + k < P) ? t_low[k] : 0u;
                 upper[k] = 0u;
             }
-            wave::block_barrier();  // (the settled columns below land on the rows the other waves open their accumulators from)
-            PHE_TILE_MARK(2);  // accumulators opened + barrier
             // Two fold digits per request group, two groups in flight: while one group is multiplied the table words (scalar
             // cache / L2 -> SGPRs) and digits (LDS) of the next one travel — 2 x 2L multiply-adds per wave, twice that with the
             // SIMD's other wave, to cover an L2 round trip (the 84 KB table streams through a 16 KB scalar cache: every read
             // of it is an L2 read).  The table carries kFoldPadRows zero rows past the last digit for the look-ahead.
-            const uint32_t* tw = A.table + (size_t)wv * (size_t)(A.digits_padded + kFoldPadRows) * CW;
+            const uint32_t* tw = A.table + (size_t)wv * (size_t)(D + kFoldPadRows) * CW;
             const uint32_t* digits = tile + (size_t)P * kTile + e;
             wave::ScalarRow<CW> ca[2], cb[2];
             wave::DigitPair da, db;
@@ -155,8 +322,8 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* top,
             ca[1].request(tw + CW);
             da.template request<0>(digits);
 #pragma unroll 1
-            for (int i0 = 0; i0 < A.digits_padded; i0 += kFoldChunk) {
-                const int n = (A.digits_padded - i0 < kFoldChunk) ? A.digits_padded - i0 : kFoldChunk;
+            for (int i0 = 0; i0 < D; i0 += kFoldChunk) {
+                const int n = (D - i0 < kFoldChunk) ? D - i0 : kFoldChunk;
 #pragma unroll 1
                 for (int i = 0; i < n; i += 4) {
                     const uint32_t* t4 = tw + (size_t)(i0 + i) * CW;
@@ -172,36 +339,37 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* top,
                     da.template request<4>(d4);
                     multiply(cb, db);
                 }
-#pragma unroll
-                for (int k = 0; k < CW; ++k) {
-                    upper[k] += acc[k] >> 32;
-                    acc[k] &= 0xffffffffull;
-                }
+                tile_hand_over<CW>(acc, upper);
             }
-            PHE_TILE_MARK(3);  // fold
             wave::arrived(ca[0], ca[1], da);  // (the look-ahead past the last digit: nothing may still be travelling to an SGPR)
-            // the carries run inside the lane; what leaves the block (< 2^38) is added by the settle phase one column up
-            uint64_t carry = 0;
+            PHE_TILE_MARK(3);  // fold
+            uint32_t y[CW];
+            const uint64_t carry = tile_block_carries<CW>(y, acc, upper);
 #pragma unroll
             for (int k = 0; k < CW; ++k) {
-                const uint64_t v = acc[k] + carry;
-                const uint32_t digit = (uint32_t)v & kLimbMask;
-                carry = (v >> kRadixBits) + (upper[k] << (32 - kRadixBits));
                 const int c = c0 + k;
-                if (c < P) tile[(size_t)e * P + c] = digit;
-                else top[e * kTableRowSlack + (c - P)] = digit;
+                if (c < P) tile[(size_t)e * P + c] = y[k];
+                else top[e * kTableRowSlack + (c - P)] = y[k];
             }
-            carries[(wv * kTile + e) * 2u] = (uint32_t)carry;
-            carries[(wv * kTile + e) * 2u + 1u] = (uint32_t)(carry >> 32);
+            fold_carry[(wv * kTile + e) * 2u] = (uint32_t)carry;
+            fold_carry[(wv * kTile + e) * 2u + 1u] = (uint32_t)(carry >> 32);
         }
         PHE_TILE_MARK(4);  // carries, columns to LDS
         wave::block_barrier();
         PHE_TILE_MARK(5);  // barrier
-        // ---- phase 3: back on the limb groups: y canonical, q^ = floor(y / N) - 1 or - 2, r = y - q^ N < 3 N, the residue ---------
+        // the next tile's rows travel under the settle (not under the fold: 64 rows per load instruction keep L2 busy, and the
+        // fold lives on the latency of its table words from L2 — measured: the fold took 2.3 times as long with them in flight)
+        // (requested for the last tile as well — its own rows again — so that the registers are dead from the cut to this point
+        // on every path: a conditional request keeps the old values alive through the product and spills them)
+        request_rows(tile_i + n_blocks < n_tiles ? tile_i + n_blocks : tile_i);
+        // ---- settle: 16 lanes per element (lane g = columns [L g, L g + L)), two elements per limb group: wv * 8 + it * 4 + lane / 16 ----
 #pragma unroll 1
         for (int it = 0; it < 2; ++it) {
-            const uint32_t e = element(it);
-            const uint64_t raw_item = tile_i * kTile + e;
+            const Lanes<GS> ln(lane);
+            const uint32_t g = ln.g;
+            const uint32_t es = wv * 8u + (uint32_t)it * 4u + wave::reread(lane) / GS;
+            uint32_t* row = rows + (wv * 4u + wave::reread(lane) / GS) * T::kRowT;
+            const uint64_t raw_item = tile_i * kTile + es;
             const bool live = raw_item < A.batch;
             const uint64_t item = live ? raw_item : A.batch - 1;
             uint64_t acc[L];
@@ -211,15 +379,14 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* top,
 #pragma unroll
                 for (int k = 0; k < L; ++k) {
                     const int c = (int)gi * L + k;
-                    acc[k] = (c < P) ? tile[(size_t)e * P + c] : top[e * kTableRowSlack + (c - P)];
+                    acc[k] = (c < P) ? tile[(size_t)es * P + c] : top[es * kTableRowSlack + (c - P)];
                 }
                 if ((gi & 1u) == 0u && gi >= 2u) {  // column 2L w' opens block w': the carry of block w' - 1 enters here
                     const uint32_t wb = gi / 2u - 1u;
-                    acc[0] += ((uint64_t)carries[(wb * kTile + e) * 2u + 1u] << 32) | carries[(wb * kTile + e) * 2u];
+                    acc[0] += ((uint64_t)fold_carry[(wb * kTile + es) * 2u + 1u] << 32) | fold_carry[(wb * kTile + es) * 2u];
                 }
             }
-            normalize_partial<G, L>(t, acc, ln);
-            normalize_full<G, L>(t, ln);
+            normalize_partial<GS, L>(t, acc, ln);  // (almost-normalised is enough for the estimate: limbs < 2^29 + a carry)
             lds_put<L>(row, t, g);
             uint32_t q0, q1;
             {
@@ -230,20 +397,20 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* top,
                 q0 = (uint32_t)q & kLimbMask;
                 q1 = (uint32_t)(q >> kRadixBits);
             }
-            {
+            {   // r = y - q^ N = (y + q^ (W^S - N)) mod W^S  <  3 N
                 uint32_t c0[L], c1[L];
                 load_row<L>(c0, cst + S, g);
                 load_row<L>(c1, cst + 2 * S, g);
 #pragma unroll
                 for (int k = 0; k < L; ++k) acc[k] = wave::mad64(q1, c1[k], wave::mad64(q0, c0[k], (uint64_t)t[k]));
             }
-            normalize_partial<G, L>(t, acc, ln);  // (the carry out of the top lane — q^ itself — is the multiple of W^S dropped)
+            normalize_partial<GS, L>(t, acc, ln);  // (the carry out of the top lane — q^ itself — is the multiple of W^S dropped)
             load_row<L>(n, cst, g);
-            canonicalize<G, L>(t, n, ln);
-            store_words<G, L>(A.out + item * A.out_stride, A.limbs, t, row, wave::reread(g), live);
+            canonicalize<GS, L>(t, n, ln);
+            store_words<GS, L>(A.out + item * A.out_stride, A.limbs, t, row, wave::reread(g), live);
         }
         PHE_TILE_MARK(6);  // settle + store
-        wave::block_barrier();  // the settled columns are read: the next tile's products may take the buffer
+        wave::block_barrier();  // the settled columns are read: the next tile's digits may take the buffer
         PHE_TILE_MARK(7);  // barrier
     }
 #if defined(PHE_TILE_PROFILE)

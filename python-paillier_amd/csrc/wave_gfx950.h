@@ -183,6 +183,17 @@ PHE_DEV uint64_t reread64(uint64_t x) {
 // address space itself (a per-lane choice between two LDS areas) instead of flat_* ones.
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 PHE_DEV lds_u32* as_lds(uint32_t* p) { return (lds_u32*)p; }
+// ... re-read (see reread_vptr): the address is recomputed here, and stays an LDS address (ds_* with immediate offsets)
+PHE_DEV lds_u32* reread_lds(uint32_t* p) {
+    lds_u32* q = (lds_u32*)p;
+    asm volatile("" : "+v"(q));
+    return q;
+}
+PHE_DEV const lds_u32* reread_lds(const uint32_t* p) {
+    const lds_u32* q = (const lds_u32*)p;
+    asm volatile("" : "+v"(q));
+    return q;
+}
 // two words to an 8-byte aligned LDS address as one ds_write_b64
 PHE_DEV void lds_store2(lds_u32* p, uint32_t a, uint32_t b) {
     typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
@@ -208,6 +219,18 @@ PHE_DEV void scalar_words(uint32_t (&c)[N], const uint32_t* p) {
 #pragma unroll
     for (int k = 0; k < N; ++k) c[k] = q[k];
 }
+
+// 16 bytes of global memory at a 4-byte aligned address as one global_load_dwordx4
+PHE_DEV void load16(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, const uint32_t* p) {
+    typedef uint32_t __attribute__((ext_vector_type(4), aligned(4))) u32x4_a4;
+    const u32x4_a4 v = *reinterpret_cast<const u32x4_a4*>(p);
+    a = v[0];
+    b = v[1];
+    c = v[2];
+    d = v[3];
+}
+// the instruction scheduler moves nothing across this point
+PHE_DEV void order_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 // ---- table words on the scalar path, requested ahead of their use (mul_tile.h) -------------------------------------------------
 // ScalarRow<N>: N (= 16 + 2 or 8 + 2) consecutive words at a wave-uniform address, in SGPRs.  request() issues the s_load and

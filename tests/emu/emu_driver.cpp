@@ -422,26 +422,23 @@ static void run_mul_table(TableMulArgs A, const host::TableMulPack& T) {
 // waves (one host thread each, joined by the barriers) per block
 template <int L>
 static void run_mul_tile(TableMulArgs A, const host::TableMulPack& T, int n_blocks) {
-    constexpr int G = 16, S = G * L, kRowT = S + kTableRowSlack;
-    using IO = RowIO<G, L>;
+    using TS = TileShape<L>;
     A.table = T.table_cols.data();
     A.digits_padded = T.digits_padded;
     for (int b = 0; b < n_blocks; ++b) {
         std::vector<Words4> lds((size_t)tile_lds_words<L>() / 4 + 1);
         uint32_t* tile = (uint32_t*)lds.data();
         for (size_t i = 0; i < lds.size() * 4; ++i) tile[i] = 0xdeadbeefu;   // LDS is not zero on the device either
-        uint32_t* top = tile + 2 * S * kTile;
-        uint32_t* carries = top + kTile * kTableRowSlack;
-        uint32_t* cst = carries + kTile * kTileWaves * 2;
-        uint32_t* rows = cst + 3 * S;
-        uint32_t* stage = rows + 32 * kRowT;
-        memcpy(cst, T.n.data(), S * 4);
-        memcpy(cst + S, T.ncomp.data(), S * 4);
-        memcpy(cst + 2 * S, T.ncomp1.data(), S * 4);
+        uint32_t* prod_carry = tile + TS::kRows * kTile;
+        uint32_t* top = prod_carry + 2 * 2 * kTileWaves * kTile;
+        uint32_t* fold_carry = top + kTile * kTableRowSlack;
+        uint32_t* cst = fold_carry + 2 * kTileWaves * kTile;
+        uint32_t* rows = cst + 3 * TS::S;
+        memcpy(cst, T.n.data(), TS::S * 4);
+        memcpy(cst + TS::S, T.ncomp.data(), TS::S * 4);
+        memcpy(cst + 2 * TS::S, T.ncomp1.data(), TS::S * 4);
         wave::run_block(kTileWaves, [&](uint32_t wv, uint32_t lane) {
-            const uint32_t grp = wv * 4 + lane / G;
-            mul_tile_body<L>(A, tile, top, carries, rows + grp * kRowT, stage + wv * 2 * IO::kStageWave, cst, wv, (uint32_t)b,
-                             (uint32_t)n_blocks, lane);
+            mul_tile_body<L>(A, tile, prod_carry, top, fold_carry, cst, rows, wv, (uint32_t)b, (uint32_t)n_blocks, lane);
         });
     }
 }

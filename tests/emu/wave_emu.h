@@ -270,6 +270,8 @@ struct DigitPair {
 };
 template <int N>
 inline void arrived(ScalarRow<N>&, ScalarRow<N>&, DigitPair&) {}
+inline void order_fence() {}
+inline void load16(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, const uint32_t* p) { a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
 inline uint32_t uniform(uint32_t x) { return x; }
 template <int N>
 inline void scalar_words(uint32_t (&c)[N], const uint32_t* p) {
@@ -282,6 +284,8 @@ inline uint32_t reread(uint32_t x) { return x; }  // see wave_gfx950.h: an optim
 inline uint64_t reread64(uint64_t x) { return x; }
 typedef uint32_t lds_u32;  // wave_gfx950.h: an LDS-address-space pointer on the device
 inline lds_u32* as_lds(uint32_t* p) { return p; }
+inline lds_u32* reread_lds(uint32_t* p) { return p; }
+inline const lds_u32* reread_lds(const uint32_t* p) { return p; }
 inline void lds_store2(lds_u32* p, uint32_t a, uint32_t b) { p[0] = a; p[1] = b; }
 inline void lds_store4(lds_u32* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 

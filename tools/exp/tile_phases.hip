@@ -51,7 +51,7 @@ int main(int argc, char** argv) {
         hipMemcpy(p, prof, 64, hipMemcpyDeviceToHost);
         double tot = 0;
         for (double v : p) tot += v;
-        printf("blocks %d: %.3f ms, %.1f M products/s; share of the waves' clocks: product %.1f%% | barrier %.1f%% | open %.1f%% | fold %.1f%% | "
+        printf("blocks %d: %.3f ms, %.1f M products/s; share of the waves' clocks: load %.1f%% | product %.1f%% | carries in %.1f%% | fold %.1f%% | "
                "carries %.1f%% | barrier %.1f%% | settle %.1f%% | barrier %.1f%%   (clocks per wave and tile: %.0f)\n",
                blocks, ms, batch / ms / 1e3, 100 * p[0] / tot, 100 * p[1] / tot, 100 * p[2] / tot, 100 * p[3] / tot, 100 * p[4] / tot,
                100 * p[5] / tot, 100 * p[6] / tot, 100 * p[7] / tot, tot / (8.0 * ((batch + 63) / 64)));
