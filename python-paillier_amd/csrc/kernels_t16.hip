@@ -45,8 +45,9 @@ __global__ void __launch_bounds__(kTableBlock, 1) k_mulmod_table(TableMulArgs A)
 
 // mul_tile.h: the same product with one element per lane: the workgroup owns tiles of 64 products, its eight waves split the
 // columns and meet at barriers between the phases; the fold's table words come through the scalar cache
+constexpr int kTileBlock = 64 * kTileWaves;
 template <int L>
-__global__ void __launch_bounds__(kTableBlock, 1) k_mulmod_tile(TableMulArgs A) {
+__global__ void __launch_bounds__(kTileBlock, 1) k_mulmod_tile(TableMulArgs A) {
     using T = TileShape<L>;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_t[];
     uint32_t* tile = lds_t;
@@ -55,8 +56,7 @@ __global__ void __launch_bounds__(kTableBlock, 1) k_mulmod_tile(TableMulArgs A) 
     uint32_t* fold_carry = top + kTile * kTableRowSlack;
     uint32_t* cst = fold_carry + 2 * kTileWaves * kTile;
     uint32_t* rows = cst + 3 * T::S;
-    static_assert(kTableBlock == 64 * kTileWaves, "one wave per column block");
-    for (int i = (int)threadIdx.x; i < T::S; i += kTableBlock) {
+    for (int i = (int)threadIdx.x; i < T::S; i += kTileBlock) {
         cst[i] = A.n[i];
         cst[T::S + i] = A.ncomp[i];
         cst[2 * T::S + i] = A.ncomp1[i];
@@ -76,7 +76,8 @@ static int launch_tile_L(int blocks, hipStream_t st, const TableMulArgs& A) {
         if (hipFuncSetAttribute((const void*)k_mulmod_tile<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
         allowed = true;
     }
-    k_mulmod_tile<L><<<dim3(blocks), dim3(kTableBlock), lds_bytes, st>>>(A);
+    if (A.tile_waves != kTileWaves) return -1;  // (the table's column blocks are cut for another workgroup shape)
+    k_mulmod_tile<L><<<dim3(blocks), dim3(kTileBlock), lds_bytes, st>>>(A);
     return 0;
 }
 // (A.table: the column-block layout)  -1: no kernel for this lane width; -2: the device refused the LDS size

@@ -740,7 +740,7 @@ inline PrivatePlan build_private(const uint32_t* p, const uint32_t* q, const uin
 // kernel's other areas (keys up to ~2700 bits: L = 5 or 9) — ok() false otherwise, mul_io.h's kernels serve.
 struct TableMulPack {
     int L = 0, S = 0;
-    int split = 0, digits = 0, base = 0, digits_padded = 0;
+    int split = 0, digits = 0, base = 0, digits_padded = 0, tile_waves = 0;
     double inv = 0.0;                          // W^base / N
     std::vector<uint32_t> n, ncomp, ncomp1;    // S limbs each: N, W^S - N, (W^S - N) * W mod W^S
     std::vector<uint32_t> table;               // digits rows of S words, device layout (mul_table.h table_row_limbs)
@@ -753,6 +753,7 @@ struct TableMulPack {
 // the Montgomery kernels there (818 M against 1024 M products/s: 80 limbs for a number of 71, and 5 multiply-adds per table read
 // and per shift) — kept compiled for the emulator tests, not offered by the library (build_table_mul's `offer_narrow`)
 static const int kTableL[] = {5, 9};
+constexpr int kTileWavesHost = 16;  // = mul_tile.h kTileWaves: the waves of its workgroup, the column blocks of table_cols
 constexpr size_t kTableLdsLimitBytes = 158 * 1024;  // of the 160 KB of a CU
 
 inline TableMulPack build_table_mul(const Big& N_any, int word_limbs, bool offer_narrow = true) {
@@ -797,13 +798,14 @@ inline TableMulPack build_table_mul(const Big& N_any, int word_limbs, bool offer
     const int full = L / 4, rem = L % 4;
     (void)kFullMax;
     T.table.assign((size_t)D * S, 0u);
-    const int cw = 2 * L;  // columns of one wave of mul_tile.h's fold: 8 waves x 2L = S
-    T.digits_padded = (D + 3) & ~3;
+    const int cw = S / kTileWavesHost;  // columns of one wave of mul_tile.h's fold
+    T.digits_padded = (D + 7) & ~7;
     const int d_rows = T.digits_padded + 4;  // (mul_tile.h kFoldPadRows: zero rows for the fold's look-ahead)
-    T.table_cols.assign((size_t)8 * d_rows * cw, 0u);
+    T.table_cols.assign((size_t)kTileWavesHost * d_rows * cw, 0u);
+    T.tile_waves = kTileWavesHost;
     for (int i = 0; i < D; ++i) {
         const std::vector<uint32_t> limbs = to_r29(c, S);
-        for (int w = 0; w < 8; ++w)
+        for (int w = 0; w < kTileWavesHost; ++w)
             for (int k = 0; k < cw; ++k) T.table_cols[((size_t)w * d_rows + (size_t)i) * cw + k] = limbs[(size_t)(w * cw + k)];
         uint32_t* row = T.table.data() + (size_t)i * S;
         for (int g = 0; g < 16; ++g) {
@@ -828,8 +830,9 @@ inline TableMulPack build_table_mul(const Big& N_any, int word_limbs, bool offer
     T.split = P;
     T.digits = D;
     T.lds_words = lds_words;
-    // mul_tile.h TileShape<L>::kLdsWords: tile buffer | product carries | top columns | fold carries | 3 constant rows | 32 digit rows
-    T.tile_lds_words = (2 * (size_t)S + 1) * 64 + 2 * 2 * 8 * 64 + 64 * 16 + 2 * 8 * 64 + 3 * (size_t)S + 32 * (size_t)(S + 4);
+    // mul_tile.h TileShape<L>::kLdsWords: tile buffer | product carries | top columns | fold carries | 3 constant rows | 4 W digit rows
+    T.tile_lds_words = (2 * (size_t)S + 1) * 64 + 2 * 2 * kTileWavesHost * 64 + 64 * 16 + 2 * kTileWavesHost * 64 + 3 * (size_t)S +
+                       4 * kTileWavesHost * (size_t)(S + 4);
     if (T.tile_lds_words * 4 > kTableLdsLimitBytes) T.tile_lds_words = 0;
     return T;
 }

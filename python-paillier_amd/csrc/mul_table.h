@@ -36,7 +36,8 @@ struct TableMulArgs {
     double inv;              // W^base / N
     int split;               // P: limbs of T below it are kept, the ones above are folded
     int digits;              // D: fold digits = (S - P) top limbs of the low half + the limbs the high half can have
-    int digits_padded;       // mul_tile.h: D rounded up to a multiple of 4 (the column-block table has zero rows from D on)
+    int digits_padded;       // mul_tile.h: D rounded up to a multiple of 8 (the column-block table has zero rows from D on)
+    int tile_waves;          // mul_tile.h: column blocks the table was cut into (= kTileWaves of the kernel)
     int base;                // limb index the quotient estimate reads y from (4 limbs: base ... base + 3)
     const uint32_t* a;
     const uint32_t* b;

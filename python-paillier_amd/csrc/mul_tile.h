@@ -50,7 +50,8 @@
 namespace phe {
 
 constexpr int kTile = 64;        // elements of a tile = lanes of a wave
-constexpr int kTileWaves = 8;    // waves of the workgroup; 2 * kTileWaves column blocks of 2L columns make the product
+constexpr int kTileWaves = 16;   // waves of the workgroup (W); 2 W column blocks of S / W columns make the product
+                                 // (key_setup.h kTileWavesHost: the table's column blocks)
 constexpr int kFoldPadRows = 4;  // zero rows the column-block table carries past its last digit (the fold's look-ahead)
 constexpr int kFoldChunk = 48;   // fold digits between two hand-overs of the accumulators' upper halves (48 * 2^58.01 + 2^32 < 2^64)
 
@@ -58,7 +59,8 @@ template <int L>
 struct TileShape {
     static constexpr int S = 16 * L;    // columns of the fold and of the settle; digit rows of an operand (the ones past its
                                         // last digit hold zeros)
-    static constexpr int CW = 2 * L;    // columns of a block: what one wave folds, what one lane of the settle holds
+    static constexpr int CW = S / kTileWaves;  // columns of a block: what one wave folds (L or 2L: lanes of the settle)
+    static constexpr int kFoldGroup = CW >= 16 ? 2 : 4;  // fold digits per request group (~36 table words in flight per group)
     static constexpr int kRows = 2 * S + 1;  // rows of the tile buffer: A (S rows + one zero row) | B (S rows); T (2S rows) over both
     // 32-bit words wave w must see to cut its digits [CW w, CW w + CW): from the 16-byte piece that holds bit 29 CW w on
     // (rows are whole 16-byte pieces: a piece is either inside the row or beyond it)
@@ -74,9 +76,9 @@ struct TileShape {
     }
     static constexpr int kChunks = max_chunks();
     static constexpr int kRowT = S + kLdsPad;  // a settle group's digit row
-    // LDS words: tile buffer | product carries (2 words x 16 blocks x 64) | top columns | fold carries | n, ncomp, ncomp1 | 32 digit rows
+    // LDS words: tile buffer | product carries (2 words x 2W blocks x 64) | top columns | fold carries | n, ncomp, ncomp1 | 4W digit rows
     static constexpr int kLdsWords = kRows * kTile + 2 * 2 * kTileWaves * kTile + kTile * kTableRowSlack + 2 * kTileWaves * kTile +
-                                     3 * S + 32 * kRowT;
+                                     3 * S + 4 * kTileWaves * kRowT;
 };
 template <int L>
 constexpr int tile_lds_words() {
@@ -174,8 +176,8 @@ PHE_DEV void tile_request_row(Words4 (&raw)[TileShape<L>::kChunks], const uint32
 
 // A.table: the fold table in the COLUMN-BLOCK layout [wave w][digit i][2L words]: limbs [2L w, 2L (w + 1)) of W^(P+i) mod N,
 // A.digits_padded + kFoldPadRows rows per wave (key_setup.h:build_table_mul writes both layouts).
-// tile: TileShape::kRows * 64 words; prod_carry: 2 * 16 * 64; top: 64 * kTableRowSlack; fold_carry: 2 * 8 * 64; cst: n | ncomp |
-// ncomp1 (S limbs each); rows: 32 digit rows of kRowT words.  `wv` must be wave-uniform; every wave of the workgroup runs the
+// tile: TileShape::kRows * 64 words; prod_carry: 2 * 2W * 64; top: 64 * kTableRowSlack; fold_carry: 2 * W * 64; cst: n | ncomp |
+// ncomp1 (S limbs each); rows: 4 W digit rows of kRowT words.  `wv` must be wave-uniform; every wave of the workgroup runs the
 // same number of tiles (the barriers).  Rows of a, b, out: A.limbs words (a multiple of 4), 16-byte aligned.
 template <int L>
 PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod_carry, uint32_t* top, uint32_t* fold_carry,
@@ -216,7 +218,7 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
         if (wv == 0u) buf_a[S * kTile + e] = 0u;
         wave::block_barrier();
         PHE_TILE_MARK(0);  // load
-        // ---- product: column blocks wv (low) and wv + 8 (high) of T = a*b ---------------------------------------------------------
+        // ---- product: column blocks wv (low) and wv + W (high) of T = a*b ---------------------------------------------------------
         uint32_t t_low[CW], t_high[CW];
         uint64_t out_low, out_high;
         {
@@ -245,7 +247,7 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
                 tile_product_steps<CW, false>(acc, win, a_col, b_col);
             }
             out_low = tile_block_carries<CW>(t_low, acc, upper);
-            // high block: columns p0 = CW (wv + 8) ...; steps i = p0 - (S - 1) ... : the window opens on b[S - 1] alone
+            // high block: columns p0 = CW (wv + W) ...; steps i = p0 - (S - 1) ... : the window opens on b[S - 1] alone
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
                 acc[c] = 0;
@@ -254,7 +256,7 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
             }
             win[0] = buf_b[(S - 1) * kTile + (int)e];
             {
-                const int i0 = CW * (int)wv + 1;  // (the last of the CW (8 - wv) steps reads a[S]: the zero row)
+                const int i0 = CW * (int)wv + 1;  // (the last of the CW (W - wv) steps reads a[S]: the zero row)
                 const uint32_t* a_col = buf_a + i0 * kTile + e;
                 const uint32_t* b_col = buf_b + (S - 2) * kTile + e;
 #pragma unroll 1
@@ -269,8 +271,8 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
         }
         prod_carry[(wv * kTile + e) * 2u] = (uint32_t)out_low;
         prod_carry[(wv * kTile + e) * 2u + 1u] = (uint32_t)(out_low >> 32);
-        prod_carry[((wv + 8u) * kTile + e) * 2u] = (uint32_t)out_high;
-        prod_carry[((wv + 8u) * kTile + e) * 2u + 1u] = (uint32_t)(out_high >> 32);
+        prod_carry[((wv + kTileWaves) * kTile + e) * 2u] = (uint32_t)out_high;
+        prod_carry[((wv + kTileWaves) * kTile + e) * 2u + 1u] = (uint32_t)(out_high >> 32);
         PHE_TILE_MARK(1);  // product
         wave::block_barrier();  // every wave is through with A and B, every carry-out is in LDS
         {
@@ -283,13 +285,13 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
                 t[1] += (uint32_t)(c >> kRadixBits) + (d0 >> kRadixBits);
             };
             if (wv != 0u) enter(t_low, wv);
-            enter(t_high, wv + 8u);
+            enter(t_high, wv + kTileWaves);
             // (the low block's columns below P never reach LDS: they open this wave's own fold accumulators — same columns)
             wave::lds_u32* t_rows = wave::reread_lds(tile + (size_t)(wv * CW) * kTile + e);
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
                 if ((int)wv * CW + c >= P) t_rows[c * kTile] = t_low[c];
-                t_rows[(8 * CW + c) * kTile] = t_high[c];
+                t_rows[(kTileWaves * CW + c) * kTile] = t_high[c];
             }
             if (wv == 0u) tile[2 * S * kTile + e] = 0u;  // (row 2S: the fold's look-ahead reads it)
         }
@@ -304,44 +306,45 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
                 acc[k] = (c0 + k < P) ? t_low[k] : 0u;
                 upper[k] = 0u;
             }
-            // Two fold digits per request group, two groups in flight: while one group is multiplied the table words (scalar
-            // cache / L2 -> SGPRs) and digits (LDS) of the next one travel — 2 x 2L multiply-adds per wave, twice that with the
-            // SIMD's other wave, to cover an L2 round trip (the 84 KB table streams through a 16 KB scalar cache: every read
+            // kFoldGroup fold digits per request group, two groups in flight: while one group is multiplied the table words
+            // (scalar cache / L2 -> SGPRs) and digits (LDS) of the next one travel — 36 multiply-adds per wave, times the waves
+            // of the SIMD, to cover an L2 round trip (the 84 KB table streams through a 16 KB scalar cache: every read
             // of it is an L2 read).  The table carries kFoldPadRows zero rows past the last digit for the look-ahead.
             const uint32_t* tw = A.table + (size_t)wv * (size_t)(D + kFoldPadRows) * CW;
             const uint32_t* digits = tile + (size_t)P * kTile + e;
-            wave::ScalarRow<CW> ca[2], cb[2];
-            wave::DigitPair da, db;
-            auto multiply = [&](const wave::ScalarRow<CW> (&c)[2], const wave::DigitPair& d) {
+            constexpr int GD = T::kFoldGroup, GP = GD / 2;
+            wave::ScalarRow<CW> ca[GD], cb[GD];
+            wave::DigitPair da[GP], db[GP];
+            auto request = [&](wave::ScalarRow<CW> (&c)[GD], wave::DigitPair (&d)[GP], const uint32_t* t, const uint32_t* dg) __attribute__((always_inline)) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int k = 0; k < CW; ++k) acc[k] = wave::mad64(d.word(u), c[u].word(k), acc[k]);
+                for (int u = 0; u < GD; ++u) c[u].request(t + u * CW);
+                d[0].template request<0>(dg);
+                if constexpr (GP > 1) d[1].template request<2>(dg);
             };
-            ca[0].request(tw);
-            ca[1].request(tw + CW);
-            da.template request<0>(digits);
+            auto multiply = [&](const wave::ScalarRow<CW> (&c)[GD], const wave::DigitPair (&d)[GP]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < GD; ++u)
+#pragma unroll
+                    for (int k = 0; k < CW; ++k) acc[k] = wave::mad64(d[u / 2].word(u % 2), c[u].word(k), acc[k]);
+            };
+            request(ca, da, tw, digits);
 #pragma unroll 1
             for (int i0 = 0; i0 < D; i0 += kFoldChunk) {
                 const int n = (D - i0 < kFoldChunk) ? D - i0 : kFoldChunk;
 #pragma unroll 1
-                for (int i = 0; i < n; i += 4) {
+                for (int i = 0; i < n; i += 2 * GD) {
                     const uint32_t* t4 = tw + (size_t)(i0 + i) * CW;
                     const uint32_t* d4 = digits + (size_t)(i0 + i) * kTile;
-                    wave::arrived(ca[0], ca[1], da);
-                    cb[0].request(t4 + 2 * CW);
-                    cb[1].request(t4 + 3 * CW);
-                    db.template request<2>(d4);
+                    wave::arrived<CW, GD>(ca, da);
+                    request(cb, db, t4 + GD * CW, d4 + GD * kTile);
                     multiply(ca, da);
-                    wave::arrived(cb[0], cb[1], db);
-                    ca[0].request(t4 + 4 * CW);
-                    ca[1].request(t4 + 5 * CW);
-                    da.template request<4>(d4);
+                    wave::arrived<CW, GD>(cb, db);
+                    request(ca, da, t4 + 2 * GD * CW, d4 + 2 * GD * kTile);
                     multiply(cb, db);
                 }
                 tile_hand_over<CW>(acc, upper);
             }
-            wave::arrived(ca[0], ca[1], da);  // (the look-ahead past the last digit: nothing may still be travelling to an SGPR)
+            wave::arrived<CW, GD>(ca, da);  // (the look-ahead past the last digit: nothing may still be travelling to an SGPR)
             PHE_TILE_MARK(3);  // fold
             uint32_t y[CW];
             const uint64_t carry = tile_block_carries<CW>(y, acc, upper);
@@ -362,12 +365,13 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
         // (requested for the last tile as well — its own rows again — so that the registers are dead from the cut to this point
         // on every path: a conditional request keeps the old values alive through the product and spills them)
         request_rows(tile_i + n_blocks < n_tiles ? tile_i + n_blocks : tile_i);
-        // ---- settle: 16 lanes per element (lane g = columns [L g, L g + L)), two elements per limb group: wv * 8 + it * 4 + lane / 16 ----
+        // ---- settle: 16 lanes per element (lane g = columns [L g, L g + L)); a wave's 64 / W elements four at a time ----------------------
+        constexpr int kPerWave = kTile / kTileWaves, kLanesPerBlock = CW / L;
 #pragma unroll 1
-        for (int it = 0; it < 2; ++it) {
+        for (int it = 0; it < kPerWave / 4; ++it) {
             const Lanes<GS> ln(lane);
             const uint32_t g = ln.g;
-            const uint32_t es = wv * 8u + (uint32_t)it * 4u + wave::reread(lane) / GS;
+            const uint32_t es = wv * (uint32_t)kPerWave + (uint32_t)it * 4u + wave::reread(lane) / GS;
             uint32_t* row = rows + (wv * 4u + wave::reread(lane) / GS) * T::kRowT;
             const uint64_t raw_item = tile_i * kTile + es;
             const bool live = raw_item < A.batch;
@@ -381,8 +385,8 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
                     const int c = (int)gi * L + k;
                     acc[k] = (c < P) ? tile[(size_t)es * P + c] : top[es * kTableRowSlack + (c - P)];
                 }
-                if ((gi & 1u) == 0u && gi >= 2u) {  // column 2L w' opens block w': the carry of block w' - 1 enters here
-                    const uint32_t wb = gi / 2u - 1u;
+                if (gi % kLanesPerBlock == 0u && gi >= (uint32_t)kLanesPerBlock) {  // the lane that opens block w': the carry of block w' - 1 enters
+                    const uint32_t wb = gi / kLanesPerBlock - 1u;
                     acc[0] += ((uint64_t)fold_carry[(wb * kTile + es) * 2u + 1u] << 32) | fold_carry[(wb * kTile + es) * 2u];
                 }
             }

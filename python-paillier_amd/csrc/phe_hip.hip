@@ -921,6 +921,10 @@ static int launch_var(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* bas
 // into LDS before its first product — measured against the Montgomery kernels on one box (profiles/r04g_*): 2^11 rows 71 M against
 // 87 M/s, 2^12 140 against 171, 2^13 276 against 212, 2^20 368 against 313
 static const size_t kTableMulMinRows = 8192;
+// ... and from this many rows on the tile kernel (mul_tile.h: one element per lane, a 1024-thread workgroup per CU takes 64 products
+// at a time): measured on one box (profiles/r04k_*, r04q_*), M products/s at 2^13 / 2^14 / 2^15 / 2^20 rows: two Montgomery
+// products 211 / 264 / 287 / 303, table in LDS 276 / 312 / 328 / 363, tiles 184 / 338 / 377 / 429
+static const size_t kTileMulMinRows = 16384;
 static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, size_t a_stride, const uint32_t* b,
                       size_t b_stride, uint32_t* out, size_t out_stride, int limbs, size_t batch,
                       hipStream_t stream, int b_plain_limbs = 0, int one_product = 0, int a_limbs = 0, bool plain_mulmod = false) {
@@ -952,8 +956,9 @@ static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, 
         B.limbs = limbs;
         B.batch = batch;
         B.digits_padded = T.digits_padded;
+        B.tile_waves = T.tile_waves;
         int rc = -1;
-        if (ctx->tmul_cols) {
+        if (ctx->tmul_cols && batch >= kTileMulMinRows) {
             // by tiles of 64 products per workgroup, the fold on one element per lane with the table words on the scalar path
             // (mul_tile.h); PHE_HIP_NO_TILE_MUL=1 keeps the kernel with the table in LDS
             TableMulArgs C = B;

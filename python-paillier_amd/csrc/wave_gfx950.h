@@ -260,7 +260,25 @@ struct ScalarRow<10> {
     }
     PHE_DEV uint32_t word(int k) const { return k < 8 ? lo[k] : hi[k - 8]; }
 };
-// every request issued so far has landed (and every LDS read: the counter is shared); the rows named are the ones read next
+template <>
+struct ScalarRow<9> {
+    u32x8 lo;
+    uint32_t hi;
+    PHE_DEV void request(const uint32_t* p) {
+        asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20" : "=&s"(lo), "=&s"(hi) : "s"(p) : "memory");
+    }
+    PHE_DEV uint32_t word(int k) const { return k < 8 ? lo[k] : hi; }
+};
+typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
+template <>
+struct ScalarRow<5> {
+    u32x4 lo;
+    uint32_t hi;
+    PHE_DEV void request(const uint32_t* p) {
+        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x10" : "=&s"(lo), "=&s"(hi) : "s"(p) : "memory");
+    }
+    PHE_DEV uint32_t word(int k) const { return k < 4 ? lo[k] : hi; }
+};
 // Two LDS words 64 rows of 4 bytes apart (rows ROW and ROW + 1 of a [row][64 lanes] buffer, this lane's column), requested the
 // same way: were the read left to the compiler, its own wait for it — the counter is shared with the scalar loads — would sit
 // in front of the first use and wait for the requests issued since.
@@ -273,9 +291,13 @@ struct DigitPair {
     }
     PHE_DEV uint32_t word(int u) const { return v[u]; }
 };
-template <int N>
-PHE_DEV void arrived(ScalarRow<N>& a, ScalarRow<N>& b, DigitPair& d) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a.lo), "+s"(a.hi), "+s"(b.lo), "+s"(b.hi), "+v"(d.v)::"memory");
+// every request issued so far has landed (and every LDS read: the counter is shared); c / d: the group read next (handing
+// them through here is what orders their uses after the wait)
+template <int N, int GD>
+PHE_DEV void arrived(ScalarRow<N> (&c)[GD], DigitPair (&d)[GD / 2]) {
+    static_assert(GD == 2 || GD == 4, "request groups of two or four fold digits");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c[0].lo), "+s"(c[0].hi), "+s"(c[1].lo), "+s"(c[1].hi), "+v"(d[0].v)::"memory");
+    if constexpr (GD == 4) asm volatile("" : "+s"(c[2].lo), "+s"(c[2].hi), "+s"(c[3].lo), "+s"(c[3].hi), "+v"(d[1].v)::"memory");
 }
 
 // 32x32+64 -> 64 multiply-accumulate: v_mad_u64_u32 with a full 64-bit addend.  The radix-2^29 core

@@ -425,6 +425,8 @@ static void run_mul_tile(TableMulArgs A, const host::TableMulPack& T, int n_bloc
     using TS = TileShape<L>;
     A.table = T.table_cols.data();
     A.digits_padded = T.digits_padded;
+    A.tile_waves = T.tile_waves;
+    static_assert(host::kTileWavesHost == kTileWaves, "the table's column blocks are the kernel's waves");
     for (int b = 0; b < n_blocks; ++b) {
         std::vector<Words4> lds((size_t)tile_lds_words<L>() / 4 + 1);
         uint32_t* tile = (uint32_t*)lds.data();

@@ -437,10 +437,11 @@ def test_product_by_one_plain_product_and_one_table_fold(emu, key_bits):
 
 @pytest.mark.parametrize("key_bits", [1024, 2048])
 def test_product_by_tiles_with_the_fold_on_one_element_per_lane(emu, key_bits):
-    """csrc/mul_tile.h (round 4): the arithmetic of mul_table.h by tiles of 64 products per workgroup — the product on 16-lane
-    groups, the fold on lane = element against the column-block table (the scalar-path words), the settle back on the groups;
-    8 emulated waves joined by the barriers.  Same canonical residues on the golden raw_add vectors, the edge operands, and
-    batches that are not a multiple of the tile (ragged last tile, more tiles than workgroups, fewer tiles than workgroups)."""
+    """csrc/mul_tile.h (round 4): the arithmetic of mul_table.h by tiles of 64 products per workgroup, ONE ELEMENT PER LANE: rows cut
+    to 29-bit digits in registers, the product as column blocks (a digit of a times a sliding window of b), the fold against the
+    column-block table (the scalar-path words), the settle on 16-lane groups; the workgroup's waves emulated as host threads joined
+    by the barriers.  Same canonical residues on the golden raw_add vectors, the edge operands (all-ones rows: every column sum
+    at its maximum), and batches that are not a multiple of the tile (ragged last tile, more tiles than workgroups, fewer)."""
     g = load_golden(key_bits)
     s2 = key_bits // 16
     n = H(g["n"])

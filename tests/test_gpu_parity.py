@@ -363,7 +363,7 @@ def test_raw_add_by_one_plain_product_and_one_table_fold(native, c_oracle, key_b
         ctx.sync()
         took_table = bool(ctx.last_launch()["path"] & ctx.PATH_TABLE_MUL)
         assert took_table == (batch >= 8192), (batch, ctx.last_launch())
-        assert bool(ctx.last_launch()["path"] & ctx.PATH_TILE_MUL) == took_table      # by tiles, the fold on lane = element (mul_tile.h)
+        assert bool(ctx.last_launch()["path"] & ctx.PATH_TILE_MUL) == (batch >= 16384)   # by tiles of 64, one element per lane (mul_tile.h)
         got = out.to_host()
         if took_table:
             other = in_lds.mulmod(a, b)

@@ -24,16 +24,16 @@ int main(int argc, char** argv) {
     hipMalloc((void**)&o, h.size() * 4);
     hipMemcpy(a, h.data(), h.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(b, h.data() + 64, (h.size() - 64) * 4, hipMemcpyHostToDevice);
-    std::vector<uint32_t> t((size_t)8 * (DP + kFoldPadRows) * 2 * L + 3 * S);
+    std::vector<uint32_t> t((size_t)kTileWaves * (DP + kFoldPadRows) * (S / kTileWaves) + 3 * S);
     for (auto& w : t) w = ((uint32_t)rand() * 2654435761u) & kLimbMask;
     hipMalloc((void**)&tbl, t.size() * 4);
     hipMemcpy(tbl, t.data(), t.size() * 4, hipMemcpyHostToDevice);
-    cst = tbl + (size_t)8 * (DP + kFoldPadRows) * 2 * L;
+    cst = tbl + (size_t)kTileWaves * (DP + kFoldPadRows) * (S / kTileWaves);
     hipMalloc((void**)&prof, 64);
     TableMulArgs A;
     A.n = cst; A.ncomp = cst + S; A.ncomp1 = cst + 2 * S; A.table = tbl; A.inv = 1e-9; A.split = P; A.digits = D; A.digits_padded = DP;
     A.base = P - 2; A.a = a; A.b = b; A.out = o; A.a_stride = A.b_stride = A.out_stride = limbs; A.limbs = limbs; A.batch = batch;
-    A.profile = prof;
+    A.profile = prof; A.tile_waves = kTileWaves;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
@@ -54,7 +54,7 @@ int main(int argc, char** argv) {
         printf("blocks %d: %.3f ms, %.1f M products/s; share of the waves' clocks: load %.1f%% | product %.1f%% | carries in %.1f%% | fold %.1f%% | "
                "carries %.1f%% | barrier %.1f%% | settle %.1f%% | barrier %.1f%%   (clocks per wave and tile: %.0f)\n",
                blocks, ms, batch / ms / 1e3, 100 * p[0] / tot, 100 * p[1] / tot, 100 * p[2] / tot, 100 * p[3] / tot, 100 * p[4] / tot,
-               100 * p[5] / tot, 100 * p[6] / tot, 100 * p[7] / tot, tot / (8.0 * ((batch + 63) / 64)));
+               100 * p[5] / tot, 100 * p[6] / tot, 100 * p[7] / tot, tot / ((double)kTileWaves * ((batch + 63) / 64)));
     }
     return 0;
 }
