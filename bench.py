@@ -1007,7 +1007,8 @@ def main():
                     continue
                 if name == "raw_add_resident_chain":
                     adds = rec["additions_per_s"] / world
-                    half = (counted["raw_add"] / 2) if counted else None      # one of the two products of the plain form
+                    two = counted.get("raw_add_two_montgomery_products", counted.get("raw_add")) if counted else None
+                    half = (two / 2) if two else None                           # one of the two products of the Montgomery form
                     rec["roofline"] = {"bound": "valu_int32", "canonical_mac32_per_op": canon["raw_add"],
                                        "canonical_frac": canon["raw_add"] * adds / peak,
                                        "executed_mad_per_op": half * 9 / 8 if half else None,
@@ -1020,6 +1021,8 @@ def main():
                                    "canonical_frac": canon[ck] * per_gpu / peak,
                                    "executed_mad_per_op": ex, "frac": (ex * per_gpu / peak) if ex else None}
             add_bytes = 3 * s2 * 4
+            if counted and counted.get("raw_add_form"):
+                ops["raw_add"]["roofline"]["form"] = counted["raw_add_form"]
             ops["raw_add"]["roofline"].update(hbm_algorithmic_GBps=add_bytes * ops["raw_add"]["value"] / world / 1e9,
                                               hbm_frac=add_bytes * ops["raw_add"]["value"] / world / 8e12)
         out = {

@@ -723,6 +723,15 @@ int emu_decrypt(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const 
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
+// what the LIBRARY takes for phe_hip_mulmod on large batches of this modulus (phe_hip.hip launch_mul: build_table_mul without the
+// narrow lane widths): 0 two Montgomery products, 1 the table in LDS (mul_table.h) only, 2 tiles (mul_tile.h)
+int emu_table_mul_offered(const uint32_t* N, int limbs) {
+    try {
+        const host::TableMulPack T = host::build_table_mul(host::big_from(N, limbs, limbs), limbs, false);
+        return !T.ok() ? 0 : (T.tile_lds_words ? 2 : 1);
+    } catch (...) { return 0; }
+}
+
 int emu_mulmod_table(const uint32_t* N, int limbs, const uint32_t* a, const uint32_t* b, uint32_t* out, uint64_t B) {
     try {
         if (B == 0) return 0;

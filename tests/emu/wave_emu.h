@@ -209,6 +209,14 @@ inline void block_barrier() {
     if (e->cur == 0 && block_barrier_object()) pthread_barrier_wait(block_barrier_object());
 }
 
+// every mad64 is one v_mad_u64_u32 lane-operation on the device: counted here so that tools/count_executed_mads.py can
+// state EXACTLY how many multiply-adds a kernel issues per element (bench.py's roofline.executed), not a hand model
+// (per host thread; run_block adds what its wave threads counted to the caller's)
+inline uint64_t& mad_counter() {
+    static thread_local uint64_t count = 0;
+    return count;
+}
+
 // run `body(wave, lane)` for the waves of one workgroup, one host thread per wave; block_barrier() joins them
 inline void run_block(int n_waves, const std::function<void(uint32_t, uint32_t)>& body) {
     pthread_barrier_t bar;
@@ -217,20 +225,25 @@ inline void run_block(int n_waves, const std::function<void(uint32_t, uint32_t)>
     struct Arg {
         const std::function<void(uint32_t, uint32_t)>* body;
         uint32_t wave;
+        uint64_t mads;
     };
     std::vector<pthread_t> th((size_t)n_waves);
     std::vector<Arg> args((size_t)n_waves);
     for (int w = 0; w < n_waves; ++w) {
-        args[(size_t)w] = Arg{&body, (uint32_t)w};
+        args[(size_t)w] = Arg{&body, (uint32_t)w, 0};
         pthread_create(&th[(size_t)w], nullptr, [](void* p) -> void* {
             Arg* a = (Arg*)p;
             const uint32_t wv = a->wave;
             const auto* fn = a->body;
             run_wave([&](uint32_t lane) { (*fn)(wv, lane); });
+            a->mads = mad_counter();
             return nullptr;
         }, &args[(size_t)w]);
     }
-    for (int w = 0; w < n_waves; ++w) pthread_join(th[(size_t)w], nullptr);
+    for (int w = 0; w < n_waves; ++w) {
+        pthread_join(th[(size_t)w], nullptr);
+        mad_counter() += args[(size_t)w].mads;
+    }
     block_barrier_object() = nullptr;
     pthread_barrier_destroy(&bar);
 }
@@ -289,12 +302,6 @@ inline const lds_u32* reread_lds(const uint32_t* p) { return p; }
 inline void lds_store2(lds_u32* p, uint32_t a, uint32_t b) { p[0] = a; p[1] = b; }
 inline void lds_store4(lds_u32* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) { p[0] = a; p[1] = b; p[2] = c; p[3] = d; }
 
-// every mad64 is one v_mad_u64_u32 lane-operation on the device: counted here so that tools/count_executed_mads.py can
-// state EXACTLY how many multiply-adds a kernel issues per element (bench.py's roofline.executed), not a hand model
-inline uint64_t& mad_counter() {
-    static thread_local uint64_t count = 0;
-    return count;
-}
 inline uint64_t mad64(uint32_t a, uint32_t b, uint64_t c) {
     ++mad_counter();
     return (uint64_t)a * b + c;

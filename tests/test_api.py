@@ -608,6 +608,7 @@ def test_obfuscator_pool_is_handed_out_once_across_threads():
     eng = _engine.Engine.__new__(_engine.Engine)
     eng._lock = threading.RLock()
     eng.ct_limbs = Block.cols
+    eng._pair_words = 0                                   # (no pair form on this stand-in: the pool holds ciphertext rows)
     eng._obf = _engine.ObfuscatorPool()
     eng._obf.add(Block(0, 20000))
     taken, barrier = [[] for _ in range(8)], threading.Barrier(8)
@@ -651,6 +652,7 @@ def test_pool_survives_the_private_engine_taking_over_under_concurrent_takers(mo
             time.sleep(0.02)                                  # a slow context creation widens the window
             self._lock = threading.RLock()
             self.n, self.ct_limbs = n, Block.cols
+            self._pair_words = 0                               # (no pair form on this stand-in)
             self._obf = _engine.ObfuscatorPool()
             built.append("priv" if p is not None else "pub")
 

@@ -48,7 +48,12 @@ def test_exact_counts_back_the_model():
     enc, dec = bench.executed_mads(2048, info)
     assert abs(counted["encrypt"] / enc - 1) < 0.01 and abs(counted["decrypt"] / dec - 1) < 0.01
     assert counted["encrypt"] < bench.mac32_counts(2048)[0]
-    assert counted["raw_add"] == 4 * 144 * 144                 # two full-width 144-limb Montgomery products
+    assert counted["raw_add_two_montgomery_products"] == 4 * 144 * 144       # two full-width 144-limb Montgomery products
+    # ... which is not what a large batch runs any more (round 4): one plain product + one fold against the key's table, by tiles
+    # with one element per lane (mul_tile.h) — about half the multiply-adds (padding of the column blocks included)
+    assert counted["raw_add_form"] == "tiles" and counted["raw_add"] == counted["raw_add_tiles"]
+    assert 0.95 * 2 * 144 * 144 < counted["raw_add_table_in_lds"] < counted["raw_add_tiles"] < 1.1 * 2 * 144 * 144
+    assert bench.counted_mads(1024, dict(info, lane_limbs_pub=218))[0]["raw_add_form"] == "two_montgomery_products"
     # the count per geometry of the CRT halves (the ladder may end on another rung than the narrowest: 3072 bits run the halves
     # on 4 x 14): same work on 2 x 18 and 4 x 9 (both 36 limbs), more on 56 limbs than on 54
     assert counted["decrypt_by_halves_geometry"]["218"] == counted["decrypt"] == counted["decrypt_by_halves_geometry"]["409"]

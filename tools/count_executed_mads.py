@@ -83,7 +83,7 @@ def main():
         # the same per geometry of the CRT halves: the ladder may end on another rung than the narrowest (3072 bits: 4 x 14,
         # not 2 x 27, since the wide-rung factor of rung_cost) — bench.py looks the count up by what last_launch reported
         by_geom = {}
-        for group in (0, 4):
+        for group in (0, 1, 4):
             emu.set_group(group)
             emu.set_wave_tail(wave_tail)
             try:
@@ -95,8 +95,20 @@ def main():
             by_geom[str(G * 100 + L)] = count() / B
             assert np.array_equal(back, m)
         res["decrypt_by_halves_geometry"] = by_geom
-        emu.mulmod(nsq_arr, c, np.ascontiguousarray(c[::-1]))
-        res["raw_add"] = count() / B
+        # _raw_add as the library runs it on large batches: two Montgomery products, or — where the key's table is offered —
+        # one plain product + one fold (mul_table.h; by tiles with one element per lane: mul_tile.h); every form is counted
+        c_rev = np.ascontiguousarray(c[::-1])
+        want = emu.mulmod(nsq_arr, c, c_rev)
+        res["raw_add_two_montgomery_products"] = count() / B
+        offered = int(emu.L.emu_table_mul_offered(nsq_arr.ctypes.data_as(ctypes.c_void_p), s2))
+        res["raw_add_form"] = ["two_montgomery_products", "table_in_lds", "tiles"][offered]
+        if offered:
+            assert np.array_equal(emu.mulmod_table(nsq_arr, c, c_rev), want)
+            res["raw_add_table_in_lds"] = count() / B
+        if offered == 2:
+            assert np.array_equal(emu.mulmod_table(nsq_arr, c, c_rev, tiles=True, blocks=1), want)
+            res["raw_add_tiles"] = count() / B
+        res["raw_add"] = res["raw_add_" + res["raw_add_form"]]
         emu.add_plain(n_arr, c, m)
         res["add_plain"] = count() / B
         for name, ebits in (("raw_mul_56bit", 56), ("raw_mul_63bit", 63)):
