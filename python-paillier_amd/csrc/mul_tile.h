@@ -218,6 +218,7 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
         if (wv == 0u) buf_a[S * kTile + e] = 0u;
         wave::block_barrier();
         PHE_TILE_MARK(0);  // load
+        wave::set_priority(3);
         // ---- product: column blocks wv (low) and wv + W (high) of T = a*b ---------------------------------------------------------
         uint32_t t_low[CW], t_high[CW];
         uint64_t out_low, out_high;
@@ -239,11 +240,13 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
                 const uint32_t* b_col = buf_b + ((int)wv * CW - 1) * kTile + e;
 #pragma unroll 1
                 for (uint32_t t = 0; t < wv; ++t) {
+                    wave::set_priority(3 - (int)(4u * t / (kTileWaves + 1u)));  // (blocks done of kTileWaves + 1: see set_priority)
                     tile_product_steps<CW, true>(acc, win, a_col, b_col);
                     a_col += CW * kTile;
                     b_col -= CW * kTile;
                     if (t & 1u) tile_hand_over<CW>(acc, upper);  // (2 CW products of < 2^58.01 between two hand-overs)
                 }
+                wave::set_priority(3 - (int)(4u * wv / (kTileWaves + 1u)));
                 tile_product_steps<CW, false>(acc, win, a_col, b_col);
             }
             out_low = tile_block_carries<CW>(t_low, acc, upper);
@@ -261,6 +264,7 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
                 const uint32_t* b_col = buf_b + (S - 2) * kTile + e;
 #pragma unroll 1
                 for (uint32_t t = 0; t < (uint32_t)kTileWaves - wv; ++t) {
+                    wave::set_priority(3 - (int)(4u * (wv + 1u + t) / (kTileWaves + 1u)));
                     tile_product_steps<CW, true>(acc, win, a_col, b_col);
                     a_col += CW * kTile;
                     b_col -= CW * kTile;
@@ -275,6 +279,7 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
         prod_carry[((wv + kTileWaves) * kTile + e) * 2u + 1u] = (uint32_t)(out_high >> 32);
         PHE_TILE_MARK(1);  // product
         wave::block_barrier();  // every wave is through with A and B, every carry-out is in LDS
+        PHE_TILE_MARK(2);  // barrier
         {
             // what left the block below enters the two lowest digits (digit 1 stays below 2^29 + 2^10: almost-normalised, as
             // the fold's bound wants it); T over A and B
@@ -296,7 +301,7 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
             if (wv == 0u) tile[2 * S * kTile + e] = 0u;  // (row 2S: the fold's look-ahead reads it)
         }
         wave::block_barrier();
-        PHE_TILE_MARK(2);  // carries in, T written
+        PHE_TILE_MARK(3);  // carries in, T written, barrier
         // ---- fold: this wave's 2L columns of y = T_low + sum_i T[P + i] * C_i -----------------------------------------------------
         {
             const int c0 = (int)wv * CW;
@@ -333,6 +338,7 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
                 const int n = (D - i0 < kFoldChunk) ? D - i0 : kFoldChunk;
 #pragma unroll 1
                 for (int i = 0; i < n; i += 2 * GD) {
+                    wave::set_priority(3 - 4 * (i0 + i) / D);
                     const uint32_t* t4 = tw + (size_t)(i0 + i) * CW;
                     const uint32_t* d4 = digits + (size_t)(i0 + i) * kTile;
                     wave::arrived<CW, GD>(ca, da);
@@ -345,7 +351,7 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
                 tile_hand_over<CW>(acc, upper);
             }
             wave::arrived<CW, GD>(ca, da);  // (the look-ahead past the last digit: nothing may still be travelling to an SGPR)
-            PHE_TILE_MARK(3);  // fold
+            PHE_TILE_MARK(4);  // fold
             uint32_t y[CW];
             const uint64_t carry = tile_block_carries<CW>(y, acc, upper);
 #pragma unroll
@@ -357,9 +363,8 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
             fold_carry[(wv * kTile + e) * 2u] = (uint32_t)carry;
             fold_carry[(wv * kTile + e) * 2u + 1u] = (uint32_t)(carry >> 32);
         }
-        PHE_TILE_MARK(4);  // carries, columns to LDS
         wave::block_barrier();
-        PHE_TILE_MARK(5);  // barrier
+        PHE_TILE_MARK(5);  // carries, columns to LDS, barrier
         // the next tile's rows travel under the settle (not under the fold: 64 rows per load instruction keep L2 busy, and the
         // fold lives on the latency of its table words from L2 — measured: the fold took 2.3 times as long with them in flight)
         // (requested for the last tile as well — its own rows again — so that the registers are dead from the cut to this point
@@ -418,8 +423,11 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
         PHE_TILE_MARK(7);  // barrier
     }
 #if defined(PHE_TILE_PROFILE)
-    if (lane == 0u)
+    if (lane == 0u) {
         for (int i = 0; i < 8; ++i) atomicAdd((unsigned long long*)A.profile + i, (unsigned long long)prof_[i]);
+        atomicAdd((unsigned long long*)A.profile + 8 + wv, (unsigned long long)prof_[1]);        // product clocks by wave
+        atomicAdd((unsigned long long*)A.profile + 8 + 16 + wv, (unsigned long long)prof_[4]);   // fold clocks by wave
+    }
 #endif
 }
 

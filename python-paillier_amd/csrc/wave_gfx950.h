@@ -229,6 +229,18 @@ PHE_DEV void load16(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, const ui
     c = v[2];
     d = v[3];
 }
+// Issue priority of this wave among the waves of its SIMD (0 lowest ... 3; the arbiter takes the highest priority first, the
+// oldest wave among equals).  The waves of a workgroup that share a SIMD are served oldest first: with equal work the youngest
+// finishes last and alone — and a lone wave fills half of the SIMD's issue slots.  A wave that lowers its priority as it gets
+// through its share lets the ones behind it catch up (mul_tile.h).
+PHE_DEV void set_priority(int level) {
+    switch (level) {
+        case 3: __builtin_amdgcn_s_setprio(3); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(0); break;
+    }
+}
 // the instruction scheduler moves nothing across this point
 PHE_DEV void order_fence() { __builtin_amdgcn_sched_barrier(0); }
 

@@ -284,6 +284,7 @@ struct DigitPair {
 template <int N, int GD>
 inline void arrived(ScalarRow<N> (&)[GD], DigitPair (&)[GD / 2]) {}
 inline void order_fence() {}
+inline void set_priority(int) {}
 inline void load16(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, const uint32_t* p) { a = p[0]; b = p[1]; c = p[2]; d = p[3]; }
 inline uint32_t uniform(uint32_t x) { return x; }
 template <int N>
