@@ -55,7 +55,6 @@ __global__ void __launch_bounds__(kTileBlock, 1) k_mulmod_tile(TableMulArgs A) {
     uint32_t* top = prod_carry + 2 * 2 * kTileWaves * kTile;
     uint32_t* fold_carry = top + kTile * kTableRowSlack;
     uint32_t* cst = fold_carry + 2 * kTileWaves * kTile;
-    uint32_t* rows = cst + 3 * T::S;
     for (int i = (int)threadIdx.x; i < T::S; i += kTileBlock) {
         cst[i] = A.n[i];
         cst[T::S + i] = A.ncomp[i];
@@ -63,7 +62,7 @@ __global__ void __launch_bounds__(kTileBlock, 1) k_mulmod_tile(TableMulArgs A) {
     }
     __syncthreads();
     const uint32_t wv = wave::uniform(threadIdx.x / 64u);
-    mul_tile_body<L>(A, tile, prod_carry, top, fold_carry, cst, rows, wv, blockIdx.x, gridDim.x, threadIdx.x & 63u);
+    mul_tile_body<L>(A, tile, prod_carry, top, fold_carry, cst, wv, blockIdx.x, gridDim.x, threadIdx.x & 63u);
 }
 
 namespace t16 {
@@ -85,6 +84,7 @@ int launch_mul_tile(int L, int blocks, hipStream_t st, const TableMulArgs& A) {
     switch (L) {
         case 5: return launch_tile_L<5>(blocks, st, A);
         case 9: return launch_tile_L<9>(blocks, st, A);
+        case 14: return launch_tile_L<14>(blocks, st, A);
         default: return -1;
     }
 }

@@ -737,7 +737,8 @@ inline PrivatePlan build_private(const uint32_t* p, const uint32_t* q, const uin
 // ---- a*b mod N as one plain product + one fold against a table (csrc/mul_table.h) ---------------------------------------------
 // G = 16 lanes x L limbs, S = 16 L >= (bits(N) + 38) / 29 limbs; P = ceil(bits(N) / 29): the limbs of T = a*b at and above P are
 // the D fold digits, row i of the table is W^(P+i) mod N (W = 2^29).  Offered while the table fits the LDS of a CU beside the
-// kernel's other areas (keys up to ~2700 bits: L = 5 or 9) — ok() false otherwise, mul_io.h's kernels serve.
+// kernel's other areas (keys up to ~2700 bits: L = 5 or 9); mul_tile.h keeps the table in L2 and serves 3072-bit keys (L = 14) too —
+// ok() false when neither is offered: mul_io.h's kernels serve.
 struct TableMulPack {
     int L = 0, S = 0;
     int split = 0, digits = 0, base = 0, digits_padded = 0, tile_waves = 0;
@@ -747,12 +748,14 @@ struct TableMulPack {
     std::vector<uint32_t> table_cols;          // the same rows in the column-block layout [wave][digit][2L words] (mul_tile.h)
     size_t lds_words = 0;
     size_t tile_lds_words = 0;                 // LDS of mul_tile.h's workgroup (no table in it)
-    bool ok() const { return L != 0; }
+    bool ok() const { return L != 0; }                  // some form of the product is offered:
+    bool in_lds() const { return lds_words != 0; }      //   mul_table.h (L = 5, 9: the table fits a CU's LDS beside the rest)
+    bool tiles() const { return tile_lds_words != 0; }  //   mul_tile.h
 };
 // lane widths offered: 9 (n^2 of ~1850 ... 2048-bit keys).  5 limbs per lane (1024-bit keys) was built and measured SLOWER than
 // the Montgomery kernels there (818 M against 1024 M products/s: 80 limbs for a number of 71, and 5 multiply-adds per table read
 // and per shift) — kept compiled for the emulator tests, not offered by the library (build_table_mul's `offer_narrow`)
-static const int kTableL[] = {5, 9};
+static const int kTableL[] = {5, 9, 14};
 constexpr int kTileWavesHost = 16;  // = mul_tile.h kTileWaves: the waves of its workgroup, the column blocks of table_cols
 constexpr size_t kTableLdsLimitBytes = 158 * 1024;  // of the 160 KB of a CU
 
@@ -775,8 +778,13 @@ inline TableMulPack build_table_mul(const Big& N_any, int word_limbs, bool offer
     if (n_lo < 2 || n_lo > 16 || hi_limbs > S) return T;
     // LDS of the 512-thread workgroup (mul_table.h table_lds_words): table | 3 constant rows | 32 digit rows | 8 x 2 staging areas
     const int k_words = (S * kRadixBits + 31) / 32, k_vec = (k_words + 1 + 63) / 64;
-    const size_t lds_words = (size_t)D * S + 3 * (size_t)S + 32 * (size_t)(S + 16) + 8 * 2 * (size_t)(256 * k_vec);
-    if (lds_words * 4 > kTableLdsLimitBytes) return T;
+    size_t lds_words = (size_t)D * S + 3 * (size_t)S + 32 * (size_t)(S + 16) + 8 * 2 * (size_t)(256 * k_vec);
+    if (lds_words * 4 > kTableLdsLimitBytes || L > 9) lds_words = 0;  // (mul_table.h is compiled for L = 5, 9)
+    // mul_tile.h TileShape<L>::kLdsWords: tile buffer (the settle's digit rows inside it) | product carries | top columns | fold carries | 3 constant rows
+    const size_t tile_rows = std::max<size_t>(2 * (size_t)S + 1, (size_t)(S - 2) + (size_t)(S + 4));
+    size_t tile_lds_words = tile_rows * 64 + 2 * 2 * kTileWavesHost * 64 + 64 * 16 + 2 * kTileWavesHost * 64 + 3 * (size_t)S;
+    if (tile_lds_words * 4 > kTableLdsLimitBytes) tile_lds_words = 0;
+    if (!lds_words && !tile_lds_words) return T;
     const int w32 = (kRadixBits * S + 31) / 32 + 1;  // words that hold W^S
     const Big N = big_resize(N_any, w32);
     if ((N[0] & 1u) == 0u) return T;
@@ -830,10 +838,7 @@ inline TableMulPack build_table_mul(const Big& N_any, int word_limbs, bool offer
     T.split = P;
     T.digits = D;
     T.lds_words = lds_words;
-    // mul_tile.h TileShape<L>::kLdsWords: tile buffer | product carries | top columns | fold carries | 3 constant rows | 4 W digit rows
-    T.tile_lds_words = (2 * (size_t)S + 1) * 64 + 2 * 2 * kTileWavesHost * 64 + 64 * 16 + 2 * kTileWavesHost * 64 + 3 * (size_t)S +
-                       4 * kTileWavesHost * (size_t)(S + 4);
-    if (T.tile_lds_words * 4 > kTableLdsLimitBytes) T.tile_lds_words = 0;
+    T.tile_lds_words = tile_lds_words;
     return T;
 }
 

@@ -30,6 +30,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "mont_core.h"
 #include "mul_io.h"
 #include "mul_table.h"
@@ -60,8 +62,13 @@ struct TileShape {
     static constexpr int S = 16 * L;    // columns of the fold and of the settle; digit rows of an operand (the ones past its
                                         // last digit hold zeros)
     static constexpr int CW = S / kTileWaves;  // columns of a block: what one wave folds (L or 2L: lanes of the settle)
-    static constexpr int kFoldGroup = CW >= 16 ? 2 : 4;  // fold digits per request group (~36 table words in flight per group)
-    static constexpr int kRows = 2 * S + 1;  // rows of the tile buffer: A (S rows + one zero row) | B (S rows); T (2S rows) over both
+    static constexpr int kFoldGroup = CW > 10 ? 2 : 4;  // fold digits per request group (28 ... 40 table words in flight per group)
+    static constexpr int kRowT = S + kLdsPad;  // a settle group's digit row
+    // rows of the tile buffer: A (S rows + one zero row) | B (S rows); T (2S rows) over both; during the settle the settled
+    // columns y[element][column] lie in rows [0, P) and the 64 digit rows of the limb groups from row S - 2 on (P <= S - 2: the
+    // fold's digits there are dead by then)
+    static constexpr int kSettleRow0 = S - 2;
+    static constexpr int kRows = (2 * S + 1 > kSettleRow0 + kRowT) ? 2 * S + 1 : kSettleRow0 + kRowT;
     // 32-bit words wave w must see to cut its digits [CW w, CW w + CW): from the 16-byte piece that holds bit 29 CW w on
     // (rows are whole 16-byte pieces: a piece is either inside the row or beyond it)
     static constexpr int first_word(int w) { return ((kRadixBits * CW * w) >> 5) & ~3; }
@@ -75,36 +82,45 @@ struct TileShape {
         return m;
     }
     static constexpr int kChunks = max_chunks();
-    static constexpr int kRowT = S + kLdsPad;  // a settle group's digit row
-    // LDS words: tile buffer | product carries (2 words x 2W blocks x 64) | top columns | fold carries | n, ncomp, ncomp1 | 4W digit rows
-    static constexpr int kLdsWords = kRows * kTile + 2 * 2 * kTileWaves * kTile + kTile * kTableRowSlack + 2 * kTileWaves * kTile +
-                                     3 * S + 4 * kTileWaves * kRowT;
+    static_assert(4 * kTileWaves == kTile, "one digit row per limb group of the settle: 64 rows of kRowT words = kRowT rows of the buffer");
+    // LDS words: tile buffer | product carries (2 words x 2W blocks x 64) | top columns | fold carries | n, ncomp, ncomp1
+    static constexpr int kLdsWords = kRows * kTile + 2 * 2 * kTileWaves * kTile + kTile * kTableRowSlack + 2 * kTileWaves * kTile + 3 * S;
 };
 template <int L>
 constexpr int tile_lds_words() {
     return TileShape<L>::kLdsWords;
 }
 
-// 64-bit column sums of one lane -> digits below 2^29 and the carry that leaves the block (sum = acc + upper * 2^32)
+// A column sum of up to 2S products of < 2^58.01 (almost 2^66) is kept as  acc + upper * 2^B:  acc a 64-bit accumulator that is cut
+// back below 2^B at every hand-over (so that 48 more products fit), upper the sum of what was cut.  B = 32 costs nothing to cut
+// (the accumulator's upper register) but the sum of the cuts needs 34 bits — two registers per column; B = 36 fits 32 bits (one
+// shift more per hand-over).  Narrow blocks (2048-bit keys: 9 columns) have the registers and take B = 32 (same box: 2 % faster);
+// at 14 columns (3072-bit keys) the second register per column spills inside the product loop and B = 36 is 18 % faster.
 template <int CW>
-PHE_DEV uint64_t tile_block_carries(uint32_t (&digit)[CW], const uint64_t (&acc)[CW], const uint64_t (&upper)[CW]) {
+struct TileUpper {
+    static constexpr int kBits = CW > 10 ? 36 : 32;
+    typedef typename std::conditional<(CW > 10), uint32_t, uint64_t>::type word;
+};
+template <int CW>
+PHE_DEV void tile_hand_over(uint64_t (&acc)[CW], typename TileUpper<CW>::word (&upper)[CW]) {
+    constexpr int B = TileUpper<CW>::kBits;
+#pragma unroll
+    for (int k = 0; k < CW; ++k) {
+        upper[k] += (typename TileUpper<CW>::word)(acc[k] >> B);
+        acc[k] &= (1ull << B) - 1u;
+    }
+}
+// the column sums of one lane -> digits below 2^29 and the carry that leaves the block (< 2^38)
+template <int CW>
+PHE_DEV uint64_t tile_block_carries(uint32_t (&digit)[CW], const uint64_t (&acc)[CW], const typename TileUpper<CW>::word (&upper)[CW]) {
     uint64_t carry = 0;
 #pragma unroll
     for (int k = 0; k < CW; ++k) {
         const uint64_t v = (acc[k] & 0xffffffffull) + carry;
         digit[k] = (uint32_t)v & kLimbMask;
-        carry = (v >> kRadixBits) + ((upper[k] + (acc[k] >> 32)) << (32 - kRadixBits));
+        carry = (v >> kRadixBits) + ((acc[k] >> 32) << (32 - kRadixBits)) + ((uint64_t)upper[k] << (TileUpper<CW>::kBits - kRadixBits));
     }
     return carry;
-}
-// the upper halves of the accumulators to their own sums (D * 2^58 can pass 2^65: they need more than 32 bits)
-template <int CW>
-PHE_DEV void tile_hand_over(uint64_t (&acc)[CW], uint64_t (&upper)[CW]) {
-#pragma unroll
-    for (int k = 0; k < CW; ++k) {
-        upper[k] += acc[k] >> 32;
-        acc[k] &= 0xffffffffull;
-    }
 }
 
 // CW steps of a column block of the product.  Before: win[j] = b[q0 + j] (q0 = the block's lowest column minus the step
@@ -114,21 +130,33 @@ PHE_DEV void tile_hand_over(uint64_t (&acc)[CW], uint64_t (&upper)[CW]) {
 // the digits that would enter lie below b[0] (the last CW steps of a low block).
 template <int CW, bool LOADS>
 PHE_DEV void tile_product_steps(uint64_t (&acc)[CW], uint32_t (&win)[CW], const uint32_t* a_col, const uint32_t* b_col) {
-    // the 2 CW digits of the block first, then CW * CW multiply-adds with nothing to wait for (left to place the reads itself
-    // the compiler puts each one in front of its first use, with the wait for it)
-    uint32_t ad[CW], bd[CW];
+    // the digits of (half) the block first, then the multiply-adds with nothing to wait for (left to place the reads itself the
+    // compiler puts each one in front of its first use, with the wait for it).  Wide blocks take the digits in two halves: 2 CW
+    // registers for them are what spills at CW = 14.
+    constexpr int kParts = CW > 10 ? 2 : 1, kPer = (CW + kParts - 1) / kParts;
     const uint32_t* b_low = b_col - (CW - 1) * kTile;
 #pragma unroll
-    for (int u = 0; u < CW; ++u) {
-        ad[u] = a_col[u * kTile];
-        bd[u] = LOADS ? b_low[(CW - 1 - u) * kTile] : 0u;  // (offsets from the block's lowest row: immediates of the LDS reads)
-    }
-    wave::order_fence();
+    for (int part = 0; part < kParts; ++part) {
+        uint32_t ad[kPer], bd[kPer];
 #pragma unroll
-    for (int u = 0; u < CW; ++u) {
+        for (int v = 0; v < kPer; ++v) {
+            const int u = part * kPer + v;
+            if (u < CW) {
+                ad[v] = a_col[u * kTile];
+                bd[v] = LOADS ? b_low[(CW - 1 - u) * kTile] : 0u;  // (offsets from the block's lowest row: immediates of the LDS reads)
+            }
+        }
+        wave::order_fence();
 #pragma unroll
-        for (int c = 0; c < CW; ++c) acc[c] = wave::mad64(ad[u], win[(c - u + CW) % CW], acc[c]);
-        win[CW - 1 - u] = bd[u];
+        for (int v = 0; v < kPer; ++v) {
+            const int u = part * kPer + v;
+            if (u < CW) {
+#pragma unroll
+                for (int c = 0; c < CW; ++c) acc[c] = wave::mad64(ad[v], win[(c - u + CW) % CW], acc[c]);
+                win[CW - 1 - u] = bd[v];
+            }
+        }
+        wave::order_fence();
     }
 }
 
@@ -177,15 +205,15 @@ PHE_DEV void tile_request_row(Words4 (&raw)[TileShape<L>::kChunks], const uint32
 // A.table: the fold table in the COLUMN-BLOCK layout [wave w][digit i][2L words]: limbs [2L w, 2L (w + 1)) of W^(P+i) mod N,
 // A.digits_padded + kFoldPadRows rows per wave (key_setup.h:build_table_mul writes both layouts).
 // tile: TileShape::kRows * 64 words; prod_carry: 2 * 2W * 64; top: 64 * kTableRowSlack; fold_carry: 2 * W * 64; cst: n | ncomp |
-// ncomp1 (S limbs each); rows: 4 W digit rows of kRowT words.  `wv` must be wave-uniform; every wave of the workgroup runs the
+// ncomp1 (S limbs each).  `wv` must be wave-uniform; every wave of the workgroup runs the
 // same number of tiles (the barriers).  Rows of a, b, out: A.limbs words (a multiple of 4), 16-byte aligned.
 template <int L>
 PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod_carry, uint32_t* top, uint32_t* fold_carry,
-                           const uint32_t* cst, uint32_t* rows, uint32_t wv, uint32_t block, uint32_t n_blocks, uint32_t lane) {
+                           const uint32_t* cst, uint32_t wv, uint32_t block, uint32_t n_blocks, uint32_t lane) {
     using T = TileShape<L>;
     constexpr int S = T::S, CW = T::CW, GS = 16;  // (GS: lanes per element of the settle)
     const int P = A.split, D = A.digits_padded;
-    PHE_BOUNDS(S - P >= 2 && S - P <= kTableRowSlack && P + D + kFoldPadRows + 2 <= T::kRows + kTableRowSlack && A.base >= 0 &&
+    PHE_BOUNDS(S - P >= 2 && S - P <= kTableRowSlack && P + D + kFoldPadRows + 2 <= T::kRows + kTableRowSlack && P <= T::kSettleRow0 && A.base >= 0 &&
                A.base + 3 < S && wv < (uint32_t)kTileWaves && A.limbs % 4 == 0 && 32 * A.limbs <= kRadixBits * S);
     uint32_t* const buf_a = tile;                    // A[digit][e]: rows 0 .. S - 1, row S zero
     uint32_t* const buf_b = tile + (S + 1) * kTile;  // B[digit][e]: rows 0 .. S - 1 (B[-1] is A's zero row)
@@ -223,7 +251,8 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
         uint32_t t_low[CW], t_high[CW];
         uint64_t out_low, out_high;
         {
-            uint64_t acc[CW], upper[CW];
+            uint64_t acc[CW];
+            typename TileUpper<CW>::word upper[CW];
             uint32_t win[CW];
             // low block: columns p0 = CW wv ...; steps i = 0 .. p0 + CW - 1, the last CW of them with nothing left of b to enter
             {
@@ -305,7 +334,8 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
         // ---- fold: this wave's 2L columns of y = T_low + sum_i T[P + i] * C_i -----------------------------------------------------
         {
             const int c0 = (int)wv * CW;
-            uint64_t acc[CW], upper[CW];
+            uint64_t acc[CW];
+            typename TileUpper<CW>::word upper[CW];
 #pragma unroll
             for (int k = 0; k < CW; ++k) {
                 acc[k] = (c0 + k < P) ? t_low[k] : 0u;
@@ -377,7 +407,7 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
             const Lanes<GS> ln(lane);
             const uint32_t g = ln.g;
             const uint32_t es = wv * (uint32_t)kPerWave + (uint32_t)it * 4u + wave::reread(lane) / GS;
-            uint32_t* row = rows + (wv * 4u + wave::reread(lane) / GS) * T::kRowT;
+            uint32_t* row = tile + (size_t)T::kSettleRow0 * kTile + (wv * 4u + wave::reread(lane) / GS) * T::kRowT;
             const uint64_t raw_item = tile_i * kTile + es;
             const bool live = raw_item < A.batch;
             const uint64_t item = live ? raw_item : A.batch - 1;

@@ -958,7 +958,7 @@ static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, 
         B.digits_padded = T.digits_padded;
         B.tile_waves = T.tile_waves;
         int rc = -1;
-        if (ctx->tmul_cols && batch >= kTileMulMinRows) {
+        if (ctx->tmul_cols && batch >= (getenv("PHE_HIP_TABLE_MUL_MIN_ROWS") ? min_rows : kTileMulMinRows)) {
             // by tiles of 64 products per workgroup, the fold on one element per lane with the table words on the scalar path
             // (mul_tile.h); PHE_HIP_NO_TILE_MUL=1 keeps the kernel with the table in LDS
             TableMulArgs C = B;
@@ -967,7 +967,7 @@ static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, 
             rc = phe::t16::launch_mul_tile(T.L, (int)std::max<size_t>(1, std::min(tiles, (size_t)ctx->n_cus)), stream, C);
             if (rc == 0) ctx->last_path |= kPathTileMul;
         }
-        if (rc != 0) {
+        if (rc != 0 && T.in_lds()) {
             (void)hipGetLastError();
             const size_t per_block = 32;  // limb groups of a 512-thread workgroup
             const int blocks = (int)std::max<size_t>(1, std::min((batch + per_block - 1) / per_block, (size_t)ctx->n_cus));
@@ -1224,10 +1224,10 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
             std::vector<uint32_t> h(T.n);
             h.insert(h.end(), T.ncomp.begin(), T.ncomp.end());
             h.insert(h.end(), T.ncomp1.begin(), T.ncomp1.end());
-            h.insert(h.end(), T.table.begin(), T.table.end());
+            if (T.in_lds()) h.insert(h.end(), T.table.begin(), T.table.end());  // (3072-bit keys: the tile kernel only, table in L2)
             HIP_TRY(hipMalloc((void**)&ctx->tmul_blob, h.size() * 4));
             HIP_TRY(hipMemcpy(ctx->tmul_blob, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-            if (T.tile_lds_words && !getenv("PHE_HIP_NO_TILE_MUL")) {
+            if (T.tiles() && !getenv("PHE_HIP_NO_TILE_MUL")) {
                 HIP_TRY(hipMalloc((void**)&ctx->tmul_cols, T.table_cols.size() * 4));
                 HIP_TRY(hipMemcpy(ctx->tmul_cols, T.table_cols.data(), T.table_cols.size() * 4, hipMemcpyHostToDevice));
             }

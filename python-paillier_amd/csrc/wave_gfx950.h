@@ -252,6 +252,7 @@ PHE_DEV void order_fence() { __builtin_amdgcn_sched_barrier(0); }
 typedef uint32_t __attribute__((ext_vector_type(16))) u32x16;
 typedef uint32_t __attribute__((ext_vector_type(8))) u32x8;
 typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
 template <int N>
 struct ScalarRow;
 template <>
@@ -262,6 +263,7 @@ struct ScalarRow<18> {
         asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x40" : "=&s"(lo), "=&s"(hi) : "s"(p) : "memory");
     }
     PHE_DEV uint32_t word(int k) const { return k < 16 ? lo[k] : hi[k - 16]; }
+    PHE_DEV void landed() { asm volatile("" : "+s"(lo), "+s"(hi)); }
 };
 template <>
 struct ScalarRow<10> {
@@ -271,6 +273,21 @@ struct ScalarRow<10> {
         asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20" : "=&s"(lo), "=&s"(hi) : "s"(p) : "memory");
     }
     PHE_DEV uint32_t word(int k) const { return k < 8 ? lo[k] : hi[k - 8]; }
+    PHE_DEV void landed() { asm volatile("" : "+s"(lo), "+s"(hi)); }
+};
+template <>
+struct ScalarRow<14> {
+    u32x8 lo;
+    u32x4 mid;
+    u32x2 hi;
+    PHE_DEV void request(const uint32_t* p) {
+        asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx4 %1, %3, 0x20\n\ts_load_dwordx2 %2, %3, 0x30"
+                     : "=&s"(lo), "=&s"(mid), "=&s"(hi)
+                     : "s"(p)
+                     : "memory");
+    }
+    PHE_DEV uint32_t word(int k) const { return k < 8 ? lo[k] : (k < 12 ? mid[k - 8] : hi[k - 12]); }
+    PHE_DEV void landed() { asm volatile("" : "+s"(lo), "+s"(mid), "+s"(hi)); }
 };
 template <>
 struct ScalarRow<9> {
@@ -280,8 +297,8 @@ struct ScalarRow<9> {
         asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20" : "=&s"(lo), "=&s"(hi) : "s"(p) : "memory");
     }
     PHE_DEV uint32_t word(int k) const { return k < 8 ? lo[k] : hi; }
+    PHE_DEV void landed() { asm volatile("" : "+s"(lo), "+s"(hi)); }
 };
-typedef uint32_t __attribute__((ext_vector_type(4))) u32x4;
 template <>
 struct ScalarRow<5> {
     u32x4 lo;
@@ -290,6 +307,7 @@ struct ScalarRow<5> {
         asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x10" : "=&s"(lo), "=&s"(hi) : "s"(p) : "memory");
     }
     PHE_DEV uint32_t word(int k) const { return k < 4 ? lo[k] : hi; }
+    PHE_DEV void landed() { asm volatile("" : "+s"(lo), "+s"(hi)); }
 };
 // Two LDS words 64 rows of 4 bytes apart (rows ROW and ROW + 1 of a [row][64 lanes] buffer, this lane's column), requested the
 // same way: were the read left to the compiler, its own wait for it — the counter is shared with the scalar loads — would sit
@@ -302,14 +320,17 @@ struct DigitPair {
         asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=&v"(v) : "v"(addr), "n"(ROW), "n"(ROW + 1) : "memory");
     }
     PHE_DEV uint32_t word(int u) const { return v[u]; }
+    PHE_DEV void landed() { asm volatile("" : "+v"(v)); }
 };
 // every request issued so far has landed (and every LDS read: the counter is shared); c / d: the group read next (handing
 // them through here is what orders their uses after the wait)
 template <int N, int GD>
 PHE_DEV void arrived(ScalarRow<N> (&c)[GD], DigitPair (&d)[GD / 2]) {
-    static_assert(GD == 2 || GD == 4, "request groups of two or four fold digits");
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c[0].lo), "+s"(c[0].hi), "+s"(c[1].lo), "+s"(c[1].hi), "+v"(d[0].v)::"memory");
-    if constexpr (GD == 4) asm volatile("" : "+s"(c[2].lo), "+s"(c[2].hi), "+s"(c[3].lo), "+s"(c[3].hi), "+v"(d[1].v)::"memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int u = 0; u < GD; ++u) c[u].landed();  // (volatile, so they stay behind the wait; the uses depend on what they hand back)
+#pragma unroll
+    for (int u = 0; u < GD / 2; ++u) d[u].landed();
 }
 
 // 32x32+64 -> 64 multiply-accumulate: v_mad_u64_u32 with a full 64-bit addend.  The radix-2^29 core

@@ -435,12 +435,11 @@ static void run_mul_tile(TableMulArgs A, const host::TableMulPack& T, int n_bloc
         uint32_t* top = prod_carry + 2 * 2 * kTileWaves * kTile;
         uint32_t* fold_carry = top + kTile * kTableRowSlack;
         uint32_t* cst = fold_carry + 2 * kTileWaves * kTile;
-        uint32_t* rows = cst + 3 * TS::S;
         memcpy(cst, T.n.data(), TS::S * 4);
         memcpy(cst + TS::S, T.ncomp.data(), TS::S * 4);
         memcpy(cst + 2 * TS::S, T.ncomp1.data(), TS::S * 4);
         wave::run_block(kTileWaves, [&](uint32_t wv, uint32_t lane) {
-            mul_tile_body<L>(A, tile, prod_carry, top, fold_carry, cst, rows, wv, (uint32_t)b, (uint32_t)n_blocks, lane);
+            mul_tile_body<L>(A, tile, prod_carry, top, fold_carry, cst, wv, (uint32_t)b, (uint32_t)n_blocks, lane);
         });
     }
 }
@@ -723,12 +722,12 @@ int emu_decrypt(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const 
     } catch (const std::exception& e) { g_err = e.what(); return 1; }
 }
 
-// what the LIBRARY takes for phe_hip_mulmod on large batches of this modulus (phe_hip.hip launch_mul: build_table_mul without the
-// narrow lane widths): 0 two Montgomery products, 1 the table in LDS (mul_table.h) only, 2 tiles (mul_tile.h)
+// what the LIBRARY offers for phe_hip_mulmod on this modulus besides the two Montgomery products (phe_hip.hip launch_mul:
+// build_table_mul without the narrow lane widths): bit 0 the table in LDS (mul_table.h), bit 1 tiles (mul_tile.h: large batches)
 int emu_table_mul_offered(const uint32_t* N, int limbs) {
     try {
         const host::TableMulPack T = host::build_table_mul(host::big_from(N, limbs, limbs), limbs, false);
-        return !T.ok() ? 0 : (T.tile_lds_words ? 2 : 1);
+        return !T.ok() ? 0 : ((T.in_lds() ? 1 : 0) | (T.tiles() ? 2 : 0));
     } catch (...) { return 0; }
 }
 
@@ -747,10 +746,12 @@ int emu_mulmod_table(const uint32_t* N, int limbs, const uint32_t* a, const uint
         A.a = (const uint32_t*)a4.data(); A.b = (const uint32_t*)b4.data(); A.out = (uint32_t*)o4.data();
         A.a_stride = A.b_stride = A.out_stride = (size_t)limbs; A.limbs = limbs; A.batch = B;
         if (limbs % 4) return 2;
+        if (!g_tile_mul && !T.in_lds()) return 2;
         if (g_tile_mul) {
-            if (!T.tile_lds_words) return 2;
+            if (!T.tiles()) return 2;
             if (T.L == 5) run_mul_tile<5>(A, T, g_tile_blocks);
             else if (T.L == 9) run_mul_tile<9>(A, T, g_tile_blocks);
+            else if (T.L == 14) run_mul_tile<14>(A, T, g_tile_blocks);
             else return 2;
         } else if (T.L == 5) run_mul_table<5>(A, T);
         else if (T.L == 9) run_mul_table<9>(A, T);

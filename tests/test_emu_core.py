@@ -2,6 +2,8 @@
 compiled for the host on a fiber-based wavefront emulator (tests/emu/) and compared, limb for limb,
 with the golden fixtures (real reference) and the libgmp oracle."""
 import ctypes
+import json
+import os
 import random
 
 import numpy as np
@@ -435,7 +437,7 @@ def test_product_by_one_plain_product_and_one_table_fold(emu, key_bits):
     assert table_mads * 1.9 < two_products, (table_mads, two_products)        # about half the multiply-adds per product
 
 
-@pytest.mark.parametrize("key_bits", [1024, 2048])
+@pytest.mark.parametrize("key_bits", [1024, 2048, 3072])
 def test_product_by_tiles_with_the_fold_on_one_element_per_lane(emu, key_bits):
     """csrc/mul_tile.h (round 4): the arithmetic of mul_table.h by tiles of 64 products per workgroup, ONE ELEMENT PER LANE: rows cut
     to 29-bit digits in registers, the product as column blocks (a digit of a times a sliding window of b), the fold against the
@@ -462,14 +464,20 @@ def test_product_by_tiles_with_the_fold_on_one_element_per_lane(emu, key_bits):
     assert limbs_to_ints(out) == want
     assert limbs_to_ints(emu.mulmod_table(Nl, a[:70], b[:70], tiles=True, blocks=3)) == want[:70]   # a workgroup without a tile
     assert limbs_to_ints(emu.mulmod_table(Nl, a[:5], b[:5], tiles=True, blocks=1)) == want[:5]
-    assert np.array_equal(out, emu.mulmod_table(Nl, a, b))                 # ... and the bits of mul_table.h
+    in_lds = emu.mulmod_table(Nl, a, b)                                    # ... and the bits of mul_table.h where its table fits LDS
+    assert (in_lds is None) == (key_bits == 3072) and (in_lds is None or np.array_equal(out, in_lds))
 
 
 def test_table_product_is_not_offered_where_the_table_does_not_fit(emu):
     g = load_golden(3072)
     N = H(g["n"]) ** 2
     a = ints_to_limbs([5, 6], 192)
-    assert emu.mulmod_table(int_to_limbs(N, 192), a, a) is None
+    assert emu.mulmod_table(int_to_limbs(N, 192), a, a) is None                        # 212 rows of 224 limbs: not in LDS
+    assert limbs_to_ints(emu.mulmod_table(int_to_limbs(N, 192), a, a, tiles=True)) == [25, 36]   # ... the tile kernel keeps it in L2
+    p4 = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "paillier_4096_primes.json")))
+    N = (int(p4["p"], 16) * int(p4["q"], 16)) ** 2
+    a = ints_to_limbs([5, 6], 256)
+    assert emu.mulmod_table(int_to_limbs(N, 256), a, a, tiles=True) is None              # 4096-bit keys: no lane width compiled
 
 
 @pytest.mark.parametrize("key_bits", [256, 1024, 2048, 3072])

@@ -325,7 +325,7 @@ def test_one_product_entry_and_debt_constants(native, key_bits, batch, group):
     assert native.limbs_to_ints(out.to_host()) == [x * y % N for x, y in zip(a, b)]
 
 
-@pytest.mark.parametrize("key_bits", [1024, 2048])
+@pytest.mark.parametrize("key_bits", [1024, 2048, 3072])
 def test_raw_add_by_one_plain_product_and_one_table_fold(native, c_oracle, key_bits, monkeypatch):
     """Round 4: phe_hip_mulmod / _raw_add (phe/paillier.py:705-719 -> phe/util.py:53-64) as ONE plain
     product + ONE fold against the key's table in LDS (csrc/mul_table.h, k_mulmod_table) — the path asserted, every row of
@@ -362,12 +362,13 @@ def test_raw_add_by_one_plain_product_and_one_table_fold(native, c_oracle, key_b
         ctx.mulmod_dev(da.ptr, db.ptr, out.ptr, batch)
         ctx.sync()
         took_table = bool(ctx.last_launch()["path"] & ctx.PATH_TABLE_MUL)
-        assert took_table == (batch >= 8192), (batch, ctx.last_launch())
+        # 3072-bit keys: the table (212 rows of 224 limbs) does not fit LDS — no k_mulmod_table, the tile kernel from 16384 rows on
+        assert took_table == (batch >= (8192 if key_bits < 3072 else 16384)), (batch, ctx.last_launch())
         assert bool(ctx.last_launch()["path"] & ctx.PATH_TILE_MUL) == (batch >= 16384)   # by tiles of 64, one element per lane (mul_tile.h)
         got = out.to_host()
         if took_table:
             other = in_lds.mulmod(a, b)
-            assert in_lds.last_launch()["path"] & (ctx.PATH_TABLE_MUL | ctx.PATH_TILE_MUL) == ctx.PATH_TABLE_MUL
+            assert in_lds.last_launch()["path"] & (ctx.PATH_TABLE_MUL | ctx.PATH_TILE_MUL) == (ctx.PATH_TABLE_MUL if key_bits < 3072 else 0)
             assert np.array_equal(got, other), batch
         assert native.limbs_to_ints(got[:len(edge)]) == [x * y % N for x, y in edge], batch
         if batch <= 20000:
@@ -384,7 +385,7 @@ def test_raw_add_by_one_plain_product_and_one_table_fold(native, c_oracle, key_b
     a = rs.integers(0, 1 << 32, size=(9000, s2), dtype=np.uint32)
     b = rs.integers(0, 1 << 32, size=(9000, s2), dtype=np.uint32)
     got = ctx.mulmod(a, b)
-    assert ctx.last_launch()["path"] & ctx.PATH_TABLE_MUL
+    assert bool(ctx.last_launch()["path"] & ctx.PATH_TABLE_MUL) == (key_bits < 3072)          # (9000 rows)
     assert native.limbs_to_ints(got[:200]) == [int(x) * int(y) % N for x, y in zip(native.limbs_to_ints(a[:200]), native.limbs_to_ints(b[:200]))]
     # rows 4 bytes off a 16-byte boundary: the plain Montgomery body
     flat = lambda v: np.concatenate([np.zeros(1, np.uint32), v.reshape(-1)])
