@@ -70,11 +70,9 @@ namespace t16 {
 template <int L>
 static int launch_tile_L(int blocks, hipStream_t st, const TableMulArgs& A) {
     constexpr size_t lds_bytes = (size_t)tile_lds_words<L>() * 4;
-    static bool allowed = false;
-    if (!allowed) {
-        if (hipFuncSetAttribute((const void*)k_mulmod_tile<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
-        allowed = true;
-    }
+    // (per launch, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE, and one process may drive
+    //  several — phe/fleet.py; a few microseconds beside a kernel of tens)
+    if (hipFuncSetAttribute((const void*)k_mulmod_tile<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
     if (A.tile_waves != kTileWaves) return -1;  // (the table's column blocks are cut for another workgroup shape)
     k_mulmod_tile<L><<<dim3(blocks), dim3(kTileBlock), lds_bytes, st>>>(A);
     return 0;
@@ -91,11 +89,8 @@ int launch_mul_tile(int L, int blocks, hipStream_t st, const TableMulArgs& A) {
 
 template <int L>
 static int launch_L(int blocks, size_t lds_bytes, hipStream_t st, const TableMulArgs& A) {
-    static size_t allowed = 0;  // (one attribute call per size: the default cap of dynamic LDS is 64 KB)
-    if (lds_bytes > allowed) {
-        if (hipFuncSetAttribute((const void*)k_mulmod_table<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
-        allowed = lds_bytes;
-    }
+    // (the default cap of dynamic LDS is 64 KB; set per launch: see launch_tile_L)
+    if (hipFuncSetAttribute((const void*)k_mulmod_table<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
     k_mulmod_table<L><<<dim3(blocks), dim3(kTableBlock), lds_bytes, st>>>(A);
     return 0;
 }
