@@ -468,6 +468,28 @@ def test_product_by_tiles_with_the_fold_on_one_element_per_lane(emu, key_bits):
     assert (in_lds is None) == (key_bits == 3072) and (in_lds is None or np.array_equal(out, in_lds))
 
 
+@pytest.mark.parametrize("bits", [3685, 3713, 3900, 4095, 4130, 5850, 6000, 6143])
+def test_tile_product_on_moduli_of_every_width_a_lane_count_takes(emu, bits):
+    """mul_tile.h / mul_table.h take ANY odd modulus whose limbs fill the lanes to within 16 (n_lo = S - P fold digits come from the
+    low half): widths across the range of L = 9 (S = 144) and L = 14 (S = 224), first and last digit counts included; the same
+    residues as Python integers for operands up to the full row width.  Widths between the lane counts are not offered."""
+    rng = random.Random(bits)
+    N = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+    limbs = -(-bits // 128) * 4                                            # rows of whole 16-byte pieces
+    top = (1 << (32 * limbs)) - 1
+    pairs = [(top, top), (N - 1, N - 1), (N, 3), (1, 0)] + [(rng.randrange(top), rng.randrange(top)) for _ in range(6)]
+    pairs += [(rng.randrange(N), rng.randrange(N)) for _ in range(60)]
+    a = ints_to_limbs([x for x, _ in pairs], limbs)
+    b = ints_to_limbs([y for _, y in pairs], limbs)
+    out = emu.mulmod_table(int_to_limbs(N, limbs), a, b, tiles=True, blocks=2)
+    digits = -(-bits // 29)
+    lanes = 144 if digits <= 144 else 224
+    offered = 2 <= lanes - digits <= 16 and -(-(bits + 38) // 29) <= lanes
+    assert (out is not None) == offered, (bits, digits)
+    if offered:
+        assert limbs_to_ints(out) == [x * y % N for x, y in pairs]
+
+
 def test_table_product_is_not_offered_where_the_table_does_not_fit(emu):
     g = load_golden(3072)
     N = H(g["n"]) ** 2
