@@ -607,10 +607,48 @@ PHE_DEV void split_exit(uint32_t* out, int out_limbs, uint32_t (&X0)[L], uint32_
 }
 
 // ---- the batched exponentiation -------------------------------------------------------------------------------
+// The window table of one number: entry j = the pair (X0 | X1), 2 G L words.  Limb groups keep an entry's words consecutive (lane g
+// reads its L limbs of each word: the group reads 2 G L consecutive words).  ONE lane per number (G = 1) would read 64 entries of 64
+// different numbers with one instruction — 64 rows 2 L words apart; there the 64 tables of a wave are interleaved,
+// [entry][word][lane]: every read and write of the wave is 256 consecutive bytes.
+template <int G, int L>
+struct WindowTable {
+    static constexpr int H = G * L, S2 = 2 * H;
+    uint32_t* base;
+    PHE_DEV WindowTable(uint32_t* table, uint32_t slot, uint32_t lane, int entries) {
+        if constexpr (G == 1) base = table + (size_t)(slot - lane) * (size_t)entries * S2 + lane;  // (a wave's slots are consecutive)
+        else base = table + (size_t)slot * (size_t)entries * S2;
+    }
+    PHE_DEV void store(int j, const uint32_t (&x0)[L], const uint32_t (&x1)[L], uint32_t g) const {
+        if constexpr (G == 1) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                base[((size_t)j * S2 + k) * 64] = x0[k];
+                base[((size_t)j * S2 + H + k) * 64] = x1[k];
+            }
+        } else {
+            store_row<L>(base + (size_t)j * S2, x0, g);
+            store_row<L>(base + (size_t)j * S2 + H, x1, g);
+        }
+    }
+    PHE_DEV void load(uint32_t (&x0)[L], uint32_t (&x1)[L], int j, uint32_t g) const {
+        if constexpr (G == 1) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) {
+                x0[k] = base[((size_t)j * S2 + k) * 64];
+                x1[k] = base[((size_t)j * S2 + H + k) * 64];
+            }
+        } else {
+            load_row<L>(x0, base + (size_t)j * S2, g);
+            load_row<L>(x1, base + (size_t)j * S2 + H, g);
+        }
+    }
+};
+
 template <int G, int L, int MODE, bool U = false>
 PHE_DEV void modexp_split_body(const SplitArgs& A, uint32_t* lds_row, uint32_t slot, uint32_t total_slots,
                                uint32_t lane) {
-    constexpr int H = G * L, S2 = 2 * H;
+    constexpr int H = G * L;
     const Lanes<G> ln(lane);
     const uint32_t g = ln.g;
     SplitLane<G, L, U> K;
@@ -619,7 +657,7 @@ PHE_DEV void modexp_split_body(const SplitArgs& A, uint32_t* lds_row, uint32_t s
     K.rows_ = A.mod.rows;
     K.row_a = lds_row;
     K.row_c = lds_row + H;
-    uint32_t* tbl = A.table + (size_t)slot * (size_t)A.tbl_entries * S2;
+    const WindowTable<G, L> tbl(A.table, slot, lane, A.tbl_entries);
     const uint64_t n_iter = (A.batch + total_slots - 1) / total_slots;
     for (uint64_t it = 0; it < n_iter; ++it) {
         uint64_t item = slot + it * (uint64_t)total_slots;
@@ -628,8 +666,7 @@ PHE_DEV void modexp_split_body(const SplitArgs& A, uint32_t* lds_row, uint32_t s
         uint32_t X0[L], X1[L], Y0[L], Y1[L];
         split_conv<G, L>(X0, X1, A.base + item * (uint64_t)A.base_limbs, A.base_limbs, A.base_chunks, A.mod, K, ln);
         // ---- odd powers base^1, base^3, ... ---------------------------------------------------------------
-        store_row<L>(tbl, X0, g);
-        store_row<L>(tbl + H, X1, g);
+        tbl.store(0, X0, X1, g);
         if (A.tbl_entries > 1) {
 #pragma unroll
             for (int k = 0; k < L; ++k) {
@@ -639,21 +676,18 @@ PHE_DEV void modexp_split_body(const SplitArgs& A, uint32_t* lds_row, uint32_t s
             split_square<G, L>(Y0, Y1, K, ln);  // base^2
             for (int j = 1; j < A.tbl_entries; ++j) {
                 split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
-                store_row<L>(tbl + (size_t)j * S2, X0, g);
-                store_row<L>(tbl + (size_t)j * S2 + H, X1, g);
+                tbl.store(j, X0, X1, g);
             }
         }
         // ---- left-to-right sliding window ------------------------------------------------------------------
-        load_row<L>(X0, tbl + (size_t)A.first_idx * S2, g);
-        load_row<L>(X1, tbl + (size_t)A.first_idx * S2 + H, g);
+        tbl.load(X0, X1, A.first_idx, g);
         for (int op = 0; op < A.n_ops; ++op) {
             const uint32_t w = A.sched[op];
             const int nsq = (int)(w >> 8);
             const int sel = (int)(w & 0xffu);
             for (int s = 0; s < nsq; ++s) split_square<G, L>(X0, X1, K, ln);
             if (sel) {
-                load_row<L>(Y0, tbl + (size_t)(sel - 1) * S2, g);
-                load_row<L>(Y1, tbl + (size_t)(sel - 1) * S2 + H, g);
+                tbl.load(Y0, Y1, sel - 1, g);
                 split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
             }
         }

@@ -231,7 +231,8 @@ PHE_DEV void load16(uint32_t& a, uint32_t& b, uint32_t& c, uint32_t& d, const ui
 }
 // Issue priority of this wave among the waves of its SIMD (0 lowest ... 3; the arbiter takes the highest priority first, the
 // oldest wave among equals).  The waves of a workgroup that share a SIMD are served oldest first: with equal work the youngest
-// finishes last and alone — and a lone wave fills half of the SIMD's issue slots.  A wave that lowers its priority as it gets
+// finishes last and alone — and a lone wave leaves many of the SIMD's issue slots empty (a chain-free multiply-add loop: 0.38 of the
+// nominal rate from one wave per SIMD, 0.68 from two).  A wave that lowers its priority as it gets
 // through its share lets the ones behind it catch up (mul_tile.h).
 PHE_DEV void set_priority(int level) {
     switch (level) {
