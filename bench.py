@@ -845,7 +845,30 @@ def main():
                 if use_dist:
                     dist.broadcast_object_list(box, src=0)
                 return box[0]
-            comm = library_communicator(ctx4, rank, world, exchange)
+            # A communicator that cannot be created (no librccl to dlopen, an RCCL error) must not take the headline with it:
+            # every rank learns whether ALL ranks got one (a rank that went on alone would hang the others in the collective),
+            # the line says what happened, and only a gather that RAN and differs from torch's makes the run exit non-zero.
+            comm, lib_error, uid = None, None, None
+            if rank == 0:                     # (the id first, on its own: a rank 0 that fails here must still reach the broadcast)
+                try:
+                    uid = native.comm_unique_id()
+                except Exception as e:  # noqa: BLE001
+                    lib_error = "%s: %s" % (type(e).__name__, e)
+            uid = exchange(uid)
+            if uid is not None:
+                try:
+                    comm = library_communicator(ctx4, rank, world, lambda _ignored: uid)
+                except Exception as e:  # noqa: BLE001
+                    lib_error = "%s: %s" % (type(e).__name__, e)
+            if comm is None:
+                print("bench.py rank %d: the library's RCCL communicator could not be created: %s" % (rank, lib_error or "no id from rank 0"),
+                      file=sys.stderr, flush=True)
+            if max_over_ranks([0.0 if comm is not None else 1.0])[0] != 0.0:
+                if comm is not None:
+                    comm.close()
+                comm = None
+                lib_gather = {"error": lib_error or "another rank could not create its communicator"}
+        if lib_gather_wanted and comm is not None:
             full2 = be.empty(total, t2)
             comm.allgather_dev(c4.data_ptr(), full2.data_ptr(), rows, t2, be.stream)      # first call: connection set-up
             barrier()
