@@ -398,6 +398,40 @@ def test_raw_add_by_one_plain_product_and_one_table_fold(native, c_oracle, key_b
     assert np.array_equal(out.to_host().reshape(-1)[1:].reshape(9000, s2), got)
 
 
+@pytest.mark.parametrize("key_bits", [1920, 3040])
+def test_raw_add_by_tiles_on_keys_off_the_limb_grid(native, key_bits):
+    """The tile kernel (csrc/mul_tile.h) takes any n^2 whose limbs fill the lanes to within 16: keys between the golden sizes —
+    1920 bits (n^2: 133 limbs of the 144 of L = 9, 11 fold digits from the low half) and 3040 bits (210 of 224, L = 14) — made
+    here with the package's own key generation; every row of a batch on the tile path against Python integers, edge operands in
+    front, the path asserted."""
+    from phe import paillier
+    from phe._device import DeviceArray
+    pub, _ = paillier.generate_paillier_keypair(n_length=key_bits)
+    n_int = pub.n
+    assert n_int.bit_length() == key_bits
+    N = n_int * n_int
+    s1 = -(-key_bits // 128) * 4                       # words of n, rows of whole 16-byte pieces
+    s2 = 2 * s1
+    ctx = native.Context(n_int, n_limbs=s1)
+    rs = np.random.Generator(np.random.PCG64(key_bits))
+    batch = 16384 + 77
+    top = (1 << (32 * s2)) - 1
+    edge = [(0, 5), (1, N - 1), (N - 1, N - 1), (top, top), (top, 1), (N, 7), (N + 1, N + 1)]
+    a = rs.integers(0, 1 << 32, size=(batch, s2), dtype=np.uint32)
+    b = rs.integers(0, 1 << 32, size=(batch, s2), dtype=np.uint32)
+    a[:len(edge)] = native.ints_to_limbs([x for x, _ in edge], s2)
+    b[:len(edge)] = native.ints_to_limbs([y for _, y in edge], s2)
+    da, db = DeviceArray.from_host(ctx, a), DeviceArray.from_host(ctx, b)
+    out = DeviceArray(ctx, batch, s2)
+    ctx.mulmod_dev(da.ptr, db.ptr, out.ptr, batch)
+    ctx.sync()
+    assert ctx.last_launch()["path"] & ctx.PATH_TILE_MUL, ctx.last_launch()
+    got = native.limbs_to_ints(out.to_host())
+    idx = list(range(len(edge))) + list(range(len(edge), batch, 37)) + [batch - 1]
+    ai, bi = native.limbs_to_ints(a[idx]), native.limbs_to_ints(b[idx])
+    assert [got[i] for i in idx] == [int(x) * int(y) % N for x, y in zip(ai, bi)]
+
+
 def test_negative_scalars_invert_only_the_rows_that_take_the_branch(native, c_oracle):
     """_raw_mul's negative branch (phe/paillier.py:745-749: powmod(invert(c), n - s)) on a resident vector with few negative
     scalars: only those rows are inverted — phe_hip_gather_rows_dev, the simultaneous inversion of the subset,
