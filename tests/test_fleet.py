@@ -123,6 +123,34 @@ def test_encrypt_decrypt_add_mul_fan_out_over_two_contexts(two_contexts, monkeyp
 
 
 @pytest.mark.gpu
+def test_large_host_additions_take_the_tile_kernel_on_both_contexts_at_once(monkeypatch):
+    """`vec + vec` on host vectors of 40,000 rows through two contexts: each shard (20,000 rows) is one launch of k_mulmod_tile
+    (csrc/mul_tile.h) on its own stream from its own worker thread — the kernels' dynamic-LDS limit is raised per launch, per
+    device — and the sum is bit-identical to the one-context sum and decrypts to x + y."""
+    g = load_golden(2048)
+    rows = 40000
+    rng = np.random.RandomState(11)
+    x, y = rng.randint(-10 ** 6, 10 ** 6, size=rows), rng.randint(-10 ** 6, 10 ** 6, size=rows)
+    monkeypatch.delenv("PHE_HIP_DEVICES", raising=False)
+    pub1 = paillier.PaillierPublicKey(H(g["n"]))
+    a1, b1 = pub1.encrypt_batch(x), pub1.encrypt_batch(y)
+    one = a1 + b1
+    monkeypatch.setenv("PHE_HIP_DEVICES", "0,0")
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    fl = priv._get_fleet()
+    assert fl is not None and len(fl) == 2
+    a = paillier.EncryptedVector(pub, a1._limbs.copy(), a1.exponent_array.copy())
+    b = paillier.EncryptedVector(pub, b1._limbs.copy(), b1.exponent_array.copy())
+    both = a + b
+    assert np.array_equal(both._limbs, one._limbs)
+    for eng in fl.engines():
+        path = eng.ctx.last_launch()["path"]
+        assert path & eng.ctx.PATH_TILE_MUL, path                                 # 20,000 rows per context: by tiles
+    assert priv.decrypt_batch(both) == (x + y).tolist()
+
+
+@pytest.mark.gpu
 def test_resident_shards_and_per_device_pools(monkeypatch):
     """encrypt_batch_sharded: one resident vector per context, each worked on by ITS engine; obfuscators made ahead of time are
     split over the contexts' pools and every one is used once"""
