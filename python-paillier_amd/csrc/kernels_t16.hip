@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(kTableBlock, 1) k_mulmod_table(TableMulArgs A)
                       threadIdx.x & 63u);
 }
 
-// mul_tile.h: the same product with one element per lane: the workgroup owns tiles of 64 products, its eight waves split the
+// mul_tile.h: the same product with one element per lane: the workgroup owns tiles of 64 products, its sixteen waves split the
 // columns and meet at barriers between the phases; the fold's table words come through the scalar cache
 constexpr int kTileBlock = 64 * kTileWaves;
 template <int L>

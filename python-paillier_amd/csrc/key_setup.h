@@ -745,7 +745,7 @@ struct TableMulPack {
     double inv = 0.0;                          // W^base / N
     std::vector<uint32_t> n, ncomp, ncomp1;    // S limbs each: N, W^S - N, (W^S - N) * W mod W^S
     std::vector<uint32_t> table;               // digits rows of S words, device layout (mul_table.h table_row_limbs)
-    std::vector<uint32_t> table_cols;          // the same rows in the column-block layout [wave][digit][2L words] (mul_tile.h)
+    std::vector<uint32_t> table_cols;          // the same rows in the column-block layout [wave][digit][S / 16 words] (mul_tile.h)
     size_t lds_words = 0;
     size_t tile_lds_words = 0;                 // LDS of mul_tile.h's workgroup (no table in it)
     bool ok() const { return L != 0; }                  // some form of the product is offered:

@@ -1,30 +1,34 @@
 // mul_tile.h — a*b mod N (phe/util.py:53-64 mulmod; phe/paillier.py:705-719 _raw_add) as one plain product and one fold
-// against the key's table (the arithmetic of mul_table.h) with LANE = ELEMENT: a 512-thread workgroup takes a tile of 64
-// products, every lane of every wave works on "its" element, and the eight waves split the COLUMNS of the numbers.
+// against the key's table (the arithmetic of mul_table.h) with LANE = ELEMENT: a workgroup of W = 16 waves (1024 threads, four
+// per SIMD) takes a tile of 64 products, every lane of every wave works on "its" element, and the waves split the COLUMNS of
+// the numbers: S = 16 L columns in W blocks of C = S / W = L (9 for 2048-bit keys, 14 for 3072-bit keys).
 //
 // Why: in the limb-group form (16 lanes per number) a row of the product is 9 multiply-adds against 13 other instructions
 // (digit broadcast, shift across lanes, carries, masks), and the fold reads every table word from LDS once per lane — 4 bytes
 // of LDS per multiply-add, twice what a CU's LDS delivers.  Measured (tools/exp/tile_phases.hip, profiles/r04l): the product
 // ran at 40 % multiply-add density, the LDS-fed fold at a quarter of the multiply-add peak.  With one element per lane
 //   * nothing crosses lanes: the digits of 64 numbers lie side by side in LDS (buffer[row r][lane e]: every read and write of
-//     a wave is 256 consecutive bytes), a step of the product is ONE digit of a (LDS) times a sliding window of 2L digits of b
-//     held in registers — 2L multiply-adds, two LDS words, no shift (the window "moves" by register renaming in the unrolled
+//     a wave is 256 consecutive bytes), a step of the product is ONE digit of a (LDS) times a sliding window of C digits of b
+//     held in registers — C multiply-adds, two LDS words, no shift (the window "moves" by register renaming in the unrolled
 //     code), no mask, no broadcast;
 //   * a table word of the fold is the same for all 64 lanes: it comes through the scalar data cache into an SGPR and enters
-//     v_mad_u64_u32 as its scalar operand (wave::ScalarRow): no LDS, no VGPR, 4 bytes per 64 multiply-adds.  The 84 KB table
-//     ([wave][digit][2L words]) streams from L2; the requests run two fold digits ahead of the multiply-adds.
+//     v_mad_u64_u32 as its scalar operand (wave::ScalarRow): no LDS, no VGPR, 4 bytes per 64 multiply-adds.  The table (84 KB
+//     at 2048 bits, 190 KB at 3072; [wave][digit][C words]) streams from L2; the requests run a group of fold digits ahead of
+//     the multiply-adds.
 //
-// Phases of a tile (S = 16 L columns; wave w owns the column blocks named; `|` = workgroup barrier):
-//   load     wave w: digits [2L w, 2L w + 2L) of a and b of all 64 elements: 16-byte global loads of the lane's own row
-//            (issued one tile ahead), re-sliced to 29 bits in registers, to A[digit][e], B[digit][e]                        |
-//   product  wave w: columns [2L w, +2L) and [2L (w + 8), +2L) of T = a*b — 9 * 2L steps of 2L multiply-adds, the same for
-//            every wave; 64-bit column sums, carries inside the lane, the block's carry-out to LDS                          |
+// Phases of a tile (wave w owns the column blocks named; `|` = workgroup barrier):
+//   load     wave w: digits [C w, C w + C) of a and b of all 64 elements: 16-byte global loads of the lane's own row (issued
+//            one tile ahead, under the settle), re-sliced to 29 bits in registers, to A[digit][e], B[digit][e]              |
+//   product  wave w: columns [C w, +C) and [C (w + W), +C) of T = a*b — (W + 1) C steps of C multiply-adds, the same for every
+//            wave; 64-bit column sums, carries inside the lane, the block's carry-out to LDS                                |
 //            the carry-out of the block below enters the block's two lowest digits; T[row][e] over A and B                  |
-//   fold     wave w: columns [2L w, +2L) of y = T_low + sum_i T[P + i] * C_i     (the accumulators open from the wave's own
-//            low block of the product: the same columns)
-//            carries inside the lane, y to LDS as [element][column], the block's carry-out beside it                        |
-//   settle   16 lanes per element (two elements per limb group, one after the other): y canonical, q^ = floor(y / N) - 1 or - 2 from four limbs,
-//            r = y - q^ N < 3 N, conditional subtractions, 16-byte stores                                                   |
+//   fold     wave w: columns [C w, +C) of y = T_low + sum_i T[P + i] * C_i (the accumulators open from the wave's own low block
+//            of the product: the same columns); carries inside the lane, y to LDS as [element][column], the block's
+//            carry-out beside it                                                                                            |
+//   settle   16 lanes per element (a wave's four elements at once): y canonical, q^ = floor(y / N) - 1 or - 2 from four limbs,
+//            r = y - q^ N < 3 N, conditional subtractions, 16-byte stores; the groups' digit rows lie inside the tile buffer  |
+// Within the product and the fold a wave lowers its issue priority as it gets through its share (wave::set_priority): the waves
+// of a SIMD are served oldest first and would otherwise finish one after the other, the last one alone.
 // Same bits as mul_table.h, mul_io.h and gmpy2.mod(gmpy2.mul(a, b), c).
 #pragma once
 #include <stddef.h>
@@ -61,7 +65,7 @@ template <int L>
 struct TileShape {
     static constexpr int S = 16 * L;    // columns of the fold and of the settle; digit rows of an operand (the ones past its
                                         // last digit hold zeros)
-    static constexpr int CW = S / kTileWaves;  // columns of a block: what one wave folds (L or 2L: lanes of the settle)
+    static constexpr int CW = S / kTileWaves;  // C: columns of a block = what one wave folds = what one lane of the settle holds (L)
     static constexpr int kFoldGroup = CW > 10 ? 2 : 4;  // fold digits per request group (28 ... 40 table words in flight per group)
     static constexpr int kRowT = S + kLdsPad;  // a settle group's digit row
     // rows of the tile buffer: A (S rows + one zero row) | B (S rows); T (2S rows) over both; during the settle the settled
@@ -202,7 +206,7 @@ PHE_DEV void tile_request_row(Words4 (&raw)[TileShape<L>::kChunks], const uint32
     }
 }
 
-// A.table: the fold table in the COLUMN-BLOCK layout [wave w][digit i][2L words]: limbs [2L w, 2L (w + 1)) of W^(P+i) mod N,
+// A.table: the fold table in the COLUMN-BLOCK layout [wave w][digit i][C words]: limbs [C w, C (w + 1)) of W^(P+i) mod N,
 // A.digits_padded + kFoldPadRows rows per wave (key_setup.h:build_table_mul writes both layouts).
 // tile: TileShape::kRows * 64 words; prod_carry: 2 * 2W * 64; top: 64 * kTableRowSlack; fold_carry: 2 * W * 64; cst: n | ncomp |
 // ncomp1 (S limbs each).  `wv` must be wave-uniform; every wave of the workgroup runs the
@@ -331,7 +335,7 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
         }
         wave::block_barrier();
         PHE_TILE_MARK(3);  // carries in, T written, barrier
-        // ---- fold: this wave's 2L columns of y = T_low + sum_i T[P + i] * C_i -----------------------------------------------------
+        // ---- fold: this wave's C columns of y = T_low + sum_i T[P + i] * C_i ------------------------------------------------------
         {
             const int c0 = (int)wv * CW;
             uint64_t acc[CW];

@@ -246,7 +246,7 @@ PHE_DEV void set_priority(int level) {
 PHE_DEV void order_fence() { __builtin_amdgcn_sched_barrier(0); }
 
 // ---- table words on the scalar path, requested ahead of their use (mul_tile.h) -------------------------------------------------
-// ScalarRow<N>: N (= 16 + 2 or 8 + 2) consecutive words at a wave-uniform address, in SGPRs.  request() issues the s_load and
+// ScalarRow<N>: N (5, 9, 10, 14 or 18: one to three s_load of 1 ... 16 words) consecutive words at a wave-uniform address, in SGPRs.  request() issues the s_load and
 // returns at once; the words may be read after arrived() — the s_waitcnt is written by hand because the compiler, left to
 // place the loads itself, sinks them to their first use and waits there (scalar loads return out of order: the only wait
 // there is waits for every outstanding one, so a wait in front of a use must come BEFORE the next requests are issued).
