@@ -82,9 +82,40 @@ struct SplitArgs {
     const uint32_t* item_meta;
 };
 
+// ---- squarings: the symmetric half of X0*X0 ---------------------------------------------------------------------
+// A squaring sweep multiplies the digits of X0 (LDS) into the lanes' limbs of the SAME number: x_i*x_j is asked for at row i by
+// the lane that holds limb j AND at row j by the lane that holds limb i (phe/util.py:50 gmpy2.powmod -> mpz_powm ->
+// mpn_sqr_basecase computes it once).  Taking the products above the diagonal (j >= i) would idle the low lanes in lock step
+// with the busy ones; instead every lane takes, in every row, the limbs of ONE residue band: with i = t*L + r and j = g*L + k
+// the difference j - i is k - r modulo L whatever lane and trip, and of the two orders of a pair exactly one has
+// (k - r) mod L in 1 .. ceil(L/2) - 1.  That one is taken doubled; the classes equal to their own negative (0, and L/2 for even
+// L) are taken once in BOTH orders, which is the same thing (and the diagonal x_i^2 once).  L/2 + 1 multiply-adds per row
+// instead of L, each row index a compile-time constant of the unrolled trip, the same work in every lane.  A column's sum at
+// the row that retires it is the full product's (both rows of a pair lie at or below the pair's column); within a stay of L
+// rows in one lane a column takes the weight of L products as before (its k + r is constant, so k - r runs over every class of
+// one parity twice for even L, over every class once for odd L), hence the accumulator bounds of the full sweep hold.
+template <int L>
+constexpr int sq_weight(int k, int r) {  // limb k of the lane, row r of the trip: 0 = the mirror image takes it, 1 = once, 2 = doubled
+    const int c = ((k - r) % L + L) % L;
+    if (c == 0 || 2 * c == L) return 1;
+    return 2 * c < L ? 2 : 0;
+}
+// acc[(k + j) % L] += x * b[k] over the limbs a squaring row takes (x: the row's digit of X0, b: the lane's limbs of X0)
+template <int L>
+PHE_DEV void sq_row(uint64_t (&acc)[L], uint32_t x, const uint32_t (&b)[L], int j) {
+    const uint32_t x2 = x << 1;  // limbs stay below 2^29 + 2^8
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        const int w = sq_weight<L>(k, j);
+        if (w == 2) acc[(k + j) % L] = wave::mad64(x2, b[k], acc[(k + j) % L]);
+        else if (w == 1) acc[(k + j) % L] = wave::mad64(x, b[k], acc[(k + j) % L]);
+    }
+}
+
 // ---- single-word passes (used by the conversions out of the pair form) -----------------------------------------
 // out = (a*b + m*n) / R with the quotient digits m_i stored to m_row (LDS, H words); a: H digits in LDS.
-template <int G, int L, bool U = false>
+// SQ: b holds the limbs of the number whose digits a holds (a squaring: sq_row)
+template <int G, int L, bool U = false, bool SQ = false>
 PHE_DEV void montmul_q(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b)[L], uint32_t* m_row,
                        const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln, int rows = G * L) {
     uint64_t acc[L];
@@ -96,8 +127,12 @@ PHE_DEV void montmul_q(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b
 #pragma unroll
         for (int j = 0; j < L; ++j) {
             const uint32_t ai = a[i + j];
+            if constexpr (SQ) {
+                sq_row<L>(acc, ai, b, j);
+            } else {
 #pragma unroll
-            for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(ai, b[k], acc[(k + j) % L]);
+                for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(ai, b[k], acc[(k + j) % L]);
+            }
             const uint32_t m = wave::grp_bcast0<G>((U ? (uint32_t)acc[j] : (uint32_t)acc[j] * n0inv) & kLimbMask, ln);
             mq[j] = m;
 #pragma unroll
@@ -275,8 +310,9 @@ struct Trip {
 };
 
 // z0 = (a*b0 + m*n) / R,   z1 = (m + a*b1 + m2*n) / R.     a: H digits in LDS.
-// Squaring: b0 = X0, b1 = 2*X1.  Conversion of a plain chunk a: (b0, b1) = pair(R^(j+2)).
-template <int G, int L, bool U = false>
+// Squaring: b0 = X0, b1 = 2*X1 (SQ: a holds the digits of b0 itself, the first word takes the symmetric half: sq_row).
+// Conversion of a plain chunk a: (b0, b1) = pair(R^(j+2)).
+template <int G, int L, bool U = false, bool SQ = false>
 PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a, const uint32_t (&b0)[L],
                         const uint32_t (&b1)[L], const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln, int rows = G * L) {
     const uint32_t lane0 = kLimbMask & ~ln.not_low;  // digit mask in lane 0 of the group, 0 elsewhere
@@ -308,8 +344,12 @@ PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
         for (int jj = 0; jj < kT; ++jj) {
             const int j = jj % L;
             const uint32_t ai = Trip<G, L>::kAhead ? dig_a[jj] : a[i + jj];
+            if constexpr (SQ) {
+                sq_row<L>(p, ai, b0, j);
+            } else {
 #pragma unroll
-            for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(ai, b0[k], p[(k + j) % L]);
+                for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(ai, b0[k], p[(k + j) % L]);
+            }
 #pragma unroll
             for (int k = 0; k < L; ++k) q[(k + j) % L] = wave::mad64(ai, b1[k], q[(k + j) % L]);
             PHE_QUOTIENT_STEP()
@@ -400,14 +440,14 @@ struct SplitLane {  // what every pass needs, loaded once per kernel (U: the mod
 
 // (z0, z1) = (a*b0 + m*n, m + a*b1 + m2*n) / R with a already in row_a: one fused sweep, or two single sweeps with the
 // quotient digits handed over through row_c when the lanes are too wide for the fused one
-template <int G, int L, bool U>
+template <int G, int L, bool U, bool SQ = false>
 PHE_DEV void pair_mul_plain(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t (&b0)[L], const uint32_t (&b1)[L],
                             const SplitLane<G, L, U>& K, const Lanes<G>& ln) {
     if constexpr (L <= kMaxFusedL) {
-        pair_pass2<G, L, U>(z0, z1, K.row_a, b0, b1, K.n, K.n0inv, ln, K.rows());
+        pair_pass2<G, L, U, SQ>(z0, z1, K.row_a, b0, b1, K.n, K.n0inv, ln, K.rows());
     } else {
         uint32_t u[L];
-        montmul_q<G, L, U>(u, K.row_a, b0, K.row_c, K.n, K.n0inv, ln, K.rows());
+        montmul_q<G, L, U, SQ>(u, K.row_a, b0, K.row_c, K.n, K.n0inv, ln, K.rows());
         wave::lds_fence();
         montmul_addend<G, L, U>(z1, K.row_a, b1, K.row_c, K.n, K.n0inv, ln, K.rows());
 #pragma unroll
@@ -422,7 +462,7 @@ PHE_DEV void split_square(uint32_t (&X0)[L], uint32_t (&X1)[L], const SplitLane<
 #pragma unroll
     for (int k = 0; k < L; ++k) d[k] = X1[k];
     add_normalize<G, L>(d, X1, ln);  // 2*X1
-    pair_mul_plain<G, L>(X0, X1, X0, d, K, ln);
+    pair_mul_plain<G, L, U, true>(X0, X1, X0, d, K, ln);  // (row_a holds the very limbs of X0: the symmetric half is exact)
 }
 
 template <int G, int L, bool U>
@@ -796,7 +836,9 @@ PHE_DEV uint32_t late_quotient_step(uint64_t (&acc)[L], int jl, uint32_t extra, 
 }
 
 // iteration T (mod L) of a trip: the first word's step i + 1 (digit an = a_(i+1)) and the second word's step i (ai = a_i, ci = c_i)
-template <int G, int L, bool MUL, int T>
+// SQ (with MUL false): a squaring — b0 holds the limbs of the number whose digits the sweep reads, the first word takes the symmetric
+// half (sq_row; the first word's step s adds a_s*b0 into the frame whose lowest column is s mod L)
+template <int G, int L, bool MUL, int T, bool SQ = false>
 PHE_DEV void late_iteration(uint64_t (&p)[L], uint64_t (&q)[L], uint32_t an, uint32_t ai, uint32_t ci, const uint32_t (&b0)[L],
                             const uint32_t (&b1)[L], const uint32_t (&nbar)[L], const LateMasks<G>& mk, const Lanes<G>& ln) {
     constexpr int jl = T % L, j = (T + 1) % L;         // first word: lowest column before / after the shift of its step
@@ -808,8 +850,12 @@ PHE_DEV void late_iteration(uint64_t (&p)[L], uint64_t (&q)[L], uint32_t an, uin
     uint32_t dq = 0, unused = 0;
     const uint32_t m = late_quotient_step<G, L, kNarrowP, true>(p, jl, 0u, dq, mk, ln);    // dq: digit i of Q (lane 0)
     const uint32_t m2 = late_quotient_step<G, L, kNarrowQ, false>(q, jlq, dq, unused, mk, ln);
+    if constexpr (SQ) {
+        sq_row<L>(p, an, b0, j);
+    } else {
 #pragma unroll
-    for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(an, b0[k], p[(k + j) % L]);
+        for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(an, b0[k], p[(k + j) % L]);
+    }
 #pragma unroll
     for (int k = 0; k < L; ++k) q[(k + jq) % L] = wave::mad64(ai, b1[k], q[(k + jq) % L]);
     if constexpr (MUL) {
@@ -826,18 +872,18 @@ PHE_DEV void late_iteration(uint64_t (&p)[L], uint64_t (&q)[L], uint32_t an, uin
     for (int k = 0; k < L; ++k) q[(k + jq) % L] = wave::mad64(m2, nbar[k], q[(k + jq) % L]);
 }
 
-template <int G, int L, bool MUL, int N, int T = 0>
+template <int G, int L, bool MUL, int N, bool SQ = false, int T = 0>
 PHE_DEV void late_trip(uint64_t (&p)[L], uint64_t (&q)[L], const uint32_t (&da)[N + 1], const uint32_t (&dc)[N], const uint32_t (&b0)[L],
                        const uint32_t (&b1)[L], const uint32_t (&nbar)[L], const LateMasks<G>& mk, const Lanes<G>& ln) {
     if constexpr (T < N) {
-        late_iteration<G, L, MUL, T % L>(p, q, da[T + 1], da[T], dc[T], b0, b1, nbar, mk, ln);
-        late_trip<G, L, MUL, N, T + 1>(p, q, da, dc, b0, b1, nbar, mk, ln);
+        late_iteration<G, L, MUL, T % L, SQ>(p, q, da[T + 1], da[T], dc[T], b0, b1, nbar, mk, ln);
+        late_trip<G, L, MUL, N, SQ, T + 1>(p, q, da, dc, b0, b1, nbar, mk, ln);
     }
 }
 
 // z0 = (a*b0 + Q*n~) / R,   z1 = (Q + a*b1 [+ c*b0] + Q2*n~) / R;   a (and c): digit rows in LDS, `rows` digits each (a multiple of L);
 // word `rows` of a must be 0 (see `load` below).   MUL: the product (a, c) * (b0, b1); else a squaring / a conversion.
-template <int G, int L, bool MUL>
+template <int G, int L, bool MUL, bool SQ = false>
 PHE_DEV void pair_late(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a, const uint32_t* c, const uint32_t (&b0)[L],
                        const uint32_t (&b1)[L], const uint32_t (&nbar)[L], const Lanes<G>& ln, int rows) {
     constexpr int kI = LateShape<G, L>::kIter;
@@ -861,8 +907,12 @@ PHE_DEV void pair_late(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a, 
     // prologue: the first word's step 0
     {
         const uint32_t a0 = a[0];
+        if constexpr (SQ) {
+            sq_row<L>(p, a0, b0, 0);
+        } else {
 #pragma unroll
-        for (int k = 0; k < L; ++k) p[k] = wave::mad64(a0, b0[k], p[k]);
+            for (int k = 0; k < L; ++k) p[k] = wave::mad64(a0, b0[k], p[k]);
+        }
     }
     int i = 0;
     if constexpr (G == 64) {
@@ -872,12 +922,12 @@ PHE_DEV void pair_late(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a, 
 #pragma unroll 1
         for (; i + 2 * kI <= rows; i += 2 * kI) {
             load(da_b, dc_b, i + kI, TagI());
-            late_trip<G, L, MUL, kI>(p, q, da_a, dc_a, b0, b1, nbar, mk, ln);
+            late_trip<G, L, MUL, kI, SQ>(p, q, da_a, dc_a, b0, b1, nbar, mk, ln);
             if (i + 3 * kI <= rows) load(da_a, dc_a, i + 2 * kI, TagI());
-            late_trip<G, L, MUL, kI>(p, q, da_b, dc_b, b0, b1, nbar, mk, ln);
+            late_trip<G, L, MUL, kI, SQ>(p, q, da_b, dc_b, b0, b1, nbar, mk, ln);
         }
         if (i + kI <= rows) {  // (set a holds this trip: fetched before the loop, or by its last pass)
-            late_trip<G, L, MUL, kI>(p, q, da_a, dc_a, b0, b1, nbar, mk, ln);
+            late_trip<G, L, MUL, kI, SQ>(p, q, da_a, dc_a, b0, b1, nbar, mk, ln);
             i += kI;
         }
     } else {
@@ -885,14 +935,14 @@ PHE_DEV void pair_late(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a, 
         for (; i + kI <= rows; i += kI) {
             uint32_t da[kI + 1], dc[kI];
             load(da, dc, i, TagI());
-            late_trip<G, L, MUL, kI>(p, q, da, dc, b0, b1, nbar, mk, ln);
+            late_trip<G, L, MUL, kI, SQ>(p, q, da, dc, b0, b1, nbar, mk, ln);
         }
     }
 #pragma unroll 1
     for (; i < rows; i += L) {  // what whole trips did not cover: L iterations at a time
         uint32_t da[L + 1], dc[L];
         load(da, dc, i, TagL());
-        late_trip<G, L, MUL, L>(p, q, da, dc, b0, b1, nbar, mk, ln);
+        late_trip<G, L, MUL, L, SQ>(p, q, da, dc, b0, b1, nbar, mk, ln);
     }
     // epilogue: the second word's step `rows` (no digit, and Q has no digit `rows`)
     {
@@ -928,7 +978,7 @@ PHE_DEV void late_square(uint32_t (&X0)[L], uint32_t (&X1)[L], const LateLane<G,
 #pragma unroll
     for (int k = 0; k < L; ++k) d[k] = X1[k];
     add_normalize<G, L>(d, X1, ln);  // 2*X1
-    pair_late<G, L, false>(X0, X1, K.row_a, nullptr, X0, d, K.nbar, ln, K.rows);
+    pair_late<G, L, false, true>(X0, X1, K.row_a, nullptr, X0, d, K.nbar, ln, K.rows);
 }
 
 template <int G, int L>
