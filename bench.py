@@ -79,9 +79,10 @@ def mac32_ops(key_bits):
 
 def executed_mads(key_bits, info):
     """MODEL of the v_mad_u64_u32 lane-operations one encrypt / one decrypt executes (29-bit limbs; t squarings,
-    ceil(t/(w+1)) + 2^(w-1) products for the window w in use).  Split engine: a squaring is 4 H^2, a product 5 H^2, entry
-    4 H^2 per input chunk (+5 H^2 when more than one), exit ~10 H^2 (csrc/split_core.h); full-width engine: 2 S^2 per
-    Montgomery product.  Only the fallback when profiles/executed_mads_r*.json has no exact count for the geometry."""
+    ceil(t/(w+1)) + 2^(w-1) products for the window w in use).  Split engine: a squaring is (3 + s/L) H^2 with s = L/2 + 1
+    (even L) or (L + 1)/2 (odd L) limbs per lane and row in the symmetric first word (csrc/split_core.h sq_row; 4 H^2 before
+    round 5), a product 5 H^2, entry 4 H^2 per input chunk (+5 H^2 when more than one), exit ~10 H^2; full-width engine:
+    2 S^2 per Montgomery product.  Only the fallback when profiles/executed_mads_r*.json has no exact count for the geometry."""
     E_sq = lambda t: t
     # sliding windows of w = 6 bits (32 odd powers) from ~1000-bit exponents on, w = 5 (16) below: key_setup.h:pick_window
     E_mul = lambda t: (-(-t // 7) + 32) if t > 900 else (-(-t // 6) + 16)
@@ -91,7 +92,8 @@ def executed_mads(key_bits, info):
         H = G * L
         if split:
             chunks = max(1, -(-in_bits // (29 * H)))
-            return (4 * E_sq(t) + 5 * E_mul(t) + 4 * chunks + (5 if chunks > 1 else 0) + 10 + extra) * H * H
+            sq = 3 + (L // 2 + 1 if L % 2 == 0 else (L + 1) // 2) / L
+            return int(round((sq * (E_sq(t) + 1) - 4 + 5 * E_mul(t) + 4 * chunks + (5 if chunks > 1 else 0) + 10 + extra) * H * H))
         return (E_sq(t) + E_mul(t) + 3) * 2 * H * H
 
     enc = modexp(key_bits, info["lane_limbs_pub"], info["engine_pub"] == "split", key_bits, 2)

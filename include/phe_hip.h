@@ -109,6 +109,15 @@ int phe_hip_ctx_set_blocks_per_cu(phe_hip_ctx* ctx, int blocks_per_cu);
  * through the scalar cache instead of LDS; PHE_HIP_NO_TILE_MUL=1 keeps the kernel with the table in LDS); *geom_pub / *geom_priv = G*100 + L of the
  * exponentiation kernels used.  Any pointer may be NULL. */
 int phe_hip_ctx_ladder(const phe_hip_ctx* ctx, int* pub_geoms, int* priv_geoms, int capacity, int* n_pub, int* n_priv);
+/* The MEASURED ladder.  Without it a rung's time is an estimate from its shape; with it the rung of a call is the one whose measured
+ * launch time at that batch size is least.  `table`: text, one line per measurement "key_bits family G rows ns" — key width in bits
+ * (lines of other widths are ignored), kernel family (1: fixed-exponent r^n of encrypt / obfuscate, 2: the CRT halves of decrypt,
+ * 3: per-element exponents of _raw_mul), lanes per number of the rung, batch size, launch time in nanoseconds; '#' starts a comment.
+ * Made by `tools/bench_sweep.py --calibrate` (every rung pinned in turn; python-paillier_amd/phe/ladder_gfx950.txt is the committed
+ * one, loaded by the host mirror when a context is made).  Between two measured sizes the time is interpolated, below the smallest it
+ * stays (latency-bound), above the largest it scales with the rows; a family is chosen by measurement only when EVERY rung it could
+ * take has a table.  table = NULL forgets the table.  *accepted = lines kept (may be NULL). */
+int phe_hip_ctx_load_ladder(phe_hip_ctx* ctx, const char* table, int* accepted);
 int phe_hip_ctx_set_group(phe_hip_ctx* ctx, int group);
 int phe_hip_ctx_last_launch(const phe_hip_ctx* ctx, int* path, int* geom_pub, int* geom_priv);
 
@@ -294,11 +303,13 @@ int phe_hip_select_rows_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t*
 /* Rows of `limbs` words moved by an index list (device, `count` 32-bit row indices): gather dst[j] = src[idx[j]], scatter
  * dst[idx[j]] = src[j].  With them the negative-scalar branch of _raw_mul (phe/paillier.py:745-749: powmod(invert(c), n - s))
  * inverts only the rows that take it — gather, phe_hip_invert_dev on the subset, scatter into a copy of the vector — instead of
- * inverting the whole vector and selecting. */
-int phe_hip_gather_rows_dev(phe_hip_ctx* ctx, const uint32_t* src, const uint32_t* idx, uint32_t* dst, int limbs, size_t count,
-                            void* stream);
-int phe_hip_scatter_rows_dev(phe_hip_ctx* ctx, const uint32_t* src, const uint32_t* idx, uint32_t* dst, int limbs, size_t count,
-                             void* stream);
+ * inverting the whole vector and selecting.
+ * src_rows / dst_rows: the rows the INDEXED buffer holds.  An index at or beyond it never leaves that buffer: the scatter skips the
+ * row, the gather writes a row of zeros.  Ordered like every *_dev entry point (one stream order per context). */
+int phe_hip_gather_rows_dev(phe_hip_ctx* ctx, const uint32_t* src, size_t src_rows, const uint32_t* idx, uint32_t* dst, int limbs,
+                            size_t count, void* stream);
+int phe_hip_scatter_rows_dev(phe_hip_ctx* ctx, const uint32_t* src, const uint32_t* idx, uint32_t* dst, size_t dst_rows, int limbs,
+                             size_t count, void* stream);
 
 /* ---- device memory helpers for hosts without a tensor library ------------------------------- */
 int phe_hip_malloc(phe_hip_ctx* ctx, size_t bytes, void** dptr);

@@ -17,9 +17,11 @@
 // window tables (one per resident limb group) stay L2/MALL-resident regardless of batch size.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <algorithm>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -258,14 +260,22 @@ __global__ void __launch_bounds__(256) k_select_rows(const uint32_t* a, const ui
 
 // rows of `limbs` words moved by an index list: gather dst[j] = src[idx[j]], scatter dst[idx[j]] = src[j] (j < count) — the
 // negative-scalar branch of _raw_mul inverts only the rows that take it (phe/paillier.py:745-749)
+// far_rows: rows of the indexed side (gather: src, scatter: dst).  An index beyond it touches nothing on that side: the scatter skips
+// the row, the gather fills it with zeros (never a read or write outside the caller's buffer for a bad index of the public API).
 template <bool SCATTER>
-__global__ void __launch_bounds__(256) k_move_rows(const uint32_t* src, const uint32_t* idx, uint32_t* dst, int limbs, uint64_t count) {
+__global__ void __launch_bounds__(256) k_move_rows(const uint32_t* src, const uint32_t* idx, uint32_t* dst, int limbs, uint64_t count,
+                                                   uint64_t far_rows) {
     const uint64_t total = count * (uint64_t)limbs;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t j = i / (uint64_t)limbs, w = i - j * (uint64_t)limbs;
-        const uint64_t far = (uint64_t)idx[j] * (uint64_t)limbs + w;
-        if (SCATTER) dst[far] = src[i];
-        else dst[i] = src[far];
+        const uint64_t row = idx[j];
+        const bool inside = row < far_rows;
+        const uint64_t far = row * (uint64_t)limbs + w;
+        if (SCATTER) {
+            if (inside) dst[far] = src[i];
+        } else {
+            dst[i] = inside ? src[far] : 0u;
+        }
     }
 }
 
@@ -380,6 +390,10 @@ struct phe_hip_ctx {
     bool no_late = false;              // PHE_HIP_NO_LATE=1: the small-batch rungs stay on the round-3 kernels (textbook row order; A/B measurements, tests)
     bool force_unit = false;           // PHE_HIP_FORCE_UNIT=1: r^n through the scaled modulus whatever the batch size (tests)
     int force_group = 0;               // phe_hip_ctx_set_group: 0 = pick by batch size; G = the rung whose groups are G lanes wide
+    // the measured ladder (phe_hip_ctx_load_ladder): per (kernel family, group width) the launch time at a few batch sizes, made by
+    // `tools/bench_sweep.py --calibrate` with every rung pinned.  Key: family * 256 + G.  Empty: the estimate of rung_cost.
+    struct LadderPoint { double rows, ns; };
+    std::map<int, std::vector<LadderPoint>> ladder;
     // what the last launch on this context took (phe_hip_ctx_last_launch): tests assert the path they meant to exercise
     int last_path = 0, last_geom_pub = 0, last_geom_priv = 0;
     // one stream order per context: every *_dev call waits for the previous call's work when it is issued on another
@@ -928,10 +942,9 @@ static const size_t kTileMulMinRows = 16384;
 static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, size_t a_stride, const uint32_t* b,
                       size_t b_stride, uint32_t* out, size_t out_stride, int limbs, size_t batch,
                       hipStream_t stream, int b_plain_limbs = 0, int one_product = 0, int a_limbs = 0, bool plain_mulmod = false) {
-    static const size_t min_rows = [] {  // (PHE_HIP_TABLE_MUL_MIN_ROWS: measurements of the crossover)
-        const char* e = getenv("PHE_HIP_TABLE_MUL_MIN_ROWS");
-        return e ? (size_t)std::max(1, atoi(e)) : kTableMulMinRows;
-    }();
+    static const char* const min_rows_env = getenv("PHE_HIP_TABLE_MUL_MIN_ROWS");  // (measurements of the crossover; read once)
+    static const size_t min_rows = min_rows_env ? (size_t)std::max(1, atoi(min_rows_env)) : kTableMulMinRows;
+    static const size_t tile_min_rows = min_rows_env ? min_rows : kTileMulMinRows;
     if (plain_mulmod && ctx->tmul_blob && !b_plain_limbs && !one_product && !a_limbs && batch >= min_rows && limbs == ctx->pub.s2 &&
         limbs % 4 == 0 && ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15u) == 0) && a_stride % 4 == 0 && b_stride % 4 == 0 &&
         out_stride % 4 == 0 && b_stride != 0) {
@@ -958,7 +971,7 @@ static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, 
         B.digits_padded = T.digits_padded;
         B.tile_waves = T.tile_waves;
         int rc = -1;
-        if (ctx->tmul_cols && batch >= (getenv("PHE_HIP_TABLE_MUL_MIN_ROWS") ? min_rows : kTileMulMinRows)) {
+        if (ctx->tmul_cols && batch >= tile_min_rows) {
             // by tiles of 64 products per workgroup, the fold on one element per lane with the table words on the scalar path
             // (mul_tile.h); PHE_HIP_NO_TILE_MUL=1 keeps the kernel with the table in LDS
             TableMulArgs C = B;
@@ -1038,6 +1051,7 @@ static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, 
 struct RungShape {
     int G = 0, L = 0, rows = 0;  // G == 0: this rung has no kernel of the family asked for
     double wide = 1.0;           // what a rung too wide for the fused sweeps costs on top of the estimate (split_shape)
+    int family = 0;              // RungFamily: which measured table serves (measured_cost)
 };
 // Rungs with more than kMaxFusedL limbs per lane (3072-bit keys: 4 x 27 and, for the CRT halves, 2 x 27) run every pair
 // product as two single sweeps with the quotient digits handed over through LDS, and the estimate above is too kind to them
@@ -1062,7 +1076,23 @@ static double rung_cost(const phe_hip_ctx* ctx, size_t batch, const RungShape& r
     const double residencies = (wide && w <= 1.0) ? 1.16 : std::max(1.0, w);
     return (double)r.rows * (19.0 * r.L + 52.0) * (wide ? r.wide : 1.0) * residencies;
 }
-// rung index (0 = the members of the context, k >= 1 = the k-th extra rung): least estimated time for this batch
+// The MEASURED cost of a rung: the launch time (ns) of `batch` numbers of family r.family on groups of r.G lanes, from the table the
+// context was given (phe_hip_ctx_load_ladder) — piecewise linear in the batch size between the measured sizes; below the smallest
+// one the launch is latency-bound (its time stays), above the largest one it scales with the rows.  < 0: no table for this rung.
+static double measured_cost(const phe_hip_ctx* ctx, size_t batch, const RungShape& r) {
+    const auto it = ctx->ladder.find(r.family * 256 + r.G);
+    if (it == ctx->ladder.end() || it->second.empty()) return -1.0;
+    const std::vector<phe_hip_ctx::LadderPoint>& p = it->second;
+    const double b = (double)batch;
+    if (b <= p.front().rows) return p.front().ns;
+    if (b >= p.back().rows) return p.back().ns * b / p.back().rows;
+    size_t hi = 1;
+    while (p[hi].rows < b) ++hi;
+    const double t = (b - p[hi - 1].rows) / (p[hi].rows - p[hi - 1].rows);
+    return p[hi - 1].ns + t * (p[hi].ns - p[hi - 1].ns);
+}
+// rung index (0 = the members of the context, k >= 1 = the k-th extra rung): least time for this batch — measured when the
+// context holds a table for EVERY candidate rung of the family (the two kinds of cost are not comparable), estimated otherwise
 template <class Shape>
 static int pick_rung(const phe_hip_ctx* ctx, size_t batch, int n_rungs, Shape shape, int concurrent = 1) {
     if (ctx->force_group) {
@@ -1072,12 +1102,17 @@ static int pick_rung(const phe_hip_ctx* ctx, size_t batch, int n_rungs, Shape sh
             if (shape(k).G) return k;
         return 0;
     }
+    bool measured = !ctx->ladder.empty();
+    for (int k = 0; measured && k < n_rungs; ++k) {
+        const RungShape r = shape(k);
+        if (r.G && measured_cost(ctx, batch, r) < 0) measured = false;
+    }
     int best = -1;
     double best_cost = 0;
     for (int k = 0; k < n_rungs; ++k) {
         const RungShape r = shape(k);
         if (!r.G) continue;
-        const double c = rung_cost(ctx, batch, r, concurrent);
+        const double c = measured ? measured_cost(ctx, batch, r) : rung_cost(ctx, batch, r, concurrent);
         if (best < 0 || c < best_cost * 0.97) {  // a wider rung must be clearly better: ties go to the narrower one
             best = k;
             best_cost = c;
@@ -1116,6 +1151,7 @@ static RungShape split_shape(const DevSplit& sp, int family = kFamOther, bool la
     sh.L = late ? sp.q_L : sp.L;
     sh.rows = late ? sp.q_rows + (sp.G == 64 ? 1 : 0) : sp.rows;
     sh.wide = wide_rung_factor(family);
+    sh.family = family;
     return sh;
 }
 // the pair-form kernels modulo n
@@ -1225,12 +1261,24 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
             h.insert(h.end(), T.ncomp.begin(), T.ncomp.end());
             h.insert(h.end(), T.ncomp1.begin(), T.ncomp1.end());
             if (T.in_lds()) h.insert(h.end(), T.table.begin(), T.table.end());  // (3072-bit keys: the tile kernel only, table in L2)
-            HIP_TRY(hipMalloc((void**)&ctx->tmul_blob, h.size() * 4));
-            HIP_TRY(hipMemcpy(ctx->tmul_blob, h.data(), h.size() * 4, hipMemcpyHostToDevice));
-            if (T.tiles() && !getenv("PHE_HIP_NO_TILE_MUL")) {
-                HIP_TRY(hipMalloc((void**)&ctx->tmul_cols, T.table_cols.size() * 4));
-                HIP_TRY(hipMemcpy(ctx->tmul_cols, T.table_cols.data(), T.table_cols.size() * 4, hipMemcpyHostToDevice));
-            }
+            // an OPTIONAL fast path: a failed allocation or copy leaves the context on the Montgomery kernels (like a key width
+            // build_table_mul does not offer) instead of failing its creation
+            const auto put = [](uint32_t*& dptr, const std::vector<uint32_t>& words) {
+                if (hipMalloc((void**)&dptr, words.size() * 4) != hipSuccess) {
+                    dptr = nullptr;
+                    (void)hipGetLastError();
+                    return false;
+                }
+                if (hipMemcpy(dptr, words.data(), words.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+                    (void)hipGetLastError();
+                    (void)hipFree(dptr);
+                    dptr = nullptr;
+                    return false;
+                }
+                return true;
+            };
+            if (!put(ctx->tmul_blob, h)) ctx->tmul = host::TableMulPack();
+            else if (T.tiles() && !getenv("PHE_HIP_NO_TILE_MUL")) (void)put(ctx->tmul_cols, T.table_cols);  // (without it: the table-in-LDS kernel)
         }
     }
     ctx->force_unit = getenv("PHE_HIP_FORCE_UNIT") != nullptr;
@@ -1472,6 +1520,38 @@ int phe_hip_ctx_ladder(const phe_hip_ctx* ctx, int* pub_geoms, int* priv_geoms, 
         for (const auto& R : ctx->priv_rungs) put(priv_geoms, sp_priv ? geom_code(R.plan.psplit.G, R.plan.psplit.L) : geom_code(R.plan.psq.G, R.plan.psq.L));
     }
     if (n_priv) *n_priv = k;
+    return PHE_HIP_OK;
+}
+
+int phe_hip_ctx_load_ladder(phe_hip_ctx* ctx, const char* table, int* accepted) {
+    if (check_ctx(ctx)) return PHE_HIP_EINVAL;
+    if (accepted) *accepted = 0;
+    ctx->ladder.clear();
+    if (!table) return PHE_HIP_OK;  // (null: back to the estimate)
+    // lines "key_bits family G rows ns" (anything after '#' ignored); only the lines of this context's key width are kept
+    std::map<int, std::vector<phe_hip_ctx::LadderPoint>> got;
+    int count = 0;
+    const char* p = table;
+    while (*p) {
+        const char* e = strchr(p, '\n');
+        std::string line(p, e ? (size_t)(e - p) : strlen(p));
+        p = e ? e + 1 : p + line.size();
+        const size_t hash = line.find('#');
+        if (hash != std::string::npos) line.resize(hash);
+        int bits = 0, family = 0, G = 0;
+        double rows = 0, ns = 0;
+        if (sscanf(line.c_str(), "%d %d %d %lf %lf", &bits, &family, &G, &rows, &ns) != 5) continue;
+        if (bits != 32 * ctx->pub.s1 || family < 0 || family > 3 || G < 1 || G > 64 || !(rows >= 1) || !(ns > 0)) continue;
+        got[family * 256 + G].push_back({rows, ns});
+        ++count;
+    }
+    for (auto& kv : got) {
+        std::sort(kv.second.begin(), kv.second.end(), [](const phe_hip_ctx::LadderPoint& a, const phe_hip_ctx::LadderPoint& b) { return a.rows < b.rows; });
+        for (size_t i = 1; i < kv.second.size(); ++i)
+            if (kv.second[i].rows == kv.second[i - 1].rows) return fail(PHE_HIP_EINVAL, "ladder table: a batch size twice for one rung");
+    }
+    ctx->ladder.swap(got);
+    if (accepted) *accepted = count;
     return PHE_HIP_OK;
 }
 
@@ -2630,6 +2710,7 @@ int phe_hip_select_rows_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t*
     if (batch == 0) return PHE_HIP_OK;
     if (!a || !b || !mask || !out || limbs < 1) return fail(PHE_HIP_EINVAL, "null buffer / limbs");
     if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);  // (ordered against the context's earlier work on other streams, like every *_dev entry point)
     const size_t total = batch * (size_t)limbs;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)ctx->n_cus * 8);
     k_select_rows<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(a, b, mask, out, limbs, (uint64_t)batch);
@@ -2638,25 +2719,26 @@ int phe_hip_select_rows_dev(phe_hip_ctx* ctx, const uint32_t* a, const uint32_t*
 }
 
 static int move_rows(phe_hip_ctx* ctx, bool scatter, const uint32_t* src, const uint32_t* idx, uint32_t* dst, int limbs, size_t count,
-                     void* stream) {
+                     size_t far_rows, void* stream) {
     if (check_ctx(ctx)) return PHE_HIP_EINVAL;
     if (count == 0) return PHE_HIP_OK;
     if (!src || !idx || !dst || limbs < 1) return fail(PHE_HIP_EINVAL, "null buffer / limbs");
     if (int rc = bind_device(ctx)) return rc;
+    PHE_CTX_ORDER(ctx, stream);
     const size_t total = count * (size_t)limbs;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, (size_t)ctx->n_cus * 8);
-    if (scatter) k_move_rows<true><<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(src, idx, dst, limbs, (uint64_t)count);
-    else k_move_rows<false><<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(src, idx, dst, limbs, (uint64_t)count);
+    if (scatter) k_move_rows<true><<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(src, idx, dst, limbs, (uint64_t)count, (uint64_t)far_rows);
+    else k_move_rows<false><<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(src, idx, dst, limbs, (uint64_t)count, (uint64_t)far_rows);
     HIP_TRY(hipGetLastError());
     return PHE_HIP_OK;
 }
-int phe_hip_gather_rows_dev(phe_hip_ctx* ctx, const uint32_t* src, const uint32_t* idx, uint32_t* dst, int limbs, size_t count,
-                            void* stream) {
-    return move_rows(ctx, false, src, idx, dst, limbs, count, stream);
+int phe_hip_gather_rows_dev(phe_hip_ctx* ctx, const uint32_t* src, size_t src_rows, const uint32_t* idx, uint32_t* dst, int limbs,
+                            size_t count, void* stream) {
+    return move_rows(ctx, false, src, idx, dst, limbs, count, src_rows, stream);
 }
-int phe_hip_scatter_rows_dev(phe_hip_ctx* ctx, const uint32_t* src, const uint32_t* idx, uint32_t* dst, int limbs, size_t count,
-                             void* stream) {
-    return move_rows(ctx, true, src, idx, dst, limbs, count, stream);
+int phe_hip_scatter_rows_dev(phe_hip_ctx* ctx, const uint32_t* src, const uint32_t* idx, uint32_t* dst, size_t dst_rows, int limbs,
+                             size_t count, void* stream) {
+    return move_rows(ctx, true, src, idx, dst, limbs, count, dst_rows, stream);
 }
 
 // ---- decimal wire format (csrc/radix_conv.h, kernels_radix.hip) -------------------------------------------------

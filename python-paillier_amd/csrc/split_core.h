@@ -95,6 +95,8 @@ struct SplitArgs {
 // rows in one lane a column takes the weight of L products as before (its k + r is constant, so k - r runs over every class of
 // one parity twice for even L, over every class once for odd L), hence the accumulator bounds of the full sweep hold.
 template <int L>
+constexpr bool sq_has_doubled() { return L >= 3; }  // (L = 1, 2: every class is its own negative)
+template <int L>
 constexpr int sq_weight(int k, int r) {  // limb k of the lane, row r of the trip: 0 = the mirror image takes it, 1 = once, 2 = doubled
     const int c = ((k - r) % L + L) % L;
     if (c == 0 || 2 * c == L) return 1;
@@ -102,8 +104,7 @@ constexpr int sq_weight(int k, int r) {  // limb k of the lane, row r of the tri
 }
 // acc[(k + j) % L] += x * b[k] over the limbs a squaring row takes (x: the row's digit of X0, b: the lane's limbs of X0)
 template <int L>
-PHE_DEV void sq_row(uint64_t (&acc)[L], uint32_t x, const uint32_t (&b)[L], int j) {
-    const uint32_t x2 = x << 1;  // limbs stay below 2^29 + 2^8
+PHE_DEV void sq_row(uint64_t (&acc)[L], uint32_t x, uint32_t x2, const uint32_t (&b)[L], int j) {  // x2 = 2*x (limbs stay below 2^29 + 2^8)
 #pragma unroll
     for (int k = 0; k < L; ++k) {
         const int w = sq_weight<L>(k, j);
@@ -128,7 +129,7 @@ PHE_DEV void montmul_q(uint32_t (&out)[L], const uint32_t* a, const uint32_t (&b
         for (int j = 0; j < L; ++j) {
             const uint32_t ai = a[i + j];
             if constexpr (SQ) {
-                sq_row<L>(acc, ai, b, j);
+                sq_row<L>(acc, ai, ai << 1, b, j);
             } else {
 #pragma unroll
                 for (int k = 0; k < L; ++k) acc[(k + j) % L] = wave::mad64(ai, b[k], acc[(k + j) % L]);
@@ -312,9 +313,11 @@ struct Trip {
 // z0 = (a*b0 + m*n) / R,   z1 = (m + a*b1 + m2*n) / R.     a: H digits in LDS.
 // Squaring: b0 = X0, b1 = 2*X1 (SQ: a holds the digits of b0 itself, the first word takes the symmetric half: sq_row).
 // Conversion of a plain chunk a: (b0, b1) = pair(R^(j+2)).
+// a2 (SQ only, may be null): the digits of a doubled, a second LDS row — a digit read instead of a shift on the vector pipe per row
 template <int G, int L, bool U = false, bool SQ = false>
 PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a, const uint32_t (&b0)[L],
-                        const uint32_t (&b1)[L], const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln, int rows = G * L) {
+                        const uint32_t (&b1)[L], const uint32_t (&n)[L], uint32_t n0inv, const Lanes<G>& ln, int rows = G * L,
+                        const uint32_t* a2 = nullptr) {
     const uint32_t lane0 = kLimbMask & ~ln.not_low;  // digit mask in lane 0 of the group, 0 elsewhere
     const uint32_t dmask = kLimbMask & ln.not_top;
     // = kLimbMask in every lane (no lane of a group of >= 2 is both top and low), but plain VGPR data to the compiler,
@@ -324,6 +327,7 @@ PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
 #pragma unroll
     for (int k = 0; k < L; ++k) p[k] = q[k] = 0;
     constexpr int kT = Trip<G, L>::kDigits;
+    constexpr bool kSqRow2 = SQ && sq_has_doubled<L>() && !Trip<G, L>::kAhead;
     uint32_t ahead_a[kT];
     if constexpr (Trip<G, L>::kAhead) {
 #pragma unroll
@@ -345,7 +349,7 @@ PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
             const int j = jj % L;
             const uint32_t ai = Trip<G, L>::kAhead ? dig_a[jj] : a[i + jj];
             if constexpr (SQ) {
-                sq_row<L>(p, ai, b0, j);
+                sq_row<L>(p, ai, kSqRow2 ? a2[i + jj] : ai << 1, b0, j);  // (kSqRow2: the caller filled a2, split_square)
             } else {
 #pragma unroll
                 for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(ai, b0[k], p[(k + j) % L]);
@@ -444,7 +448,7 @@ template <int G, int L, bool U, bool SQ = false>
 PHE_DEV void pair_mul_plain(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t (&b0)[L], const uint32_t (&b1)[L],
                             const SplitLane<G, L, U>& K, const Lanes<G>& ln) {
     if constexpr (L <= kMaxFusedL) {
-        pair_pass2<G, L, U, SQ>(z0, z1, K.row_a, b0, b1, K.n, K.n0inv, ln, K.rows());
+        pair_pass2<G, L, U, SQ>(z0, z1, K.row_a, b0, b1, K.n, K.n0inv, ln, K.rows(), SQ ? K.row_c : nullptr);
     } else {
         uint32_t u[L];
         montmul_q<G, L, U, SQ>(u, K.row_a, b0, K.row_c, K.n, K.n0inv, ln, K.rows());
@@ -458,7 +462,18 @@ PHE_DEV void pair_mul_plain(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t
 template <int G, int L, bool U>
 PHE_DEV void split_square(uint32_t (&X0)[L], uint32_t (&X1)[L], const SplitLane<G, L, U>& K, const Lanes<G>& ln) {
     uint32_t d[L];
-    lds_put<L>(K.row_a, X0, ln.g);
+    if constexpr (L <= kMaxFusedL && sq_has_doubled<L>() && !Trip<G, L>::kAhead) {
+        // digits of X0 in row_a, the same doubled in row_c (free during a fused squaring): the sweep reads both
+        wave::lds_fence();
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            K.row_a[ln.g * L + k] = X0[k];
+            K.row_c[ln.g * L + k] = X0[k] << 1;
+        }
+        wave::lds_fence();
+    } else {
+        lds_put<L>(K.row_a, X0, ln.g);
+    }
 #pragma unroll
     for (int k = 0; k < L; ++k) d[k] = X1[k];
     add_normalize<G, L>(d, X1, ln);  // 2*X1
@@ -851,7 +866,7 @@ PHE_DEV void late_iteration(uint64_t (&p)[L], uint64_t (&q)[L], uint32_t an, uin
     const uint32_t m = late_quotient_step<G, L, kNarrowP, true>(p, jl, 0u, dq, mk, ln);    // dq: digit i of Q (lane 0)
     const uint32_t m2 = late_quotient_step<G, L, kNarrowQ, false>(q, jlq, dq, unused, mk, ln);
     if constexpr (SQ) {
-        sq_row<L>(p, an, b0, j);
+        sq_row<L>(p, an, an << 1, b0, j);
     } else {
 #pragma unroll
         for (int k = 0; k < L; ++k) p[(k + j) % L] = wave::mad64(an, b0[k], p[(k + j) % L]);
@@ -908,7 +923,7 @@ PHE_DEV void pair_late(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a, 
     {
         const uint32_t a0 = a[0];
         if constexpr (SQ) {
-            sq_row<L>(p, a0, b0, 0);
+            sq_row<L>(p, a0, a0 << 1, b0, 0);
         } else {
 #pragma unroll
             for (int k = 0; k < L; ++k) p[k] = wave::mad64(a0, b0[k], p[k]);

@@ -295,7 +295,7 @@ class Engine:
             idx = np.nonzero(neg)[0].astype(np.uint32)
             idx_d = DeviceArray.from_host(self.ctx, idx)
             sub = DeviceArray(self.ctx, count, self.ct_limbs)
-            self.ctx.gather_rows_dev(c.ptr, idx_d.ptr, sub.ptr, self.ct_limbs, count)
+            self.ctx.gather_rows_dev(c.ptr, c.rows, idx_d.ptr, sub.ptr, self.ct_limbs, count)
             inv = DeviceArray(self.ctx, count, self.ct_limbs)
             try:
                 self.ctx.invert_dev(sub.ptr, inv.ptr, count)
@@ -304,7 +304,7 @@ class Engine:
                     e.bad_index = int(idx[e.bad_index])
                 raise
             base = c.copy()
-            self.ctx.scatter_rows_dev(inv.ptr, idx_d.ptr, base.ptr, self.ct_limbs, count)
+            self.ctx.scatter_rows_dev(inv.ptr, idx_d.ptr, base.ptr, base.rows, self.ct_limbs, count)
             self.ctx.sync()
             return base
         inv = DeviceArray(self.ctx, c.rows, self.ct_limbs)
@@ -907,6 +907,8 @@ class Engine:
         self.ctx.montmul_dev(a.ptr, const.ptr, True, out.ptr, a.rows, stream or 0)
         if stream is None:
             self.ctx.sync()
+        else:
+            out._keep_const = const     # queued, not run yet: the constant lives as long as the result (the cache may evict it)
         return out
 
     def montmul_tree_dev(self, store, debt):
@@ -923,6 +925,7 @@ class Engine:
             self.ctx.montmul_dev(store.rows_view(0, half).ptr, store.rows_view(half, 2 * half).ptr, False, merged.ptr, half, st or 0)
             if odd:                                           # the row left over is taken to the new debt: * R^-(debt+1)
                 const = self._mont_const_row(-(debt + 1) + 1)
+                keep.append(const)                            # (the cache may evict the row while the queued kernel still reads it)
                 self.ctx.montmul_dev(store.rows_view(2 * half, 2 * half + 1).ptr, const.ptr, True,
                                      merged.rows_view(half, half + 1).ptr, 1, st or 0)
             keep.append(merged)

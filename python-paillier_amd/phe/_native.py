@@ -83,8 +83,8 @@ def lib():
         L.phe_hip_memcpy_d2d.argtypes = [vp, vp, vp, sz, vp]
         L.phe_hip_invert_dev.argtypes = [vp, vp, vp, sz, ctypes.POINTER(sz), vp]
         L.phe_hip_select_rows_dev.argtypes = [vp, vp, vp, vp, vp, ci, sz, vp]
-        L.phe_hip_gather_rows_dev.argtypes = [vp, vp, vp, vp, ci, sz, vp]
-        L.phe_hip_scatter_rows_dev.argtypes = [vp, vp, vp, vp, ci, sz, vp]
+        L.phe_hip_gather_rows_dev.argtypes = [vp, vp, sz, vp, vp, ci, sz, vp]
+        L.phe_hip_scatter_rows_dev.argtypes = [vp, vp, vp, vp, sz, ci, sz, vp]
         L.phe_hip_selftest_prims.argtypes = [ci, vp]
         L.phe_hip_comm_unique_id.argtypes = [vp]
         L.phe_hip_comm_create.argtypes = [vp, vp, ci, ci, ctypes.POINTER(vp)]
@@ -93,6 +93,7 @@ def lib():
         L.phe_hip_comm_destroy.restype = None
         L.phe_hip_ctx_ladder.argtypes = [vp, vp, vp, ci, ctypes.POINTER(ci), ctypes.POINTER(ci)]
         L.phe_hip_ctx_set_group.argtypes = [vp, ci]
+        L.phe_hip_ctx_load_ladder.argtypes = [vp, ctypes.c_char_p, ctypes.POINTER(ci)]
         L.phe_hip_ctx_last_launch.argtypes = [vp] + [ctypes.POINTER(ci)] * 3
         L.phe_hip_ctx_release_scratch.argtypes = [vp]
         L.phe_hip_pair_words.argtypes = [vp, ctypes.POINTER(ci)]
@@ -119,10 +120,27 @@ EXPORTED_SYMBOLS = [
     "phe_hip_stream_destroy", "phe_hip_miller_rabin", "phe_hip_montmul_dev", "phe_hip_mont_radix_bits",
     "phe_hip_comm_unique_id", "phe_hip_comm_create", "phe_hip_allgather_dev", "phe_hip_comm_destroy",
     "phe_hip_encrypt_owner", "phe_hip_encrypt_owner_dev", "phe_hip_ctx_owner_encrypt",
-    "phe_hip_ctx_ladder", "phe_hip_ctx_set_group", "phe_hip_ctx_last_launch", "phe_hip_ctx_release_scratch",
+    "phe_hip_ctx_ladder", "phe_hip_ctx_set_group", "phe_hip_ctx_load_ladder", "phe_hip_ctx_last_launch", "phe_hip_ctx_release_scratch",
     "phe_hip_pair_words", "phe_hip_to_pair_dev", "phe_hip_pair_mul_dev", "phe_hip_from_pair_dev", "phe_hip_pair_reduce_dev",
     "phe_hip_pair_powmod_dev", "phe_hip_pair_multiexp_rows_dev",
 ]
+
+
+LADDER_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ladder_gfx950.txt")
+_ladder_text = None
+
+
+def measured_ladder_text():
+    """the committed calibration of the geometry ladder (tools/bench_sweep.py --calibrate on an MI355X), or None.
+    PHE_HIP_LADDER_FILE names another table; PHE_HIP_NO_MEASURED_LADDER=1 keeps the library's estimate."""
+    global _ladder_text
+    if _ladder_text is None:
+        try:
+            with open(os.environ.get("PHE_HIP_LADDER_FILE", LADDER_FILE)) as f:
+                _ladder_text = f.read()
+        except OSError:
+            _ladder_text = ""
+    return _ladder_text or None
 
 
 def _raise(rc, bad_index=None):
@@ -240,6 +258,17 @@ class Context:
             _check(L.phe_hip_ctx_create_private(_ptr(n_arr), self.n_limbs, *[_ptr(a) for a in arrs], pq, device,
                                                 ctypes.byref(self._h)))
             self.has_private = True
+        self.measured_ladder_lines = 0
+        if not os.environ.get("PHE_HIP_NO_MEASURED_LADDER"):
+            self.load_ladder(measured_ladder_text())
+
+    def load_ladder(self, text):
+        """Give the context a measured ladder (include/phe_hip.h phe_hip_ctx_load_ladder: lines "key_bits family G rows ns"; None
+        forgets it: the rung of a call is then picked from the estimate).  Returns the lines kept (those of this key width)."""
+        kept = ctypes.c_int(0)
+        _check(lib().phe_hip_ctx_load_ladder(self._h, text.encode() if text else None, ctypes.byref(kept)))
+        self.measured_ladder_lines = kept.value
+        return kept.value
 
     def close(self):
         if self._h and self._h.value:
@@ -568,13 +597,14 @@ class Context:
     def select_rows_dev(self, a_ptr, b_ptr, mask_ptr, out_ptr, limbs, batch, stream=0):
         _check(lib().phe_hip_select_rows_dev(self._h, a_ptr, b_ptr, mask_ptr, out_ptr, limbs, batch, stream))
 
-    def gather_rows_dev(self, src_ptr, idx_ptr, dst_ptr, limbs, count, stream=0):
-        """dst[j] = src[idx[j]] for `count` rows of `limbs` words (idx: uint32 row indices on the device)"""
-        _check(lib().phe_hip_gather_rows_dev(self._h, src_ptr, idx_ptr, dst_ptr, limbs, count, stream))
+    def gather_rows_dev(self, src_ptr, src_rows, idx_ptr, dst_ptr, limbs, count, stream=0):
+        """dst[j] = src[idx[j]] for `count` rows of `limbs` words (idx: uint32 row indices on the device; an index >= src_rows
+        gives a row of zeros)"""
+        _check(lib().phe_hip_gather_rows_dev(self._h, src_ptr, src_rows, idx_ptr, dst_ptr, limbs, count, stream))
 
-    def scatter_rows_dev(self, src_ptr, idx_ptr, dst_ptr, limbs, count, stream=0):
-        """dst[idx[j]] = src[j]"""
-        _check(lib().phe_hip_scatter_rows_dev(self._h, src_ptr, idx_ptr, dst_ptr, limbs, count, stream))
+    def scatter_rows_dev(self, src_ptr, idx_ptr, dst_ptr, dst_rows, limbs, count, stream=0):
+        """dst[idx[j]] = src[j] (an index >= dst_rows is skipped)"""
+        _check(lib().phe_hip_scatter_rows_dev(self._h, src_ptr, idx_ptr, dst_ptr, dst_rows, limbs, count, stream))
 
     def stream_create(self):
         """a stream whose launches overlap the blocking h2d / d2h copies (they are ordered on the NULL stream)"""

@@ -58,6 +58,7 @@ class Fleet:
         self._make = make_engine
         self._lock = threading.Lock()
         self._pool = ThreadPoolExecutor(max_workers=len(self.devices), thread_name_prefix="phe-fleet")
+        self._retired = []     # (engine of a fleet this one replaced, its slot here): resident rows made there resolve to the successor
 
     def __len__(self):
         return len(self.devices)
@@ -75,11 +76,39 @@ class Fleet:
         return [self.engine(k) for k in range(len(self.devices))]
 
     def engine_of(self, ctx):
-        """the fleet's engine that owns the native context `ctx` (a resident vector's home), or None"""
+        """the fleet's engine that owns the native context `ctx` (a resident vector's home) — or, for a context of a fleet this
+        one replaced (succeed), the engine that took its place on the SAME device —, or None"""
         for eng in self._engines:
             if eng is not None and eng.ctx is ctx:
                 return eng
+        for old, k in self._retired:
+            if old.ctx is ctx:
+                return self.engine(k)
         return None
+
+    def engine_on(self, device):
+        """an engine of the fleet on `device` (device pointers are valid across the contexts of one GPU), or None"""
+        for k, d in enumerate(self.devices):
+            if d == device:
+                return self.engine(k)
+        return None
+
+    def succeed(self, old):
+        """Take the place of the fleet `old` (same device list): every engine `old` had made gets its successor here NOW, on the
+        same device and with the same obfuscator pool OBJECT (rows are taken under one lock whichever engine a thread is in),
+        and resident rows made by `old`'s engines resolve to those successors (engine_of).  The key pair's engines replacing a
+        public key's (PaillierPrivateKey._get_engine): a vector that encrypt_batch_sharded left on device k must be decrypted
+        by an engine ON device k that holds the private key — never by the device-0 engine."""
+        assert list(old.devices) == self.devices
+        for k, eng in enumerate(old._engines):
+            if eng is None:
+                continue
+            if k > 0:
+                self.engine(k)._obf = eng._obf
+            if eng is not self._engines[k]:
+                self._retired.append((eng, k))
+        self._retired.extend(old._retired)
+        return self
 
     def shards(self, rows, min_rows=None):
         """contiguous [lo, hi) bounds, one per device that gets work (at least `min_rows` rows each; one shard = no fan-out)"""

@@ -107,13 +107,25 @@ class PaillierPublicKey(object):
     def _engine_for(self, store):
         """the engine that owns a resident array (a vector made by encrypt_batch_sharded lives on ITS device), else the
         key's ordinary engine"""
-        fl = self._fleet
+        primary = self._get_engine()
         ctx = getattr(store, "ctx", None)
-        if fl is not None and ctx is not None:
+        if ctx is None or ctx is primary.ctx:
+            return primary
+        fl = self._fleet
+        if fl is not None:
             eng = fl.engine_of(ctx)
             if eng is not None:
                 return eng
-        return self._get_engine()
+        device = getattr(ctx, "device", None)
+        if device is None or device == primary.device:
+            return primary          # another context of the primary's GPU (e.g. the public engine a key pair's engine replaced)
+        if fl is not None:
+            eng = fl.engine_on(device)
+            if eng is not None:
+                return eng
+        # never launch one device's kernels on another device's pointers (nothing here enables peer access)
+        raise RuntimeError("resident rows live on device %r, which no engine of this key serves (engines on %r): move them "
+                           "through the host (vector.to_host())" % (device, [primary.device] + (fl.devices[1:] if fl else [])))
 
     def __repr__(self):
         return "<PaillierPublicKey {}>".format(hex(hash(self))[2:][:10])
@@ -173,24 +185,32 @@ class PaillierPublicKey(object):
         return EncryptedNumber(self, c, encoding.exponent)
 
     # ---- offline / online split ------------------------------------------------------------------------
-    def precompute_obfuscators(self, count):
+    def precompute_obfuscators(self, count, sharded=False):
         """Make `count` obfuscators r^n mod n^2 (fresh r from the OS CSPRNG) ahead of time and keep them in HBM.
         encrypt_batch without r_values and EncryptedVector.obfuscate() then consume them — one product per element
         instead of a modular exponentiation — and fall back to drawing on the spot when the pool is short.  Every
-        obfuscator is used once.  Returns the number available."""
+        obfuscator is used once.  Returns the number available.  With a fleet (PHE_HIP_DEVICES) the pool is cut the way the
+        batch that will consume it is cut: `encrypt_batch` of `count` rows by default, `encrypt_batch_sharded` of `count` rows
+        (one part per device whatever the size) with sharded=True."""
         fl = self._get_fleet()
         count = int(count)
-        if fl is not None and count >= 2 * len(fl):
-            # every device fills ITS pool with its contiguous share (a pool is never shared across devices)
-            fl.each(lambda eng, k: eng.fill_obfuscator_pool(shard_bounds(count, len(fl), k)[1] - shard_bounds(count, len(fl), k)[0]))
+        bounds = fl.shards(count, min_rows=1 if sharded else None) if fl is not None else []
+        if len(bounds) > 1:
+            # the devices a batch of `count` rows fans out to fill THEIR pools with the shares that batch will take from them
+            # (a pool is never shared across devices; a batch too small to fan out, and every scalar call, is served by the
+            # primary engine alone — so a small `count` goes there whole instead of being spread where nothing would use it)
+            futures = [fl._pool.submit(fl.engine(k).fill_obfuscator_pool, hi - lo) for k, (lo, hi) in enumerate(bounds)]
+            for f in futures:
+                f.result()
             return self.obfuscators_available()
         return self._get_engine().fill_obfuscator_pool(count)
 
-    def obfuscators_available(self):
+    def obfuscators_available(self, per_device=False):
+        """obfuscators made ahead of time and not used yet; per_device=True: the list, one entry per engine that exists (an
+        obfuscator is only ever used by the device that holds it)"""
         fl = self._fleet
-        if fl is not None:
-            return sum(eng.obfuscators_available() for eng in fl.made())
-        return self._get_engine().obfuscators_available()
+        counts = [eng.obfuscators_available() for eng in (fl.made() if fl is not None else [self._get_engine()])]
+        return counts if per_device else sum(counts)
 
     def discard_obfuscators(self):
         """forget the obfuscators made ahead of time: the next encryptions draw and exponentiate on the spot again"""
@@ -334,7 +354,14 @@ class PaillierPrivateKey(object):
                     # the further devices of a fleet get key-pair engines too (built on first use), each with a pool of its own
                     n, p, q, hp, hq, pinv = pub.n, self.p, self.q, self.hp, self.hq, self.p_inverse
                     pub._fleet_factory = lambda device: Engine(n, p, q, hp, hq, pinv, device=device)
-                    pub._fleet = None
+                    old_fleet, pub._fleet = pub._fleet, None
+                    if old_fleet is not None:
+                        # the public key already fanned out (encrypt_batch_sharded / precompute_obfuscators before the first
+                        # private-key call): its resident parts live on devices 1..k and its pools hold obfuscators there.
+                        # The key pair's fleet is built NOW, engine for engine on the same devices, each adopting the pool of
+                        # the engine it replaces; the old contexts resolve to their successors (Fleet.succeed)
+                        from . import fleet
+                        pub._fleet = fleet.Fleet(fresh, pub._fleet_factory, old_fleet.devices).succeed(old_fleet)
                 self._engine = fresh
             return self._engine
 

@@ -120,7 +120,7 @@ def test_bench_strong_scaling_shards_one_job_over_the_ranks():
     args = [a for a in SELFTEST]
     args[args.index("--batch") + 1] = "7"
     out = _run_bench([sys.executable, "bench.py", "--gpus", "2", "--scaling", "strong"] + args)
-    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["rccl_ranks"] == 2
     assert out["config"]["batch_whole_job"] == 7 and out["config"]["batch_per_gpu"] == 4
     assert out["bit_exact"]["roundtrip_full_batch"] is True
     cfg4 = out["config4"]

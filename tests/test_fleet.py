@@ -160,9 +160,9 @@ def test_resident_shards_and_per_device_pools(monkeypatch):
     priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
     fl = priv._get_fleet()
     rows = 3001
-    assert pub.precompute_obfuscators(rows + 9) == rows + 9
+    assert pub.precompute_obfuscators(rows + 9, sharded=True) == rows + 9      # cut like encrypt_batch_sharded: a part per context
     per_pool = [eng.obfuscators_available() for eng in fl.engines()]
-    assert per_pool == [1505, 1505] and fl.engine(0)._obf is not fl.engine(1)._obf
+    assert per_pool == [1505, 1505] == pub.obfuscators_available(per_device=True) and fl.engine(0)._obf is not fl.engine(1)._obf
     peek = [set(eng.peek_obfuscators(50)) for eng in fl.engines()]
     assert not (peek[0] & peek[1])                                                # different r^n in the two pools
     x = np.linspace(-7.5, 9.25, rows)
@@ -176,3 +176,97 @@ def test_resident_shards_and_per_device_pools(monkeypatch):
     assert np.allclose(priv.decrypt_batch(mixed), x[:1500] + x[1501:], rtol=0, atol=1e-9)
     pub.discard_obfuscators()
     assert pub.obfuscators_available() == 0
+
+
+def test_three_contexts_uneven_shards_through_encrypt_add_decrypt(monkeypatch):
+    """no multi-GPU hardware has run this path, so the plumbing must not be able to fail there — three
+    emulator contexts (distinct device ids), 26 rows cut 9 + 9 + 8, encrypt_batch -> `+` -> `*` -> decrypt_batch, a pool and a
+    lock per context, results in shard order"""
+    import emu_backend
+    emu_backend.install(monkeypatch)
+    monkeypatch.setenv("PHE_HIP_DEVICES", "0,1,2")
+    monkeypatch.setattr(fleet, "MIN_ROWS_PER_DEVICE", 2)
+    g = load_golden(256)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    fl = priv._get_fleet()
+    assert len(fl) == 3 and [e.device for e in fl.engines()] == [0, 1, 2]
+    assert len({id(e._obf) for e in fl.engines()}) == 3 and len({id(e.ctx) for e in fl.engines()}) == 3
+    assert fl.shards(26) == [(0, 9), (9, 18), (18, 26)]
+    rows_seen = {}
+    for e in fl.engines():
+        for name in ("raw_encrypt", "raw_decrypt", "raw_add"):
+            def counted(*a, _f=getattr(e, name), _key=(e.device, name), **kw):
+                first = a[0]
+                rows_seen[_key] = rows_seen.get(_key, 0) + (first.shape[0] if hasattr(first, "shape") else len(first))
+                return _f(*a, **kw)
+            monkeypatch.setattr(e, name, counted)
+    rng = np.random.RandomState(3)
+    x, y = rng.uniform(-50, 50, size=26), rng.uniform(-50, 50, size=26)
+    a, b = pub.encrypt_batch(x), pub.encrypt_batch(y)
+    assert [rows_seen[(d, "raw_encrypt")] for d in (0, 1, 2)] == [18, 18, 16]
+    monkeypatch.setattr(fleet, "MIN_ROWS_PER_DEVICE", 1)                    # (the sum's threshold is 8 x this)
+    total = a + b
+    assert [rows_seen.get((d, "raw_add"), 0) for d in (0, 1, 2)] == [9, 9, 8]
+    monkeypatch.setattr(fleet, "MIN_ROWS_PER_DEVICE", 2)
+    got = priv.decrypt_batch(total)
+    assert [rows_seen[(d, "raw_decrypt")] for d in (0, 1, 2)] == [9, 9, 8]
+    assert np.allclose(got, x + y, rtol=0, atol=1e-9)
+
+
+class _Rows:  # what _engine_for looks at of a resident array: the native context it was made in
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+
+def test_private_engine_takes_over_a_public_fleet_device_for_device(monkeypatch):
+    """`pub.encrypt_batch_sharded(x)` BEFORE the first private-key call builds a public-only fleet; the
+    key pair's engine then replaces the public one.  The resident parts made on devices 1..k must resolve to engines ON those
+    devices that hold the private key (never to the device-0 engine: nothing enables peer access), and the per-device
+    obfuscator pools must travel with their devices."""
+    import emu_backend
+    emu_backend.install(monkeypatch)
+    monkeypatch.setenv("PHE_HIP_DEVICES", "0,1,2")
+    g = load_golden(256)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    old = pub._get_fleet()                                               # public-only: what encrypt_batch_sharded would use
+    old_engines = old.engines()
+    assert not any(e.ctx.has_private for e in old_engines)
+    parts = [_Rows(e.ctx) for e in old_engines]                          # "resident vectors", one per device
+    assert [pub._engine_for(p) for p in parts] == old_engines
+    priv._get_engine()                                                   # the key pair's engine takes over
+    new = pub._get_fleet()
+    assert new is not old and new is priv._get_fleet() and new.devices == [0, 1, 2]
+    homes = [pub._engine_for(p) for p in parts]
+    assert [e.device for e in homes] == [0, 1, 2] and all(e.ctx.has_private for e in homes)
+    assert homes == new.engines() and homes[0] is priv._get_engine()
+    assert [e._obf for e in homes] == [e._obf for e in old_engines]      # each pool stayed with its device
+    # a second take-over (another PaillierPrivateKey object for the same public key) keeps resolving the first fleet's contexts
+    stranger = _Rows(type("Ctx", (), {"device": 7})())
+    with pytest.raises(RuntimeError, match="device 7"):
+        pub._engine_for(stranger)
+    same_gpu = _Rows(type("Ctx", (), {"device": 2})())                   # an unknown context of a served GPU: pointers are valid there
+    assert pub._engine_for(same_gpu) is homes[2]
+
+
+@pytest.mark.gpu
+def test_shards_made_before_the_private_engine_exists_decrypt_where_they_live(monkeypatch):
+    """the documented flow, in the order ADVICE round 4 found broken: generate -> pub.encrypt_batch_sharded -> priv.decrypt_batch
+    (two contexts on device 0 stand in for two GPUs; the second part's home must be the successor of the context that made it)"""
+    monkeypatch.setenv("PHE_HIP_DEVICES", "0,0")
+    g = load_golden(2048)
+    pub = paillier.PaillierPublicKey(H(g["n"]))
+    priv = paillier.PaillierPrivateKey(pub, H(g["p"]), H(g["q"]))
+    x = np.linspace(-3.5, 8.25, 4100)
+    pub.precompute_obfuscators(64, sharded=True)
+    parts = pub.encrypt_batch_sharded(x)                                 # public-only fleet
+    old = pub._fleet
+    assert len(parts) == 2 and all(p.on_device for p in parts) and not any(e.ctx.has_private for e in old.made())
+    pools = [e._obf for e in old.engines()]
+    got = priv.decrypt_batch(parts)                                      # builds the key pair's engines
+    assert np.allclose(got, x, rtol=0, atol=1e-9)
+    new = pub._fleet
+    assert new is not old and [e._obf for e in new.engines()] == pools
+    assert [parts[i]._eng() is new.engine(i) for i in (0, 1)] == [True, True]
+    assert np.allclose(priv.decrypt_batch([p + p for p in parts]), 2 * x, rtol=0, atol=1e-9)

@@ -464,14 +464,26 @@ def test_negative_scalars_invert_only_the_rows_that_take_the_branch(native, c_or
     idx = np.array([5, 2999, 0, 77], dtype=np.uint32)
     idx_d = DeviceArray.from_host(eng.ctx, idx)
     sub = DeviceArray(eng.ctx, 4, s2)
-    eng.ctx.gather_rows_dev(c_dev.ptr, idx_d.ptr, sub.ptr, s2, 4)
+    eng.ctx.gather_rows_dev(c_dev.ptr, rows, idx_d.ptr, sub.ptr, s2, 4)
     eng.ctx.sync()
     assert np.array_equal(sub.to_host(), src[idx.astype(np.int64)])
     dst = DeviceArray.from_host(eng.ctx, np.zeros((rows, s2), np.uint32))
-    eng.ctx.scatter_rows_dev(sub.ptr, idx_d.ptr, dst.ptr, s2, 4)
+    eng.ctx.scatter_rows_dev(sub.ptr, idx_d.ptr, dst.ptr, rows, s2, 4)
     eng.ctx.sync()
     back = dst.to_host()
     assert np.array_equal(back[idx.astype(np.int64)], src[idx.astype(np.int64)]) and int(np.count_nonzero(back.any(axis=1))) == 4
+    # an index beyond the indexed buffer never leaves it: the gather gives a row of zeros, the scatter skips the row
+    short = 100                                                    # pretend the indexed side holds only 100 rows: 2999 is out of range
+    eng.ctx.gather_rows_dev(c_dev.ptr, short, idx_d.ptr, sub.ptr, s2, 4)
+    eng.ctx.sync()
+    got = sub.to_host()
+    assert np.array_equal(got[[0, 2, 3]], src[[5, 0, 77]]) and not got[1].any()
+    dst2 = DeviceArray.from_host(eng.ctx, np.zeros((rows, s2), np.uint32))
+    sub = DeviceArray.from_host(eng.ctx, src[idx.astype(np.int64)])
+    eng.ctx.scatter_rows_dev(sub.ptr, idx_d.ptr, dst2.ptr, short, s2, 4)
+    eng.ctx.sync()
+    back2 = dst2.to_host()
+    assert not back2[2999].any() and int(np.count_nonzero(back2.any(axis=1))) == 3
     # no inverse: the index is the row's place in the vector, not in the subset
     bad = list(cs)
     where = int(np.nonzero(neg)[0][17])

@@ -56,12 +56,22 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def test_two_rank_gloo_encrypt_and_allgather(tmp_path):
+def _run_ranks(tmp_path, world, port):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, PHE_ROOT=ROOT, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
     res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    assert res.stdout.count("ok") == 2
+    assert res.stdout.count("ok") == world
+
+
+def test_two_rank_gloo_encrypt_and_allgather(tmp_path):
+    _run_ranks(tmp_path, 2, 29617)
+
+
+def test_three_rank_gloo_encrypt_and_allgather(tmp_path):
+    """7 rows over 3 ranks (3 + 2 + 2): ragged shards, padding rows in the gather, an odd world size — the first hardware run
+    with N > 2 must not be the first time this cut is made"""
+    _run_ranks(tmp_path, 3, 29619)
