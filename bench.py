@@ -194,6 +194,20 @@ def pmc_valu_per_unit(kernel_key):
     return None, None
 
 
+def measured_ops_traffic(key_bits):
+    """PMC records of the kernels behind the `ops` entries (configs[2]) from the newest committed hbm_traffic_r*.json that has them:
+    {op name: {"bytes_per_row", "valu_wave_instructions_per_row", "kernel", ...}}, file — tools/gpu_pmc_traffic.sh, legs ops<bits>"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "hbm_traffic_r*.json")))
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                recs = json.load(f)["ops"][str(key_bits)]
+            return recs, os.path.basename(path)
+        except Exception:
+            continue
+    return {}, None
+
+
 def host_cores():
     """Usable host cores: CPU affinity, further limited by a cgroup CPU quota if one is set."""
     try:
@@ -370,10 +384,10 @@ class HipBackend:
         return self.torch.arange(0, rows, step, dtype=self.torch.int32, device=self.dev)
 
     def gather_rows(self, ctx, src, idx, dst, count):
-        ctx.gather_rows_dev(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), src.shape[1], count, self.stream)
+        ctx.gather_rows_dev(src.data_ptr(), src.shape[0], idx.data_ptr(), dst.data_ptr(), src.shape[1], count, self.stream)
 
     def scatter_rows(self, ctx, src, idx, dst, count):
-        ctx.scatter_rows_dev(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), src.shape[1], count, self.stream)
+        ctx.scatter_rows_dev(src.data_ptr(), idx.data_ptr(), dst.data_ptr(), dst.shape[0], src.shape[1], count, self.stream)
 
     def copy_rows(self, dst, src, rows):
         dst[:rows].copy_(src[:rows])
@@ -1045,6 +1059,17 @@ def main():
                 rec["roofline"] = {"bound": "valu_int32", "canonical_mac32_per_op": canon[ck],
                                    "canonical_frac": canon[ck] * per_gpu / peak,
                                    "executed_mad_per_op": ex, "frac": (ex * per_gpu / peak) if ex else None}
+            # HBM traffic and VALU instructions of each op's kernel as the PMC counters saw them (separate rocprofv3 --pmc passes on the
+            # committed tree: tools/gpu_pmc_traffic.sh), per launch like `traffic` of the headline roofline
+            pmc_ops, pmc_ops_src = measured_ops_traffic(args.key_bits)
+            for name, rec in ops.items():
+                t = pmc_ops.get(name)
+                if not t or "roofline" not in rec:
+                    continue
+                rec["roofline"].update(
+                    traffic=t.get("bytes_per_row") and t["bytes_per_row"] * B, traffic_bytes_per_op=t.get("bytes_per_row"),
+                    pmc_valu_wave_instructions_per_op=t.get("valu_wave_instructions_per_row"), pmc_kernel=t.get("kernel"),
+                    pmc_source=pmc_ops_src, pmc_stale=committed_count_is_stale(pmc_ops_src))
             add_bytes = 3 * s2 * 4
             if counted and counted.get("raw_add_form"):
                 ops["raw_add"]["roofline"]["form"] = counted["raw_add_form"]

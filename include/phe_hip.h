@@ -96,7 +96,7 @@ int phe_hip_ctx_set_blocks_per_cu(phe_hip_ctx* ctx, int blocks_per_cu);
  * entries each are written; *n_pub / *n_priv = how many exist; the widest rung is G = 64, one number per wavefront, for a
  * handful of numbers).  phe_hip_ctx_set_group: 0 = choose by batch size (default), G in {2, 4, 8, 16, 64} = always the rung of
  * G-lane groups (the next wider one if there is none) — for tests and measurements.
- * phe_hip_ctx_last_launch: what the last encrypt / obfuscate / decrypt / pair call took: *path = bit set of
+ * phe_hip_ctx_last_launch: what the last encrypt / obfuscate / decrypt / powmod / pair call took: *path = bit set of
  * 1 (r^n modulo the scaled modulus k*n), 2 (key owner's CRT form), 4 (decrypt halves side by side in one grid),
  * 8 (host batch pipelined through pinned chunks), 16 (fused obfuscate kernel), 32 (every number on a PAIR of wavefronts: the
  * lowest-latency form, taken for a handful of numbers on the G = 64 rung), 64 (the L-function / CRT tail of a decrypt on one

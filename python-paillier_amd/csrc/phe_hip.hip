@@ -2037,11 +2037,15 @@ int phe_hip_powmod_dev(phe_hip_ctx* ctx, const uint32_t* base, const uint32_t* e
     if (max_exp_bits <= 0 || max_exp_bits > 32 * exp_limbs) max_exp_bits = 32 * exp_limbs;
     if (int rc = bind_device(ctx)) return rc;
     PHE_CTX_ORDER(ctx, stream);
-    if (const DevSplit& sp = pick_nsplit(ctx, batch, kFamVarExp); ctx->use_split && sp.G)
+    ctx->last_path = 0;  // (phe_hip_ctx_last_launch describes THIS call)
+    if (const DevSplit& sp = pick_nsplit(ctx, batch, kFamVarExp); ctx->use_split && sp.G) {
+        ctx->last_geom_pub = geom_code(sp.G, sp.L);
         return launch_var_split(ctx, sp, base, ctx->pub.s2, e, exp_limbs, max_exp_bits, out, ctx->pub.s2, batch,
                                 (hipStream_t)stream);
-    return launch_var(ctx, pick_nsq(ctx, batch), base, ctx->pub.s2, e, exp_limbs, max_exp_bits, out, ctx->pub.s2, batch,
-                      (hipStream_t)stream);
+    }
+    const DevModulus& fw = pick_nsq(ctx, batch);
+    ctx->last_geom_pub = geom_code(fw.G, fw.L);
+    return launch_var(ctx, fw, base, ctx->pub.s2, e, exp_limbs, max_exp_bits, out, ctx->pub.s2, batch, (hipStream_t)stream);
 }
 
 // out[r] = prod_i b_i^e[r][i] mod n^2, b_i = base_i or base_inv_i where neg[r][i] — `rows` encrypted dot products over

@@ -94,10 +94,26 @@ struct SplitArgs {
 // the row that retires it is the full product's (both rows of a pair lie at or below the pair's column); within a stay of L
 // rows in one lane a column takes the weight of L products as before (its k + r is constant, so k - r runs over every class of
 // one parity twice for even L, over every class once for odd L), hence the accumulator bounds of the full sweep hold.
+// Measurement-only variants (tools/exp/build_variants.sh, never shipped): PHE_VARIANT_SQFULL = every product once in both orders (the
+// round-4 squaring: 4 H^2); PHE_VARIANT_SQROW = the doubled digit read from a second digit row in LDS (split_square fills it)
+// instead of one shift per row on the vector pipe — 18 instructions fewer per trip of 1,392 and still 1.2 % SLOWER on the same box
+// (630.9 k against 638.4 k encrypts/s; full squares 586.6 k: profiles/r05c_ab_squaring.txt): the second row's stores and reads
+// sit on the squaring's critical path between two sweeps, the shifts do not.
+#if defined(PHE_VARIANT_SQFULL)
+constexpr bool kSqSymmetric = false;
+#else
+constexpr bool kSqSymmetric = true;
+#endif
+#if defined(PHE_VARIANT_SQROW)
+constexpr bool kSqDoubledRow = true;
+#else
+constexpr bool kSqDoubledRow = false;
+#endif
 template <int L>
-constexpr bool sq_has_doubled() { return L >= 3; }  // (L = 1, 2: every class is its own negative)
+constexpr bool sq_has_doubled() { return kSqSymmetric && L >= 3; }  // (L = 1, 2: every class is its own negative)
 template <int L>
 constexpr int sq_weight(int k, int r) {  // limb k of the lane, row r of the trip: 0 = the mirror image takes it, 1 = once, 2 = doubled
+    if (!kSqSymmetric) return 1;
     const int c = ((k - r) % L + L) % L;
     if (c == 0 || 2 * c == L) return 1;
     return 2 * c < L ? 2 : 0;
@@ -327,7 +343,7 @@ PHE_DEV void pair_pass2(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t* a,
 #pragma unroll
     for (int k = 0; k < L; ++k) p[k] = q[k] = 0;
     constexpr int kT = Trip<G, L>::kDigits;
-    constexpr bool kSqRow2 = SQ && sq_has_doubled<L>() && !Trip<G, L>::kAhead;
+    constexpr bool kSqRow2 = SQ && kSqDoubledRow && sq_has_doubled<L>() && !Trip<G, L>::kAhead;
     uint32_t ahead_a[kT];
     if constexpr (Trip<G, L>::kAhead) {
 #pragma unroll
@@ -462,7 +478,7 @@ PHE_DEV void pair_mul_plain(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t
 template <int G, int L, bool U>
 PHE_DEV void split_square(uint32_t (&X0)[L], uint32_t (&X1)[L], const SplitLane<G, L, U>& K, const Lanes<G>& ln) {
     uint32_t d[L];
-    if constexpr (L <= kMaxFusedL && sq_has_doubled<L>() && !Trip<G, L>::kAhead) {
+    if constexpr (L <= kMaxFusedL && kSqDoubledRow && sq_has_doubled<L>() && !Trip<G, L>::kAhead) {
         // digits of X0 in row_a, the same doubled in row_c (free during a fused squaring): the sweep reads both
         wave::lds_fence();
 #pragma unroll

@@ -21,11 +21,14 @@ def test_executed_multiply_adds_model():
     info = {"lane_limbs_pub": 418, "lane_limbs_priv": 218, "engine_pub": "split", "engine_priv": "split"}
     enc, dec = bench.executed_mads(2048, info)
     H = 72
-    # 2048 squarings at 4 H^2, ceil(2048/7) + 32 products at 5 H^2 (6-bit windows), entry 4 H^2, exit 10 H^2, nude factor 2 H^2
-    assert enc == (4 * 2048 + 5 * (293 + 32) + 4 + 10 + 2) * H * H
-    # decrypt: two half-width exponentiations over 1024-bit exponents on H = 36, inputs of 4 chunks (+ one product)
+    # 2048 + 1 squarings (the ladder's and base^2 of the table) at (3 + 10/18) H^2 — round 5: the symmetric half of X0*X0, 10 of the
+    # 18 limbs of a lane per row (csrc/split_core.h sq_row; 4 H^2 before) —, ceil(2048/7) + 32 products at 5 H^2 (6-bit windows; one
+    # of them was the square: - 4 + ...), entry 4 H^2, exit 10 H^2, nude factor 2 H^2
+    sq = 3 + 10 / 18
+    assert enc == round((sq * 2049 - 4 + 5 * (293 + 32) + 4 + 10 + 2) * H * H)
+    # decrypt: two half-width exponentiations over 1024-bit exponents on H = 36 (2 lanes x 18), inputs of 4 chunks (+ one product)
     h = 36
-    assert dec == 2 * (4 * 1024 + 5 * (147 + 32) + 4 * 4 + 5 + 10) * h * h
+    assert dec == 2 * round((sq * 1025 - 4 + 5 * (147 + 32) + 4 * 4 + 5 + 10) * h * h)
     assert enc < bench.mac32_counts(2048)[0]                   # the split engine issues fewer multiplies than the canonical count
     full = {"lane_limbs_pub": 436, "lane_limbs_priv": 236, "engine_pub": "full", "engine_priv": "full"}
     enc_full, _ = bench.executed_mads(2048, full)

@@ -18,8 +18,15 @@ pub = paillier.PaillierPublicKey(int(g["n"], 16))
 priv = paillier.PaillierPrivateKey(pub, int(g["p"], 16), int(g["q"], 16))
 rng = np.random.default_rng(5)
 x, w = rng.random(B), rng.standard_normal(B)
-pub.encrypt_batch(x[:64], device=True)          # context creation / first-launch costs out of the timings
-res = {"batch": B}
+# Context creation and first-launch costs out of the timings: the key pair's engine is built FIRST (it
+# replaces the public key's: phe/keys.py PaillierPrivateKey._get_engine), and every call shape timed below runs once on a few rows
+# — device and host forms, the operators, the decrypts — so that no timed call is a first call (module load, window tables, staging).
+priv._get_engine()
+_w = pub.encrypt_batch(x[:4096], device=True)
+priv.decrypt_batch(_w), priv.decrypt_batch(pub.encrypt_batch(x[:4096]))
+(_w * w[:4096] + _w).dot(w[:4096])
+del _w
+res = {"batch": B, "warmed": "key-pair engine built and every call shape run once on 4096 rows before timing"}
 
 
 def timed(name, fn):

@@ -20,6 +20,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from csrc_hash import csrc_hash  # noqa: E402
 
 MODES = {0: "encrypt", 1: "obfuscate", 2: "half_decrypt"}
+# legs named ops<key bits> (tools/gpu_pmc_traffic.sh: `tools/bench_sweep.py --ops add,mul,pair_add` at ONE batch size, so that rows =
+# dispatches x batch holds for them too): the kernel behind each entry of bench.py's `ops` object (configs[2])
+OP_OF = [(r"^k_mulmod_tile<", "raw_add"), (r"^k_mulmod_table<", "raw_add_table_in_lds"), (r"^k_mulmod_staged<", "raw_add_two_montgomery_products"),
+         (r"^k_modexp_var_split<\d+,\d+,false>", "raw_mul_float56"), (r"^k_modexp_var_split<\d+,\d+,true>", "raw_mul_float56_resident_pair_form"),
+         (r"^k_pair_mul<", "raw_add_resident_pair_form"), (r"^k_to_pair<", "to_pair_form"), (r"^k_from_pair<", "from_pair_form")]
 
 
 def counters(directory):
@@ -69,6 +74,9 @@ def main():
                 continue                                       # (the one encrypt launch that makes the ciphertexts)
             if leg == "encrypt" and ("half_decrypt" in key or "tail" in key):
                 continue
+            ops_leg = re.match(r"ops(\d+)$", leg)
+            if ops_leg and (key.startswith("k_modexp_split<") or "tail" in key):
+                continue                                       # (the launches that make the operands)
             n_disp = max(valu.get(name, {}).get("dispatches:SQ_INSTS_VALU", 0), fetch.get(name, {}).get("dispatches:FETCH_SIZE", 0),
                          write.get(name, {}).get("dispatches:WRITE_SIZE", 0))
             rows = n_disp * args.batch
@@ -84,6 +92,15 @@ def main():
                 rec["valu_wave_instructions_per_row"] = rec["sq_insts_valu"] / rows
             if "fetch_bytes" in rec and "write_bytes" in rec:
                 rec["bytes_per_row"] = (rec["fetch_bytes"] + rec["write_bytes"]) / rows
+            if "GRBM_GUI_ACTIVE" in valu.get(name, {}) and "SQ_BUSY_CYCLES" in valu.get(name, {}):
+                rec["grbm_gui_active"] = valu[name]["GRBM_GUI_ACTIVE"]
+                rec["sq_busy_cycles"] = valu[name]["SQ_BUSY_CYCLES"]
+            if ops_leg:
+                rec["kernel"] = key
+                op = next((o for pat, o in OP_OF if re.match(pat, key)), None)
+                if op:
+                    out.setdefault("ops", {}).setdefault(ops_leg.group(1), {})[op] = rec
+                continue
             out[key] = rec
     print(json.dumps(out, indent=1))
 

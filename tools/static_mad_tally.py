@@ -4,7 +4,8 @@ sweep loops of the headline kernel, times their trip counts, against what the CP
 
 k_modexp_split<4,18,encrypt,unit> (2048-bit keys: H = 72 limbs of the scaled modulus on 4 lanes x 18): a pair SQUARE is one loop of
 H / 18 = 4 trips, a pair PRODUCT one loop of 4 trips; a wave holds 16 numbers, so multiply-adds per number = instructions per trip x 4
-trips x 64 lanes / 16 numbers.  The closed form bench.py:executed_mads uses is 4 H^2 per square and 5 H^2 per product; the
+trips x 64 lanes / 16 numbers.  The closed form bench.py:executed_mads uses is (3 + 10/18) H^2 per square (round 5: the symmetric half of
+X0*X0, 10 of 18 limbs per lane and row — csrc/split_core.h sq_row; 4 H^2 before) and 5 H^2 per product; the
 emulator's count of the whole encryption must then equal squares x 4 H^2 + products x 5 H^2 + entry/exit (tests/test_bench_contract.py
 holds the closed form within 1 % of the emulator).  Usage: python tools/static_mad_tally.py [--out profiles/...txt]"""
 import argparse
@@ -27,7 +28,9 @@ def main():
     name = name[0] if name else None
     lines = []
     H, L, per_wave = 72, 18, 16
-    want = {"square": 4 * H * H, "product": 5 * H * H}
+    sq_limbs = L // 2 + 1                      # limbs a lane takes per row of a squaring's first word (even L)
+    want = {"square": (3 * L + sq_limbs) * H * H // L, "product": 5 * H * H}
+    label = {"square": "(3 + %d/%d) H^2" % (sq_limbs, L), "product": "5 H^2"}
     ok = False
     if name:
         loops = meta[name]["loops"]
@@ -38,7 +41,7 @@ def main():
             per_number = mads * (H // L) * 64 // per_wave
             kind = [k for k, v in want.items() if abs(per_number / v - 1) < 0.005]
             lines.append("  loop of %4d instructions, %4d multiply-adds per trip -> x %d trips x 64 lanes / %d numbers = %6d per number%s"
-                         % (insts, mads, H // L, per_wave, per_number, (" = %s (%d H^2 = %d)" % (kind[0], want[kind[0]] // (H * H), want[kind[0]])) if kind else ""))
+                         % (insts, mads, H // L, per_wave, per_number, (" = %s (%s = %d)" % (kind[0], label[kind[0]], want[kind[0]])) if kind else ""))
             for k in kind:
                 found[k] = per_number
         ok = set(found) == set(want)
@@ -51,11 +54,11 @@ def main():
         sys.path.insert(0, ROOT)
         import bench
         enc, _ = bench.executed_mads(2048, {"lane_limbs_pub": 418, "lane_limbs_priv": 218, "engine_pub": "split", "engine_priv": "split"})
-        lines.append("closed form bench.py:executed_mads = (4 x 2048 squares + 5 x 325 products + 16 entry/exit) H^2 = %d = %.1f H^2"
+        lines.append("closed form bench.py:executed_mads = ((3 + 10/18) x 2049 squares + 5 x 325 products + 12 entry/exit) H^2 = %d = %.1f H^2"
                      % (enc, enc / (H * H)))
     except Exception as e:  # noqa: BLE001
         lines.append("closed form not evaluated: %r" % (e,))
-    lines.append("static tally agrees with 4 H^2 per square and 5 H^2 per product within 0.5 %%: %s" % ("yes" if ok else "NO"))
+    lines.append("static tally agrees with (3 + 10/18) H^2 per square and 5 H^2 per product within 0.5 %%: %s" % ("yes" if ok else "NO"))
     text = "\n".join(lines)
     print(text)
     if args.out:
