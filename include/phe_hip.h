@@ -106,7 +106,9 @@ int phe_hip_ctx_set_blocks_per_cu(phe_hip_ctx* ctx, int blocks_per_cu);
  * product as ONE plain product + ONE fold against the key's table in LDS instead of two Montgomery products — batches from 2048
  * rows on, keys whose table fits a CU's LDS (up to ~2700 bits); PHE_HIP_NO_TABLE_MUL=1 keeps the Montgomery kernels), 512 (with 256:
  * that product by tiles of 64 per workgroup with ONE ELEMENT PER LANE — batches from 16384 rows on; the fold's table words come
- * through the scalar cache instead of LDS; PHE_HIP_NO_TILE_MUL=1 keeps the kernel with the table in LDS); *geom_pub / *geom_priv = G*100 + L of the
+ * through the scalar cache instead of LDS; PHE_HIP_NO_TILE_MUL=1 keeps the kernel with the table in LDS; keys of ~810 ... 1024 bits take
+ * the tiles on an 8-wave workgroup, 8 x 9 columns, with no table-in-LDS form below 16384 rows: PHE_HIP_NO_TILE8=1 keeps the Montgomery
+ * kernels there); *geom_pub / *geom_priv = G*100 + L of the
  * exponentiation kernels used.  Any pointer may be NULL. */
 int phe_hip_ctx_ladder(const phe_hip_ctx* ctx, int* pub_geoms, int* priv_geoms, int capacity, int* n_pub, int* n_priv);
 /* The MEASURED ladder.  Without it a rung's time is an estimate from its shape; with it the rung of a call is the one whose measured

@@ -45,44 +45,50 @@ __global__ void __launch_bounds__(kTableBlock, 1) k_mulmod_table(TableMulArgs A)
 
 // mul_tile.h: the same product with one element per lane: the workgroup owns tiles of 64 products, its sixteen waves split the
 // columns and meet at barriers between the phases; the fold's table words come through the scalar cache
-constexpr int kTileBlock = 64 * kTileWaves;
-template <int L>
-__global__ void __launch_bounds__(kTileBlock, 1) k_mulmod_tile(TableMulArgs A) {
-    using T = TileShape<L>;
+// W = 16: 1024 threads, one workgroup per CU (four waves per SIMD: 128 registers each).  W = 8 (round 5; 1024-bit keys): 512 threads
+// and 58 KB of LDS — two workgroups per CU, i.e. the same four waves per SIMD, in two groups whose barriers do not meet
+template <int L, int W>
+__global__ void __launch_bounds__(64 * W, W == 8 ? 4 : 1) k_mulmod_tile(TableMulArgs A) {
+    using T = TileShape<L, W>;
+    constexpr int kBlock = 64 * W;
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_t[];
     uint32_t* tile = lds_t;
     uint32_t* prod_carry = tile + T::kRows * kTile;
-    uint32_t* top = prod_carry + 2 * 2 * kTileWaves * kTile;
+    uint32_t* top = prod_carry + 2 * 2 * W * kTile;
     uint32_t* fold_carry = top + kTile * kTableRowSlack;
-    uint32_t* cst = fold_carry + 2 * kTileWaves * kTile;
-    for (int i = (int)threadIdx.x; i < T::S; i += kTileBlock) {
+    uint32_t* cst = fold_carry + 2 * W * kTile;
+    for (int i = (int)threadIdx.x; i < T::S; i += kBlock) {
         cst[i] = A.n[i];
         cst[T::S + i] = A.ncomp[i];
         cst[2 * T::S + i] = A.ncomp1[i];
     }
     __syncthreads();
     const uint32_t wv = wave::uniform(threadIdx.x / 64u);
-    mul_tile_body<L>(A, tile, prod_carry, top, fold_carry, cst, wv, blockIdx.x, gridDim.x, threadIdx.x & 63u);
+    mul_tile_body<L, W>(A, tile, prod_carry, top, fold_carry, cst, wv, blockIdx.x, gridDim.x, threadIdx.x & 63u);
 }
 
 namespace t16 {
 
-template <int L>
+template <int L, int W>
 static int launch_tile_L(int blocks, hipStream_t st, const TableMulArgs& A) {
-    constexpr size_t lds_bytes = (size_t)tile_lds_words<L>() * 4;
+    constexpr size_t lds_bytes = (size_t)tile_lds_words<L, W>() * 4;
     // (per launch, not once per process: the attribute belongs to the function ON THE CURRENT DEVICE, and one process may drive
     //  several — phe/fleet.py; a few microseconds beside a kernel of tens)
-    if (hipFuncSetAttribute((const void*)k_mulmod_tile<L>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
-    if (A.tile_waves != kTileWaves) return -1;  // (the table's column blocks are cut for another workgroup shape)
-    k_mulmod_tile<L><<<dim3(blocks), dim3(kTileBlock), lds_bytes, st>>>(A);
+    if (hipFuncSetAttribute((const void*)k_mulmod_tile<L, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes) != hipSuccess) return -2;
+    k_mulmod_tile<L, W><<<dim3(blocks), dim3(64 * W), lds_bytes, st>>>(A);
     return 0;
 }
-// (A.table: the column-block layout)  -1: no kernel for this lane width; -2: the device refused the LDS size
+// workgroups of mul_tile.h a CU holds at once: LDS decides (one of 1024 threads, two of 512)
+int tile_blocks_per_cu(int waves) { return waves == 8 ? 2 : 1; }
+// (A.table: the column-block layout, cut for A.tile_waves waves)  -1: no kernel for this lane width and workgroup shape; -2: the
+// device refused the LDS size
 int launch_mul_tile(int L, int blocks, hipStream_t st, const TableMulArgs& A) {
+    if (A.tile_waves == 8) return L == 9 ? launch_tile_L<9, 8>(blocks, st, A) : -1;
+    if (A.tile_waves != kTileWaves) return -1;  // (the table's column blocks are cut for another workgroup shape)
     switch (L) {
-        case 5: return launch_tile_L<5>(blocks, st, A);
-        case 9: return launch_tile_L<9>(blocks, st, A);
-        case 14: return launch_tile_L<14>(blocks, st, A);
+        case 5: return launch_tile_L<5, kTileWaves>(blocks, st, A);
+        case 9: return launch_tile_L<9, kTileWaves>(blocks, st, A);
+        case 14: return launch_tile_L<14, kTileWaves>(blocks, st, A);
         default: return -1;
     }
 }

@@ -759,30 +759,40 @@ static const int kTableL[] = {5, 9, 14};
 constexpr int kTileWavesHost = 16;  // = mul_tile.h kTileWaves: the waves of its workgroup, the column blocks of table_cols
 constexpr size_t kTableLdsLimitBytes = 158 * 1024;  // of the 160 KB of a CU
 
-inline TableMulPack build_table_mul(const Big& N_any, int word_limbs, bool offer_narrow = true) {
+// waves: the workgroup shape of mul_tile.h the pack is cut for — 16 (S = 16 L columns; also what mul_table.h's limb groups of 16 lanes
+// need) or 8 (S = 8 L, tiles only; round 5): n^2 of a 1024-bit key needs 72 columns = 8 x 9 exactly, where 16 x 5 pads to 80
+constexpr int kTileL8 = 9;  // the lane width compiled for 8-wave workgroups
+inline TableMulPack build_table_mul(const Big& N_any, int word_limbs, bool offer_narrow = true, int waves = kTileWavesHost) {
     TableMulPack T;
     const int bits = big_bits(N_any);
-    if (bits < 64 || bits > 32 * word_limbs) return T;
+    if (bits < 64 || bits > 32 * word_limbs || (waves != 16 && waves != 8)) return T;
     const int need = (bits + 38 + kRadixBits - 1) / kRadixBits;
     int L = 0;
-    for (int cand : kTableL)
-        if (16 * cand >= need) {
-            L = cand;
-            break;
-        }
-    if (!L || (!offer_narrow && (L < 9 || 16 * L - need >= 16))) return T;  // (the library: only where the lanes are well filled)
-    const int S = 16 * L, P = (bits + kRadixBits - 1) / kRadixBits, n_lo = S - P;
+    if (waves == 8) {
+        if (8 * kTileL8 >= need) L = kTileL8;
+    } else {
+        for (int cand : kTableL)
+            if (16 * cand >= need) {
+                L = cand;
+                break;
+            }
+    }
+    if (!L || (!offer_narrow && (L < 9 || waves * L - need >= 16))) return T;  // (the library: only where the lanes are well filled)
+    const int S = waves * L, P = (bits + kRadixBits - 1) / kRadixBits, n_lo = S - P;
     // limbs the high half of a product of two `word_limbs`-word numbers can have, on top of the S low ones
     const int hi_limbs = std::max(0, (2 * 32 * word_limbs + kRadixBits - 1) / kRadixBits - S);
     const int D = n_lo + hi_limbs;
-    if (n_lo < 2 || n_lo > 16 || hi_limbs > S) return T;
+    // (16 waves: the quotient estimate reads limbs P - 2 ... P + 1 and the settle rows start at S - 2: P <= S - 2; 8 waves: P = S - 1 is
+    //  taken too — the estimate moves down a limb, the settle rows start at S: mul_tile.h TileShape)
+    if (n_lo < (waves == 8 ? 1 : 2) || n_lo > 16 || hi_limbs > S) return T;
     // LDS of the 512-thread workgroup (mul_table.h table_lds_words): table | 3 constant rows | 32 digit rows | 8 x 2 staging areas
     const int k_words = (S * kRadixBits + 31) / 32, k_vec = (k_words + 1 + 63) / 64;
     size_t lds_words = (size_t)D * S + 3 * (size_t)S + 32 * (size_t)(S + 16) + 8 * 2 * (size_t)(256 * k_vec);
-    if (lds_words * 4 > kTableLdsLimitBytes || L > 9) lds_words = 0;  // (mul_table.h is compiled for L = 5, 9)
-    // mul_tile.h TileShape<L>::kLdsWords: tile buffer (the settle's digit rows inside it) | product carries | top columns | fold carries | 3 constant rows
-    const size_t tile_rows = std::max<size_t>(2 * (size_t)S + 1, (size_t)(S - 2) + (size_t)(S + 4));
-    size_t tile_lds_words = tile_rows * 64 + 2 * 2 * kTileWavesHost * 64 + 64 * 16 + 2 * kTileWavesHost * 64 + 3 * (size_t)S;
+    if (lds_words * 4 > kTableLdsLimitBytes || L > 9 || waves != 16) lds_words = 0;  // (mul_table.h is compiled for 16 lanes x L = 5, 9)
+    // mul_tile.h TileShape<L, W>::kLdsWords: tile buffer (the settle's digit rows inside it) | product carries | top columns | fold carries | 3 constant rows
+    const size_t settle_row0 = waves == 16 ? (size_t)(S - 2) : (size_t)S;
+    const size_t tile_rows = std::max<size_t>(2 * (size_t)S + 1, settle_row0 + (size_t)(S + 4));
+    size_t tile_lds_words = tile_rows * 64 + 2 * 2 * (size_t)waves * 64 + 64 * 16 + 2 * (size_t)waves * 64 + 3 * (size_t)S;
     if (tile_lds_words * 4 > kTableLdsLimitBytes) tile_lds_words = 0;
     if (!lds_words && !tile_lds_words) return T;
     const int w32 = (kRadixBits * S + 31) / 32 + 1;  // words that hold W^S
@@ -806,17 +816,17 @@ inline TableMulPack build_table_mul(const Big& N_any, int word_limbs, bool offer
     const int full = L / 4, rem = L % 4;
     (void)kFullMax;
     T.table.assign((size_t)D * S, 0u);
-    const int cw = S / kTileWavesHost;  // columns of one wave of mul_tile.h's fold
+    const int cw = S / waves;  // columns of one wave of mul_tile.h's fold
     T.digits_padded = (D + 7) & ~7;
     const int d_rows = T.digits_padded + 4;  // (mul_tile.h kFoldPadRows: zero rows for the fold's look-ahead)
-    T.table_cols.assign((size_t)kTileWavesHost * d_rows * cw, 0u);
-    T.tile_waves = kTileWavesHost;
+    T.table_cols.assign((size_t)waves * d_rows * cw, 0u);
+    T.tile_waves = waves;
     for (int i = 0; i < D; ++i) {
         const std::vector<uint32_t> limbs = to_r29(c, S);
-        for (int w = 0; w < kTileWavesHost; ++w)
+        for (int w = 0; w < waves; ++w)
             for (int k = 0; k < cw; ++k) T.table_cols[((size_t)w * d_rows + (size_t)i) * cw + k] = limbs[(size_t)(w * cw + k)];
         uint32_t* row = T.table.data() + (size_t)i * S;
-        for (int g = 0; g < 16; ++g) {
+        for (int g = 0; g < 16 && waves == 16; ++g) {  // (mul_table.h's layout: limb groups of 16 lanes)
             for (int q = 0; q < full; ++q)
                 for (int e = 0; e < 4; ++e) row[q * 64 + 4 * g + e] = limbs[(size_t)(g * L + 4 * q + e)];
             for (int r = 0; r < rem; ++r) row[full * 64 + g * rem + r] = limbs[(size_t)(g * L + 4 * full + r)];
@@ -830,7 +840,7 @@ inline TableMulPack build_table_mul(const Big& N_any, int word_limbs, bool offer
             const int bit = bits - 1 - b;
             top64 = (top64 << 1) | ((N[(size_t)(bit >> 5)] >> (bit & 31)) & 1u);
         }
-        T.base = P - 2;
+        T.base = std::min(P - 2, S - 4);  // the four limbs the estimate reads end at the top limb a y < 2^37 N can have
         T.inv = __builtin_ldexp(1.0 / (double)top64, kRadixBits * T.base - (bits - 64));
     }
     T.L = L;

@@ -1,7 +1,9 @@
 // mul_tile.h — a*b mod N (phe/util.py:53-64 mulmod; phe/paillier.py:705-719 _raw_add) as one plain product and one fold
 // against the key's table (the arithmetic of mul_table.h) with LANE = ELEMENT: a workgroup of W = 16 waves (1024 threads, four
 // per SIMD) takes a tile of 64 products, every lane of every wave works on "its" element, and the waves split the COLUMNS of
-// the numbers: S = 16 L columns in W blocks of C = S / W = L (9 for 2048-bit keys, 14 for 3072-bit keys).
+// the numbers: S = 16 L columns in W blocks of C = S / W = L (9 for 2048-bit keys, 14 for 3072-bit keys).  Round 5: the same body on
+// W = 8 waves (512 threads, S = 8 L = 72 columns: n^2 of a 1024-bit key, two workgroups per CU) — TileShape<L, W> below; where this
+// header says "16 waves" read W.
 //
 // Why: in the limb-group form (16 lanes per number) a row of the product is 9 multiply-adds against 13 other instructions
 // (digit broadcast, shift across lanes, carries, masks), and the fold reads every table word from LDS once per lane — 4 bytes
@@ -61,17 +63,25 @@ constexpr int kTileWaves = 16;   // waves of the workgroup (W); 2 W column block
 constexpr int kFoldPadRows = 4;  // zero rows the column-block table carries past its last digit (the fold's look-ahead)
 constexpr int kFoldChunk = 48;   // fold digits between two hand-overs of the accumulators' upper halves (48 * 2^58.01 + 2^32 < 2^64)
 
-template <int L>
+// W: the waves of the workgroup = the column blocks of a number = the lanes per element of the settle.  W = 16 (1024 threads, one
+// workgroup per CU): S = 16 L columns — 2048-bit keys (L = 9), 3072-bit keys (L = 14).  W = 8 (512 threads, round 5): S = 8 L — n^2 of
+// a 1024-bit key needs 72 columns (2048 bits + 38 of headroom), exactly 8 x 9, where 16 x 5 = 80 columns cost (80/72)^2 = 1.23x the
+// multiply-adds at 5 instead of 9 multiply-adds per step; its 58 KB of LDS let two workgroups share a CU, so one's barriers
+// and settle run under the other's product and fold.
+template <int L, int W = kTileWaves>
 struct TileShape {
-    static constexpr int S = 16 * L;    // columns of the fold and of the settle; digit rows of an operand (the ones past its
+    static_assert(W == 16 || W == 8, "the settle runs on limb groups of W lanes: one DPP row, or half of one");
+    static constexpr int kWaves = W;
+    static constexpr int S = W * L;     // columns of the fold and of the settle; digit rows of an operand (the ones past its
                                         // last digit hold zeros)
-    static constexpr int CW = S / kTileWaves;  // C: columns of a block = what one wave folds = what one lane of the settle holds (L)
+    static constexpr int CW = S / W;    // C: columns of a block = what one wave folds = what one lane of the settle holds (L)
     static constexpr int kFoldGroup = CW > 10 ? 2 : 4;  // fold digits per request group (28 ... 40 table words in flight per group)
     static constexpr int kRowT = S + kLdsPad;  // a settle group's digit row
     // rows of the tile buffer: A (S rows + one zero row) | B (S rows); T (2S rows) over both; during the settle the settled
-    // columns y[element][column] lie in rows [0, P) and the 64 digit rows of the limb groups from row S - 2 on (P <= S - 2: the
-    // fold's digits there are dead by then)
-    static constexpr int kSettleRow0 = S - 2;
+    // columns y[element][column] lie in rows [0, P) and the 64 digit rows of the limb groups from row kSettleRow0 >= P on (the
+    // fold's digits there are dead by then).  W = 16: S - 2 (P <= S - 2 there; 3072-bit keys need the rows: 147 KB of LDS);
+    // W = 8: S (P may be S - 1: the 71 digits of a 2048-bit n^2 in 72 columns)
+    static constexpr int kSettleRow0 = W == 16 ? S - 2 : S;
     static constexpr int kRows = (2 * S + 1 > kSettleRow0 + kRowT) ? 2 * S + 1 : kSettleRow0 + kRowT;
     // 32-bit words wave w must see to cut its digits [CW w, CW w + CW): from the 16-byte piece that holds bit 29 CW w on
     // (rows are whole 16-byte pieces: a piece is either inside the row or beyond it)
@@ -79,20 +89,20 @@ struct TileShape {
     static constexpr int word_skip(int w) { return ((kRadixBits * CW * w) >> 5) & 3; }
     static constexpr int max_chunks() {
         int m = 0;
-        for (int w = 0; w < kTileWaves; ++w) {
+        for (int w = 0; w < W; ++w) {
             const int c = (word_skip(w) + ((kRadixBits * (CW - 1)) >> 5) + 3 + 3) / 4;
             m = c > m ? c : m;
         }
         return m;
     }
     static constexpr int kChunks = max_chunks();
-    static_assert(4 * kTileWaves == kTile, "one digit row per limb group of the settle: 64 rows of kRowT words = kRowT rows of the buffer");
+    static_assert((kTile / W) * W == kTile, "one digit row per limb group of the settle: 64 rows of kRowT words = kRowT rows of the buffer");
     // LDS words: tile buffer | product carries (2 words x 2W blocks x 64) | top columns | fold carries | n, ncomp, ncomp1
-    static constexpr int kLdsWords = kRows * kTile + 2 * 2 * kTileWaves * kTile + kTile * kTableRowSlack + 2 * kTileWaves * kTile + 3 * S;
+    static constexpr int kLdsWords = kRows * kTile + 2 * 2 * W * kTile + kTile * kTableRowSlack + 2 * W * kTile + 3 * S;
 };
-template <int L>
+template <int L, int W = kTileWaves>
 constexpr int tile_lds_words() {
-    return TileShape<L>::kLdsWords;
+    return TileShape<L, W>::kLdsWords;
 }
 
 // A column sum of up to 2S products of < 2^58.01 (almost 2^66) is kept as  acc + upper * 2^B:  acc a 64-bit accumulator that is cut
@@ -167,9 +177,9 @@ PHE_DEV void tile_product_steps(uint64_t (&acc)[CW], uint32_t (&win)[CW], const 
 // digits [CW wv, CW wv + CW) of the number whose 32-bit words from TileShape::first_word(wv) on are in `w` (4 per piece); SKIP =
 // TileShape::word_skip(wv) words lie before the one that holds the first digit's lowest bit.  One funnel shift by the
 // wave-uniform bit offset of that digit, then every digit sits at a compile-time position.
-template <int L, int SKIP>
-PHE_DEV void tile_cut_digits(uint32_t* column, const Words4 (&w)[TileShape<L>::kChunks], uint32_t wv) {
-    using T = TileShape<L>;
+template <int L, int W, int SKIP>
+PHE_DEV void tile_cut_digits(uint32_t* column, const Words4 (&w)[TileShape<L, W>::kChunks], uint32_t wv) {
+    using T = TileShape<L, W>;
     constexpr int kWords = 4 * T::kChunks;
     uint32_t v[kWords + 1];
 #pragma unroll
@@ -195,10 +205,12 @@ PHE_DEV void tile_cut_digits(uint32_t* column, const Words4 (&w)[TileShape<L>::k
 
 // a lane's row of the batch from word w0 (a multiple of 4) on, as the 16-byte pieces its wave cuts its digits from (pieces at
 // or beyond the row read as zero)
-template <int L>
-PHE_DEV void tile_request_row(Words4 (&raw)[TileShape<L>::kChunks], const uint32_t* p, int w0, int limbs) {
+template <int L, int W>
+using TileRaw = Words4[TileShape<L, W>::kChunks];  // (an alias: `Words4 (&raw)[TileShape<L, W>::kChunks]` does not parse as a parameter)
+template <int L, int W>
+PHE_DEV void tile_request_row(TileRaw<L, W>& raw, const uint32_t* p, int w0, int limbs) {
 #pragma unroll
-    for (int c = 0; c < TileShape<L>::kChunks; ++c) {
+    for (int c = 0; c < TileShape<L, W>::kChunks; ++c) {
         Words4 z;
         z.x = z.y = z.z = z.w = 0u;
         raw[c] = z;
@@ -211,13 +223,14 @@ PHE_DEV void tile_request_row(Words4 (&raw)[TileShape<L>::kChunks], const uint32
 // tile: TileShape::kRows * 64 words; prod_carry: 2 * 2W * 64; top: 64 * kTableRowSlack; fold_carry: 2 * W * 64; cst: n | ncomp |
 // ncomp1 (S limbs each).  `wv` must be wave-uniform; every wave of the workgroup runs the
 // same number of tiles (the barriers).  Rows of a, b, out: A.limbs words (a multiple of 4), 16-byte aligned.
-template <int L>
+template <int L, int W = kTileWaves>
 PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod_carry, uint32_t* top, uint32_t* fold_carry,
                            const uint32_t* cst, uint32_t wv, uint32_t block, uint32_t n_blocks, uint32_t lane) {
-    using T = TileShape<L>;
-    constexpr int S = T::S, CW = T::CW, GS = 16;  // (GS: lanes per element of the settle)
+    using T = TileShape<L, W>;
+    constexpr int S = T::S, CW = T::CW, GS = W;  // (GS: lanes per element of the settle — lane g holds columns [L g, L g + L))
+    constexpr int kTileWaves = W;                // (shadows the 16-wave constant: everything below is written in the waves of THIS shape)
     const int P = A.split, D = A.digits_padded;
-    PHE_BOUNDS(S - P >= 2 && S - P <= kTableRowSlack && P + D + kFoldPadRows + 2 <= T::kRows + kTableRowSlack && P <= T::kSettleRow0 && A.base >= 0 &&
+    PHE_BOUNDS(S - P >= 1 && S - P <= kTableRowSlack && P + D + kFoldPadRows + 2 <= T::kRows + kTableRowSlack && P <= T::kSettleRow0 && A.base >= 0 &&
                A.base + 3 < S && wv < (uint32_t)kTileWaves && A.limbs % 4 == 0 && 32 * A.limbs <= kRadixBits * S);
     uint32_t* const buf_a = tile;                    // A[digit][e]: rows 0 .. S - 1, row S zero
     uint32_t* const buf_b = tile + (S + 1) * kTile;  // B[digit][e]: rows 0 .. S - 1 (B[-1] is A's zero row)
@@ -227,8 +240,8 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
     auto request_rows = [&](uint64_t tile_i) __attribute__((always_inline)) {
         uint64_t item = tile_i * kTile + wave::reread(lane);
         if (item >= A.batch) item = A.batch - 1;
-        tile_request_row<L>(raw_a, A.a + item * A.a_stride + w0, w0, A.limbs);
-        tile_request_row<L>(raw_b, A.b + item * A.b_stride + w0, w0, A.limbs);
+        tile_request_row<L, W>(raw_a, A.a + item * A.a_stride + w0, w0, A.limbs);
+        tile_request_row<L, W>(raw_b, A.b + item * A.b_stride + w0, w0, A.limbs);
     };
     if (block < n_tiles) request_rows(block);
 #if defined(PHE_TILE_PROFILE)
@@ -240,8 +253,8 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
         switch (((kRadixBits * CW * wv) >> 5) & 3u) {  // (wave-uniform: words of the first piece before the first digit)
 #define PHE_TILE_CUT(SKIP)                                \
     case SKIP:                                            \
-        tile_cut_digits<L, SKIP>(buf_a + e, raw_a, wv);   \
-        tile_cut_digits<L, SKIP>(buf_b + e, raw_b, wv);   \
+        tile_cut_digits<L, W, SKIP>(buf_a + e, raw_a, wv);   \
+        tile_cut_digits<L, W, SKIP>(buf_b + e, raw_b, wv);   \
         break;
             PHE_TILE_CUT(0) PHE_TILE_CUT(1) PHE_TILE_CUT(2) PHE_TILE_CUT(3)
 #undef PHE_TILE_CUT
@@ -405,13 +418,14 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
         // on every path: a conditional request keeps the old values alive through the product and spills them)
         request_rows(tile_i + n_blocks < n_tiles ? tile_i + n_blocks : tile_i);
         // ---- settle: 16 lanes per element (lane g = columns [L g, L g + L)); a wave's 64 / W elements four at a time ----------------------
-        constexpr int kPerWave = kTile / kTileWaves, kLanesPerBlock = CW / L;
+        constexpr int kPerWave = kTile / kTileWaves, kLanesPerBlock = CW / L, kAtOnce = kTile / GS;  // (elements a wave settles / at a time)
+        static_assert(kPerWave == kAtOnce, "a wave settles its elements in one pass (GS = W)");
 #pragma unroll 1
-        for (int it = 0; it < kPerWave / 4; ++it) {
+        for (int it = 0; it < kPerWave / kAtOnce; ++it) {
             const Lanes<GS> ln(lane);
             const uint32_t g = ln.g;
-            const uint32_t es = wv * (uint32_t)kPerWave + (uint32_t)it * 4u + wave::reread(lane) / GS;
-            uint32_t* row = tile + (size_t)T::kSettleRow0 * kTile + (wv * 4u + wave::reread(lane) / GS) * T::kRowT;
+            const uint32_t es = wv * (uint32_t)kPerWave + (uint32_t)it * (uint32_t)kAtOnce + wave::reread(lane) / GS;
+            uint32_t* row = tile + (size_t)T::kSettleRow0 * kTile + (wv * (uint32_t)kAtOnce + wave::reread(lane) / GS) * T::kRowT;
             const uint64_t raw_item = tile_i * kTile + es;
             const bool live = raw_item < A.batch;
             const uint64_t item = live ? raw_item : A.batch - 1;

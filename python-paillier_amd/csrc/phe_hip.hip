@@ -123,6 +123,7 @@ namespace phe {
 namespace t16 {  // kernels_t16.hip
 int launch_mul_table(int L, int blocks, size_t lds_bytes, hipStream_t st, const TableMulArgs& A);
 int launch_mul_tile(int L, int blocks, hipStream_t st, const TableMulArgs& A);
+int tile_blocks_per_cu(int waves);
 }  // namespace t16
 }  // namespace phe
 
@@ -977,7 +978,8 @@ static int launch_mul(phe_hip_ctx* ctx, const DevModulus& M, const uint32_t* a, 
             TableMulArgs C = B;
             C.table = ctx->tmul_cols;
             const size_t tiles = (batch + 63) / 64;
-            rc = phe::t16::launch_mul_tile(T.L, (int)std::max<size_t>(1, std::min(tiles, (size_t)ctx->n_cus)), stream, C);
+            const size_t slots = (size_t)ctx->n_cus * (size_t)phe::t16::tile_blocks_per_cu(T.tile_waves);
+            rc = phe::t16::launch_mul_tile(T.L, (int)std::max<size_t>(1, std::min(tiles, slots)), stream, C);
             if (rc == 0) ctx->last_path |= kPathTileMul;
         }
         if (rc != 0 && T.in_lds()) {
@@ -1251,7 +1253,10 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
     if (!rc) rc = upload_schedule(ctx->pub.exp_n, ctx->d_exp_n);
     if (!rc && !getenv("PHE_HIP_NO_TABLE_MUL")) {
         try {
-            ctx->tmul = host::build_table_mul(ctx->pub.nsq32, ctx->pub.s2, getenv("PHE_HIP_TABLE_MUL_ANY_WIDTH") != nullptr);
+            // the 8-wave tile shape first (n^2 of ~810 ... 1025-bit keys fills its 72 columns: half the multiply-adds of the two
+            // Montgomery products these widths ran until round 5; PHE_HIP_NO_TILE8=1 keeps those), then the 16-wave / 16-lane shapes
+            if (!getenv("PHE_HIP_NO_TILE8") && !getenv("PHE_HIP_NO_TILE_MUL")) ctx->tmul = host::build_table_mul(ctx->pub.nsq32, ctx->pub.s2, false, 8);
+            if (!ctx->tmul.ok()) ctx->tmul = host::build_table_mul(ctx->pub.nsq32, ctx->pub.s2, getenv("PHE_HIP_TABLE_MUL_ANY_WIDTH") != nullptr);
         } catch (const std::exception&) {
             ctx->tmul = host::TableMulPack();
         }

@@ -420,33 +420,36 @@ static void run_mul_table(TableMulArgs A, const host::TableMulPack& T) {
 }
 // k_mulmod_tile (mul_tile.h): the same product by tiles of 64 with the fold on lane = element; one emulated workgroup of 8
 // waves (one host thread each, joined by the barriers) per block
-template <int L>
+template <int L, int W = kTileWaves>
 static void run_mul_tile(TableMulArgs A, const host::TableMulPack& T, int n_blocks) {
-    using TS = TileShape<L>;
+    using TS = TileShape<L, W>;
     A.table = T.table_cols.data();
     A.digits_padded = T.digits_padded;
     A.tile_waves = T.tile_waves;
     static_assert(host::kTileWavesHost == kTileWaves, "the table's column blocks are the kernel's waves");
+    if (T.tile_waves != W || T.S != TS::S) throw std::runtime_error("the pack is cut for another workgroup shape");
+    if ((size_t)tile_lds_words<L, W>() != T.tile_lds_words) throw std::runtime_error("host and device disagree about the tile's LDS");
     for (int b = 0; b < n_blocks; ++b) {
-        std::vector<Words4> lds((size_t)tile_lds_words<L>() / 4 + 1);
+        std::vector<Words4> lds((size_t)tile_lds_words<L, W>() / 4 + 1);
         uint32_t* tile = (uint32_t*)lds.data();
         for (size_t i = 0; i < lds.size() * 4; ++i) tile[i] = 0xdeadbeefu;   // LDS is not zero on the device either
         uint32_t* prod_carry = tile + TS::kRows * kTile;
-        uint32_t* top = prod_carry + 2 * 2 * kTileWaves * kTile;
+        uint32_t* top = prod_carry + 2 * 2 * W * kTile;
         uint32_t* fold_carry = top + kTile * kTableRowSlack;
-        uint32_t* cst = fold_carry + 2 * kTileWaves * kTile;
+        uint32_t* cst = fold_carry + 2 * W * kTile;
         memcpy(cst, T.n.data(), TS::S * 4);
         memcpy(cst + TS::S, T.ncomp.data(), TS::S * 4);
         memcpy(cst + 2 * TS::S, T.ncomp1.data(), TS::S * 4);
-        wave::run_block(kTileWaves, [&](uint32_t wv, uint32_t lane) {
-            mul_tile_body<L>(A, tile, prod_carry, top, fold_carry, cst, wv, (uint32_t)b, (uint32_t)n_blocks, lane);
+        wave::run_block(W, [&](uint32_t wv, uint32_t lane) {
+            mul_tile_body<L, W>(A, tile, prod_carry, top, fold_carry, cst, wv, (uint32_t)b, (uint32_t)n_blocks, lane);
         });
     }
 }
 static int g_tile_mul = 0, g_tile_blocks = 2;
 extern "C" {
 
-void emu_set_tile_mul(int e, int blocks) { g_tile_mul = e ? 1 : 0; g_tile_blocks = blocks > 0 ? blocks : 2; }
+// e: 0 = mul_table.h (table in LDS), 1 = mul_tile.h on 16 waves, 2 = mul_tile.h on 8 waves (S = 8 L: the shape of 1024-bit keys)
+void emu_set_tile_mul(int e, int blocks) { g_tile_mul = (e == 1 || e == 2) ? e : 0; g_tile_blocks = blocks > 0 ? blocks : 2; }
 void emu_set_engine(int e) { g_engine = e ? 1 : 0; }
 void emu_set_mul_io(int e) { g_mul_io = e ? 1 : 0; }
 void emu_set_unit(int e) { g_unit = e ? 1 : 0; }
@@ -723,9 +726,12 @@ int emu_decrypt(const uint32_t* p, const uint32_t* q, const uint32_t* hp, const 
 }
 
 // what the LIBRARY offers for phe_hip_mulmod on this modulus besides the two Montgomery products (phe_hip.hip launch_mul:
-// build_table_mul without the narrow lane widths): bit 0 the table in LDS (mul_table.h), bit 1 tiles (mul_tile.h: large batches)
+// build_table_mul without the narrow lane widths, the 8-wave tile shape first: ctx creation): bit 0 the table in LDS (mul_table.h),
+// bit 1 tiles (mul_tile.h: large batches), bit 2 (with bit 1) those tiles are the 8-wave shape (S = 8 L: keys of ~810 ... 1025 bits)
 int emu_table_mul_offered(const uint32_t* N, int limbs) {
     try {
+        const host::TableMulPack T8 = host::build_table_mul(host::big_from(N, limbs, limbs), limbs, false, 8);
+        if (T8.ok() && T8.tiles()) return 2 | 4;
         const host::TableMulPack T = host::build_table_mul(host::big_from(N, limbs, limbs), limbs, false);
         return !T.ok() ? 0 : ((T.in_lds() ? 1 : 0) | (T.tiles() ? 2 : 0));
     } catch (...) { return 0; }
@@ -734,7 +740,7 @@ int emu_table_mul_offered(const uint32_t* N, int limbs) {
 int emu_mulmod_table(const uint32_t* N, int limbs, const uint32_t* a, const uint32_t* b, uint32_t* out, uint64_t B) {
     try {
         if (B == 0) return 0;
-        const host::TableMulPack T = host::build_table_mul(host::big_from(N, limbs, limbs), limbs);
+        const host::TableMulPack T = host::build_table_mul(host::big_from(N, limbs, limbs), limbs, true, g_tile_mul == 2 ? 8 : 16);
         if (!T.ok()) return 2;
         std::vector<Words4> a4((size_t)B * limbs / 4 + 1), b4((size_t)B * limbs / 4 + 1), o4((size_t)B * limbs / 4 + 1);   // 16-byte aligned rows
         memcpy(a4.data(), a, (size_t)B * limbs * 4);
@@ -749,7 +755,10 @@ int emu_mulmod_table(const uint32_t* N, int limbs, const uint32_t* a, const uint
         if (!g_tile_mul && !T.in_lds()) return 2;
         if (g_tile_mul) {
             if (!T.tiles()) return 2;
-            if (T.L == 5) run_mul_tile<5>(A, T, g_tile_blocks);
+            if (g_tile_mul == 2) {
+                if (T.L == 9) run_mul_tile<9, 8>(A, T, g_tile_blocks);
+                else return 2;
+            } else if (T.L == 5) run_mul_tile<5>(A, T, g_tile_blocks);
             else if (T.L == 9) run_mul_tile<9>(A, T, g_tile_blocks);
             else if (T.L == 14) run_mul_tile<14>(A, T, g_tile_blocks);
             else return 2;

@@ -99,12 +99,12 @@ class Emu:
         self._ck(self.L.emu_mulmod(P(N), N.shape[0], P(a), P(b), P(out), ctypes.c_uint64(a.shape[0])))
         return out
 
-    def mulmod_table(self, N, a, b, tiles=False, blocks=2):
+    def mulmod_table(self, N, a, b, tiles=False, blocks=2, waves=16):
         """a*b mod N by the table kernel's body (csrc/mul_table.h: one plain product + one fold against the key's table); None
         where the library would not offer it (the table does not fit a CU's LDS).  tiles: by csrc/mul_tile.h instead (tiles of
         64 products per workgroup of 8 waves, the fold on lane = element), `blocks` emulated workgroups"""
         out = np.zeros_like(a)
-        self.L.emu_set_tile_mul(1 if tiles else 0, blocks)
+        self.L.emu_set_tile_mul((2 if waves == 8 else 1) if tiles else 0, blocks)   # (waves=8: the 512-thread workgroup shape, S = 8 L)
         try:
             rc = self.L.emu_mulmod_table(P(N), N.shape[0], P(a), P(b), P(out), ctypes.c_uint64(a.shape[0]))
         finally:

@@ -468,6 +468,55 @@ def test_product_by_tiles_with_the_fold_on_one_element_per_lane(emu, key_bits):
     assert (in_lds is None) == (key_bits == 3072) and (in_lds is None or np.array_equal(out, in_lds))
 
 
+def test_product_by_tiles_on_eight_waves_for_1024_bit_keys(emu):
+    """Round 5: n^2 of a 1024-bit key needs 72 columns (2048 bits + 38 of fold headroom) — 8 waves x 9, the
+    shape TileShape<9, 8> (512 threads, 58 KB of LDS: two workgroups per CU), where the 16-wave kernel pads to 16 x 5 = 80.  P = 71 of
+    the 72 columns are the modulus's own: ONE low fold digit, the quotient estimate one limb further down, the settle on 8-lane
+    groups.  Golden raw_add vectors, edge operands (all-ones rows: every column sum at its maximum), ragged tiles; the same residues as
+    the 16-wave shape and as Python integers; other moduli of the shape's range; rows too wide for 2 x 72 product digits are not offered."""
+    g = load_golden(1024)
+    s2 = 64
+    n = H(g["n"])
+    N = n * n
+    rng = random.Random(1024 + 8)
+    top = (1 << (32 * s2)) - 1
+    pairs = [(H(e["a"]), H(e["b"])) for e in g["raw_add"]]
+    pairs += [(0, 5), (1, N - 1), (N - 1, N - 1), (top, top), (top, 1), (N, 7), (N + 1, N + 1), (1 << (32 * s2 - 1), 3)]
+    pairs += [(rng.randrange(top), rng.randrange(top)) for _ in range(6)]
+    pairs += [(rng.randrange(N), rng.randrange(N)) for _ in range(200 - len(pairs))]
+    pairs += [(top, top), (N - 1, 2), (3, 0)]                              # 203 rows: 4 tiles, the last one with 11 live rows
+    a = ints_to_limbs([x for x, _ in pairs], s2)
+    b = ints_to_limbs([y for _, y in pairs], s2)
+    want = [x * y % N for x, y in pairs]
+    Nl = int_to_limbs(N, s2)
+    out = emu.mulmod_table(Nl, a, b, tiles=True, blocks=2, waves=8)
+    assert out is not None and limbs_to_ints(out) == want
+    assert limbs_to_ints(emu.mulmod_table(Nl, a[:70], b[:70], tiles=True, blocks=3, waves=8)) == want[:70]   # a workgroup without a tile
+    assert limbs_to_ints(emu.mulmod_table(Nl, a[:5], b[:5], tiles=True, blocks=1, waves=8)) == want[:5]
+    assert np.array_equal(out, emu.mulmod_table(Nl, a, b, tiles=True, blocks=2))       # the 16 x 5 shape: the same bits
+    assert emu.L.emu_table_mul_offered(Nl.ctypes.data_as(ctypes.c_void_p), s2) == 6   # what the library takes: tiles, on 8 waves
+    emu.L.emu_mad_count.restype = ctypes.c_uint64
+    emu.L.emu_mad_count(1)
+    emu.mulmod_table(Nl, a[:64], b[:64], tiles=True, blocks=1, waves=8)
+    eight = int(emu.L.emu_mad_count(1)) // 64
+    emu.mulmod_table(Nl, a[:64], b[:64], tiles=True, blocks=1)
+    sixteen = int(emu.L.emu_mad_count(1)) // 64
+    emu.mulmod(Nl, a[:64], b[:64])
+    two_products = int(emu.L.emu_mad_count(1)) // 64
+    assert eight == 11160 and eight * 1.12 < sixteen and eight * 1.8 < two_products, (eight, sixteen, two_products)
+    # other widths of the shape: random moduli of 2048 and 2040 bits (rows of 64 words), one of 1700 bits (rows of 56 words)
+    for bits in (2048, 2040, 1700):
+        M = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+        limbs = -(-bits // 128) * 4
+        full = (1 << (32 * limbs)) - 1
+        prs = [(full, full), (M - 1, M - 1), (M, 3), (1, 0)] + [(rng.randrange(full), rng.randrange(full)) for _ in range(20)]
+        got = emu.mulmod_table(int_to_limbs(M, limbs), ints_to_limbs([x for x, _ in prs], limbs), ints_to_limbs([y for _, y in prs], limbs),
+                               tiles=True, blocks=1, waves=8)
+        assert got is not None and limbs_to_ints(got) == [x * y % M for x, y in prs], bits
+    M = rng.getrandbits(2049) | (1 << 2048) | 1                            # rows of 68 words: their product has more than 2 x 72 digits
+    assert emu.mulmod_table(int_to_limbs(M, 68), ints_to_limbs([5], 68), ints_to_limbs([6], 68), tiles=True, blocks=1, waves=8) is None
+
+
 @pytest.mark.parametrize("bits", [3685, 3713, 3900, 4095, 4130, 5850, 6000, 6143])
 def test_tile_product_on_moduli_of_every_width_a_lane_count_takes(emu, bits):
     """mul_tile.h / mul_table.h take ANY odd modulus whose limbs fill the lanes to within 16 (n_lo = S - P fold digits come from the

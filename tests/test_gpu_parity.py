@@ -325,6 +325,54 @@ def test_one_product_entry_and_debt_constants(native, key_bits, batch, group):
     assert native.limbs_to_ints(out.to_host()) == [x * y % N for x, y in zip(a, b)]
 
 
+def test_raw_add_of_1024_bit_keys_by_tiles_on_eight_waves(native, c_oracle, monkeypatch):
+    """Round 5: 1024-bit keys — BASELINE configs[0]'s size, the one the reference publishes figures for — take
+    _raw_add (phe/paillier.py:705-719) as one plain product + one fold BY DEFAULT from 16384 rows on: k_mulmod_tile<9, 8> (csrc/mul_tile.h
+    TileShape<9, 8>: 72 columns on 8 waves, two workgroups per CU) instead of two Montgomery products.  The path asserted; every row
+    against the Montgomery kernels (PHE_HIP_NO_TABLE_MUL) and a sample against Python integers either side of the switch; golden
+    raw_add vectors and edge operands (0, 1, n^2 - 1, all-ones rows, operands above n^2); ragged last tile; in place."""
+    from phe._device import DeviceArray
+    g = load_golden(1024)
+    s2 = 64
+    n_int = H(g["n"])
+    N = n_int * n_int
+    ctx = make_ctx(native, g, private=False)
+    monkeypatch.setenv("PHE_HIP_NO_TABLE_MUL", "1")
+    plain = make_ctx(native, g, private=False)
+    monkeypatch.delenv("PHE_HIP_NO_TABLE_MUL")
+    rs = np.random.Generator(np.random.PCG64(1024 + 8))
+    top = (1 << (32 * s2)) - 1
+    edge = [(H(e["a"]), H(e["b"])) for e in g["raw_add"]] + [(0, 5), (1, N - 1), (N - 1, N - 1), (top, top), (top, 1), (N, 7), (N + 1, N + 1)]
+    for batch in (16383, 16384, 40001, 140000):
+        a = rs.integers(0, 1 << 32, size=(batch, s2), dtype=np.uint32)
+        b = rs.integers(0, 1 << 32, size=(batch, s2), dtype=np.uint32)
+        a[:, s2 - 1] &= 0x3fffffff
+        b[:, s2 - 1] &= 0x3fffffff
+        a[:len(edge)] = native.ints_to_limbs([x for x, _ in edge], s2)
+        b[:len(edge)] = native.ints_to_limbs([y for _, y in edge], s2)
+        a[-1], b[-1] = a[3], b[3]                                       # (the all-ones rows again, in the ragged last tile)
+        da, db = DeviceArray.from_host(ctx, a), DeviceArray.from_host(ctx, b)
+        out = DeviceArray(ctx, batch, s2)
+        ctx.mulmod_dev(da.ptr, db.ptr, out.ptr, batch)
+        ctx.sync()
+        path = ctx.last_launch()["path"]
+        assert bool(path & ctx.PATH_TILE_MUL) == (batch >= 16384) and bool(path & ctx.PATH_TABLE_MUL) == (batch >= 16384), (batch, path)
+        got = out.to_host()
+        assert native.limbs_to_ints(got[:len(edge)]) == [x * y % N for x, y in edge], batch
+        want = plain.mulmod(a, b)                                        # two Montgomery products, every row
+        assert not plain.last_launch()["path"] & ctx.PATH_TABLE_MUL
+        assert np.array_equal(got, want), batch
+        idx = np.arange(len(edge), batch, max(1, batch // 200))
+        assert native.limbs_to_ints(got[idx]) == [int(x) * int(y) % N for x, y in zip(native.limbs_to_ints(a[idx]), native.limbs_to_ints(b[idx]))]
+        ctx.mulmod_dev(da.ptr, db.ptr, da.ptr, batch)                   # in place: out = a
+        ctx.sync()
+        assert np.array_equal(da.to_host(), got), batch
+    monkeypatch.setenv("PHE_HIP_NO_TILE8", "1")                          # the switch back: the Montgomery kernels at every size
+    old = make_ctx(native, g, private=False)
+    a, b = a[:20000], b[:20000]
+    assert np.array_equal(old.mulmod(a, b), got[:20000]) and not old.last_launch()["path"] & ctx.PATH_TABLE_MUL
+
+
 @pytest.mark.parametrize("key_bits", [1024, 2048, 3072])
 def test_raw_add_by_one_plain_product_and_one_table_fold(native, c_oracle, key_bits, monkeypatch):
     """Round 4: phe_hip_mulmod / _raw_add (phe/paillier.py:705-719 -> phe/util.py:53-64) as ONE plain
@@ -335,6 +383,7 @@ def test_raw_add_by_one_plain_product_and_one_table_fold(native, c_oracle, key_b
     the Montgomery kernels there — PHE_HIP_TABLE_MUL_ANY_WIDTH offers it.)"""
     from phe._device import DeviceArray
     monkeypatch.setenv("PHE_HIP_TABLE_MUL_ANY_WIDTH", "1")
+    monkeypatch.setenv("PHE_HIP_NO_TILE8", "1")     # (1024 bits: the 16 x 5 forms under test here; the 8-wave tiles it takes by default: next test)
     g = load_golden(key_bits)
     s1, s2 = key_bits // 32, key_bits // 16
     n_int = H(g["n"])

@@ -106,8 +106,10 @@ def main():
             assert np.array_equal(emu.mulmod_table(nsq_arr, c, c_rev), want)
             res["raw_add_table_in_lds"] = count() / B
         if offered & 2:
-            assert np.array_equal(emu.mulmod_table(nsq_arr, c, c_rev, tiles=True, blocks=1), want)
+            waves = 8 if offered & 4 else 16          # (the 512-thread workgroup shape: n^2 of a 1024-bit key in 8 x 9 columns)
+            assert np.array_equal(emu.mulmod_table(nsq_arr, c, c_rev, tiles=True, blocks=1, waves=waves), want)
             res["raw_add_tiles"] = count() / B
+            res["raw_add_tile_waves"] = waves
         res["raw_add"] = res["raw_add_" + res["raw_add_form"]]
         emu.add_plain(n_arr, c, m)
         res["add_plain"] = count() / B

@@ -12,7 +12,7 @@ done
 # the kernels behind bench.py's `ops` object (configs[2]; VERDICT round 4 missing 6): k_mulmod_tile<9> / <14>, k_modexp_var_split, k_pair_mul,
 # k_to_pair — tools/bench_sweep.py at ONE batch size ($B rows per dispatch), the same three passes
 OPS_LEGS=""
-for bits in ${OPS_BITS:-2048 3072}; do
+for bits in ${OPS_BITS:-1024 2048 3072}; do
   sweep="python $R/tools/bench_sweep.py --key-bits $bits --min 17 --max 17 --ops add,mul,pair_add --budget-ms 30"
   timeout 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_SALU SQ_INSTS_LDS -d $R/$O/pmc_ops${bits}_valu -- $sweep > $R/$O/pmc_ops${bits}_valu.log 2>&1; echo "ops $bits valu rc=$?"
   timeout 300 rocprofv3 --pmc FETCH_SIZE -d $R/$O/pmc_ops${bits}_fetch -- $sweep > $R/$O/pmc_ops${bits}_fetch.log 2>&1; echo "ops $bits fetch rc=$?"
