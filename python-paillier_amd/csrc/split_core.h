@@ -771,7 +771,11 @@ PHE_DEV void modexp_split_body(const SplitArgs& A, uint32_t* lds_row, uint32_t s
             split_conv<G, L>(Y0, Y1, A.post + item * (uint64_t)A.post_limbs, A.post_limbs, A.post_chunks, A.mod, K, ln);
             split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
         }
-        if (U && A.exit_mod.n != nullptr) {
+        bool quick = false;
+        if constexpr (U && G >= 16) quick = A.exit_mod.n != nullptr;  // (only 16-lane rungs are launched with it: phe_hip.hip prepare_late;
+                                                                      //  a compile-time no for the narrow groups keeps the second copy of
+                                                                      //  the way out — ~5 k instructions — out of the throughput kernels)
+        if (quick) {
             // "quick" rungs (16-lane groups on the scaled modulus with R = 2^(29 rows), rows = the limbs it needs: key_setup.h
             // QuickPack): the way out works modulo the TRUE modulus with the same R — X0 - n~*X1 = X0 - n*(k*X1), one constant row
             // k*(n-1) where split_exit uses n-1 otherwise (see modexp_split_ab_body) — straight to the canonical residue, the
