@@ -3,7 +3,7 @@
 # batch and of a decrypt-only run, the batch sweeps at three key widths, the scalar-loop shape of configs[4]'s file, the reference's
 # benchmark loop, scalar latencies, the API-level rates.
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
-R=$PWD; O=gpurun_out/${TAG:-r05i}; mkdir -p $O
+R=$PWD; O=gpurun_out/${TAG:-r05l}; mkdir -p $O
 export TMPDIR=/tmp
 (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d $R/$O/prof_kt -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/$O/prof_kt.log 2>&1; echo "kt rc=$?")
 (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$O/prof_kt_dec -- python $R/bench.py --batch 262144 --steps 3 --warmup 1 --no-cpu-baseline --no-ops --no-config4 --only decrypt > $R/$O/prof_kt_dec.log 2>&1; echo "kt dec rc=$?")
