@@ -93,3 +93,33 @@ def test_integer_model_of_the_algebra():
     import split_model
     for bits, h in ((64, 3), (200, 8), (521, 19)):
         assert split_model.check(bits, h, seed=bits)
+
+
+def _sq_weight(L, k, r):
+    """csrc/split_core.h sq_weight, restated: limb k of a lane, row r of the unrolled trip"""
+    c = (k - r) % L
+    if c == 0 or 2 * c == L:
+        return 1
+    return 2 if 2 * c < L else 0
+
+
+@pytest.mark.parametrize("G,L", [(4, 18), (2, 18), (1, 18), (4, 27), (2, 27), (8, 9), (8, 14), (16, 5), (16, 3), (64, 2), (64, 1), (4, 9), (2, 9)])
+def test_the_residue_band_of_a_squaring_covers_every_digit_product_once(G, L):
+    """Round 5, the combinatorics behind sq_row (the arithmetic itself is pinned by the tests above and by test_emu_core.py): with row
+    i = t L + r and limb j = g L + k the selection depends on (k - r) mod L only — the same in every lane g and trip t — and
+      * every unordered pair {i, j}, i != j, is taken with total weight 2 over its two orders (row i x limb j, row j x limb i),
+      * every diagonal product x_i^2 once,
+      * every lane takes L/2 + 1 (even L) or (L + 1)/2 (odd L) limbs in every row,
+      * a column, while it stays L rows in one lane (its k + r constant), takes the weight of L products — the full sweep's, so the
+        accumulator bounds of the full sweep hold for the symmetric one."""
+    H = G * L
+    w = lambda i, j: _sq_weight(L, j % L, i % L)          # row i, the lane that holds limb j
+    for i in range(H):
+        assert w(i, i) == 1
+        for j in range(i + 1, H):
+            assert w(i, j) + w(j, i) == 2, (i, j)
+    per_row = L // 2 + 1 if L % 2 == 0 else (L + 1) // 2
+    for r in range(L):
+        assert sum(1 for k in range(L) if _sq_weight(L, k, r)) == per_row
+    for s in range(L):                                    # a column's stay: k + r = s (mod L) over the L rows of a trip
+        assert sum(_sq_weight(L, (s - r) % L, r) for r in range(L)) == L
