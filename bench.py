@@ -252,6 +252,12 @@ def parse_args(argv=None):
     ap.add_argument("--oracle-sample", type=int, default=4096, help="strided rows of the timed batch checked against libgmp")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--selftest-emu", action="store_true", help="CPU contract test: gloo + wave emulator, not a measurement")
+    ap.add_argument("--ops-sample", type=int, default=4096, help="strided rows of every configs[2] result checked against libgmp")
+    ap.add_argument("--config4-sample", type=int, default=4096,
+                    help="strided rows of the configs[3] job checked against libgmp (the shard boundaries are always checked)")
+    ap.add_argument("--inject-fault", choices=["cpu_baseline", "raw_add", "config4"], default=None,
+                    help="TEST HOOK (tests/test_bench_contract.py): flip one bit of one result row of that leg after it was computed "
+                         "and before it is checked — the run must then exit non-zero")
     return ap.parse_args(argv)
 
 
@@ -478,6 +484,17 @@ class EmuSelftestBackend:
         out[:rows] = self.npmod.where(mask[:rows, None] != 0, b[:rows], a[:rows])
 
 
+def config4_memory_budget(rows, total, t1, t2, gathered, lib_gathered):
+    """Bytes the configs[3] leg allocates on ONE GPU: `rows` of the `total`-row job live here (operands m, r of t1 words, the
+    ciphertext shard of t2 words), the gathered vector once per all-gather form that runs, the engine's window tables and
+    scratch (an upper bound: 576 B x 32 entries per resident limb group, a few hundred MB at most).
+    tests/test_bench_contract.py holds the real 3072-bit / 8M job on 8 ranks against the 288 GB of an MI355X with it."""
+    return {"operands_m_r": 2 * rows * t1 * 4, "ciphertext_shard": rows * t2 * 4,
+            "gathered_vector_torch": (total * t2 * 4) if gathered else 0,
+            "gathered_vector_library_rccl": (total * t2 * 4) if lib_gathered else 0,
+            "window_tables_and_scratch_upper_bound": 2 << 30}
+
+
 def clamp_operands(m, r, s1, n_int):
     """random words -> m < n, 1 <= r < n (n has exactly 32*s1 bits in every fixture key)"""
     top = (n_int >> (32 * (s1 - 1)))                     # the top word of n: >= 2^31
@@ -620,7 +637,7 @@ def main():
         ops = {}
         c2 = be.roll(c)
         out = be.empty(B, s2)
-        idx = strided(B, 96)
+        idx = strided(B, args.ops_sample)
         warm_rows = min(B, 16384)                                  # above the small-batch threshold: warms the kernels that are timed
 
         def run_op(name, fn, reps, check, note=None):
@@ -634,6 +651,9 @@ def main():
                 be.record(b)
             barrier()
             dt = max_over_ranks([time.perf_counter() - t0])[0]
+            if args.inject_fault == name and rank == 0:         # test hook: a wrong row in the result must fail the run
+                be.sync()
+                out[idx[-1], 0] ^= 1
             ok = check() if rank == 0 else None
             ops[name] = {"value": job_rows * reps / dt, "unit": "ops/s", "reps": reps, "ms_per_pass": dt / reps * 1e3,
                          "launch_ms_avg": sum(be.elapsed_ms(a, b) for a, b in evs) / reps,
@@ -817,10 +837,7 @@ def main():
         lib_gather_wanted = (args.lib_allgather or world > 1) and not args.no_lib_allgather and be.name == "hip" and total % world == 0
         # what this rank is about to allocate for the leg, said BEFORE it is allocated (a first N > 1 run that dies of memory
         # should say where): operands m, r + ciphertext shard, the gathered vector (twice with the library's gather), tables
-        budget = {"operands_m_r": 2 * rows * t1 * 4, "ciphertext_shard": rows * t2 * 4,
-                  "gathered_vector_torch": (total * t2 * 4) if use_dist else 0,
-                  "gathered_vector_library_rccl": (total * t2 * 4) if lib_gather_wanted else 0,
-                  "window_tables_and_scratch_upper_bound": 2 << 30}
+        budget = config4_memory_budget(rows, total, t1, t2, use_dist, lib_gather_wanted)
         print("bench.py rank %d/%d configs[3] memory budget: %s = %.2f GB on this GPU (resident from configs[1]: %.2f GB)"
               % (rank, world, ", ".join("%s %.2f GB" % (k, v / 1e9) for k, v in budget.items()), sum(budget.values()) / 1e9,
                  (2 * B * s1 + B * s2 + B * s1) * 4 / 1e9), file=sys.stderr, flush=True)
@@ -908,9 +925,17 @@ def main():
         if rank == 0:
             bounds = [shard_bounds(total, world, k) for k in range(world)]
             idx = sorted(set([0, total - 1] + [b[0] for b in bounds if b[0] < total] + [max(0, b[1] - 1) for b in bounds] +
-                             list(range(0, total, max(1, total // 48)))))
-            ms, rs = zip(*[operands(i, 1) for i in idx])
-            want = orc.encrypt(native.int_to_limbs(k4["n"], t1), be.np(be.cat(list(ms))), be.np(be.cat(list(rs))), nthreads=cores)
+                             strided(total, args.config4_sample)))
+            ms, rs = [], []
+            for b in sorted(set(i // blk for i in idx)):        # the operands of the checked rows, one 2^16-row block at a time
+                mb, rb = operands(b * blk, min(blk, total - b * blk))
+                sel = [i - b * blk for i in idx if i // blk == b]
+                ms.append(be.take(mb, sel))
+                rs.append(be.take(rb, sel))
+            want = orc.encrypt(native.int_to_limbs(k4["n"], t1), be.np(be.cat(ms)), be.np(be.cat(rs)), nthreads=cores)
+            if args.inject_fault == "config4":                  # test hook: a wrong row in the gathered vector must fail the run
+                be.sync()
+                full[idx[-1], 0] ^= 1
             got = full[idx].cpu().numpy().view(np.uint32)
             cfg4_ok = cfg4_ok and bool(np.array_equal(got, want))
             cfg4 = {"workload": "configs[3]: %d-bit key, %d plaintexts sharded over %d GPU(s) (%d per GPU%s), ONE all-gather "
@@ -945,6 +970,9 @@ def main():
             res = fn(count)
             return count, time.perf_counter() - t0, res
 
+        if args.inject_fault == "cpu_baseline":                 # test hook: a wrong ciphertext inside the libgmp sample must fail the run
+            be.sync()
+            c[min(1, B - 1), 0] ^= 1
         m_h, r_h, c_h = be.np(m), be.np(r), be.np(c)
         ne, t_enc_cpu, ch = cpu_timed(lambda k: orc.encrypt(n_arr, m_h[:k], r_h[:k], nthreads=cores), 12.0)
         cpu_ok = bool(np.array_equal(ch, c_h[:ne]))
@@ -956,7 +984,9 @@ def main():
                          "decrypt: first %d ciphertexts, %.1f s" % (ne, orc.gmp_version, cores, t_enc_cpu, nd, t_dec_cpu),
                "decrypts_per_s": nd / t_dec_cpu, "matches_gpu": cpu_ok}
 
-    ok = roundtrip_ok and sample_ok is not False and ops_ok and cfg4_ok
+    # every comparison the line reports feeds the exit code: the full round trip, the strided libgmp sample, each ops leg, the
+    # small-call leg, configs[3] and the cpu_baseline leg's rows (the largest libgmp sample of the line)
+    ok = roundtrip_ok and sample_ok is not False and ops_ok and cfg4_ok and latency_ok and (cpu is None or cpu["matches_gpu"])
     if rank == 0:
         enc_mac, dec_mac = mac32_counts(args.key_bits)
         peak, sustained, peak_src = valu_peak_mac32()

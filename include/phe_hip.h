@@ -53,6 +53,13 @@ typedef struct phe_hip_ctx phe_hip_ctx;
 /* Message for the last non-OK status returned on this thread. */
 const char* phe_hip_last_error(void);
 
+/* Version of this interface as the LIBRARY was built with it.  A binding compares it with the PHE_HIP_ABI_VERSION of the header
+ * it mirrors before the first call (phe/_native.py lib()): argument lists changed under unchanged symbol names twice
+ * (round 5: phe_hip_gather_rows_dev / phe_hip_scatter_rows_dev gained a row-count bound), and a stale mirror would still link.
+ * Bumped on every change to an existing signature or to the meaning of an argument; new entry points alone do not bump it. */
+#define PHE_HIP_ABI_VERSION 6
+int phe_hip_abi_version(void);
+
 /* Number of visible HIP devices. */
 int phe_hip_device_count(int* count);
 

@@ -352,6 +352,7 @@ struct DevTail {
 struct phe_hip_ctx {
     int device = 0;
     int n_cus = 256;
+    std::string arch;  // hipDeviceProp_t::gcnArchName ("gfx950:sramecc+:xnack-"): a measured ladder names the arch it was made on
     int blocks_per_cu = 0;  // 0 = ask the occupancy API per kernel (PHE_HIP_BLOCKS_PER_CU / set_blocks_per_cu override)
     int prefer_group = 0;  // 0 = automatic geometry; PHE_HIP_GROUP=4|8|16 sets the narrowest limb group allowed
     bool has_private = false;
@@ -726,6 +727,9 @@ static int prepare_late(phe_hip_ctx* ctx, const DevSplit& M, const DevSchedule& 
                         const uint32_t* post, int post_limbs, uint32_t* out, int out_limbs, size_t batch, int per_cu, bool second_table,
                         SplitArgs& A, int& blocks) {
     if (per_cu < 0) return fail(PHE_HIP_EINVAL, "no late kernel for this geometry");
+    // the way out modulo the true modulus (A.exit_mod) is compiled into the 16-lane and whole-wave kernels only
+    // (split_core.h modexp_split_body): a narrower rung launched with it would return residues of the scaled modulus
+    if (M.G < 16) return fail(PHE_HIP_EINVAL, "the quick way out needs groups of 16 lanes or the whole wave");
     blocks = grid_blocks(ctx, batch, M.G, per_cu);
     const size_t rows = (size_t)blocks * (size_t)(kBlock / M.G);
     uint32_t** tbl = second_table ? &ctx->table2 : &ctx->table;
@@ -1062,11 +1066,14 @@ struct RungShape {
 // on 8 x 14 once two waves per SIMD are there (factor 1.10 on the estimate), the CRT halves are 7 % slower on 2 x 27 than on
 // 4 x 14 and the per-element exponents 7 % slower on 4 x 27 than on 8 x 14 (factor 1.25); with ONE wave per SIMD those
 // kernels reach 86 % of their two-wave rate where the fused ones reach 90-95 % (factor 1.16 while w <= 1).
-enum RungFamily : int { kFamOther = 0, kFamFixedExp = 1, kFamHalves = 2, kFamVarExp = 3 };
+// (kFamHalvesLongExp: the CRT halves with the exponent n — the key owner's encryption.  Same kernels and the same wide-rung factor as
+//  kFamHalves, but no measured table serves it: family 2's launch times were taken with the decrypt's exponents, half as long)
+enum RungFamily : int { kFamOther = 0, kFamFixedExp = 1, kFamHalves = 2, kFamVarExp = 3, kFamHalvesLongExp = 4 };
 static double wide_rung_factor(int family) {
     switch (family) {
         case kFamFixedExp: return 1.10;
         case kFamHalves:
+        case kFamHalvesLongExp:
         case kFamVarExp: return 1.25;
         default: return 1.0;  // not measured: the plain estimate, as before
     }
@@ -1104,7 +1111,9 @@ static int pick_rung(const phe_hip_ctx* ctx, size_t batch, int n_rungs, Shape sh
             if (shape(k).G) return k;
         return 0;
     }
-    bool measured = !ctx->ladder.empty();
+    // (the tables are keyed by family and group width alone: launch times taken with the default kernels must not steer the
+    //  variants the measurement switches select — PHE_HIP_NO_LATE, PHE_HIP_FORCE_UNIT, a blocks-per-CU override)
+    bool measured = !ctx->ladder.empty() && !ctx->no_late && !ctx->force_unit && ctx->blocks_per_cu == 0;
     for (int k = 0; measured && k < n_rungs; ++k) {
         const RungShape r = shape(k);
         if (r.G && measured_cost(ctx, batch, r) < 0) measured = false;
@@ -1219,6 +1228,8 @@ extern "C" {
 
 const char* phe_hip_last_error(void) { return g_err.c_str(); }
 
+int phe_hip_abi_version(void) { return PHE_HIP_ABI_VERSION; }
+
 int phe_hip_device_count(int* count) {
     if (!count) return fail(PHE_HIP_EINVAL, "null count");
     HIP_TRY(hipGetDeviceCount(count));
@@ -1232,6 +1243,7 @@ static int ctx_common(phe_hip_ctx* ctx, const uint32_t* n, int n_limbs, int devi
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     ctx->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    ctx->arch = prop.gcnArchName;
     if (const char* e = getenv("PHE_HIP_BLOCKS_PER_CU")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 8) ctx->blocks_per_cu = v;
@@ -1542,7 +1554,21 @@ int phe_hip_ctx_load_ladder(phe_hip_ctx* ctx, const char* table, int* accepted) 
         std::string line(p, e ? (size_t)(e - p) : strlen(p));
         p = e ? e + 1 : p + line.size();
         const size_t hash = line.find('#');
-        if (hash != std::string::npos) line.resize(hash);
+        if (hash != std::string::npos) {
+            // a header comment may say what the table was measured ON ("arch: gfx950", "cus: 256"): launch times of another chip
+            // or another CU count must not pick this device's rungs — such a table is not an error, it is simply not taken
+            const std::string note = line.substr(hash);
+            const size_t at_cus = note.find("cus:"), at_arch = note.find("arch:");
+            if (at_cus != std::string::npos) {
+                int cus = 0;
+                if (sscanf(note.c_str() + at_cus + 4, "%d", &cus) == 1 && cus != ctx->n_cus) return PHE_HIP_OK;
+            }
+            if (at_arch != std::string::npos) {
+                char arch[64] = {0};
+                if (sscanf(note.c_str() + at_arch + 5, "%63s", arch) == 1 && ctx->arch.compare(0, strlen(arch), arch) != 0) return PHE_HIP_OK;
+            }
+            line.resize(hash);
+        }
         int bits = 0, family = 0, G = 0;
         double rows = 0, ns = 0;
         if (sscanf(line.c_str(), "%d %d %d %lf %lf", &bits, &family, &G, &rows, &ns) != 5) continue;
@@ -1640,7 +1666,7 @@ int phe_hip_encrypt_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_t* r, 
 // they fit one residency together, one number on a pair of wavefronts for a handful of numbers.  Sets last_geom_priv and the
 // path bits it took (|= into ctx->last_path).
 static int launch_crt_halves(phe_hip_ctx* ctx, const DevSchedule& Ep, const DevSchedule& Eq, const uint32_t* base, int base_limbs,
-                             uint32_t* xp, uint32_t* xq, int S, size_t batch, hipStream_t st) {
+                             uint32_t* xp, uint32_t* xq, int S, size_t batch, hipStream_t st, int family = kFamHalves) {
     int rc = PHE_HIP_OK;
     // the rung of the halves: the two exponentiations are independent, so a batch that cannot fill the chip with one of them
     // runs both side by side (one grid, the q half with its own window tables) and needs only half the lanes
@@ -1654,7 +1680,7 @@ static int launch_crt_halves(phe_hip_ctx* ctx, const DevSchedule& Ep, const DevS
         return split_ok && late_offered(ctx, psplit_of(k)) && late_offered(ctx, qsplit_of(k)) && psplit_of(k).q_L == qsplit_of(k).q_L;
     };
     const auto shape = [&](int k) {
-        if (split_ok) return split_shape(qsplit_of(k), kFamHalves, late_rung(k));
+        if (split_ok) return split_shape(qsplit_of(k), family, late_rung(k));
         RungShape sh;
         sh.G = qsq_of(k).G;
         sh.L = qsq_of(k).L;
@@ -1725,7 +1751,9 @@ int phe_hip_encrypt_owner_dev(phe_hip_ctx* ctx, const uint32_t* m, const uint32_
     uint32_t* yp = ctx->scratch;
     uint32_t* yq = ctx->scratch + batch * (size_t)S;
     // the halves on the rung this batch size calls for (the lift below takes canonical residues: any rung's will do)
-    rc = launch_crt_halves(ctx, ctx->d_exp_n, ctx->d_exp_n, r, ctx->pub.s1, yp, yq, S, batch, st);
+    // (its own family: the measured ladder's family 2 was timed with the decrypt's exponents p - 1, q - 1; the exponent n here is
+    //  twice as long, so this job keeps the estimate)
+    rc = launch_crt_halves(ctx, ctx->d_exp_n, ctx->d_exp_n, r, ctx->pub.s1, yp, yq, S, batch, st, kFamHalvesLongExp);
     if (rc) return rc;
     const int QS = ctx->d_qsq.S;
     CrtLiftArgs A;

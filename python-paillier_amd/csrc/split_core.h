@@ -772,6 +772,7 @@ PHE_DEV void modexp_split_body(const SplitArgs& A, uint32_t* lds_row, uint32_t s
             split_mul<G, L>(X0, X1, Y0, Y1, K, ln);
         }
         bool quick = false;
+        PHE_BOUNDS(G >= 16 || A.exit_mod.n == nullptr);  // (phe_hip.hip prepare_late refuses narrower rungs: they hold no quick way out)
         if constexpr (U && G >= 16) quick = A.exit_mod.n != nullptr;  // (only 16-lane rungs are launched with it: phe_hip.hip prepare_late;
                                                                       //  a compile-time no for the narrow groups keeps the second copy of
                                                                       //  the way out — ~5 k instructions — out of the throughput kernels)

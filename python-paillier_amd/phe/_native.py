@@ -18,6 +18,7 @@ _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.environ.get("PHE_HIP_LIB") or os.path.join(_PKG_ROOT, "lib", "libphe_hip.so")
 
 OK, EINVAL, EHIP, ENOINVERSE = 0, 1, 2, 3
+ABI_VERSION = 6          # include/phe_hip.h PHE_HIP_ABI_VERSION as mirrored below (tests/test_abi_exports.py compares the two)
 
 _lib = None
 
@@ -36,6 +37,16 @@ def lib():
                 "This package has no CPU fallback." % LIB_PATH)
         L = ctypes.CDLL(LIB_PATH)
         vp, sz, ci = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        # the argtypes below mirror include/phe_hip.h at PHE_HIP_ABI_VERSION = ABI_VERSION: a library built from another revision of
+        # the header would still link (argument lists have changed under unchanged names) and read shifted arguments
+        try:
+            L.phe_hip_abi_version.argtypes = []
+            have = L.phe_hip_abi_version()
+        except AttributeError:
+            have = None
+        if have != ABI_VERSION:
+            raise NativeLibraryMissing("%s speaks ABI version %s, this package mirrors version %d of include/phe_hip.h: rebuild "
+                                       "(python __graft_entry__.py build)" % (LIB_PATH, have, ABI_VERSION))
         L.phe_hip_last_error.restype = ctypes.c_char_p
         L.phe_hip_device_count.argtypes = [ctypes.POINTER(ci)]
         L.phe_hip_ctx_create_public.argtypes = [vp, ci, ci, ctypes.POINTER(vp)]
@@ -108,7 +119,7 @@ def lib():
 
 
 EXPORTED_SYMBOLS = [
-    "phe_hip_last_error", "phe_hip_device_count", "phe_hip_ctx_create_public", "phe_hip_ctx_create_private",
+    "phe_hip_last_error", "phe_hip_abi_version", "phe_hip_device_count", "phe_hip_ctx_create_public", "phe_hip_ctx_create_private",
     "phe_hip_ctx_destroy", "phe_hip_ctx_info", "phe_hip_ctx_set_blocks_per_cu", "phe_hip_encrypt",
     "phe_hip_obfuscate", "phe_hip_decrypt", "phe_hip_mulmod", "phe_hip_powmod", "phe_hip_invert",
     "phe_hip_encrypt_dev", "phe_hip_obfuscate_dev", "phe_hip_decrypt_dev", "phe_hip_mulmod_dev",
@@ -260,7 +271,13 @@ class Context:
             self.has_private = True
         self.measured_ladder_lines = 0
         if not os.environ.get("PHE_HIP_NO_MEASURED_LADDER"):
-            self.load_ladder(measured_ladder_text())
+            # an optimisation, never a reason for a key to fail: a malformed table (PHE_HIP_LADDER_FILE) leaves the estimate in
+            # place; a table measured on another chip (its header names arch and CU count) is not taken by the library
+            try:
+                self.load_ladder(measured_ladder_text())
+            except (ValueError, RuntimeError) as e:
+                self.measured_ladder_lines = 0
+                self.ladder_error = str(e)
 
     def load_ladder(self, text):
         """Give the context a measured ladder (include/phe_hip.h phe_hip_ctx_load_ladder: lines "key_bits family G rows ns"; None

@@ -58,7 +58,8 @@ class Fleet:
         self._make = make_engine
         self._lock = threading.Lock()
         self._pool = ThreadPoolExecutor(max_workers=len(self.devices), thread_name_prefix="phe-fleet")
-        self._retired = []     # (engine of a fleet this one replaced, its slot here): resident rows made there resolve to the successor
+        self._retired = []     # (native context of an engine of a fleet this one replaced, its slot here): resident rows made there resolve to the successor
+        self._inherit = {}     # slot -> obfuscator pool object of the replaced fleet's engine there: adopted when the successor is made
 
     def __len__(self):
         return len(self.devices)
@@ -68,7 +69,10 @@ class Fleet:
         if eng is None:
             with self._lock:
                 if self._engines[k] is None:
-                    self._engines[k] = self._make(self.devices[k])
+                    made = self._make(self.devices[k])
+                    if k in self._inherit:                     # the pool OBJECT of the engine this one succeeds (see succeed)
+                        made._obf = self._inherit.pop(k)
+                    self._engines[k] = made
                 eng = self._engines[k]
         return eng
 
@@ -81,8 +85,8 @@ class Fleet:
         for eng in self._engines:
             if eng is not None and eng.ctx is ctx:
                 return eng
-        for old, k in self._retired:
-            if old.ctx is ctx:
+        for old_ctx, k in self._retired:
+            if old_ctx is ctx:
                 return self.engine(k)
         return None
 
@@ -94,20 +98,35 @@ class Fleet:
         return None
 
     def succeed(self, old):
-        """Take the place of the fleet `old` (same device list): every engine `old` had made gets its successor here NOW, on the
-        same device and with the same obfuscator pool OBJECT (rows are taken under one lock whichever engine a thread is in),
-        and resident rows made by `old`'s engines resolve to those successors (engine_of).  The key pair's engines replacing a
+        """Take the place of the fleet `old` (same device list): every engine `old` had made gets a successor here on the same
+        device, with the same obfuscator pool OBJECT (rows are taken under one lock whichever engine a thread is in), and
+        resident rows made by `old`'s engines resolve to those successors (engine_of).  The key pair's engines replacing a
         public key's (PaillierPrivateKey._get_engine): a vector that encrypt_batch_sharded left on device k must be decrypted
-        by an engine ON device k that holds the private key — never by the device-0 engine."""
+        by an engine ON device k that holds the private key — never by the device-0 engine.
+
+        The successors are made on FIRST USE (engine(k) adopts the pool then): the caller holds the key's engine lock, and a
+        context per device at ~0.1 s each would stall every thread waiting on it.  Of a retired engine only its native context
+        is kept — resident rows name it as their home and free their memory through it —, with its window tables and scratch
+        rows given back to the device; the replaced fleet's worker threads are told to exit."""
         assert list(old.devices) == self.devices
         for k, eng in enumerate(old._engines):
             if eng is None:
                 continue
             if k > 0:
-                self.engine(k)._obf = eng._obf
+                if self._engines[k] is not None:
+                    self._engines[k]._obf = eng._obf
+                else:
+                    self._inherit[k] = eng._obf
             if eng is not self._engines[k]:
-                self._retired.append((eng, k))
+                self._retired.append((eng.ctx, k))
+                try:
+                    eng.ctx.release_scratch()
+                except Exception:  # noqa: BLE001 — a backend without scratch to give back (the emulator)
+                    pass
         self._retired.extend(old._retired)
+        self._inherit.update({k: v for k, v in old._inherit.items() if self._engines[k] is None and k not in self._inherit})
+        if old._pool is not self._pool:
+            old._pool.shutdown(wait=False)
         return self
 
     def shards(self, rows, min_rows=None):

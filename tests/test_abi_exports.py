@@ -54,3 +54,19 @@ def test_errors_without_gpu_are_loud():
         pytest.skip("a GPU is present")
     with pytest.raises((RuntimeError, ValueError)):
         _native.Context(126869)
+
+
+def test_abi_version_is_checked_before_the_first_call(monkeypatch):
+    """argument lists changed under unchanged symbol names; a mirror built against another revision of the header
+    would link and pass shifted arguments.  The header's PHE_HIP_ABI_VERSION, the library's phe_hip_abi_version() and the
+    binding's ABI_VERSION must be one number, and a binding that mirrors another version must refuse to load the library."""
+    from phe import _native
+    header = open(os.path.join(ROOT, "include", "phe_hip.h")).read()
+    declared = int(re.search(r"#define\s+PHE_HIP_ABI_VERSION\s+(\d+)", header).group(1))
+    assert declared == _native.ABI_VERSION == _native.lib().phe_hip_abi_version()
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "ABI_VERSION", declared + 1)
+    with pytest.raises(ImportError, match="ABI version"):
+        _native.lib()
+    monkeypatch.setattr(_native, "ABI_VERSION", declared)
+    assert _native.lib().phe_hip_abi_version() == declared

@@ -143,3 +143,87 @@ def test_bench_single_process_line():
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["matches_gpu"] is True
     roof = out["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic", "canonical_frac"} <= set(roof)
+
+
+def _run_bench_raw(cmd, timeout=600):
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    return res.returncode, (json.loads(lines[0]) if len(lines) == 1 else None), res.stderr[-3000:]
+
+
+def test_a_wrong_row_in_the_cpu_baseline_sample_fails_the_run():
+    """`cpu_baseline.matches_gpu` — the largest libgmp sample of the line — used to be reported and
+    ignored.  One flipped bit in a ciphertext that ONLY that leg looks at (--oracle-sample 1 checks row 0, the fault sits in
+    row 1) must make bench.py exit non-zero, with the line saying which comparison failed."""
+    rc, out, err = _run_bench_raw([sys.executable, "bench.py"] + SELFTEST + ["--oracle-sample", "1", "--inject-fault", "cpu_baseline"])
+    assert rc != 0, err
+    assert out["bit_exact"] == {"roundtrip_full_batch": True, "strided_sample_vs_gmp_oracle": True, "strided_sample_rows": 1}
+    assert out["cpu_baseline"]["matches_gpu"] is False
+    assert all(rec["bit_exact_strided_sample_vs_gmp_oracle"] is True for rec in out["ops"].values())
+    # the same command without the fault exits 0
+    rc, out, err = _run_bench_raw([sys.executable, "bench.py"] + SELFTEST + ["--oracle-sample", "1"])
+    assert rc == 0 and out["cpu_baseline"]["matches_gpu"] is True, err
+
+
+def test_a_wrong_row_in_an_ops_result_or_in_the_gathered_vector_fails_the_run():
+    rc, out, err = _run_bench_raw([sys.executable, "bench.py"] + SELFTEST + ["--inject-fault", "raw_add"])
+    assert rc != 0 and out["ops"]["raw_add"]["bit_exact_strided_sample_vs_gmp_oracle"] is False, err
+    assert out["ops"]["raw_add"]["rows_checked"] == 6            # every row of the 6-row selftest batch (default: 4,096 strided rows)
+    assert out["ops"]["obfuscate"]["bit_exact_strided_sample_vs_gmp_oracle"] is True
+    rc, out, err = _run_bench_raw([sys.executable, "bench.py"] + SELFTEST + ["--inject-fault", "config4"])
+    assert rc != 0 and out["config4"]["bit_exact_boundaries_and_sample_vs_gmp_oracle"] is False, err
+    assert out["config4"]["rows_checked"] == 9
+
+
+def test_sample_sizes_of_the_default_line():
+    """what a default run checks against libgmp: 4,096 strided rows of the headline batch, of every ops result and of the
+    configs[3] job (plus its shard boundaries)"""
+    a = bench.parse_args([])
+    assert (a.oracle_sample, a.ops_sample, a.config4_sample) == (4096, 4096, 4096) and a.inject_fault is None
+
+
+def test_eight_ranks_weak_and_strong():
+    """the shape of the driver's 8-GPU run (python -m torch.distributed.run --nproc-per-node 8 bench.py --gpus 8), on gloo + the
+    wave emulator: eight ranks, ragged configs[3] shards (9 rows over 8 ranks: 2 1 1 1 1 1 1 1), one all-gather, one line"""
+    out = _run_bench([sys.executable, "bench.py", "--gpus", "8"] + SELFTEST, timeout=1200)
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["scaling"] == "weak"
+    assert out["config"]["batch_whole_job"] == 48 and out["config"]["batch_per_gpu"] == 6
+    assert out["bit_exact"]["roundtrip_full_batch"] is True and out["bit_exact"]["strided_sample_vs_gmp_oracle"] is True
+    cfg4 = out["config4"]
+    assert cfg4["total"] == 9 and cfg4["rows_per_gpu"] == 2 and cfg4["bit_exact_boundaries_and_sample_vs_gmp_oracle"] is True
+    assert cfg4["rows_checked"] == 9 and cfg4["all_gather"]["bytes_received_per_gpu"] == 9 * 16 * 4
+    assert out["cpu_baseline"] is None
+    args = [a for a in SELFTEST]
+    args[args.index("--batch") + 1] = "19"                      # 19 rows over 8 ranks: 3 3 3 2 2 2 2 2
+    out = _run_bench([sys.executable, "bench.py", "--gpus", "8", "--scaling", "strong"] + args, timeout=1200)
+    assert out["n_gpus"] == 8 and out["rccl_ranks"] == 8 and out["scaling"] == "strong"
+    assert out["config"]["batch_whole_job"] == 19 and out["config"]["batch_per_gpu"] == 3
+    assert out["bit_exact"]["roundtrip_full_batch"] is True
+    assert out["config4"]["total"] == 9 and out["config4"]["bit_exact_boundaries_and_sample_vs_gmp_oracle"] is True
+
+
+def test_memory_budget_of_the_real_eight_gpu_job():
+    """BASELINE configs[3] as the driver will run it: 3072-bit key, 8M plaintexts over 8 GPUs (2^20 per GPU), the gathered
+    vector held once by torch's all-gather and once more by the library's own RCCL gather — far inside 288 GB of HBM, also
+    with configs[1]'s operands still resident and also for the strong form's single-GPU point (the whole 8M job on one GPU)"""
+    from phe.sharding import shard_bounds
+    t1, t2, total = 96, 192, 1 << 23
+    resident_cfg1 = (2 * 64 + 128 + 64) * 4 << 20               # m, r, c, m_back of the 2^20-row headline batch
+    for world in (1, 2, 4, 8):
+        for rank in range(world):
+            lo, hi = shard_bounds(total, world, rank)
+            b = bench.config4_memory_budget(hi - lo, total, t1, t2, world > 1, world > 1)
+            assert b["ciphertext_shard"] == (hi - lo) * 768 and b["operands_m_r"] == (hi - lo) * 768
+            assert b["gathered_vector_torch"] == (total * 768 if world > 1 else 0) == b["gathered_vector_library_rccl"]
+            assert sum(b.values()) + resident_cfg1 < 0.1 * 288e9, (world, rank, sum(b.values()))
+    b8 = bench.config4_memory_budget(1 << 20, total, t1, t2, True, True)
+    assert b8["gathered_vector_torch"] == 6442450944            # the 6.4 GB of SURVEY 8(a) row a4, twice on every GPU
+    assert 15.5e9 < sum(b8.values()) + resident_cfg1 < 18e9
+    # weak form (the default line): 2^20 rows per GPU at every N, the gathered vector grows with N
+    bw = bench.config4_memory_budget(1 << 20, 8 << 20, t1, t2, True, True)
+    assert bw == b8

@@ -238,7 +238,13 @@ def test_private_engine_takes_over_a_public_fleet_device_for_device(monkeypatch)
     priv._get_engine()                                                   # the key pair's engine takes over
     new = pub._get_fleet()
     assert new is not old and new is priv._get_fleet() and new.devices == [0, 1, 2]
+    # the successors on devices 1.. are made on FIRST USE (the take-over runs under the key's engine lock), the
+    # replaced fleet's worker threads are told to exit, and of a retired engine only its native context is kept
+    assert len(new.made()) == 1 and sorted(new._inherit) == [1, 2]
+    assert old._pool._shutdown and all(not hasattr(c, "ctx") for c, _ in new._retired)
+    assert sorted(k for _, k in new._retired) == [0, 1, 2] and [c for c, _ in new._retired] == [e.ctx for e in old_engines]
     homes = [pub._engine_for(p) for p in parts]
+    assert not new._inherit                                              # adopted when the successors were made
     assert [e.device for e in homes] == [0, 1, 2] and all(e.ctx.has_private for e in homes)
     assert homes == new.engines() and homes[0] is priv._get_engine()
     assert [e._obf for e in homes] == [e._obf for e in old_engines]      # each pool stayed with its device

@@ -78,3 +78,32 @@ def test_a_fresh_context_takes_its_rungs_from_the_table(monkeypatch):
     ctx.load_ladder(None)
     c3 = ctx.encrypt(m, r)
     assert ctx.last_launch()["geom_pub"] // 100 != 64 and np.array_equal(c2, c3)
+
+
+def test_committed_table_names_the_chip_it_was_measured_on():
+    with open(_native.LADDER_FILE) as f:
+        head = f.read(600)
+    assert "arch: gfx950" in head and "cus: 256" in head
+
+
+@pytest.mark.gpu
+def test_a_table_of_another_chip_or_a_malformed_one_leaves_the_estimate(monkeypatch, tmp_path):
+    """launch times of another part must not pick this device's rungs (the header's arch / CU count decide), and
+    a malformed table named by PHE_HIP_LADDER_FILE must not stop a key from being created."""
+    g = load_golden(2048)
+    H = lambda k: int(g[k], 16)
+    ctx = _native.Context(H("n"), device=0)
+    own = ctx.measured_ladder_lines
+    assert own > 0
+    body = "2048 1 4 1024 5\n2048 1 16 1024 9\n"
+    assert ctx.load_ladder("# arch: gfx950 cus: 256\n" + body) == 2
+    assert ctx.load_ladder("# arch: gfx942 cus: 256\n" + body) == 0          # another architecture
+    assert ctx.load_ladder("# arch: gfx950 cus: 304\n" + body) == 0          # another CU count
+    assert ctx.load_ladder(body) == 2                                        # no header: taken (tests, hand-made tables)
+    bad = tmp_path / "bad_ladder.txt"
+    bad.write_text("2048 1 4 1024 5\n2048 1 4 1024 6\n")                     # one batch size twice for one rung
+    monkeypatch.setattr(_native, "_ladder_text", None)
+    monkeypatch.setenv("PHE_HIP_LADDER_FILE", str(bad))
+    ctx2 = _native.Context(H("n"), device=0)                                 # does not raise
+    assert ctx2.measured_ladder_lines == 0 and "twice" in ctx2.ladder_error
+    monkeypatch.setattr(_native, "_ladder_text", None)

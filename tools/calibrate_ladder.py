@@ -47,7 +47,10 @@ def main():
     say = lambda s: (out_lines.append(s), sys.stdout.write(s + "\n"), sys.stdout.flush())
     if not args.check:
         say("# measured geometry ladder: key_bits family G rows ns   (family 1 encrypt r^n, 2 CRT halves of decrypt, 3 _raw_mul 56-bit)")
-        say("# device: %s   made: %s   csrc_sha256: %s" % (torch.cuda.get_device_name(0), time.strftime("%Y-%m-%d"), csrc_hash()))
+        prop = torch.cuda.get_device_properties(0)
+        say("# device: %s   arch: %s   cus: %d   made: %s   csrc_sha256: %s"
+            % (torch.cuda.get_device_name(0), getattr(prop, "gcnArchName", "gfx950").split(":")[0], prop.multi_processor_count,
+               time.strftime("%Y-%m-%d"), csrc_hash()))
     report = {}
     for bits in args.key_bits:
         k = key(bits)
