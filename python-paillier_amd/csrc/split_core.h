@@ -42,6 +42,18 @@ namespace phe {
 // and adds up to three products per digit to one accumulator: both stop at about L = 21 limbs per lane.  Wider lanes
 // run every word of a pair product as its own single-accumulator sweep (two products per digit, L <= 31).
 constexpr int kMaxFusedL = 21;
+// ... of which the sweeps with TWO products per digit and accumulator (pair_pass2: squarings and the conversions in) have room for
+// more by the arithmetic: 2 L products of < 2^58.0000014 and the per-row carries stay below 2^64 up to L = 31.  Round 6 tried them
+// fused on the L = 27 rungs (3072-bit keys: n on 4 x 27, p and q on 2 x 27) — PHE_VARIANT_WIDE_FUSED, measurement only: bit-exact and
+// FOURTEEN times slower (12.9 k against 182.7 k encrypts/s, same box: profiles/r06b_wide_rungs_fused_squarings.txt): two accumulator
+// sets of 27 columns and three operand rows are 7 L = 189 registers before a single temporary, and the 256-register sweep loop
+// spills every row.  The wide rungs stay on single sweeps.
+#if defined(PHE_VARIANT_WIDE_FUSED)
+constexpr int kMaxFusedPass2L = 27;
+#else
+constexpr int kMaxFusedPass2L = kMaxFusedL;
+#endif
+static_assert(kMaxFusedPass2L <= 31, "2 L products of < 2^58.0000014 per accumulator and stay must stay below 2^64");
 
 // per-modulus constants (device pointers; H = G*L words of 29-bit limbs per row)
 struct SplitConsts {
@@ -463,7 +475,7 @@ struct SplitLane {  // what every pass needs, loaded once per kernel (U: the mod
 template <int G, int L, bool U, bool SQ = false>
 PHE_DEV void pair_mul_plain(uint32_t (&z0)[L], uint32_t (&z1)[L], const uint32_t (&b0)[L], const uint32_t (&b1)[L],
                             const SplitLane<G, L, U>& K, const Lanes<G>& ln) {
-    if constexpr (L <= kMaxFusedL) {
+    if constexpr (L <= kMaxFusedPass2L) {
         pair_pass2<G, L, U, SQ>(z0, z1, K.row_a, b0, b1, K.n, K.n0inv, ln, K.rows(), SQ ? K.row_c : nullptr);
     } else {
         uint32_t u[L];
