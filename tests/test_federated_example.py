@@ -61,9 +61,9 @@ def test_scalar_api_protocol_on_gpu(key_bits, capsys):
     sys.stderr.write("configs[4], scalar API, %d-bit key on the GPU: %.2f s\n%s" % (key_bits, elapsed, out))
 
 
-def test_scalar_api_protocol_two_rounds_on_emulator(monkeypatch):
+def test_scalar_api_protocol_one_round_on_emulator(monkeypatch):
     import emu_backend
     emu_backend.install(monkeypatch)
-    errors, _, calls = fed.run_scalar(key_length=256, n_rounds=2, verbose=False)
-    assert calls == {"encrypt": 110, "add": 88, "decrypt": 22}
-    assert np.allclose(errors, plaintext_rounds(2), rtol=1e-9)
+    errors, _, calls = fed.run_scalar(key_length=256, n_rounds=1, verbose=False)
+    assert calls == {"encrypt": 55, "add": 44, "decrypt": 11}
+    assert np.allclose(errors, plaintext_rounds(1), rtol=1e-9)
