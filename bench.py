@@ -21,7 +21,8 @@ The same JSON line also carries
   config4      — configs[3]: a 3072-bit key, one shard of 2^20 plaintexts per GPU (8M on 8 GPUs; at N = 1 that one shard;
                  --scaling strong: the 8M job itself cut over the ranks present), the ciphertext shards concatenated on every GPU
                  by ONE RCCL all-gather (phe.sharding.all_gather_rows)
-                 and, for N > 1, once more by the library's own RCCL communicator (phe_hip_allgather_dev), bits compared;
+                 and, for N > 1, once more by the library's own RCCL communicator (phe_hip_allgather_dev), bits compared — as the
+                 LAST leg, under a watchdog (--lib-allgather-timeout): if it hangs the line goes out without it;
                  shard-boundary rows + a strided sample against the oracle;
   roofline     — dominant kernel (k_modexp_split<4,18,encrypt>): `frac` = multiply-adds the kernel EXECUTES
                  (v_mad_u64_u32 lane-operations, exact count from profiles/executed_mads_r*.json, cross-checked with the
@@ -249,13 +250,16 @@ def parse_args(argv=None):
     ap.add_argument("--lib-allgather", action="store_true",
                     help="N = 1: repeat the configs[3] gather through the library's own RCCL communicator (always on for N > 1)")
     ap.add_argument("--no-lib-allgather", action="store_true")
+    ap.add_argument("--lib-allgather-timeout", type=float, default=240.0,
+                    help="seconds the library's own RCCL gather may take (communicator set-up included) before the line is printed "
+                         "without it: a second RCCL instance that hangs must not cost the run its line")
     ap.add_argument("--oracle-sample", type=int, default=4096, help="strided rows of the timed batch checked against libgmp")
     ap.add_argument("--blocks-per-cu", type=int, default=0)
     ap.add_argument("--selftest-emu", action="store_true", help="CPU contract test: gloo + wave emulator, not a measurement")
     ap.add_argument("--ops-sample", type=int, default=4096, help="strided rows of every configs[2] result checked against libgmp")
     ap.add_argument("--config4-sample", type=int, default=4096,
                     help="strided rows of the configs[3] job checked against libgmp (the shard boundaries are always checked)")
-    ap.add_argument("--inject-fault", choices=["cpu_baseline", "raw_add", "config4"], default=None,
+    ap.add_argument("--inject-fault", choices=["cpu_baseline", "raw_add", "config4", "lib_allgather"], default=None,
                     help="TEST HOOK (tests/test_bench_contract.py): flip one bit of one result row of that leg after it was computed "
                          "and before it is checked — the run must then exit non-zero")
     return ap.parse_args(argv)
@@ -823,7 +827,7 @@ def main():
         latency["bit_exact"] = bool(latency_ok)
 
     # ---- configs[3]: a shard per GPU under a 3072-bit key + ONE all-gather of the ciphertext shards ---------------
-    cfg4, cfg4_ok = None, True
+    cfg4, cfg4_ok, lib_state = None, True, None
     if not args.no_config4:
         k4 = golden(args.config4_key_bits)
         t1, t2 = args.config4_key_bits // 32, args.config4_key_bits // 16
@@ -834,7 +838,8 @@ def main():
         lo, hi = shard_bounds(total, world, rank)
         rows = hi - lo
         blk = 1 << 16
-        lib_gather_wanted = (args.lib_allgather or world > 1) and not args.no_lib_allgather and be.name == "hip" and total % world == 0
+        lib_gather_wanted = ((args.lib_allgather or world > 1) and not args.no_lib_allgather and be.name == "hip" and total % world == 0) \
+            or bool(os.environ.get("PHE_BENCH_TEST_LIB_GATHER_HANG"))
         # what this rank is about to allocate for the leg, said BEFORE it is allocated (a first N > 1 run that dies of memory
         # should say where): operands m, r + ciphertext shard, the gathered vector (twice with the library's gather), tables
         budget = config4_memory_budget(rows, total, t1, t2, use_dist, lib_gather_wanted)
@@ -868,60 +873,10 @@ def main():
         barrier()
         t_gather = time.perf_counter() - t0
         t_enc, t_gather = max_over_ranks([t_enc, t_gather])
-        lib_gather = None
-        if lib_gather_wanted:
-            # the same exchange issued by the library's own RCCL communicator (include/phe_hip.h phe_hip_allgather_dev):
-            # the path of a host without a process group; the id travels over the torch group here
-            from phe.sharding import library_communicator
-            def exchange(uid):
-                box = [uid]
-                if use_dist:
-                    dist.broadcast_object_list(box, src=0)
-                return box[0]
-            # A communicator that cannot be created (no librccl to dlopen, an RCCL error) must not take the headline with it:
-            # every rank learns whether ALL ranks got one (a rank that went on alone would hang the others in the collective),
-            # the line says what happened, and only a gather that RAN and differs from torch's makes the run exit non-zero.
-            comm, lib_error, uid = None, None, None
-            if rank == 0:                     # (the id first, on its own: a rank 0 that fails here must still reach the broadcast)
-                try:
-                    uid = native.comm_unique_id()
-                except Exception as e:  # noqa: BLE001
-                    lib_error = "%s: %s" % (type(e).__name__, e)
-            uid = exchange(uid)
-            if uid is not None:
-                try:
-                    comm = library_communicator(ctx4, rank, world, lambda _ignored: uid)
-                except Exception as e:  # noqa: BLE001
-                    lib_error = "%s: %s" % (type(e).__name__, e)
-            if comm is None:
-                print("bench.py rank %d: the library's RCCL communicator could not be created: %s" % (rank, lib_error or "no id from rank 0"),
-                      file=sys.stderr, flush=True)
-            if max_over_ranks([0.0 if comm is not None else 1.0])[0] != 0.0:
-                if comm is not None:
-                    comm.close()
-                comm = None
-                lib_gather = {"error": lib_error or "another rank could not create its communicator"}
-        if lib_gather_wanted and comm is not None:
-            full2 = be.empty(total, t2)
-            comm.allgather_dev(c4.data_ptr(), full2.data_ptr(), rows, t2, be.stream)      # first call: connection set-up
-            barrier()
-            t0 = time.perf_counter()
-            comm.allgather_dev(c4.data_ptr(), full2.data_ptr(), rows, t2, be.stream)
-            barrier()
-            t_lib = max_over_ranks([time.perf_counter() - t0])[0]
-            lib_gather = {"seconds": t_lib, "GBps_per_gpu": total * t2 * 4 / t_lib / 1e9,
-                          "same_bits_as_torch_all_gather": be.equal(full2, full)}
-            if not lib_gather["same_bits_as_torch_all_gather"]:
-                # say WHERE: the first row on which the library's gather and torch's differ (the run exits non-zero below)
-                diff = (be.as_tensor(full2) != be.as_tensor(full)).any(dim=1).nonzero()
-                first = int(diff[0]) if len(diff) else -1
-                lib_gather["first_differing_row"] = first
-                lib_gather["first_differing_row_owner_rank"] = next((k for k in range(world) if shard_bounds(total, world, k)[0] <= first < shard_bounds(total, world, k)[1]), None)
-                print("bench.py rank %d: library RCCL all-gather differs from torch's at row %d of %d (%d rows differ)"
-                      % (rank, first, total, len(diff)), file=sys.stderr, flush=True)
-            cfg4_ok = cfg4_ok and lib_gather["same_bits_as_torch_all_gather"]
-            comm.close()
-            del full2
+        # The same exchange issued by the library's own RCCL communicator (include/phe_hip.h phe_hip_allgather_dev) runs LAST, after
+        # every other leg and every check of the line (library_allgather_leg below): it is the one path of this file that no box
+        # with more than one GPU has run yet, and a hang inside it must not cost the run its line.
+        lib_state = dict(c4=c4, full=full, rows=rows, total=total, t2=t2, ctx4=ctx4) if lib_gather_wanted else None
         if rank == 0:
             bounds = [shard_bounds(total, world, k) for k in range(world)]
             idx = sorted(set([0, total - 1] + [b[0] for b in bounds if b[0] < total] + [max(0, b[1] - 1) for b in bounds] +
@@ -947,7 +902,7 @@ def main():
                     "encrypt": {"seconds": t_enc, "value": total / t_enc, "unit": "encrypts/s"},
                     "all_gather": {"seconds": t_gather, "bytes_received_per_gpu": total * t2 * 4,
                                    "GBps_per_gpu": total * t2 * 4 / t_gather / 1e9 if use_dist else None},
-                    "all_gather_by_library_rccl": lib_gather,
+                    "all_gather_by_library_rccl": None,     # filled in by library_allgather_leg
                     "end_to_end_encrypts_per_s": total / (t_enc + t_gather),
                     "bit_exact_boundaries_and_sample_vs_gmp_oracle": cfg4_ok, "rows_checked": len(idx),
                     "geometry": ctx4.info()}
@@ -1127,15 +1082,112 @@ def main():
         if cpu:
             out["speedup_vs_cpu_all_cores"] = {"encrypt": value / cpu["value"],
                                                "decrypt": out["decrypt"]["value"] / cpu["decrypts_per_s"]}
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    else:
+        out = None
     if use_dist:
-        flag = max_over_ranks([0.0 if ok else 1.0])[0]
-        ok = flag == 0.0
+        ok = max_over_ranks([0.0 if ok else 1.0])[0] == 0.0
+
+    def print_line():
+        if rank == 0:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+    if lib_state is not None:
+        ok = library_allgather_leg(args, be, native, dist, use_dist, rank, world, lib_state, out, ok, print_line, barrier, max_over_ranks)
+        lib_state = None
+    print_line()
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if not ok:
         sys.exit(1)
+
+
+def library_allgather_leg(args, be, native, dist, use_dist, rank, world, st, out, ok, print_line, barrier, max_over_ranks):
+    """configs[3]'s all-gather once more, issued by the library's own RCCL communicator (include/phe_hip.h phe_hip_comm_create /
+    phe_hip_allgather_dev: the path of a host without a process group; the id travels over the torch group here), bits compared
+    with torch's gather.  Runs after every other leg, with the line assembled and the ranks' verdicts exchanged: if the second
+    RCCL instance of the process hangs (communicator set-up or the collective itself), a watchdog prints the line with
+    `all_gather_by_library_rccl.error` and ends the process with the exit code the other legs earned.  Returns ok."""
+    import threading
+    from phe.sharding import library_communicator, shard_bounds
+    c4, full, rows, total, t2, ctx4 = st["c4"], st["full"], st["rows"], st["total"], st["t2"], st["ctx4"]
+
+    def record(result):
+        if rank == 0 and out is not None and out.get("config4"):
+            out["config4"]["all_gather_by_library_rccl"] = result
+
+    def on_timeout():
+        record({"error": "no answer within %.0f s (--lib-allgather-timeout): communicator set-up or the collective hangs; "
+                         "the rest of the line was measured before this leg" % args.lib_allgather_timeout})
+        print("bench.py rank %d: the library's RCCL all-gather did not finish in %.0f s: the line goes out without it"
+              % (rank, args.lib_allgather_timeout), file=sys.stderr, flush=True)
+        print_line()
+        os._exit(0 if ok else 1)     # (the main thread sits in a collective that will not return: no clean way out)
+
+    dog = threading.Timer(args.lib_allgather_timeout, on_timeout)
+    dog.daemon = True
+    dog.start()
+    if os.environ.get("PHE_BENCH_TEST_LIB_GATHER_HANG"):        # test hook (tests/test_bench_contract.py): the leg never returns
+        time.sleep(10 * args.lib_allgather_timeout + 60)
+
+    def exchange(uid):
+        box = [uid]
+        if use_dist:
+            dist.broadcast_object_list(box, src=0)
+        return box[0]
+    # A communicator that cannot be created (no librccl to dlopen, an RCCL error) must not take the headline with it:
+    # every rank learns whether ALL ranks got one (a rank that went on alone would hang the others in the collective),
+    # the line says what happened, and only a gather that RAN and differs from torch's makes the run exit non-zero.
+    comm, lib_error, uid, lib_gather = None, None, None, None
+    if rank == 0:                     # (the id first, on its own: a rank 0 that fails here must still reach the broadcast)
+        try:
+            uid = native.comm_unique_id()
+        except Exception as e:  # noqa: BLE001
+            lib_error = "%s: %s" % (type(e).__name__, e)
+    uid = exchange(uid)
+    if uid is not None:
+        try:
+            comm = library_communicator(ctx4, rank, world, lambda _ignored: uid)
+        except Exception as e:  # noqa: BLE001
+            lib_error = "%s: %s" % (type(e).__name__, e)
+    if comm is None:
+        print("bench.py rank %d: the library's RCCL communicator could not be created: %s" % (rank, lib_error or "no id from rank 0"),
+              file=sys.stderr, flush=True)
+    if max_over_ranks([0.0 if comm is not None else 1.0])[0] != 0.0:
+        if comm is not None:
+            comm.close()
+        comm = None
+        lib_gather = {"error": lib_error or "another rank could not create its communicator"}
+    if comm is not None:
+        full2 = be.empty(total, t2)
+        comm.allgather_dev(c4.data_ptr(), full2.data_ptr(), rows, t2, be.stream)      # first call: connection set-up
+        barrier()
+        t0 = time.perf_counter()
+        comm.allgather_dev(c4.data_ptr(), full2.data_ptr(), rows, t2, be.stream)
+        barrier()
+        t_lib = max_over_ranks([time.perf_counter() - t0])[0]
+        lib_gather = {"seconds": t_lib, "GBps_per_gpu": total * t2 * 4 / t_lib / 1e9,
+                      "same_bits_as_torch_all_gather": be.equal(full2, full)}
+        if args.inject_fault == "lib_allgather":               # test hook: a library gather that differs must fail the run
+            lib_gather["same_bits_as_torch_all_gather"] = False
+        if not lib_gather["same_bits_as_torch_all_gather"]:
+            # say WHERE: the first row on which the library's gather and torch's differ (the run exits non-zero)
+            diff = (be.as_tensor(full2) != be.as_tensor(full)).any(dim=1).nonzero()
+            first = int(diff[0]) if len(diff) else -1
+            lib_gather["first_differing_row"] = first
+            lib_gather["first_differing_row_owner_rank"] = next((k for k in range(world) if shard_bounds(total, world, k)[0] <= first < shard_bounds(total, world, k)[1]), None)
+            print("bench.py rank %d: library RCCL all-gather differs from torch's at row %d of %d (%d rows differ)"
+                  % (rank, first, total, len(diff)), file=sys.stderr, flush=True)
+        same = max_over_ranks([0.0 if lib_gather["same_bits_as_torch_all_gather"] else 1.0])[0] == 0.0   # every rank holds both vectors
+        if rank == 0 and out is not None and out.get("config4"):
+            out["config4"]["bit_exact_boundaries_and_sample_vs_gmp_oracle"] = bool(out["config4"]["bit_exact_boundaries_and_sample_vs_gmp_oracle"] and same)
+        ok = ok and same
+        comm.close()
+        del full2
+    dog.cancel()
+    record(lib_gather)
+    return ok
 
 
 if __name__ == "__main__":

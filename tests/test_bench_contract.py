@@ -180,6 +180,26 @@ def test_a_wrong_row_in_an_ops_result_or_in_the_gathered_vector_fails_the_run():
     assert out["config4"]["rows_checked"] == 9
 
 
+def test_a_library_allgather_that_hangs_does_not_cost_the_line():
+    """The library's own RCCL gather (default for N > 1) is the one leg no box with more than one GPU has run: it runs last,
+    under a watchdog.  With the leg made to hang (test hook) both ranks must still end with exit code 0 and rank 0 must print the
+    whole line, `config4.all_gather_by_library_rccl.error` saying what happened."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", PHE_BENCH_TEST_LIB_GATHER_HANG="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--lib-allgather-timeout", "3"] + SELFTEST, env=env,
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    import json
+    out = json.loads(lines[0])
+    _check_two_rank_line(out)
+    assert "no answer within 3 s" in out["config4"]["all_gather_by_library_rccl"]["error"]
+    assert "did not finish" in res.stderr
+
+
 def test_sample_sizes_of_the_default_line():
     """what a default run checks against libgmp: 4,096 strided rows of the headline batch, of every ops result and of the
     configs[3] job (plus its shard boundaries)"""
