@@ -52,6 +52,31 @@ def gather_ciphertexts(local_limbs, total_rows, group=None):
     return all_gather_rows(t, total_rows, group).numpy().view(np.uint32)
 
 
+def sum_over_ranks(local_sum, group=None, public_key=None):
+    """The homomorphic sum of a sharded vector: every rank hands in the EncryptedNumber its own shard adds up to
+    (`EncryptedVector.sum()`; None for an empty shard, then with `public_key`) and gets back the sum over all ranks — the same EncryptedNumber,
+    bit for bit, on every rank.  RCCL has no reduction by modular multiplication: the G partial
+    ciphertexts (G x ct_limbs words, a few KB) are all-gathered and combined locally, in rank order.  The result equals
+    the reference's `sum(list_of_encrypted_numbers)` over the whole vector (phe/paillier.py:705-719 and :570-601 for the
+    exponent alignment): canonical residues of the same product, whatever the order of the factors."""
+    import torch.distributed as dist
+    from .ciphertext import EncryptedNumber, EncryptedVector
+    world = dist.get_world_size(group)
+    mine = None if local_sum is None else (int(local_sum.ciphertext(be_secure=False)), int(local_sum.exponent))
+    parts = [None] * world
+    dist.all_gather_object(parts, mine, group=group)
+    parts = [p for p in parts if p is not None]
+    if not parts:
+        raise ValueError("empty vector")
+    pk = local_sum.public_key if local_sum is not None else public_key
+    if pk is None:
+        raise ValueError("a rank without a partial sum must be given the public key")
+    if len(parts) == 1:
+        return EncryptedNumber(pk, parts[0][0], parts[0][1])
+    vec = EncryptedVector.from_ciphertexts(pk, [c for c, _ in parts], [e for _, e in parts])
+    return vec.sum()
+
+
 def library_communicator(ctx, rank, world_size, exchange):
     """An RCCL communicator owned by the native library (include/phe_hip.h phe_hip_comm_create) for hosts that have no
     process group of their own.  `exchange(id_bytes_or_None) -> id_bytes` is the host's channel for the 128-byte id:
