@@ -218,6 +218,248 @@ PHE_DEV void tile_request_row(TileRaw<L, W>& raw, const uint32_t* p, int w0, int
     }
 }
 
+// 32-bit words [wpw wv, wpw (wv + 1)) of every element's row from the digits [digit][element] in the tile buffer, four at a time
+template <int L, int W>
+PHE_DEV void tile_store_words(const TableMulArgs& A, const uint32_t* tile, uint32_t wv, uint32_t e, uint64_t item, bool live) {
+    using T = TileShape<L, W>;
+    constexpr int S = T::S;
+    constexpr int kMaxWpw = (((kRadixBits * S + 31) / 32 + W - 1) / W + 3) & ~3;  // (S digits never make more words than this per wave)
+    const int wpw = ((A.limbs + W - 1) / W + 3) & ~3;
+    uint32_t* out = A.out + item * A.out_stride;
+#pragma unroll
+    for (int gq = 0; gq < kMaxWpw / 4; ++gq) {
+        const int j = (int)wv * wpw + 4 * gq;  // (wave-uniform) first word of the group
+        if (4 * gq < wpw && j < A.limbs) {
+            const int bit = 32 * j, q = bit / kRadixBits, o = bit - q * kRadixBits;
+            uint32_t dg[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dg[i] = (q + i < S) ? tile[(size_t)(q + i) * kTile + e] : 0u;
+            // the 174 bits of six digits as 32-bit words at compile-time positions, then one shift by the uniform offset o < 29
+            const uint32_t z0 = dg[0] | (dg[1] << 29), z1 = (dg[1] >> 3) | (dg[2] << 26), z2 = (dg[2] >> 6) | (dg[3] << 23),
+                           z3 = (dg[3] >> 9) | (dg[4] << 20), z4 = (dg[4] >> 12) | (dg[5] << 17);
+            Words4 w4;
+            w4.x = (uint32_t)((((uint64_t)z1 << 32) | z0) >> o);
+            w4.y = (uint32_t)((((uint64_t)z2 << 32) | z1) >> o);
+            w4.z = (uint32_t)((((uint64_t)z3 << 32) | z2) >> o);
+            w4.w = (uint32_t)((((uint64_t)z4 << 32) | z3) >> o);
+            if (live) *reinterpret_cast<Words4*>(out + j) = w4;
+        }
+    }
+}
+
+// ---- the settle in the fold's own layout: lane = element, wave = column block (round 6) --------------------------------------
+// The settle above the fold (16 lanes per element, four elements of a wave at a time) issues 1,191 instructions per wave and tile —
+// a quarter of the kernel's — for 64 elements a workgroup; in the fold's layout every instruction works on 64 elements.  What crosses
+// the column blocks goes through LDS in four short exchanges:
+//   1  the fold's block carries (< 2^38) and the four limbs the quotient estimate reads                                           |
+//      every wave: q^ = floor(y / N) - 1 or - 2 (the same double-precision estimate), then THREE candidates r_m = y + (q^ + m) K,
+//      m = 0, 1, 2, K = W^S - N (the conditional subtractions of the row settle as additions of the complement: no borrow, no
+//      comparison); per candidate the block's digits and its carry-out (< 2^31)
+//   2  the candidates' block carries                                                                                              |
+//      the carry of the block below enters and ripples through the block; what is left to cross a block boundary is one bit:
+//      generate / propagate flags of every block OR-ed into one word per element and candidate; the top block adds whether its
+//      carry-out is the candidate's q0 + q1 + m — exactly then y - (q^ + m) N is not negative
+//   3  the flag words                                                                                                             |
+//      every wave: the carry look-ahead over the blocks (one add and one xor per candidate), the largest valid m, its digits
+//      (the second-order carry-in ripples through the block only if some element of the tile has one), digits to LDS
+//   4  the digits, [digit][element]                                                                                               |
+//      wave w: 32-bit words [wpw w, wpw (w + 1)) of every element's row: one funnel shift by the wave-uniform bit offset, 16-byte stores
+// 3 of 5 barriers are new; ~430 instructions per wave and tile.
+#if defined(PHE_VARIANT_SETTLE_ROWS)  // measurement only: the round-4 settle on 16 lanes per element
+constexpr bool kSettleByBlocks = false;
+#else
+constexpr bool kSettleByBlocks = true;
+#endif
+
+// y: the block's digits after the fold (< 2^29), ycarry: what left the block (< 2^38).  LDS: ycar = fold_carry (2 words per block
+// and element), ccar = prod_carry (dead since the product: one word per candidate, block and element), top: 4 x 64 estimate limbs |
+// 3 x 64 flag words | 64 words of the top block's verdicts; the tile buffer takes the final digits.  after_first: called once past
+// the first barrier (the next tile's row requests).
+template <int L, int W, class F>
+PHE_DEV void tile_settle_blocks(const TableMulArgs& A, uint32_t* tile, uint32_t* ccar, uint32_t* top, uint32_t* ycar, const uint32_t* cst,
+                                uint32_t wv, uint32_t e, uint32_t (&y)[TileShape<L, W>::CW], uint64_t ycarry, uint64_t item, bool live,
+                                F&& after_first) {
+    using T = TileShape<L, W>;
+    constexpr int S = T::S, CW = T::CW;
+    static_assert(W <= 16 && CW >= 5, "flag words: 16 generate + 16 propagate bits; at most one block boundary among four estimate limbs");
+    uint32_t* const est = top;                 // [4][64]
+    uint32_t* const flags = top + 4 * kTile;   // [3][64]
+    uint32_t* const verdict = top + 7 * kTile; // [3][64]
+    const int c0 = (int)wv * CW;
+    // ---- 1: block carries of y, estimate limbs ---------------------------------------------------------------------------------
+    ycar[(wv * kTile + e) * 2u] = (uint32_t)ycarry;
+    ycar[(wv * kTile + e) * 2u + 1u] = (uint32_t)(ycarry >> 32);
+    {
+        const int j0 = A.base - c0;  // (wave-uniform) this block's digit k is estimate limb k - j0
+#pragma unroll
+        for (int k = 0; k < CW; ++k)
+            if ((unsigned)(k - j0) < 4u) est[(k - j0) * kTile + (int)e] = y[k];
+    }
+    if (wv == 0u) {
+        flags[e] = 0u;
+        flags[kTile + e] = 0u;
+        flags[2 * kTile + e] = 0u;
+    }
+    wave::block_barrier();
+    after_first();
+    // the carry of the block below enters the two lowest digits (digit 1 stays below 2^29 + 2^10: it is only added from here on)
+    if (wv != 0u) {
+        const uint64_t c = ((uint64_t)ycar[((wv - 1u) * kTile + e) * 2u + 1u] << 32) | ycar[((wv - 1u) * kTile + e) * 2u];
+        const uint32_t d0 = y[0] + ((uint32_t)c & kLimbMask);
+        y[0] = d0 & kLimbMask;
+        y[1] += (uint32_t)(c >> kRadixBits) + (d0 >> kRadixBits);
+    }
+    // ---- the quotient estimate: four limbs of y as they left their blocks, plus the one block carry that enters among them ---------
+    uint32_t q0, q1;
+    bool fast;
+    {
+        double yd = ((double)est[3 * kTile + (int)e] * 536870912.0 + (double)est[2 * kTile + (int)e]) * 288230376151711744.0 +
+                    ((double)est[kTile + (int)e] * 536870912.0 + (double)est[e]);
+        const int wb = (A.base + CW - 1) / CW, off = wb * CW - A.base;  // first block that starts at or above limb `base`
+        if (wb >= 1 && wb < W && off <= 3) {                            // (wave-uniform) its carry-in has the weight W^off
+            const uint64_t c = ((uint64_t)ycar[((uint32_t)(wb - 1) * kTile + e) * 2u + 1u] << 32) | ycar[((uint32_t)(wb - 1) * kTile + e) * 2u];
+            const double w = off == 0 ? 1.0 : (off == 1 ? 536870912.0 : (off == 2 ? 288230376151711744.0 : 154742504910672534362390528.0));
+            yd += (double)c * w;
+        }
+        const double qe = yd * A.inv, qd = __builtin_floor(qe), frac = qe - qd;
+        // The estimate is within 2^-13 of y / N (y / N < 2^38; the limbs below `base` weigh < 2^-70 of a unit; W^base / N, the sum of the
+        // four limbs and the product are rounded to 53 bits: 3 x 2^-15).  Where its fraction keeps 2^-11 away from 0 and 1 the floor IS
+        // floor(y / N): ONE candidate, r = y - floor N, already below N.  Every wave sees the same limbs of all 64 elements, so the
+        // workgroup agrees without asking; a tile with an element too close to call (1 in 2^10) takes the three candidates.
+        fast = wave::ballot(!(qd >= 1.0 && frac > 0.00048828125 && frac < 0.99951171875)) == 0;
+        const uint64_t q = fast ? (uint64_t)qd : (qd >= 1.0 ? (uint64_t)qd - 1u : 0u);  // (the estimate may be one too high: never let r go negative)
+        q0 = (uint32_t)q & kLimbMask;
+        q1 = (uint32_t)(q >> kRadixBits);
+    }
+    if (fast) {
+        // ---- one candidate r = y + q K (mod W^S): three exchanges instead of four ---------------------------------------------------
+        uint32_t f[CW];
+        {
+            uint64_t carry = 0;
+#pragma unroll
+            for (int k = 0; k < CW; ++k) {
+                const uint64_t v = wave::mad64(q1, cst[2 * S + c0 + k], wave::mad64(q0, cst[S + c0 + k], (uint64_t)y[k])) + carry;
+                f[k] = (uint32_t)v & kLimbMask;
+                carry = v >> kRadixBits;
+            }
+            ccar[wv * kTile + e] = (uint32_t)carry;  // < 2^31
+        }
+        wave::block_barrier();
+        {
+            uint32_t c = wv != 0u ? ccar[(wv - 1u) * kTile + e] : 0u;
+            uint32_t ones = kLimbMask;
+#pragma unroll
+            for (int k = 0; k < CW; ++k) {
+                const uint32_t v = f[k] + c;
+                f[k] = v & kLimbMask;
+                c = v >> kRadixBits;
+                ones &= f[k];
+            }
+            if (wv != (uint32_t)W - 1u) {  // (what leaves the top block is the multiple of W^S dropped: q0 + q1)
+                const uint32_t word = (c << wv) | ((ones == kLimbMask ? 1u : 0u) << (16u + wv));
+                if (wave::ballot(word != 0u) != 0) wave::lds_or(flags + (int)e, word);
+            } else {
+                PHE_BOUNDS(ccar[wv * kTile + e] + c == q0 + q1 || (ones == kLimbMask && ccar[wv * kTile + e] + c + 1u == q0 + q1));
+            }
+        }
+        uint32_t* rows = tile + (size_t)c0 * kTile + e;
+#pragma unroll
+        for (int k = 0; k < CW; ++k) rows[k * kTile] = f[k];
+        wave::block_barrier();
+        {
+            const uint32_t w = flags[e];
+            if (wave::ballot(w != 0u) != 0) {  // (rare, and the same in every wave: some block carried out once more, or is all ones)
+                const uint32_t gen = w & 0xffffu, prop = w >> 16;
+                uint32_t c = ((((gen << 1) + prop) ^ prop) >> wv) & 1u;
+#pragma unroll
+                for (int k = 0; k < CW; ++k) {
+                    const uint32_t v = f[k] + c;
+                    f[k] = v & kLimbMask;
+                    c = v >> kRadixBits;
+                    rows[k * kTile] = f[k];
+                }
+                wave::block_barrier();
+            }
+        }
+        tile_store_words<L, W>(A, tile, wv, e, item, live);
+        return;
+    }
+    // ---- three candidates r_m = y + (q^ + m) K  (mod W^S), K = W^S - N, m = 2, 1, 0: one after the other (a tile in sixteen comes here:
+    // registers and code count, barriers do not); every element keeps the digits of the first one that is valid ------------------------
+    uint32_t f[CW];
+#pragma unroll
+    for (int k = 0; k < CW; ++k) f[k] = 0u;
+    uint32_t found = 0u;  // all ones once a candidate was valid
+#pragma unroll 1
+    for (int m = 2; m >= 0; --m) {
+        uint32_t d[CW];
+        uint32_t cout;
+        {
+            const uint32_t q0m = q0 + (uint32_t)m;  // (q^ + m) K = (q0 + m) K + q1 (K W): still a 32-bit multiplier
+            uint64_t carry = 0;
+#pragma unroll
+            for (int k = 0; k < CW; ++k) {
+                const uint64_t v = wave::mad64(q1, cst[2 * S + c0 + k], wave::mad64(q0m, cst[S + c0 + k], (uint64_t)y[k])) + carry;
+                d[k] = (uint32_t)v & kLimbMask;
+                carry = v >> kRadixBits;
+            }
+            cout = (uint32_t)carry;  // < 2^31
+            ccar[((uint32_t)m * W + wv) * kTile + e] = cout;
+        }
+        wave::block_barrier();
+        {   // the carry of the block below ripples through the block; one bit is left to cross a boundary
+            uint32_t c = wv != 0u ? ccar[((uint32_t)m * W + wv - 1u) * kTile + e] : 0u;
+            uint32_t ones = kLimbMask;
+#pragma unroll
+            for (int k = 0; k < CW; ++k) {
+                const uint32_t v = d[k] + c;  // < 2^29 + 2^31
+                d[k] = v & kLimbMask;
+                c = v >> kRadixBits;
+                ones &= d[k];
+            }
+            if (wv != (uint32_t)W - 1u) {
+                const uint32_t word = (c << wv) | ((ones == kLimbMask ? 1u : 0u) << (16u + wv));  // (disjoint: a block that carried out is small)
+                if (wave::ballot(word != 0u) != 0) wave::lds_or(flags + m * kTile + (int)e, word);
+            } else {
+                // what leaves the top block when y - (q^ + m) N is not negative: K W loses its top digit W - 1 in ncomp1, so
+                // (q^ + m) W^S - q1 (W - 1) W^S = (q0 + q1 + m) W^S
+                const uint32_t expect = q0 + q1 + (uint32_t)m, ctop = cout + c;
+                // bit 0: valid if no carry enters the top block; bit 1: if one does (it leaves again only through digits all ones)
+                verdict[m * kTile + (int)e] = (ctop == expect ? 1u : 0u) | ((ctop + (ones == kLimbMask ? 1u : 0u) == expect ? 1u : 0u) << 1);
+            }
+        }
+        wave::block_barrier();
+        {   // look-ahead over the blocks; the candidate's digits if it is the first valid one
+            const uint32_t w = flags[m * kTile + (int)e];
+            const uint32_t gen = w & 0xffffu, prop = w >> 16;
+            const uint32_t into = (((gen << 1) + prop) ^ prop);  // bit b: a carry enters block b
+            const uint32_t valid = 0u - ((verdict[m * kTile + (int)e] >> ((into >> (W - 1)) & 1u)) & 1u);
+            uint32_t c = (into >> wv) & 1u;
+            if (wave::ballot(c != 0u) != 0) {  // (rare: a block of all ones above a block that carried out)
+#pragma unroll
+                for (int k = 0; k < CW; ++k) {
+                    const uint32_t v = d[k] + c;
+                    d[k] = v & kLimbMask;
+                    c = v >> kRadixBits;
+                }
+            }
+            const uint32_t take = valid & ~found;
+#pragma unroll
+            for (int k = 0; k < CW; ++k) f[k] = (d[k] & take) | (f[k] & ~take);
+            found |= valid;
+        }
+    }
+    PHE_BOUNDS(found == 0xffffffffu);  // (m = 0 is valid whenever the estimate's error bound holds)
+    {
+        uint32_t* rows = tile + (size_t)c0 * kTile + e;
+#pragma unroll
+        for (int k = 0; k < CW; ++k) rows[k * kTile] = f[k];
+    }
+    wave::block_barrier();
+    // ---- 4: 32-bit words [wpw wv, wpw (wv + 1)) of every element's row ------------------------------------------------------------------
+    tile_store_words<L, W>(A, tile, wv, e, item, live);
+}
+
 // A.table: the fold table in the COLUMN-BLOCK layout [wave w][digit i][C words]: limbs [C w, C (w + 1)) of W^(P+i) mod N,
 // A.digits_padded + kFoldPadRows rows per wave (key_setup.h:build_table_mul writes both layouts).
 // tile: TileShape::kRows * 64 words; prod_carry: 2 * 2W * 64; top: 64 * kTableRowSlack; fold_carry: 2 * W * 64; cst: n | ncomp |
@@ -349,6 +591,8 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
         wave::block_barrier();
         PHE_TILE_MARK(3);  // carries in, T written, barrier
         // ---- fold: this wave's C columns of y = T_low + sum_i T[P + i] * C_i ------------------------------------------------------
+        uint32_t y_blk[CW];
+        uint64_t y_carry;
         {
             const int c0 = (int)wv * CW;
             uint64_t acc[CW];
@@ -399,16 +643,31 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
             }
             wave::arrived<CW, GD>(ca, da);  // (the look-ahead past the last digit: nothing may still be travelling to an SGPR)
             PHE_TILE_MARK(4);  // fold
-            uint32_t y[CW];
-            const uint64_t carry = tile_block_carries<CW>(y, acc, upper);
+            y_carry = tile_block_carries<CW>(y_blk, acc, upper);
+            if constexpr (!kSettleByBlocks) {
 #pragma unroll
-            for (int k = 0; k < CW; ++k) {
-                const int c = c0 + k;
-                if (c < P) tile[(size_t)e * P + c] = y[k];
-                else top[e * kTableRowSlack + (c - P)] = y[k];
+                for (int k = 0; k < CW; ++k) {
+                    const int c = c0 + k;
+                    if (c < P) tile[(size_t)e * P + c] = y_blk[k];
+                    else top[e * kTableRowSlack + (c - P)] = y_blk[k];
+                }
+                fold_carry[(wv * kTile + e) * 2u] = (uint32_t)y_carry;
+                fold_carry[(wv * kTile + e) * 2u + 1u] = (uint32_t)(y_carry >> 32);
             }
-            fold_carry[(wv * kTile + e) * 2u] = (uint32_t)carry;
-            fold_carry[(wv * kTile + e) * 2u + 1u] = (uint32_t)(carry >> 32);
+        }
+        if constexpr (kSettleByBlocks) {
+            // ---- settle: lane = element, wave = column block (tile_settle_blocks) ---------------------------------------------------
+            const uint64_t raw_item = tile_i * kTile + e;
+            const bool live = raw_item < A.batch;
+            tile_settle_blocks<L, W>(A, tile, prod_carry, top, fold_carry, cst, wv, e, y_blk, y_carry, live ? raw_item : A.batch - 1, live,
+                                     [&]() __attribute__((always_inline)) {
+                                         PHE_TILE_MARK(5);
+                                         request_rows(tile_i + n_blocks < n_tiles ? tile_i + n_blocks : tile_i);  // (see below)
+                                     });
+            PHE_TILE_MARK(6);
+            wave::block_barrier();  // the digits are read: the next tile's may take the buffer
+            PHE_TILE_MARK(7);
+            continue;
         }
         wave::block_barrier();
         PHE_TILE_MARK(5);  // carries, columns to LDS, barrier

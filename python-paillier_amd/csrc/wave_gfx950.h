@@ -136,6 +136,11 @@ PHE_DEV void block_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// OR into a word of LDS that other waves of the workgroup OR into as well (ds_or_b32; ordered by the next block_barrier)
+PHE_DEV void lds_or(uint32_t* p, uint32_t v) {
+    __hip_atomic_fetch_or((__attribute__((address_space(3))) uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // Asynchronous 16-byte copy global -> LDS without a register round trip (global_load_lds_dwordx4, "LDS-DMA"): lane l
 // of the wave lands at lds_wave_base + 16*l bytes — the destination is wave-uniform base + lane*16, the SOURCE is per
 // lane.  Lanes for which `active` is false copy nothing.  The data may be read after wait_async_copies().

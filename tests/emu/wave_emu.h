@@ -296,6 +296,7 @@ template <class T>
 inline T* reread_vptr(T* p) { return p; }
 inline uint32_t reread(uint32_t x) { return x; }  // see wave_gfx950.h: an optimisation barrier on the device, nothing here
 inline uint64_t reread64(uint64_t x) { return x; }
+inline void lds_or(uint32_t* p, uint32_t v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }  // (the waves of a workgroup are host threads)
 typedef uint32_t lds_u32;  // wave_gfx950.h: an LDS-address-space pointer on the device
 inline lds_u32* as_lds(uint32_t* p) { return p; }
 inline lds_u32* reread_lds(uint32_t* p) { return p; }

@@ -497,13 +497,18 @@ def test_product_by_tiles_on_eight_waves_for_1024_bit_keys(emu):
     assert emu.L.emu_table_mul_offered(Nl.ctypes.data_as(ctypes.c_void_p), s2) == 6   # what the library takes: tiles, on 8 waves
     emu.L.emu_mad_count.restype = ctypes.c_uint64
     emu.L.emu_mad_count(1)
-    emu.mulmod_table(Nl, a[:64], b[:64], tiles=True, blocks=1, waves=8)
+    # rows 64 .. 127 are residues below N, nothing special: the tile takes the settle's single candidate (mul_tile.h
+    # tile_settle_blocks: the quotient estimate of every element keeps away from an integer) — the count of record
+    emu.mulmod_table(Nl, a[64:128], b[64:128], tiles=True, blocks=1, waves=8)
     eight = int(emu.L.emu_mad_count(1)) // 64
-    emu.mulmod_table(Nl, a[:64], b[:64], tiles=True, blocks=1)
+    emu.mulmod_table(Nl, a[64:128], b[64:128], tiles=True, blocks=1)
     sixteen = int(emu.L.emu_mad_count(1)) // 64
-    emu.mulmod(Nl, a[:64], b[:64])
+    emu.mulmod(Nl, a[64:128], b[64:128])
     two_products = int(emu.L.emu_mad_count(1)) // 64
     assert eight == 11160 and eight * 1.12 < sixteen and eight * 1.8 < two_products, (eight, sixteen, two_products)
+    # the first tile holds the edge operands (products below N: the estimate says 0): three candidates, 2 x 72 more multiply-adds each
+    emu.mulmod_table(Nl, a[:64], b[:64], tiles=True, blocks=1, waves=8)
+    assert int(emu.L.emu_mad_count(1)) // 64 == 11160 + 2 * 2 * 72
     # other widths of the shape: random moduli of 2048 and 2040 bits (rows of 64 words), one of 1700 bits (rows of 56 words)
     for bits in (2048, 2040, 1700):
         M = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
