@@ -137,6 +137,21 @@ PHE_DEV uint64_t tile_block_carries(uint32_t (&digit)[CW], const uint64_t (&acc)
     return carry;
 }
 
+// blocks of CW products a column accumulator takes between two hand-overs: after one it is below 2^B (B = 32 or 36), K blocks and the
+// closing block of a column's low half add (K + 1) CW products of < 2^58 (1 + 2^-20): below 2^64 while (K + 1) CW <= 63
+template <int CW>
+constexpr int tile_hand_over_blocks() { return (63 - CW) / CW; }
+// A wave lowers its issue priority as it gets through its W + 1 blocks of the product (set_priority).  `done` counts them: the level
+// 3 - 4 done / (W + 1) changes at three values of `done` — three compares on the scalar unit instead of a division and a ladder of
+// branches per block (the scalar unit of a CU serves sixteen waves: round 6 found the fold waiting for it, see the fold below)
+template <int W>
+PHE_DEV void tile_priority_after(uint32_t done) {
+    constexpr uint32_t b1 = (W + 1 + 3) / 4, b2 = (2 * (W + 1) + 3) / 4, b3 = (3 * (W + 1) + 3) / 4;
+    if (done == b1) wave::set_priority(2);
+    else if (done == b2) wave::set_priority(1);
+    else if (done == b3) wave::set_priority(0);
+}
+
 // CW steps of a column block of the product.  Before: win[j] = b[q0 + j] (q0 = the block's lowest column minus the step
 // index i; digits outside b read as zero), a_col = &A[i][e], b_col = &B[q0 - 1][e].  After: the same for i + CW (q0 - CW).
 // Step u multiplies a[i + u] into every column: column c takes b[q0 + c - u], which is win[(c - u) mod CW] once the digits
@@ -148,7 +163,7 @@ PHE_DEV void tile_product_steps(uint64_t (&acc)[CW], uint32_t (&win)[CW], const 
     // compiler puts each one in front of its first use, with the wait for it).  Wide blocks take the digits in two halves: 2 CW
     // registers for them are what spills at CW = 14.
     constexpr int kParts = CW > 10 ? 2 : 1, kPer = (CW + kParts - 1) / kParts;
-    const uint32_t* b_low = b_col - (CW - 1) * kTile;
+    const wave::lds_u32* b_low = wave::reread_lds(b_col - (CW - 1) * kTile);  // (one address, CW immediates: left alone the compiler re-bases every read)
 #pragma unroll
     for (int part = 0; part < kParts; ++part) {
         uint32_t ad[kPer], bd[kPer];
@@ -526,15 +541,19 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
             {
                 const uint32_t* a_col = buf_a + e;
                 const uint32_t* b_col = buf_b + ((int)wv * CW - 1) * kTile + e;
+                int since = 0;
 #pragma unroll 1
                 for (uint32_t t = 0; t < wv; ++t) {
-                    wave::set_priority(3 - (int)(4u * t / (kTileWaves + 1u)));  // (blocks done of kTileWaves + 1: see set_priority)
+                    tile_priority_after<W>(t);  // (blocks done of W + 1)
                     tile_product_steps<CW, true>(acc, win, a_col, b_col);
                     a_col += CW * kTile;
                     b_col -= CW * kTile;
-                    if (t & 1u) tile_hand_over<CW>(acc, upper);  // (2 CW products of < 2^58.01 between two hand-overs)
+                    if (++since == tile_hand_over_blocks<CW>()) {
+                        tile_hand_over<CW>(acc, upper);
+                        since = 0;
+                    }
                 }
-                wave::set_priority(3 - (int)(4u * wv / (kTileWaves + 1u)));
+                tile_priority_after<W>(wv);
                 tile_product_steps<CW, false>(acc, win, a_col, b_col);
             }
             out_low = tile_block_carries<CW>(t_low, acc, upper);
@@ -550,13 +569,17 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
                 const int i0 = CW * (int)wv + 1;  // (the last of the CW (W - wv) steps reads a[S]: the zero row)
                 const uint32_t* a_col = buf_a + i0 * kTile + e;
                 const uint32_t* b_col = buf_b + (S - 2) * kTile + e;
+                int since = 0;
 #pragma unroll 1
                 for (uint32_t t = 0; t < (uint32_t)kTileWaves - wv; ++t) {
-                    wave::set_priority(3 - (int)(4u * (wv + 1u + t) / (kTileWaves + 1u)));
+                    tile_priority_after<W>(wv + 1u + t);
                     tile_product_steps<CW, true>(acc, win, a_col, b_col);
                     a_col += CW * kTile;
                     b_col -= CW * kTile;
-                    if (t & 1u) tile_hand_over<CW>(acc, upper);
+                    if (++since == tile_hand_over_blocks<CW>()) {
+                        tile_hand_over<CW>(acc, upper);
+                        since = 0;
+                    }
                 }
             }
             out_high = tile_block_carries<CW>(t_high, acc, upper);
@@ -611,35 +634,55 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
             constexpr int GD = T::kFoldGroup, GP = GD / 2;
             wave::ScalarRow<CW> ca[GD], cb[GD];
             wave::DigitPair da[GP], db[GP];
-            auto request = [&](wave::ScalarRow<CW> (&c)[GD], wave::DigitPair (&d)[GP], const uint32_t* t, const uint32_t* dg) __attribute__((always_inline)) {
-#pragma unroll
-                for (int u = 0; u < GD; ++u) c[u].request(t + u * CW);
-                d[0].template request<0>(dg);
-                if constexpr (GP > 1) d[1].template request<2>(dg);
+            // the rows of request group G (0: the group at t / dg, 1 and 2: the next two) of the iteration whose first table row is t and
+            // whose first digit row is dg: every offset an immediate of its load (round 6: sixteen waves share the CU's scalar unit, and a
+            // pointer add per table row, a division for the priority and the ladder of branches behind it were ~100 scalar instructions
+            // per 72 multiply-adds — the fold waited for the scalar unit, not for its multiply-adds)
+            auto request = [&](auto group, wave::ScalarRow<CW> (&c)[GD], wave::DigitPair (&d)[GP], const uint32_t* t, const uint32_t* dg) __attribute__((always_inline)) {
+                constexpr int G = decltype(group)::value;
+                c[0].template request_at<(G * GD + 0) * CW>(t);
+                c[1].template request_at<(G * GD + 1) * CW>(t);
+                if constexpr (GD > 2) {
+                    c[2].template request_at<(G * GD + 2) * CW>(t);
+                    c[3].template request_at<(G * GD + 3) * CW>(t);
+                }
+                d[0].template request<G * GD>(dg);
+                if constexpr (GP > 1) d[1].template request<G * GD + 2>(dg);
             };
+            static_assert(GD == 2 || GD == 4, "request groups of two or four fold digits");
             auto multiply = [&](const wave::ScalarRow<CW> (&c)[GD], const wave::DigitPair (&d)[GP]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int u = 0; u < GD; ++u)
 #pragma unroll
                     for (int k = 0; k < CW; ++k) acc[k] = wave::mad64(d[u / 2].word(u % 2), c[u].word(k), acc[k]);
             };
-            request(ca, da, tw, digits);
+            using G0 = std::integral_constant<int, 0>;
+            using G1 = std::integral_constant<int, 1>;
+            using G2 = std::integral_constant<int, 2>;
+            const uint32_t* t4 = tw;
+            const uint32_t* d4 = digits;
+            request(G0(), ca, da, t4, d4);
+            const int n_it = (D + 2 * GD - 1) / (2 * GD), quarter = (n_it + 3) / 4;  // (D is a multiple of 8: whole iterations)
+            int next_level = quarter, level = 3, since = 0;
 #pragma unroll 1
-            for (int i0 = 0; i0 < D; i0 += kFoldChunk) {
-                const int n = (D - i0 < kFoldChunk) ? D - i0 : kFoldChunk;
-#pragma unroll 1
-                for (int i = 0; i < n; i += 2 * GD) {
-                    wave::set_priority(3 - 4 * (i0 + i) / D);
-                    const uint32_t* t4 = tw + (size_t)(i0 + i) * CW;
-                    const uint32_t* d4 = digits + (size_t)(i0 + i) * kTile;
-                    wave::arrived<CW, GD>(ca, da);
-                    request(cb, db, t4 + GD * CW, d4 + GD * kTile);
-                    multiply(ca, da);
-                    wave::arrived<CW, GD>(cb, db);
-                    request(ca, da, t4 + 2 * GD * CW, d4 + 2 * GD * kTile);
-                    multiply(cb, db);
+            for (int it = 0; it < n_it; ++it) {
+                if (it == next_level) {  // (three times a tile)
+                    level -= 1;
+                    wave::set_priority(level);
+                    next_level += quarter;
                 }
-                tile_hand_over<CW>(acc, upper);
+                wave::arrived<CW, GD>(ca, da);
+                request(G1(), cb, db, t4, d4);
+                multiply(ca, da);
+                wave::arrived<CW, GD>(cb, db);
+                request(G2(), ca, da, t4, d4);
+                multiply(cb, db);
+                t4 += 2 * GD * CW;
+                d4 += 2 * GD * kTile;
+                if (++since == kFoldChunk / (2 * GD)) {  // (kFoldChunk products of < 2^58.01 between two hand-overs)
+                    tile_hand_over<CW>(acc, upper);
+                    since = 0;
+                }
             }
             wave::arrived<CW, GD>(ca, da);  // (the look-ahead past the last digit: nothing may still be travelling to an SGPR)
             PHE_TILE_MARK(4);  // fold

@@ -268,6 +268,10 @@ struct ScalarRow<18> {
     PHE_DEV void request(const uint32_t* p) {
         asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x40" : "=&s"(lo), "=&s"(hi) : "s"(p) : "memory");
     }
+    template <int OFFW>  // the row OFFW words past p: an immediate of the load, no pointer arithmetic on the scalar unit
+    PHE_DEV void request_at(const uint32_t* p) {
+        asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4" : "=&s"(lo), "=&s"(hi) : "s"(p), "n"(4 * OFFW), "n"(4 * OFFW + 0x40) : "memory");
+    }
     PHE_DEV uint32_t word(int k) const { return k < 16 ? lo[k] : hi[k - 16]; }
     PHE_DEV void landed() { asm volatile("" : "+s"(lo), "+s"(hi)); }
 };
@@ -277,6 +281,10 @@ struct ScalarRow<10> {
     u32x2 hi;
     PHE_DEV void request(const uint32_t* p) {
         asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx2 %1, %2, 0x20" : "=&s"(lo), "=&s"(hi) : "s"(p) : "memory");
+    }
+    template <int OFFW>
+    PHE_DEV void request_at(const uint32_t* p) {
+        asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dwordx2 %1, %2, %4" : "=&s"(lo), "=&s"(hi) : "s"(p), "n"(4 * OFFW), "n"(4 * OFFW + 0x20) : "memory");
     }
     PHE_DEV uint32_t word(int k) const { return k < 8 ? lo[k] : hi[k - 8]; }
     PHE_DEV void landed() { asm volatile("" : "+s"(lo), "+s"(hi)); }
@@ -292,6 +300,13 @@ struct ScalarRow<14> {
                      : "s"(p)
                      : "memory");
     }
+    template <int OFFW>
+    PHE_DEV void request_at(const uint32_t* p) {
+        asm volatile("s_load_dwordx8 %0, %3, %4\n\ts_load_dwordx4 %1, %3, %5\n\ts_load_dwordx2 %2, %3, %6"
+                     : "=&s"(lo), "=&s"(mid), "=&s"(hi)
+                     : "s"(p), "n"(4 * OFFW), "n"(4 * OFFW + 0x20), "n"(4 * OFFW + 0x30)
+                     : "memory");
+    }
     PHE_DEV uint32_t word(int k) const { return k < 8 ? lo[k] : (k < 12 ? mid[k - 8] : hi[k - 12]); }
     PHE_DEV void landed() { asm volatile("" : "+s"(lo), "+s"(mid), "+s"(hi)); }
 };
@@ -302,6 +317,10 @@ struct ScalarRow<9> {
     PHE_DEV void request(const uint32_t* p) {
         asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x20" : "=&s"(lo), "=&s"(hi) : "s"(p) : "memory");
     }
+    template <int OFFW>
+    PHE_DEV void request_at(const uint32_t* p) {
+        asm volatile("s_load_dwordx8 %0, %2, %3\n\ts_load_dword %1, %2, %4" : "=&s"(lo), "=&s"(hi) : "s"(p), "n"(4 * OFFW), "n"(4 * OFFW + 0x20) : "memory");
+    }
     PHE_DEV uint32_t word(int k) const { return k < 8 ? lo[k] : hi; }
     PHE_DEV void landed() { asm volatile("" : "+s"(lo), "+s"(hi)); }
 };
@@ -311,6 +330,10 @@ struct ScalarRow<5> {
     uint32_t hi;
     PHE_DEV void request(const uint32_t* p) {
         asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dword %1, %2, 0x10" : "=&s"(lo), "=&s"(hi) : "s"(p) : "memory");
+    }
+    template <int OFFW>
+    PHE_DEV void request_at(const uint32_t* p) {
+        asm volatile("s_load_dwordx4 %0, %2, %3\n\ts_load_dword %1, %2, %4" : "=&s"(lo), "=&s"(hi) : "s"(p), "n"(4 * OFFW), "n"(4 * OFFW + 0x10) : "memory");
     }
     PHE_DEV uint32_t word(int k) const { return k < 4 ? lo[k] : hi; }
     PHE_DEV void landed() { asm volatile("" : "+s"(lo), "+s"(hi)); }

@@ -270,6 +270,8 @@ struct ScalarRow {
     void request(const uint32_t* p) {
         for (int k = 0; k < N; ++k) w[k] = p[k];
     }
+    template <int OFFW>
+    void request_at(const uint32_t* p) { request(p + OFFW); }
     uint32_t word(int k) const { return w[k]; }
 };
 struct DigitPair {
