@@ -27,8 +27,11 @@
 //   fold     wave w: columns [C w, +C) of y = T_low + sum_i T[P + i] * C_i (the accumulators open from the wave's own low block
 //            of the product: the same columns); carries inside the lane, y to LDS as [element][column], the block's
 //            carry-out beside it                                                                                            |
-//   settle   16 lanes per element (a wave's four elements at once): y canonical, q^ = floor(y / N) - 1 or - 2 from four limbs,
-//            r = y - q^ N < 3 N, conditional subtractions, 16-byte stores; the groups' digit rows lie inside the tile buffer  |
+//   settle   round 6: in the fold's own layout (lane = element, wave = column block: tile_settle_blocks below) — the block carries
+//            and the four limbs of the quotient estimate through LDS |, r = y - floor(y / N) N as y + q (W^S - N) by blocks, its
+//            block carries |, a carry look-ahead over the blocks' generate / propagate bits, the digits [digit][element] |, every
+//            wave the 32-bit words [wpw w, wpw (w + 1)) of all 64 rows, 16-byte stores.  (Rounds 4-5: 16 lanes per element, a wave's
+//            four elements at once — 1,191 instructions per wave and tile, a quarter of the kernel; PHE_VARIANT_SETTLE_ROWS)            |
 // Within the product and the fold a wave lowers its issue priority as it gets through its share (wave::set_priority): the waves
 // of a SIMD are served oldest first and would otherwise finish one after the other, the last one alone.
 // Same bits as mul_table.h, mul_io.h and gmpy2.mod(gmpy2.mul(a, b), c).
@@ -158,7 +161,10 @@ PHE_DEV void tile_priority_after(uint32_t done) {
 // b[q0 - 1 ... q0 - u] have replaced win[CW - 1 ... CW - u] — the window slides by renaming, not by moving.  LOADS = false:
 // the digits that would enter lie below b[0] (the last CW steps of a low block).
 template <int CW, bool LOADS>
-PHE_DEV void tile_product_steps(uint64_t (&acc)[CW], uint32_t (&win)[CW], const uint32_t* a_col, const uint32_t* b_col) {
+PHE_DEV void tile_product_steps(uint64_t (&acc)[CW], const uint32_t (&win)[CW], uint32_t (&nxt)[CW], const uint32_t* a_col, const uint32_t* b_col) {
+    // win: the window on entry; nxt: the window the NEXT block starts from — the digits this block lets in land there directly
+    // (slot CW - 1 - u at step u), and a step reads a slot from nxt once it was replaced.  The caller alternates the two arrays from block
+    // to block, so the window never moves (round 6: CW copies per block of CW^2 multiply-adds gone).
     // the digits of (half) the block first, then the multiply-adds with nothing to wait for (left to place the reads itself the
     // compiler puts each one in front of its first use, with the wait for it).  Wide blocks take the digits in two halves: 2 CW
     // registers for them are what spills at CW = 14.
@@ -166,13 +172,13 @@ PHE_DEV void tile_product_steps(uint64_t (&acc)[CW], uint32_t (&win)[CW], const 
     const wave::lds_u32* b_low = wave::reread_lds(b_col - (CW - 1) * kTile);  // (one address, CW immediates: left alone the compiler re-bases every read)
 #pragma unroll
     for (int part = 0; part < kParts; ++part) {
-        uint32_t ad[kPer], bd[kPer];
+        uint32_t ad[kPer];
 #pragma unroll
         for (int v = 0; v < kPer; ++v) {
             const int u = part * kPer + v;
             if (u < CW) {
                 ad[v] = a_col[u * kTile];
-                bd[v] = LOADS ? b_low[(CW - 1 - u) * kTile] : 0u;  // (offsets from the block's lowest row: immediates of the LDS reads)
+                nxt[CW - 1 - u] = LOADS ? b_low[(CW - 1 - u) * kTile] : 0u;  // (offsets from the block's lowest row: immediates of the LDS reads)
             }
         }
         wave::order_fence();
@@ -181,8 +187,10 @@ PHE_DEV void tile_product_steps(uint64_t (&acc)[CW], uint32_t (&win)[CW], const 
             const int u = part * kPer + v;
             if (u < CW) {
 #pragma unroll
-                for (int c = 0; c < CW; ++c) acc[c] = wave::mad64(ad[v], win[(c - u + CW) % CW], acc[c]);
-                win[CW - 1 - u] = bd[v];
+                for (int c = 0; c < CW; ++c) {
+                    const int slot = (c - u + CW) % CW;  // replaced by the steps before this one iff slot >= CW - u
+                    acc[c] = wave::mad64(ad[v], slot >= CW - u ? nxt[slot] : win[slot], acc[c]);
+                }
             }
         }
         wave::order_fence();
@@ -541,20 +549,33 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
             {
                 const uint32_t* a_col = buf_a + e;
                 const uint32_t* b_col = buf_b + ((int)wv * CW - 1) * kTile + e;
+                // `blocks` blocks with digits of b entering, two per trip: the window alternates between win and alt and is in win
+                // again at the loop's back edge (an odd block at the end copies it back: once per column half, not once per block)
                 int since = 0;
-#pragma unroll 1
-                for (uint32_t t = 0; t < wv; ++t) {
-                    tile_priority_after<W>(t);  // (blocks done of W + 1)
-                    tile_product_steps<CW, true>(acc, win, a_col, b_col);
+                const auto block = [&](const uint32_t (&from)[CW], uint32_t (&to)[CW], uint32_t done) __attribute__((always_inline)) {
+                    tile_priority_after<W>(done);  // (blocks done of W + 1)
+                    tile_product_steps<CW, true>(acc, from, to, a_col, b_col);
                     a_col += CW * kTile;
                     b_col -= CW * kTile;
                     if (++since == tile_hand_over_blocks<CW>()) {
                         tile_hand_over<CW>(acc, upper);
                         since = 0;
                     }
+                };
+                uint32_t alt[CW];
+                uint32_t t = 0;
+#pragma unroll 1
+                for (; t + 2u <= wv; t += 2u) {
+                    block(win, alt, t);
+                    block(alt, win, t + 1u);
+                }
+                if (t < wv) {
+                    block(win, alt, t);
+#pragma unroll
+                    for (int c = 0; c < CW; ++c) win[c] = alt[c];
                 }
                 tile_priority_after<W>(wv);
-                tile_product_steps<CW, false>(acc, win, a_col, b_col);
+                tile_product_steps<CW, false>(acc, win, alt, a_col, b_col);
             }
             out_low = tile_block_carries<CW>(t_low, acc, upper);
             // high block: columns p0 = CW (wv + W) ...; steps i = p0 - (S - 1) ... : the window opens on b[S - 1] alone
@@ -570,17 +591,25 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
                 const uint32_t* a_col = buf_a + i0 * kTile + e;
                 const uint32_t* b_col = buf_b + (S - 2) * kTile + e;
                 int since = 0;
-#pragma unroll 1
-                for (uint32_t t = 0; t < (uint32_t)kTileWaves - wv; ++t) {
-                    tile_priority_after<W>(wv + 1u + t);
-                    tile_product_steps<CW, true>(acc, win, a_col, b_col);
+                const auto block = [&](const uint32_t (&from)[CW], uint32_t (&to)[CW], uint32_t done) __attribute__((always_inline)) {
+                    tile_priority_after<W>(done);
+                    tile_product_steps<CW, true>(acc, from, to, a_col, b_col);
                     a_col += CW * kTile;
                     b_col -= CW * kTile;
                     if (++since == tile_hand_over_blocks<CW>()) {
                         tile_hand_over<CW>(acc, upper);
                         since = 0;
                     }
+                };
+                uint32_t alt[CW];
+                const uint32_t n_high = (uint32_t)kTileWaves - wv;
+                uint32_t t = 0;
+#pragma unroll 1
+                for (; t + 2u <= n_high; t += 2u) {
+                    block(win, alt, wv + 1u + t);
+                    block(alt, win, wv + 2u + t);
                 }
+                if (t < n_high) block(win, alt, wv + 1u + t);  // (the window is not looked at again)
             }
             out_high = tile_block_carries<CW>(t_high, acc, upper);
         }
