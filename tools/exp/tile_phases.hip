@@ -31,7 +31,8 @@ int main(int argc, char** argv) {
     cst = tbl + (size_t)kTileWaves * (DP + kFoldPadRows) * (S / kTileWaves);
     hipMalloc((void**)&prof, 64 + 256);
     TableMulArgs A;
-    A.n = cst; A.ncomp = cst + S; A.ncomp1 = cst + 2 * S; A.table = tbl; A.inv = 1e-9; A.split = P; A.digits = D; A.digits_padded = DP;
+    A.n = cst; A.ncomp = cst + S; A.ncomp1 = cst + 2 * S; A.table = tbl; A.inv = 1e-25;  // (q of ~2^33 with a random fraction: the settle takes its single candidate on 15 tiles of 16, as on real residues)
+     A.split = P; A.digits = D; A.digits_padded = DP;
     A.base = P - 2; A.a = a; A.b = b; A.out = o; A.a_stride = A.b_stride = A.out_stride = limbs; A.limbs = limbs; A.batch = batch;
     A.profile = prof; A.tile_waves = kTileWaves;
     hipEvent_t e0, e1;
