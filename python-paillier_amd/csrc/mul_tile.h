@@ -532,6 +532,8 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
         // ---- product: column blocks wv (low) and wv + W (high) of T = a*b ---------------------------------------------------------
         uint32_t t_low[CW], t_high[CW];
         uint64_t out_low, out_high;
+        constexpr bool kParkLow = CW > 10;
+        [[maybe_unused]] volatile uint32_t parked[kParkLow ? CW : 1];
         {
             uint64_t acc[CW];
             typename TileUpper<CW>::word upper[CW];
@@ -578,6 +580,13 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
                 tile_product_steps<CW, false>(acc, win, alt, a_col, b_col);
             }
             out_low = tile_block_carries<CW>(t_low, acc, upper);
+            if constexpr (kParkLow) {
+                // wide blocks (3072-bit keys: 14 columns): the low block's digits leave the registers while the high block is multiplied —
+                // ONE store and one load per digit and tile in the lane's private memory, where the compiler, short of these CW
+                // registers, spilled a dozen values in every block of the high half's loop (138 scratch instructions per tile)
+#pragma unroll
+                for (int c = 0; c < CW; ++c) parked[c] = t_low[c];
+            }
             // high block: columns p0 = CW (wv + W) ...; steps i = p0 - (S - 1) ... : the window opens on b[S - 1] alone
 #pragma unroll
             for (int c = 0; c < CW; ++c) {
@@ -620,6 +629,10 @@ PHE_DEV void mul_tile_body(const TableMulArgs& A, uint32_t* tile, uint32_t* prod
         PHE_TILE_MARK(1);  // product
         wave::block_barrier();  // every wave is through with A and B, every carry-out is in LDS
         PHE_TILE_MARK(2);  // barrier
+        if constexpr (kParkLow) {
+#pragma unroll
+            for (int c = 0; c < CW; ++c) t_low[c] = parked[c];
+        }
         {
             // what left the block below enters the two lowest digits (digit 1 stays below 2^29 + 2^10: almost-normalised, as
             // the fold's bound wants it); T over A and B
